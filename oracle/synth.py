@@ -1,0 +1,42 @@
+"""Deterministic synthetic proposals for the eval path (TEST INFRASTRUCTURE ONLY,
+same rules as vrd_oracle.py).  Shapes follow the producer of the reference's eval
+inputs, dataloaders/vidvrd.py:706-715 (keys sids, oids, so_features_list, bboxes_list,
+cat_ids, cat_scores, traj_durations, so_offset)."""
+import torch
+
+
+def synth_proposal(n_tracklets, c_in, min_len, max_len, seed=4321, feat_stride=1, video_len=None):
+    """All ordered pairs of n tracklets whose durations overlap by >= 2 feature steps.
+    Feature tensors are handed over the way the reference dataloader does: an (L, C)
+    row-major tensor viewed as (C, L) (dataloaders/vidvrd.py:693)."""
+    g = torch.Generator().manual_seed(seed)
+    video_len = video_len or (max_len * feat_stride + 16)
+    durs, boxes = [], []
+    for _ in range(n_tracklets):
+        L = int(torch.randint(min_len * feat_stride, max_len * feat_stride + 1, (1,), generator=g))
+        L = min(L, video_len)
+        st = int(torch.randint(0, video_len - L + 1, (1,), generator=g))
+        durs.append([st, st + L])
+        xy = torch.rand(L, 2, generator=g) * 100.0
+        wh = torch.rand(L, 2, generator=g) * 50.0 + 1.0
+        boxes.append(torch.cat([xy, xy + wh], dim=1))
+    sids, oids, feats, offs = [], [], [], []
+    for s in range(n_tracklets):
+        for o in range(n_tracklets):
+            if s == o:
+                continue
+            a, b = max(durs[s][0], durs[o][0]), min(durs[s][1], durs[o][1])
+            n_steps = (b - a + feat_stride - 1) // feat_stride if b > a else 0
+            if n_steps < 2:
+                continue
+            sids.append(s)
+            oids.append(o)
+            offs.append(0)
+            feats.append(torch.randn(n_steps, c_in, generator=g).permute(1, 0))
+    return {
+        "sids": torch.tensor(sids), "oids": torch.tensor(oids),
+        "so_features_list": feats, "bboxes_list": boxes,
+        "cat_ids": torch.randint(1, 36, (n_tracklets,), generator=g),
+        "cat_scores": torch.rand(n_tracklets, generator=g),
+        "traj_durations": torch.tensor(durs), "so_offset": torch.tensor(offs),
+    }

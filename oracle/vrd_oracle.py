@@ -1,0 +1,464 @@
+"""CPU oracle for the VrdONE relation-encoding hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``vrdone_amd/`` may import this file;
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg use it, and there only as the checker / the CPU baseline.
+
+It is a *functional* restatement (plain PyTorch fp32 ops over a flat
+``state_dict``) of the reference algorithm, written from the operator
+semantics of the reference sources cited per function (paths relative to the
+reference checkout).  It is pinned against golden vectors emitted by the real
+reference in this container (``tests/golden/``, made by
+``scripts/make_golden.py``); see ``tests/test_oracle_golden.py``.
+
+Layout follows the reference: features ``(B, C, T)``, masks ``(B, 1, T)`` bool.
+"""
+import hashlib
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-5          # models/blocks.py:123
+MASKED_KEY_BIAS = -1e4  # models/blocks.py:963-964
+MASK_FILL = -10.0      # models/predictor.py:85
+
+
+# ----------------------------------------------------------------------------
+# leaf operators
+# ----------------------------------------------------------------------------
+def masked_conv1d(x, mask, weight, bias=None, stride=1, groups=1):
+    """models/blocks.py:91-113 -- conv1d (zero pad k//2) then multiply by the
+    (nearest-downsampled when stride>1) mask."""
+    k = weight.shape[-1]
+    y = F.conv1d(x, weight, bias, stride=stride, padding=k // 2, groups=groups)
+    if stride > 1:
+        mask = mask[..., ::stride]   # F.interpolate(nearest) to T/stride picks index i*stride
+    return y * mask.to(y.dtype), mask
+
+
+def channel_ln(x, weight, bias):
+    """models/blocks.py:143-158 -- LayerNorm over C for every (b, t), biased variance."""
+    mu = x.mean(dim=1, keepdim=True)
+    d = x - mu
+    var = (d * d).mean(dim=1, keepdim=True)
+    return d / torch.sqrt(var + LN_EPS) * weight + bias
+
+
+def _split_heads(x, n_head):
+    B, C, T = x.shape
+    return x.view(B, n_head, C // n_head, T).transpose(2, 3)   # (B, H, T, hd)
+
+
+def _merge_heads(x):
+    B, H, T, hd = x.shape
+    return x.transpose(2, 3).reshape(B, H * hd, T)
+
+
+def full_attention(q, k, v, kv_mask, n_head):
+    """models/local_transformer.py:163-183 (same math as :44-63) -- masked softmax(QK^T/sqrt(hd)) V."""
+    q, k, v = _split_heads(q, n_head), _split_heads(k, n_head), _split_heads(v, n_head)
+    hd = q.shape[-1]
+    att = (q * (1.0 / math.sqrt(hd))) @ k.transpose(-2, -1)
+    att = att.masked_fill(~kv_mask[:, :, None, :], float("-inf"))
+    att = F.softmax(att, dim=-1)
+    out = att @ (v * kv_mask[:, :, :, None].to(v.dtype))
+    return _merge_heads(out)
+
+
+def banded_attention(q, k, v, kv_mask, n_head, half_win):
+    """models/blocks.py:950-986 (sliding-chunk trick at :819-918) restated as the
+    banded attention it computes: query t sees keys j in [t-w, t+w] inside [0, T);
+    masked keys get -1e4 added, out-of-range keys -inf, masked query rows are
+    zeroed after the softmax."""
+    q, k, v = _split_heads(q, n_head), _split_heads(k, n_head), _split_heads(v, n_head)
+    B, H, T, hd = q.shape
+    w = half_win
+    q = q * (1.0 / math.sqrt(hd))
+    kp = F.pad(k, (0, 0, w, w)).unfold(2, 2 * w + 1, 1)        # (B,H,T,hd,2w+1)
+    vp = F.pad(v, (0, 0, w, w)).unfold(2, 2 * w + 1, 1)
+    s = torch.einsum("bhtd,bhtdw->bhtw", q, kp)
+    pos = torch.arange(T)[:, None] + torch.arange(-w, w + 1)[None, :]        # (T, 2w+1)
+    inside = (pos >= 0) & (pos < T)
+    key_ok = kv_mask[:, 0][:, pos.clamp(0, T - 1)]                             # (B,T,2w+1)
+    s = s + torch.where(key_ok, 0.0, MASKED_KEY_BIAS)[:, None]
+    s = s.masked_fill(~inside[None, None], float("-inf"))
+    p = F.softmax(s, dim=-1)
+    p = p.masked_fill(~kv_mask[:, 0][:, None, :, None], 0.0)
+    out = torch.einsum("bhtw,bhtdw->bhtd", p, vp)
+    return _merge_heads(out)
+
+
+def conv_mlp(sd, pre, x, n_layers=2):
+    """models/blocks.py:57-61 -- 1x1 convs with exact (erf) GELU in between."""
+    for i in range(n_layers):
+        x = F.conv1d(x, sd[f"{pre}.layers.{i}.weight"], sd[f"{pre}.layers.{i}.bias"])
+        if i < n_layers - 1:
+            x = F.gelu(x)
+    return x
+
+
+# ----------------------------------------------------------------------------
+# attention modules
+# ----------------------------------------------------------------------------
+def _qkv_branch(sd, pre, name, x, mask, stride):
+    """depthwise conv (no bias) * mask -> LN -> 1x1 projection (models/blocks.py:927-939,
+    models/local_transformer.py:149-161)."""
+    w = sd[f"{pre}.{name}_conv.conv.weight"]
+    y, m = masked_conv1d(x, mask, w, None, stride=stride, groups=w.shape[0])
+    y = channel_ln(y, sd[f"{pre}.{name}_norm.weight"], sd[f"{pre}.{name}_norm.bias"])
+    return F.conv1d(y, sd[f"{pre}.{name}.weight"], sd[f"{pre}.{name}.bias"]), m
+
+
+def local_mhca(sd, pre, x, mask, n_head, win, stride):
+    """LocalMaskedMHCA.forward, models/blocks.py:920-989."""
+    q, qm = _qkv_branch(sd, pre, "query", x, mask, stride)
+    k, km = _qkv_branch(sd, pre, "key", x, mask, stride)
+    v, _ = _qkv_branch(sd, pre, "value", x, mask, stride)
+    o = banded_attention(q, k, v, km, n_head, win // 2)
+    o = F.conv1d(o, sd[f"{pre}.proj.weight"], sd[f"{pre}.proj.bias"])
+    return o * qm.to(o.dtype), qm
+
+
+def mhca_qkv(sd, pre, q_in, k_in, v_in, q_mask, kv_mask, n_head, half_win=None):
+    """MaskedMHCA_QKV.forward, models/local_transformer.py:144-187 (LocalMaskedMHCA_QKV
+    :553-623 when half_win is given)."""
+    q, qm = _qkv_branch(sd, pre, "query", q_in, q_mask, 1)
+    k, km = _qkv_branch(sd, pre, "key", k_in, kv_mask, 1)
+    v, _ = _qkv_branch(sd, pre, "value", v_in, kv_mask, 1)
+    if half_win is None:
+        o = full_attention(q, k, v, km, n_head)
+    else:
+        o = banded_attention(q, k, v, km, n_head, half_win)
+    o = F.conv1d(o, sd[f"{pre}.proj.weight"], sd[f"{pre}.proj.bias"])
+    return o * qm.to(o.dtype), qm
+
+
+def mha_qkv(sd, pre, q_in, k_in, v_in, q_mask, kv_mask, n_head):
+    """MaskedMHA_QKV.forward, models/local_transformer.py:33-67."""
+    q = F.conv1d(q_in, sd[f"{pre}.query.weight"], sd[f"{pre}.query.bias"])
+    k = F.conv1d(k_in, sd[f"{pre}.key.weight"], sd[f"{pre}.key.bias"])
+    v = F.conv1d(v_in, sd[f"{pre}.value.weight"], sd[f"{pre}.value.bias"])
+    o = full_attention(q, k, v, kv_mask, n_head)
+    o = F.conv1d(o, sd[f"{pre}.proj.weight"], sd[f"{pre}.proj.bias"])
+    return o * q_mask.to(o.dtype), q_mask
+
+
+def transformer_block(sd, pre, x, mask, n_head, win, stride):
+    """TransformerBlock.forward, models/blocks.py:1070-1080 (eval: drop-path = channel scale)."""
+    h = channel_ln(x, sd[f"{pre}.ln1.weight"], sd[f"{pre}.ln1.bias"])
+    a, m = local_mhca(sd, f"{pre}.attn", h, mask, n_head, win, stride)
+    mf = m.to(x.dtype)
+    skip = x if stride == 1 else F.max_pool1d(x, stride + 1, stride, (stride + 1) // 2)
+    y = skip * mf + sd[f"{pre}.drop_path_attn.scale"] * a
+    h = channel_ln(y, sd[f"{pre}.ln2.weight"], sd[f"{pre}.ln2.bias"])
+    h = F.conv1d(h, sd[f"{pre}.mlp.0.weight"], sd[f"{pre}.mlp.0.bias"])
+    h = F.conv1d(F.gelu(h), sd[f"{pre}.mlp.3.weight"], sd[f"{pre}.mlp.3.bias"])
+    return y + sd[f"{pre}.drop_path_mlp.scale"] * (h * mf), m
+
+
+def decoder_layer(sd, pre, tgt, mem, tgt_mask, mem_mask, n_head, query_pos=None,
+                  conv_qkv_self=True, with_ffn=False, half_win=None):
+    """MaskedConvTransformerDecoderLayer.forward (cross_first=False),
+    models/local_transformer.py:807-835."""
+    def add_pos(t):
+        return t if query_pos is None else t + query_pos
+    t2 = channel_ln(tgt, sd[f"{pre}.ln1.weight"], sd[f"{pre}.ln1.bias"])
+    qk = add_pos(t2)
+    if conv_qkv_self:
+        u, m = mhca_qkv(sd, f"{pre}.self_attn", qk, qk, tgt, tgt_mask, tgt_mask, n_head, half_win)
+    else:
+        u, m = mha_qkv(sd, f"{pre}.self_attn", qk, qk, tgt, tgt_mask, tgt_mask, n_head)
+    mf = m.to(tgt.dtype)
+    tgt = tgt * mf + sd[f"{pre}.drop_path_attn1.scale"] * u
+    t2 = channel_ln(tgt, sd[f"{pre}.ln2.weight"], sd[f"{pre}.ln2.bias"])
+    c, m = mhca_qkv(sd, f"{pre}.multihead_attn", add_pos(t2), mem, mem, tgt_mask, mem_mask, n_head, half_win)
+    mf = m.to(tgt.dtype)
+    tgt = tgt * mf + sd[f"{pre}.drop_path_attn2.scale"] * c
+    if with_ffn:
+        t2 = channel_ln(tgt, sd[f"{pre}.ln3.weight"], sd[f"{pre}.ln3.bias"])
+        h = F.conv1d(t2, sd[f"{pre}.mlp.0.weight"], sd[f"{pre}.mlp.0.bias"])
+        h = F.conv1d(F.gelu(h), sd[f"{pre}.mlp.3.weight"], sd[f"{pre}.mlp.3.bias"])
+        tgt = tgt + sd[f"{pre}.drop_path_mlp.scale"] * (h * mf)
+    return tgt, m
+
+
+# ----------------------------------------------------------------------------
+# backbone / neck / predictor
+# ----------------------------------------------------------------------------
+def backbone(sd, cfg, x, mask):
+    """MaskConvTransformerBackbone.forward, models/backbones.py:154-248;
+    CLIP variant :323-436."""
+    V, E, S = cfg["visual_dim"], cfg["bbox_entity_dim"], cfg["bbox_so_dim"]
+    Cc = cfg["clip_dim"] if cfg.get("with_clip_feature", False) else 0
+    H, Hf, win = cfg["n_head"], cfg["fuse_head"], cfg["n_mha_win_size"]
+    n_conv, n_stem, n_branch = cfg["backbone_arch"]
+    assert x.shape[1] == 2 * V + 2 * Cc + S + 2 * E
+    assert cfg["fuse_qx_stride"] == 1 and cfg["fuse_kv_stride"] == 1 and cfg["embd_with_ln"]
+    assert not cfg["use_abs_pe"] and not cfg["use_rel_pe"]
+    mf = mask.to(x.dtype)
+    P = "backbone"
+    o0 = 2 * V + 2 * Cc
+    streams = [x[:, :V], x[:, V:2 * V]]
+    clips = [x[:, 2 * V:2 * V + Cc], x[:, 2 * V + Cc:o0]] if Cc else None
+    so_box = x[:, o0:o0 + S]
+    ent_box = [x[:, o0 + S:o0 + S + E], x[:, o0 + S + E:]]
+
+    def embed(name, feats):
+        out = []
+        for f in feats:
+            for i in range(n_conv):
+                f, _ = masked_conv1d(f, mask, sd[f"{P}.{name}.{i}.conv.weight"])
+                f = F.relu(channel_ln(f, sd[f"{P}.{name}_norm.{i}.weight"], sd[f"{P}.{name}_norm.{i}.bias"]))
+            out.append(f)
+        return out
+
+    streams = embed("visual_embd", streams)
+    if Cc:
+        clips = embed("clip_embd", clips)
+        streams = [conv_mlp(sd, f"{P}.visual_clip_fuse", torch.cat([f, c], 1)) * mf
+                   for f, c in zip(streams, clips)]
+    boxes = []
+    for b in ent_box:
+        b, _ = masked_conv1d(b, mask, sd[f"{P}.bbox_entity_embd.conv.weight"], sd[f"{P}.bbox_entity_embd.conv.bias"])
+        boxes.append(F.relu(channel_ln(b, sd[f"{P}.bbox_entity_norm.weight"], sd[f"{P}.bbox_entity_norm.bias"])))
+    s, o = [conv_mlp(sd, f"{P}.visual_bbox_fuse", torch.cat([f, b], 1)) * mf for f, b in zip(streams, boxes)]
+
+    hw = win // 2 if cfg["use_local"] else None
+    for i in range(n_stem):
+        s, _ = transformer_block(sd, f"{P}.stem.{i}", s, mask, H, win, 1)
+        o, _ = transformer_block(sd, f"{P}.stem.{i}", o, mask, H, win, 1)
+        s_m, _ = decoder_layer(sd, f"{P}.s_attn.{i}", s, o, mask, mask, Hf, half_win=hw)
+        o_m, _ = decoder_layer(sd, f"{P}.o_attn.{i}", o, s, mask, mask, Hf, half_win=hw)
+        s, o = s + s_m, o + o_m            # backbones.py:220-221 (stream counted twice)
+    s = channel_ln(s, sd[f"{P}.s_fuse_norm.weight"], sd[f"{P}.s_fuse_norm.bias"])
+    o = channel_ln(o, sd[f"{P}.o_fuse_norm.weight"], sd[f"{P}.o_fuse_norm.bias"])
+    so = conv_mlp(sd, f"{P}.so_fuse", torch.cat([s, o], 1)) * mf
+    bso, _ = masked_conv1d(so_box, mask, sd[f"{P}.bbox_so_embd.conv.weight"], sd[f"{P}.bbox_so_embd.conv.bias"])
+    e = conv_mlp(sd, f"{P}.so_visual_bbox_fuse", torch.cat([so, bso], 1)) * mf
+    feats, masks = [e], [mask]
+    for i in range(n_branch):
+        e, mask = transformer_block(sd, f"{P}.branch.{i}", e, mask, H, win, cfg["scale_factor"])
+        feats.append(e)
+        masks.append(mask)
+    return feats, masks
+
+
+def neck(sd, cfg, feats, masks):
+    """FPN1D_Fuse.forward, models/fpns.py:229-257 (fpn_with_ln, fpn_norm_first)."""
+    assert cfg["fpn_with_ln"] and cfg["fpn_norm_first"] and cfg["fpn_start_level"] == 0
+    top = len(feats) - 1
+    y = None
+    for l in range(top, -1, -1):
+        x = channel_ln(feats[l], sd[f"neck.input_norms.{l}.weight"], sd[f"neck.input_norms.{l}.bias"])
+        wf = sd[f"neck.fpn_convs.{l}.conv.weight"]
+        if l == top:
+            y, _ = masked_conv1d(x, masks[l], wf, None, groups=wf.shape[0])
+        else:
+            c, _ = masked_conv1d(x, masks[l], sd[f"neck.lateral_convs.{l}.conv.weight"])
+            c = channel_ln(c, sd[f"neck.lateral_norms.{l}.weight"], sd[f"neck.lateral_norms.{l}.bias"])
+            y = c + y.repeat_interleave(int(cfg["scale_factor"]), dim=-1)
+            y, _ = masked_conv1d(y, masks[l], wf, None, groups=wf.shape[0])
+        y = channel_ln(y, sd[f"neck.fpn_norms.{l}.weight"], sd[f"neck.fpn_norms.{l}.bias"])
+    wm = sd["neck.mask_features.conv.weight"]
+    return masked_conv1d(y, masks[0], wm, sd["neck.mask_features.conv.bias"], groups=wm.shape[0])
+
+
+def predictor(sd, cfg, x, mask_features, mask, output_mask, with_aux=True):
+    """MaskedTransformerPredictor.forward, models/predictor.py:85-115, with the decoder
+    of models/local_transformer.py:875-905 / :956-976."""
+    pc = cfg["predictor"]
+    assert pc["n_qx_stride"] == 0 and pc["n_kv_stride"] == 1
+    src = channel_ln(x, sd["predictor.input_norm.weight"], sd["predictor.input_norm.bias"])
+    if "predictor.input_proj.weight" in sd:
+        src = F.conv1d(src, sd["predictor.input_proj.weight"], sd["predictor.input_proj.bias"]) * mask.to(src.dtype)
+    B = src.shape[0]
+    qpos = sd["predictor.query_embed.weight"].t()[None].expand(B, -1, -1)   # (B, Dp, Q)
+    tgt = torch.zeros_like(qpos)
+    tmask = torch.ones(B, 1, qpos.shape[-1], dtype=torch.bool)
+    dn = "predictor.transformer.decoder"
+    hs = []
+    for l in range(pc["num_layers"]):
+        tgt, tmask = decoder_layer(sd, f"{dn}.layers.{l}", tgt, src, tmask, mask, pc["n_head"],
+                                   query_pos=qpos, conv_qkv_self=False, with_ffn=True)
+        hs.append(channel_ln(tgt, sd[f"{dn}.norm.weight"], sd[f"{dn}.norm.bias"]))
+    if not pc["deep_supervision"]:
+        hs = hs[-1:]
+
+    def heads(h):
+        logits = F.conv1d(h, sd["predictor.class_embed.weight"], sd["predictor.class_embed.bias"]).transpose(1, 2)
+        emb = conv_mlp(sd, "predictor.mask_embed", h, 3).transpose(1, 2)       # (B,Q,Dp)
+        seg = torch.einsum("bqc,bcm->bqm", emb, mask_features)
+        return logits, seg.masked_fill(~output_mask, MASK_FILL)
+
+    logits, seg = heads(hs[-1])
+    out = {"pred_logits": logits, "pred_masks": seg, "output_mask": output_mask}
+    if pc["deep_supervision"] and with_aux:
+        out["aux_outputs"] = [dict(zip(("pred_logits", "pred_masks"), heads(h))) for h in hs[:-1]]
+    return out
+
+
+def mask_vrd(sd, cfg, x, mask, with_aux=True):
+    """MaskVRD._mask_vrd, models/maskvrd.py:161-167."""
+    feats, masks = backbone(sd, cfg, x, mask)
+    fpn, _ = neck(sd, cfg, feats, masks)
+    return predictor(sd, cfg, feats[-1], fpn, masks[-1], masks[0], with_aux)
+
+
+# ----------------------------------------------------------------------------
+# eval-side pre/post-processing
+# ----------------------------------------------------------------------------
+def max_div_factor(cfg):
+    """models/maskvrd.py:51-63."""
+    n_levels = cfg["backbone_arch"][-1] + 1 - cfg["fpn_start_level"]
+    w = cfg["n_mha_win_size"]
+    f = 1
+    for l in range(n_levels):
+        s = cfg["scale_factor"] ** (l + cfg["fpn_start_level"])
+        f = max(f, s * (w // 2) * 2 if w > 1 else s)
+    return f
+
+
+def preprocess_eval(cfg, feats_list):
+    """MaskVRD.preprocessing eval branch, models/maskvrd.py:363-414.  Returns
+    ((x_short, m_short, ids_short), (x_long, m_long, ids_long)); a part is None when empty."""
+    L0 = cfg["max_seq_len"]
+    parts = []
+    for long in (False, True):
+        ids = [i for i, f in enumerate(feats_list) if (f.shape[1] > L0) == long]
+        if not ids:
+            parts.append(None)
+            continue
+        if long:
+            d = max_div_factor(cfg)
+            T = (max(feats_list[i].shape[1] for i in ids) + d - 1) // d * d
+        else:
+            T = L0
+        x = torch.zeros(len(ids), feats_list[0].shape[0], T)
+        lens = torch.tensor([feats_list[i].shape[1] for i in ids])
+        for r, i in enumerate(ids):
+            x[r, :, :lens[r]] = feats_list[i]
+        m = (torch.arange(T)[None, :] < lens[:, None])[:, None, :]
+        parts.append((x, m, ids))
+    return parts
+
+
+def postprocess(pred_logits, pred_masks, output_masks, data, topk, n_max_pair, feat_stride, pred_min_frames):
+    """MaskVRD.forward_test post-processing, models/maskvrd.py:247-337, as explicit
+    Python loops (small cases only).  pred_masks / output_masks are per-pair lists
+    (their T may differ between the short and long parts)."""
+    probs = F.softmax(pred_logits, dim=-1)
+    scores, cats = torch.topk(probs[..., 1:], k=topk, dim=-1)
+    cats = cats + 1
+    rows = []   # (triplet, triple_score, duration, tids, s_slice, o_slice)
+    for p, (sid, oid) in enumerate(zip(data["sids"].tolist(), data["oids"].tolist())):
+        sd_, od_ = data["traj_durations"][sid], data["traj_durations"][oid]
+        so_start = max(int(sd_[0]), int(od_[0]))
+        so_end = min(int(sd_[1]), int(od_[1]))
+        valid = int(output_masks[p].sum())
+        off = int(data["so_offset"][p])
+        Q = scores.shape[1]
+        for q in range(Q):
+            on = torch.nonzero(torch.sigmoid(pred_masks[p][q][:valid]) > 0.5).flatten()
+            for j in range(topk):
+                if on.numel() == 0:
+                    continue
+                st = int(on.min()) * feat_stride + off
+                en = int(on.max()) * feat_stride + off + 1
+                assert st >= 0 and en <= so_end - so_start
+                if en - st < pred_min_frames:
+                    continue
+                ss, os_ = so_start - int(sd_[0]), so_start - int(od_[0])
+                rows.append((
+                    [int(data["cat_ids"][sid]), int(cats[p, q, j]), int(data["cat_ids"][oid])],
+                    torch.stack([data["cat_scores"][sid], scores[p, q, j], data["cat_scores"][oid]]),
+                    [so_start + st, so_start + en], [sid, oid],
+                    (sid, ss + st, ss + en), (oid, os_ + st, os_ + en)))
+    if not rows:
+        return None
+    tri_scores = torch.stack([r[1] for r in rows])
+    avg = tri_scores.mean(dim=-1)
+    order = torch.argsort(avg, descending=True)[:n_max_pair].tolist()
+    bl = data["bboxes_list"]
+    return {
+        "triplets": [rows[i][0] for i in order],
+        "triple_scores": tri_scores[order].tolist(),
+        "triple_scores_avg": avg[order].tolist(),
+        "so_trajs": [[bl[rows[i][4][0]][rows[i][4][1]:rows[i][4][2]].tolist(),
+                      bl[rows[i][5][0]][rows[i][5][1]:rows[i][5][2]].tolist()] for i in order],
+        "pred_durations": [rows[i][2] for i in order],
+        "so_tids": [rows[i][3] for i in order],
+    }
+
+
+def forward_test(sd, cfg, infer_cfg, data):
+    """MaskVRD.forward_test, models/maskvrd.py:201-337."""
+    feats = data["so_features_list"]
+    P = len(data["sids"])
+    logits, masks, omasks = [None] * P, [None] * P, [None] * P
+    step = cfg["max_so_pair"]
+    for s0 in range(0, P, step):
+        for part in preprocess_eval(cfg, feats[s0:s0 + step]):
+            if part is None:
+                continue
+            x, m, ids = part
+            out = mask_vrd(sd, cfg, x, m, with_aux=False)
+            for r, i in enumerate(ids):
+                logits[s0 + i] = out["pred_logits"][r]
+                masks[s0 + i] = out["pred_masks"][r]
+                omasks[s0 + i] = out["output_mask"][r]
+    return postprocess(torch.stack(logits), masks, omasks, data, infer_cfg["topk"],
+                       infer_cfg["n_max_pair"], infer_cfg["feat_stride"], infer_cfg["pred_min_frames"])
+
+
+# ----------------------------------------------------------------------------
+# deterministic synthetic weights / inputs (shared by tests, smoke and bench)
+# ----------------------------------------------------------------------------
+def synth_tensor(name, shape, ln_bias_std=0.1):
+    """Name-seeded synthetic parameter: O(1) drop-path scales, LN affine
+    near identity, conv weights N(0,1)/sqrt(fan_in) so activations stay O(1)."""
+    g = torch.Generator().manual_seed(int.from_bytes(hashlib.sha256(name.encode()).digest()[:4], "little"))
+    shape = tuple(shape)
+    if name == "empty_weight":
+        return None
+    leaf = name.rsplit(".", 1)[-1]
+    is_ln = len(shape) == 3 and shape[0] == 1 and shape[2] == 1
+    if leaf == "scale":
+        return torch.rand(shape, generator=g) + 0.5
+    if is_ln and leaf == "weight":
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if is_ln and leaf == "bias":
+        return ln_bias_std * torch.randn(shape, generator=g)
+    if leaf == "bias":
+        return 0.02 * torch.randn(shape, generator=g)
+    fan_in = 1
+    for d in shape[1:]:
+        fan_in *= d
+    if "query_embed" in name:
+        fan_in = 1
+    return torch.randn(shape, generator=g) / math.sqrt(max(fan_in, 1))
+
+
+def synth_state_dict(key_shapes, eos_coef=0.1, ln_bias_std=0.1):
+    """key_shapes: ordered iterable of (name, shape) as enumerated from the reference
+    (tests/golden/state_keys_*.json)."""
+    sd = OrderedDict()
+    for name, shape in key_shapes:
+        t = synth_tensor(name, shape, ln_bias_std)
+        if t is None:
+            t = torch.ones(tuple(shape))
+            t[0] = eos_coef
+        sd[name] = t
+    return sd
+
+
+def synth_pairs(B, C_in, T_pad, lengths=None, seed=1234):
+    """x ~ N(0,1) * mask, mask[b,t] = t < len_b."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C_in, T_pad, generator=g)
+    if lengths is None:
+        lengths = torch.full((B,), T_pad, dtype=torch.long)
+    lengths = torch.as_tensor(lengths)
+    mask = (torch.arange(T_pad)[None, :] < lengths[:, None])[:, None, :]
+    return x * mask.to(x.dtype), mask

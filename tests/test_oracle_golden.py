@@ -1,0 +1,148 @@
+"""The oracle (oracle/vrd_oracle.py) against golden vectors emitted by the real reference
+(scripts/make_golden.py).  CPU only.  Tolerances: the reference's own fp32-vs-fp64
+discrepancy is 4e-6 (logits) / 3e-5 (masks)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_case
+from oracle import vrd_oracle as O
+from oracle.synth import synth_proposal
+
+torch.set_grad_enabled(False)
+LOGIT_TOL, MASK_TOL = 2e-5, 2e-4
+
+
+def c_in(mc):
+    cc = mc["clip_dim"] if mc.get("with_clip_feature", False) else 0
+    return 2 * mc["visual_dim"] + 2 * cc + mc["bbox_so_dim"] + 2 * mc["bbox_entity_dim"]
+
+
+@pytest.fixture(scope="module")
+def weights():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            mc, ic, keys = load_case(name)
+            cache[name] = (mc, ic, O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"]))
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("name", ["vidvrd", "vidor_x", "vidor_local"])
+def test_param_checksums(name, weights):
+    _, _, sd = weights(name)
+    with open(os.path.join(GOLDEN, f"param_checksums_{name}.json")) as f:
+        chk = json.load(f)
+    assert list(chk.keys()) == list(sd.keys())
+    for k, (s, a) in chk.items():
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-9 * max(1.0, a), k
+        assert abs(float(sd[k].double().abs().sum()) - a) <= 1e-9 * max(1.0, a), k
+
+
+@pytest.mark.parametrize("name,T", [("vidvrd", 96), ("vidvrd", 144), ("vidvrd", 288),
+                                    ("vidor_x", 512), ("vidor_local", 512)])
+def test_mask_vrd_matches_reference(name, T, weights):
+    mc, _, sd = weights(name)
+    g = np.load(os.path.join(GOLDEN, f"mask_vrd_{name}.npz"))
+    lens = g[f"T{T}_lengths"].tolist()
+    x, m = O.synth_pairs(len(lens), c_in(mc), T, lens, seed=1234 + T)
+    feats, masks = O.backbone(sd, mc, x, m)
+    fpn, _ = O.neck(sd, mc, feats, masks)
+    out = O.predictor(sd, mc, feats[-1], fpn, masks[-1], masks[0])
+    if f"T{T}_feat0" in g:
+        for l, ft in enumerate(feats):
+            np.testing.assert_allclose(ft[:, ::16].numpy(), g[f"T{T}_feat{l}"], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(fpn[:, ::8].numpy(), g[f"T{T}_fpn"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["pred_logits"].numpy(), g[f"T{T}_pred_logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["pred_masks"].numpy(), g[f"T{T}_pred_masks"], atol=MASK_TOL, rtol=0)
+    for i, a in enumerate(out["aux_outputs"]):
+        np.testing.assert_allclose(a["pred_logits"].numpy(), g[f"T{T}_aux{i}_pred_logits"], atol=LOGIT_TOL, rtol=0)
+        np.testing.assert_allclose(a["pred_masks"].numpy(), g[f"T{T}_aux{i}_pred_masks"], atol=MASK_TOL, rtol=0)
+
+
+def _op_sd(prefix, ref_keys):
+    return O.synth_state_dict(ref_keys)
+
+
+def test_operators_match_reference():
+    g = np.load(os.path.join(GOLDEN, "ops.npz"))
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    lens = torch.from_numpy(g["lens"])
+    B, C, T = x.shape
+    m = (torch.arange(T)[None] < lens[:, None])[:, None]
+
+    def attn_keys(p, ks=(3, 3, 3)):
+        keys = []
+        for n, k in zip(("query", "key", "value"), ks):
+            keys += [(f"{p}.{n}_conv.conv.weight", (C, 1, k)), (f"{p}.{n}_norm.weight", (1, C, 1)),
+                     (f"{p}.{n}_norm.bias", (1, C, 1))]
+        for n in ("key", "query", "value", "proj"):
+            keys += [(f"{p}.{n}.weight", (C, C, 1)), (f"{p}.{n}.bias", (C,))]
+        return keys
+
+    def ln_keys(p):
+        return [(f"{p}.weight", (1, C, 1)), (f"{p}.bias", (1, C, 1))]
+
+    for stride in (1, 2):
+        p = f"op.local_mhca_s{stride}"
+        sd = O.synth_state_dict(attn_keys(p))
+        out, _ = O.local_mhca(sd, p, x, m, 4, 7, stride)
+        np.testing.assert_allclose(out.numpy(), g[f"local_mhca_s{stride}"], atol=2e-5, rtol=0)
+        p = f"op.block_s{stride}"
+        keys = ln_keys(f"{p}.ln1") + ln_keys(f"{p}.ln2") + attn_keys(f"{p}.attn") + [
+            (f"{p}.mlp.0.weight", (4 * C, C, 1)), (f"{p}.mlp.0.bias", (4 * C,)),
+            (f"{p}.mlp.3.weight", (C, 4 * C, 1)), (f"{p}.mlp.3.bias", (C,)),
+            (f"{p}.drop_path_attn.scale", (1, C, 1)), (f"{p}.drop_path_mlp.scale", (1, C, 1))]
+        out, _ = O.transformer_block(O.synth_state_dict(keys), p, x, m, 4, 7, stride)
+        np.testing.assert_allclose(out.numpy(), g[f"block_s{stride}"], atol=5e-5, rtol=0)
+    p = "op.local_mhca_w9"
+    out, _ = O.local_mhca(O.synth_state_dict(attn_keys(p)), p, x, m, 8, 9, 1)
+    np.testing.assert_allclose(out.numpy(), g["local_mhca_w9"], atol=2e-5, rtol=0)
+    p = "op.mhca_qkv"
+    out, _ = O.mhca_qkv(O.synth_state_dict(attn_keys(p)), p, x, y, y, m, m, 4)
+    np.testing.assert_allclose(out.numpy(), g["mhca_qkv"], atol=2e-5, rtol=0)
+    for p, heads, hw in (("op.sos", 4, None), ("op.sos_local", 8, 4)):
+        keys = ln_keys(f"{p}.ln1") + ln_keys(f"{p}.ln2") + attn_keys(f"{p}.self_attn") + \
+            attn_keys(f"{p}.multihead_attn") + [(f"{p}.drop_path_attn1.scale", (1, C, 1)),
+                                                 (f"{p}.drop_path_attn2.scale", (1, C, 1))]
+        out, _ = O.decoder_layer(O.synth_state_dict(keys), p, x, y, m, m, heads, half_win=hw)
+        np.testing.assert_allclose(out.numpy(), g[p[3:]], atol=5e-5, rtol=0)
+    sd = O.synth_state_dict(ln_keys("op.ln"))
+    np.testing.assert_allclose(O.channel_ln(x, sd["op.ln.weight"], sd["op.ln.bias"]).numpy(), g["ln"], atol=1e-6, rtol=0)
+    sd = O.synth_state_dict([("op.conv3.conv.weight", (C, C, 3))])
+    out, _ = O.masked_conv1d(x, m, sd["op.conv3.conv.weight"])
+    np.testing.assert_allclose(out.numpy(), g["conv3"], atol=1e-5, rtol=0)
+
+
+def test_forward_test_matches_reference(weights):
+    mc, ic, sd = weights("vidvrd")
+    with open(os.path.join(GOLDEN, "forward_test_vidvrd.json")) as f:
+        ref = json.load(f)
+    data = synth_proposal(6, c_in(mc), 20, 130, seed=4321)
+    assert len(data["sids"]) == ref["n_pairs"]
+    assert [int(f.shape[1]) for f in data["so_features_list"]] == ref["pair_lengths"]
+    res = O.forward_test(sd, mc, ic, data)
+    assert res["triplets"] == ref["triplets"]
+    assert res["pred_durations"] == ref["pred_durations"]
+    assert res["so_tids"] == ref["so_tids"]
+    np.testing.assert_allclose(res["triple_scores"], ref["triple_scores"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(res["triple_scores_avg"], ref["triple_scores_avg"], atol=1e-5, rtol=0)
+    dig = [[len(t[0]), float(np.sum(np.asarray(t, dtype=np.float64)))] for t in res["so_trajs"]]
+    np.testing.assert_allclose(dig, ref["so_trajs_digest"], rtol=1e-9)
+
+
+def test_preprocess_eval_shapes():
+    mc, _, _ = load_case("vidvrd")
+    assert O.max_div_factor(mc) == 48
+    feats = [torch.randn(7, L) for L in (10, 96, 97, 200)]
+    short, long_ = O.preprocess_eval(mc, feats)
+    assert short[0].shape == (2, 7, 96) and short[2] == [0, 1]
+    assert long_[0].shape == (2, 7, 240) and long_[2] == [2, 3]
+    assert short[1].sum().item() == 106 and long_[1].sum().item() == 297
+    mc2, _, _ = load_case("vidor_x")
+    assert O.max_div_factor(mc2) == 64
