@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: subject-object pairs/second through MaskVRD._mask_vrd (backbone with SOS
+fusion -> 1-D FPN -> mask-segmentation predictor) on synthetic pair x frame tensors.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric): configs/vidvrd.yaml model, 2048 pairs x 256 frames, which the
+reference's eval batching pads to T_pad = 288 (models/maskvrd.py:378-379); inputs (B, 2069, 288)
+fp32 ~ N(0,1) * mask, resident in HBM before the timed region; name-seeded synthetic weights.
+A step = one pass of the hot path over the whole 2048-pair batch.  With N GPUs the pair dimension
+is sharded (2048/N per rank, strong scaling) and every step ends with an RCCL all-gather of the
+per-pair predictions (logits + masks), as BASELINE config 4 describes.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# closed-form algorithmic FLOPs per pair at T_pad (cross-checked with FlopCounterMode)
+FLOPS_PER_PAIR = {("vidvrd", 96): 6.386e9, ("vidvrd", 144): 9.650e9, ("vidvrd", 288): 19.897e9,
+                  ("vidor_x", 512): 42.038e9}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="vidvrd")
+    ap.add_argument("--pairs", type=int, default=2048)
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--pair-chunk", type=int, default=0, help="pairs per launch wave inside _mask_vrd (0 = model default)")
+    ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=16)
+    return ap.parse_args()
+
+
+def padded_len(cfg, frames, div):
+    if frames <= cfg["max_seq_len"]:
+        return cfg["max_seq_len"]
+    return (frames + div - 1) // div * div
+
+
+def cpu_baseline(model_cfg, sd_cpu, c_in, frames, t_pad, n_pairs):
+    """The oracle (CPU restatement of the reference, plain PyTorch fp32) on a bounded sample of the
+    same workload, on this box's host cores."""
+    from oracle import vrd_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    x, m = O.synth_pairs(n_pairs, c_in, t_pad, [frames] * n_pairs, seed=1234)
+    with torch.no_grad():
+        O.mask_vrd(sd_cpu, model_cfg, x[:2], m[:2], with_aux=True)        # warm-up
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.mask_vrd(sd_cpu, model_cfg, x, m, with_aux=True)            # the reference computes the aux heads too
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    return {"value": n_pairs / med, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n_pairs} pairs x {frames} frames (T_pad {t_pad}), oracle.mask_vrd, median of 3 runs, "
+                      f"{med:.2f} s/run"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vrdone_amd import _hip, configs, synth
+    from vrdone_amd.models.maskvrd import MaskVRD
+    from vrdone_amd.parallel import shard_range, gather_predictions
+
+    cfg = configs.model_config(args.config)
+    c_in = configs.input_channels(cfg)
+    model = synth.load_synthetic_weights(MaskVRD(cfg, device=dev)).to(dev).eval()
+    if args.pair_chunk:
+        model.pair_chunk = args.pair_chunk
+    t_pad = padded_len(cfg, args.frames, model.max_div_factor)
+
+    lo, hi = shard_range(args.pairs, rank, world)
+    # every rank generates only its own shard, already in HBM
+    x, m = synth.synth_pairs(hi - lo, c_in, t_pad, [args.frames] * (hi - lo), seed=1234 + rank, device=dev)
+
+    def step():
+        out = model._mask_vrd(x, m, with_aux=False)
+        if world > 1:
+            return gather_predictions(out["pred_logits"], out["pred_masks"], args.pairs, world)
+        return out["pred_logits"], out["pred_masks"]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        _hip.prof_enable(not args.no_prof)
+        _hip.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            logits, masks = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        _hip.prof_enable(False)
+    assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        prof = _hip.prof_read() if not args.no_prof else {}
+        line = {
+            "metric": "subject-object pairs/sec forward (2048 pairs x 256 frames x 512-d)",
+            "value": args.pairs * args.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}.yaml MaskVRD._mask_vrd, {args.pairs} pairs x {args.frames} frames "
+                                   f"(T_pad {t_pad}) x C_in {c_in}, embd 512, eval, last-layer heads",
+                       "pairs_per_gpu": hi - lo, "pair_chunk": model.pair_chunk,
+                       "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of predictions" if world > 1 else "")},
+        }
+        fpp = FLOPS_PER_PAIR.get((args.config, t_pad))
+        if fpp:
+            line["algorithmic_tflops"] = fpp * args.pairs * args.steps / elapsed / 1e12
+        if prof:
+            g = prof["gemm_f32_mfma"]
+            per_launch_flops = g["flops"] / max(g["launches"], 1)
+            avg_ms = g["ms"] / max(g["launches"], 1)
+            achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            line["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": achieved,
+                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                                "traffic": None, "launches": g["launches"], "avg_launch_ms": avg_ms,
+                                "flops_per_launch": per_launch_flops}
+            tot = sum(v["ms"] for v in prof.values())
+            line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
+            line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
+        if world == 1 and not args.no_cpu_baseline:
+            sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, c_in, args.frames, t_pad, args.cpu_pairs)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/*
+ * vrdone_hip.h -- C ABI of libvrdone_hip.so: hand-written gfx950 (MI355X) kernels for the
+ * VrdONE relation-encoding hot path (MaskVRD._mask_vrd and its eval post-processing).
+ *
+ * The reference has no FFI; its boundary for this path is the Python module surface of
+ * models/ (SURVEY 8b).  Each entry point below replaces the ATen call sites of the
+ * reference functions cited next to it (paths relative to the reference checkout) and is
+ * bound from Python with ctypes (vrdone_amd/_hip.py; INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every activation tensor is fp32, channels-last: a matrix of `rows` x `C` with an
+ *    explicit leading dimension `ld*` (floats between consecutive rows); row r = b*T + t.
+ *    Leading dimensions let producers write straight into concatenation buffers.
+ *  - masks are uint8 (0/1), one byte per row (the reference's (B,1,T) bool mask).
+ *  - all pointers are device pointers owned by the caller; the library allocates no
+ *    device memory and keeps no state besides the optional profiling event list.
+ *  - `stream` is a hipStream_t; work is queued asynchronously on it.
+ *  - return value: 0 on success, negative on error (message via vrd_last_error()).
+ *    Arguments are validated on the host before any launch.
+ */
+#ifndef VRDONE_HIP_H
+#define VRDONE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRD_ABI_VERSION 1
+
+enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
+
+/* kernel families, for vrd_prof_read() */
+enum vrd_kernel_id {
+    VRD_K_GEMM = 0, VRD_K_LAYERNORM = 1, VRD_K_DWCONV_LN = 2, VRD_K_LOCAL_ATTN = 3,
+    VRD_K_ATTN_SMALL = 4, VRD_K_ATTN_FLASH = 5, VRD_K_POOL = 6, VRD_K_MASK_HEAD = 7,
+    VRD_K_TRANSPOSE = 8, VRD_K_POSTPROC = 9, VRD_K_COUNT = 10
+};
+
+int vrd_abi_version(void);
+const char* vrd_last_error(void);
+
+/* ---- profiling: HIP events around every launch of a family, on the launch stream ---- */
+int vrd_prof_enable(int on);
+int vrd_prof_reset(void);
+/* synchronises the recorded events; ms = summed kernel time, flops = summed algorithmic
+ * FLOPs (GEMM / attention families; 0 elsewhere), bytes = summed algorithmic HBM bytes. */
+int vrd_prof_read(int kernel_id, double* ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- layout change at the boundary ------------------------------------------------------
+ * (B, C_total, T) -> rows (b*T+t) of `dst`, channels [c0, c0+count) of the source.
+ * Replaces the channel slicing of models/backbones.py:161-166 / :329-341 and the
+ * transposing copy of models/maskvrd.py:382-385. */
+int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count,
+                   float* dst, int64_t ld_dst, void* stream);
+/* rows (b*T+t) x C (leading dim ld_src) -> (B, C, T) contiguous. */
+int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float* dst, void* stream);
+
+/* ---- dense 1-D convolution as (implicit) GEMM on f32 MFMA -------------------------------
+ * C[r, n] = epilogue( sum_{tap, ci} A[r + tap - taps/2, ci] * W[n, tap*Cin + ci] )
+ * taps = 1: pointwise conv (nn.Conv1d k=1: models/blocks.py:728-737,1054-1060,45-48;
+ *           models/local_transformer.py:133-142; models/fpns.py:199-201;
+ *           models/predictor.py:73,79,83).
+ * taps = 3: dense k=3 conv with zero padding inside each length-T sequence
+ *           (models/backbones.py:59-63,74,127,309-313 via models/blocks.py:99).
+ * epilogue: v = acc + bias[n]; v = act(v); v *= row_mask[r]; v *= scale[n];
+ *           v += res[r, n] * (res_masked ? row_mask[r] : 1); v += res2[r, n].
+ * That covers MaskedConv1D's mask (blocks.py:111), GELU/ReLU (blocks.py:59,1056),
+ * AffineDropPath in eval (blocks.py:1148-1149) and the residual forms of
+ * blocks.py:1074-1076 and local_transformer.py:815,829,833; res2 is the SOS stream
+ * update of backbones.py:220-221.
+ * W is [N][K] row-major with K = taps*Cin, tap-major (the caller re-packs a (N,Cin,3)
+ * Conv1d weight once). */
+typedef struct {
+    const float* A;  int64_t lda;
+    const float* W;
+    const float* bias;
+    float* C;  int64_t ldc;
+    int64_t M;  int32_t N;  int32_t Cin;  int32_t taps;  int32_t T;
+    int32_t act;
+    const uint8_t* row_mask;
+    const float* scale;
+    const float* res;  int64_t ldres;  int32_t res_masked;
+    const float* res2;  int64_t ldres2;
+} vrd_gemm_args;
+int vrd_gemm(const vrd_gemm_args* a, void* stream);
+
+/* ---- channel LayerNorm (models/blocks.py:143-158), C in {256, 512} ----------------------
+ * y[r,:] = LN(x[r,:]) * gamma + beta; optional ReLU (backbones.py:174); optional
+ * post_add[(r % add_period), :] added after the affine (query_pos of
+ * models/local_transformer.py:809,820). */
+int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C,
+                  const float* gamma, const float* beta, int relu,
+                  const float* post_add, int64_t ld_add, int add_period, void* stream);
+
+/* ---- depthwise conv (+ nearest-upsample add) * mask -> LayerNorm, fused -----------------
+ * for o in [0, n_out): y_o[b,t',:] = LN_o( mask_out[b,t'] * (bias_o + sum_k w_o[c,g,k] *
+ *        xin[b, stride*t' + k - ksize/2, group_in*c + g]) ), xin = x (+ x_up[b, t/2, :]).
+ * MaskedConv1D depthwise + LayerNorm pairs of models/blocks.py:927-933,
+ * models/local_transformer.py:149-156, models/fpns.py:246-254 (group_in = 2 is the
+ * top-level Conv1d(512,256,3,groups=256) of fpns.py:181-184), and mask_features
+ * (fpns.py:226,256) with gamma = NULL (no LN) and a bias. */
+typedef struct {
+    const float* x;  int64_t ldx;
+    const float* x_up;  int64_t ldx_up;
+    int32_t B, Tin, C, ksize, stride, group_in;
+    const uint8_t* mask_out;
+    int32_t n_out;
+    const float* w[3];
+    const float* bias[3];
+    const float* gamma[3];
+    const float* beta[3];
+    int32_t relu[3];
+    float* y[3];
+    int64_t ldy[3];
+} vrd_dwconv_ln_args;
+int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
+
+/* ---- banded (local-window) attention, models/blocks.py:950-986 ---------------------------
+ * query t attends keys j in [t-half_win, t+half_win] within [0,T); masked keys get -1e4,
+ * masked query rows give 0.  q is scaled by head_dim^-0.5 inside.  C = n_head*head_dim = 512. */
+int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld,
+                   const uint8_t* mask, int B, int T, int C, int n_head, int half_win,
+                   float* out, int64_t ldo, void* stream);
+
+/* ---- global masked attention, models/local_transformer.py:163-183 and :44-63 -------------
+ * out[b,tq,h,:] = softmax_j(q.k_j / sqrt(hd) | kv_mask[b,j]) . v_j ; keys with mask 0 get
+ * -inf.  kv_mask may be NULL (all keys valid).  `algo`: 0 = auto, 1 = generic VALU kernel
+ * (any shape; the predictor's 9-query attention), 2 = f32-MFMA flash kernel (hd in {64,128}). */
+int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                  const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim,
+                  float* out, int64_t ldo, int algo, void* stream);
+
+/* ---- MaxPool1d(3,2,1) skip * mask (models/blocks.py:1040-1046,1074) and mask[::2] ------- */
+int vrd_maxpool_mask(const float* x, int64_t ldx, int B, int Tin, int C, const uint8_t* mask_in,
+                     float* y, int64_t ldy, uint8_t* mask_out, void* stream);
+
+/* ---- mask head, models/predictor.py:103-104,110-111 --------------------------------------
+ * seg[b,q,t] = sum_c emb[b,q,c] * feat[b,t,c]; -10 where out_mask[b,t] == 0.
+ * emb: (B*Q) x Dp rows; feat: (B*T) x Dp rows; seg: (B, Q, T) contiguous. */
+int vrd_mask_head(const float* emb, int64_t ld_emb, const float* feat, int64_t ld_feat,
+                  const uint8_t* out_mask, int B, int Q, int T, int Dp, float fill,
+                  float* seg, void* stream);
+
+/* ---- eval post-processing, models/maskvrd.py:247-309 -------------------------------------
+ * Per pair p and query q: softmax over classes, top-k of classes 1.., and the [first,last]
+ * frame with sigmoid(mask) > 0.5 inside the valid length.  Outputs, per (p, q):
+ *   top_score[p,q,k], top_cat[p,q,k] (class id, already +1), seg_first[p,q], seg_last[p,q]
+ *   (-1 when the query's mask is empty).
+ * logits: (P, Q, K1); masks: (P, Q, T); valid_len: (P) int32. */
+int vrd_postprocess(const float* logits, const float* masks, const int32_t* valid_len,
+                    int P, int Q, int K1, int T, int topk,
+                    float* top_score, int32_t* top_cat, int32_t* seg_first, int32_t* seg_last,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VRDONE_HIP_H */

@@ -1,0 +1,315 @@
+"""Per-operator parity on a real MI355X: the HIP kernels (through the C ABI) against the
+reference's outputs stored in tests/golden/ops.npz and against the CPU oracle.
+
+Module-level tests use the reference's call signatures on (B, C, T) tensors, so they read like
+the reference's own usage.  Tolerances are absolute, for O(1) activations in fp32."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import vrd_oracle as O
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+
+
+def seeded(module, prefix):
+    keys = [(f"{prefix}.{k}", tuple(v.shape)) for k, v in module.state_dict().items()]
+    sd = O.synth_state_dict(keys)
+    module.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items()}, strict=True)
+    return module.eval().to(DEV), sd
+
+
+@pytest.fixture(scope="module")
+def g():
+    d = dict(np.load(os.path.join(GOLDEN, "ops.npz")))
+    x, y = torch.from_numpy(d["x"]), torch.from_numpy(d["y"])
+    lens = torch.from_numpy(d["lens"])
+    m = (torch.arange(x.shape[-1])[None] < lens[:, None])[:, None]
+    d.update(xt=x, yt=y, mt=m)
+    return d
+
+
+def close(got, want, atol):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else want
+    assert got.shape == want.shape
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, atol=atol, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# modules vs reference outputs
+# ------------------------------------------------------------------------------------------------
+def test_layernorm_module(g):
+    from vrdone_amd.models.blocks import LayerNorm
+    mod, _ = seeded(LayerNorm(512), "op.ln")
+    close(mod(g["xt"].to(DEV)), g["ln"], 2e-6)
+
+
+def test_masked_conv1d_dense_k3(g):
+    from vrdone_amd.models.blocks import MaskedConv1D
+    mod, _ = seeded(MaskedConv1D(512, 512, 3, padding=1, bias=False), "op.conv3")
+    out, m = mod(g["xt"].to(DEV), g["mt"].to(DEV))
+    close(out, g["conv3"], 2e-5)
+    assert torch.equal(m.cpu(), g["mt"])
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_local_mhca(g, stride):
+    from vrdone_amd.models.blocks import LocalMaskedMHCA
+    mod, _ = seeded(LocalMaskedMHCA(512, 4, window_size=7, n_qx_stride=stride, n_kv_stride=stride),
+                    f"op.local_mhca_s{stride}")
+    out, m = mod(g["xt"].to(DEV), g["mt"].to(DEV))
+    close(out, g[f"local_mhca_s{stride}"], 5e-5)
+    assert torch.equal(m.cpu(), g["mt"][..., ::stride])
+
+
+def test_local_mhca_window9_heads8(g):
+    from vrdone_amd.models.blocks import LocalMaskedMHCA
+    mod, _ = seeded(LocalMaskedMHCA(512, 8, window_size=9), "op.local_mhca_w9")
+    close(mod(g["xt"].to(DEV), g["mt"].to(DEV))[0], g["local_mhca_w9"], 5e-5)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_transformer_block(g, stride):
+    from vrdone_amd.models.blocks import TransformerBlock
+    mod, _ = seeded(TransformerBlock(512, 4, n_ds_strides=(stride, stride), path_pdrop=0.1, mha_win_size=7),
+                    f"op.block_s{stride}")
+    out, m = mod(g["xt"].to(DEV), g["mt"].to(DEV))
+    close(out, g[f"block_s{stride}"], 1e-4)
+
+
+def test_mhca_qkv_global(g):
+    from vrdone_amd.models.local_transformer import MaskedMHCA_QKV
+    mod, _ = seeded(MaskedMHCA_QKV(512, 4, n_qx_stride=1, n_kv_stride=1), "op.mhca_qkv")
+    x, y, m = g["xt"].to(DEV), g["yt"].to(DEV), g["mt"].to(DEV)
+    close(mod(x, y, y, m, m)[0], g["mhca_qkv"], 5e-5)
+
+
+@pytest.mark.parametrize("name,heads,local", [("sos", 4, False), ("sos_local", 8, True)])
+def test_sos_decoder_layer(g, name, heads, local):
+    from vrdone_amd.models.local_transformer import MaskedConvTransformerDecoderLayer
+    mod, _ = seeded(MaskedConvTransformerDecoderLayer(512, heads, path_pdrop=0.1, n_qx_stride=1, n_kv_stride=1,
+                                                      with_ffn=False, use_local=local, win_size=9 if local else None),
+                    f"op.{name}")
+    x, y, m = g["xt"].to(DEV), g["yt"].to(DEV), g["mt"].to(DEV)
+    close(mod(x, y, m, m)[0], g[name], 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels vs oracle / plain torch on awkward shapes
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,Cin,taps,T", [
+    (1000, 512, 512, 1, 1000),      # ragged M
+    (96 * 3, 133, 256, 1, 96),      # class head: N not a tile multiple
+    (96 * 2, 512, 5, 3, 96),        # bbox_so_embd: scalar-load path, K = 15
+    (48 * 4, 512, 8, 3, 48),        # bbox_entity_embd: K = 24
+    (144 * 2, 512, 1024, 3, 144),   # visual_embd[0]
+    (7, 64, 36, 1, 7),              # tiny
+    (130, 2048, 512, 1, 130),       # MLP up-projection
+])
+def test_gemm_shapes_and_epilogue(M, N, Cin, taps, T):
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(M * 31 + N)
+    B = M // T
+    x = torch.randn(B, T, Cin, generator=gen)
+    w = torch.randn(N, Cin, taps, generator=gen) / (Cin * taps) ** 0.5
+    bias = torch.randn(N, generator=gen)
+    scale = torch.rand(N, generator=gen) + 0.5
+    res = torch.randn(B, T, N, generator=gen)
+    res2 = torch.randn(B, T, N, generator=gen)
+    mask = torch.rand(B, T, generator=gen) > 0.3
+    ref = torch.nn.functional.conv1d(x.transpose(1, 2), w, bias, padding=taps // 2).transpose(1, 2)
+    mf = mask[..., None].float()
+    # plain
+    close(ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)), ref, 3e-5)
+    # full epilogue
+    want = torch.nn.functional.gelu(ref) * mf * scale + res * mf + res2
+    got = ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV), act=ops.ACT_GELU, row_mask=mask.to(DEV),
+                        scale=scale.to(DEV), res=res.to(DEV), res_masked=True, res2=res2.to(DEV))
+    close(got, want, 3e-5)
+    # relu, unmasked residual, output into a column slab of a wider buffer
+    buf = torch.zeros(B, T, N + 64, device=DEV)
+    ops.conv_gemm(x.to(DEV), w.to(DEV), None, act=ops.ACT_RELU, res=res.to(DEV), out=buf[..., 64:])
+    want = torch.relu(torch.nn.functional.conv1d(x.transpose(1, 2), w, None, padding=taps // 2).transpose(1, 2)) + res
+    close(buf[..., 64:], want, 3e-5)
+    assert float(buf[..., :64].abs().sum()) == 0.0
+
+
+def test_gemm_reads_column_slab_input():
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    wide = torch.randn(3, 40, 1024, generator=gen)
+    w = torch.randn(256, 512, 1, generator=gen) / 512 ** 0.5
+    got = ops.conv_gemm(wide.to(DEV)[..., 512:], w.to(DEV))
+    close(got, torch.einsum("btc,nc->btn", wide[..., 512:], w[..., 0]), 3e-5)
+
+
+@pytest.mark.parametrize("C", [256, 512])
+def test_layernorm_kernel_options(C):
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(C)
+    x = torch.randn(5, 9, C, generator=gen) * 3 + 1
+    gam, bet = torch.randn(1, C, 1, generator=gen), torch.randn(1, C, 1, generator=gen)
+    pos = torch.randn(9, C, generator=gen)
+    ref = O.channel_ln(x.transpose(1, 2), gam, bet).transpose(1, 2)
+    close(ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV)), ref, 3e-6)
+    close(ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), relu=True), torch.relu(ref), 3e-6)
+    close(ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), post_add=pos.to(DEV)), ref + pos[None], 3e-6)
+    z = torch.zeros(5, 9, C)          # masked rows: LN(0) = beta
+    close(ops.layernorm(z.to(DEV), gam.to(DEV), bet.to(DEV)), bet.view(1, 1, C).expand(5, 9, C), 0)
+
+
+@pytest.mark.parametrize("C,ks,stride,gin,up", [(512, 3, 1, 1, False), (512, 3, 2, 1, False), (256, 3, 1, 1, True),
+                                                 (256, 3, 1, 2, False), (256, 1, 1, 1, False), (512, 1, 1, 1, False)])
+def test_dwconv_ln_variants(C, ks, stride, gin, up):
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(C + ks + stride + gin)
+    B, T = 3, 24
+    x = torch.randn(B, T, C * gin, generator=gen)
+    xu = torch.randn(B, T // 2, C * gin, generator=gen) if up else None
+    lens = torch.tensor([24, 13, 2])
+    mask = torch.arange(T)[None] < lens[:, None]
+    m_out = mask[:, ::stride].contiguous()
+    sets, wants = [], []
+    xin = x + (xu.repeat_interleave(2, dim=1) if up else 0)
+    for o in range(3 if gin == 1 else 1):
+        w = torch.randn(C, gin, ks, generator=gen)
+        b = torch.randn(C, generator=gen) if o == 1 else None
+        gam = None if o == 2 else torch.randn(1, C, 1, generator=gen)
+        bet = None if o == 2 else torch.randn(1, C, 1, generator=gen)
+        y, _ = O.masked_conv1d(xin.transpose(1, 2), mask[:, None], w, b, stride=stride, groups=C)
+        if gam is not None:
+            y = O.channel_ln(y, gam, bet)
+        if o == 0:
+            y = torch.relu(y)
+        wants.append(y.transpose(1, 2))
+        dv = lambda t: None if t is None else t.to(DEV)     # noqa: E731
+        sets.append(dict(weight=w.to(DEV), bias=dv(b), gamma=dv(gam), beta=dv(bet), relu=(o == 0)))
+    outs = ops.dwconv_ln(x.to(DEV), sets, mask_out=m_out.to(DEV), stride=stride, x_up=None if xu is None else xu.to(DEV))
+    for got, want in zip(outs, wants):
+        close(got, want, 2e-5)
+
+
+@pytest.mark.parametrize("H,w", [(4, 3), (8, 3), (4, 4), (8, 4)])
+def test_local_attention_kernel(H, w):
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(H * 10 + w)
+    B, T, C = 3, 8 * w, 512
+    q, k, v = (torch.randn(B, T, C, generator=gen) for _ in range(3))
+    lens = torch.tensor([T, T - 5, 1])
+    mask = torch.arange(T)[None] < lens[:, None]
+    want = O.banded_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H, w)
+    got = ops.local_attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, w)
+    close(got, want.transpose(1, 2), 2e-5)
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("H,hd,Tq,Tk", [(4, 128, 96, 96), (8, 64, 144, 144), (4, 128, 288, 288), (8, 64, 512, 512),
+                                        (4, 128, 40, 77), (4, 64, 9, 36)])
+def test_global_attention_kernels(algo, H, hd, Tq, Tk):
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(H + hd + Tq + Tk)
+    B, C = 3, H * hd
+    q = torch.randn(B, Tq, C, generator=gen) * 2.0          # spread-out scores
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    lens = torch.tensor([Tk, max(1, Tk // 3), 1])
+    mask = torch.arange(Tk)[None] < lens[:, None]
+    want = O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H).transpose(1, 2)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, algo=algo)
+    close(got, want, 3e-5)
+    # no mask at all
+    want = O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                            torch.ones(B, 1, Tk, dtype=torch.bool), H).transpose(1, 2)
+    close(ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), None, H, algo=algo), want, 3e-5)
+
+
+def test_flash_attention_online_softmax_rescale():
+    """A late key tile that dominates every earlier one forces the running-max rescale branch."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(77)
+    B, H, hd, T = 2, 4, 128, 160
+    q = torch.randn(B, T, H * hd, generator=gen)
+    k = torch.randn(B, T, H * hd, generator=gen)
+    v = torch.randn(B, T, H * hd, generator=gen)
+    k[:, 130] = q[:, 5] * 3.0            # key 130 (5th tile) aligned with query 5
+    k[:, 70, :hd] = q[:, 40, :hd] * 2.0
+    mask = torch.ones(B, T, dtype=torch.bool)
+    want = O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H).transpose(1, 2)
+    close(ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, algo=2), want, 3e-5)
+
+
+def test_maxpool_mask_kernel():
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 16, 512, generator=gen)
+    lens = torch.tensor([16, 9, 1])
+    mask = torch.arange(16)[None] < lens[:, None]
+    y, m = ops.maxpool_mask(x.to(DEV), mask.to(DEV))
+    want = torch.nn.functional.max_pool1d(x.transpose(1, 2), 3, 2, 1).transpose(1, 2) * mask[:, ::2, None]
+    close(y, want, 0)
+    assert torch.equal(m.cpu(), mask[:, ::2])
+
+
+@pytest.mark.parametrize("Q,T", [(9, 96), (10, 512), (9, 50)])
+def test_mask_head_kernel(Q, T):
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(Q + T)
+    emb, feat = torch.randn(3, Q, 256, generator=gen), torch.randn(3, T, 256, generator=gen)
+    lens = torch.tensor([T, T // 2, 3])
+    mask = torch.arange(T)[None] < lens[:, None]
+    want = torch.einsum("bqc,btc->bqt", emb, feat).masked_fill(~mask[:, None], -10.0)
+    close(ops.mask_head(emb.to(DEV), feat.to(DEV), mask.to(DEV)), want, 5e-5)
+
+
+def test_layout_round_trip():
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 77, 50, generator=gen)
+    cl = ops.to_channels_last(x.to(DEV))
+    assert torch.equal(cl.cpu(), x.transpose(1, 2))
+    assert torch.equal(ops.btc_to_bct(cl).cpu(), x)
+    slab = torch.zeros(3, 50, 20, device=DEV)
+    ops.bct_to_btc(x.to(DEV), 13, 9, slab[..., 4:13])
+    assert torch.equal(slab[..., 4:13].cpu(), x[:, 13:22].transpose(1, 2))
+    assert float(slab[..., :4].abs().sum() + slab[..., 13:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("K1,topk", [(133, 8), (51, 6), (51, 1)])
+def test_postprocess_kernel(K1, topk):
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(K1 + topk)
+    P, Q, T = 7, 9, 96
+    logits = torch.randn(P, Q, K1, generator=gen) * 2
+    masks = torch.randn(P, Q, T, generator=gen) * 3
+    masks[0, 0] = -5.0                   # an empty mask
+    masks[1, 1, 10:] = -4.0
+    valid = torch.tensor([96, 50, 2, 96, 1, 33, 96], dtype=torch.int32)
+    ts, tc, sf, sl = (t.cpu() for t in ops.postprocess(logits.to(DEV), masks.to(DEV), valid.to(DEV), topk))
+    probs = torch.softmax(logits, -1)
+    ws, wc = torch.topk(probs[..., 1:], topk, dim=-1)
+    np.testing.assert_allclose(ts.numpy(), ws.numpy(), atol=1e-6)
+    assert torch.equal(tc.long(), wc + 1)
+    for p in range(P):
+        for q in range(Q):
+            on = torch.nonzero(torch.sigmoid(masks[p, q, :valid[p]]) > 0.5).flatten()
+            if on.numel() == 0:
+                assert sf[p, q] == -1 and sl[p, q] == -1
+            else:
+                assert sf[p, q] == on.min() and sl[p, q] == on.max()
+
+
+def test_bad_arguments_raise():
+    from vrdone_amd import ops
+    x = torch.randn(2, 8, 100, device=DEV)
+    g1 = torch.ones(1, 100, 1, device=DEV)
+    with pytest.raises(RuntimeError, match="vrd_layernorm"):
+        ops.layernorm(x, g1, g1)
+    with pytest.raises(RuntimeError, match="HIP tensors"):
+        ops.layernorm(x.cpu(), g1, g1)

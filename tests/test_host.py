@@ -1,0 +1,134 @@
+"""CPU-side checks of the drop-in boundary: parameter tree / checkpoint layout, config
+handling, C-ABI exports.  No kernels are launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO, load_case
+from oracle import vrd_oracle as O
+
+
+@pytest.mark.parametrize("name", ["vidvrd", "vidor_x", "vidor_local"])
+def test_state_dict_layout_matches_reference(name):
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, _, keys = load_case(name)
+    model = MaskVRD(mc, device="cpu")
+    sd = model.state_dict()
+    got = [(k, tuple(v.shape)) for k, v in sd.items()]
+    assert got == keys          # names, shapes AND order (ModelEma zips two state_dicts)
+    synth = O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"])
+    model.load_state_dict(synth, strict=True)
+    assert model.max_div_factor == O.max_div_factor(mc)
+
+
+def test_weight_decay_grouping_contract():
+    """utils/train_utils.py:44-65 classifies parameters by module type imported from models.blocks
+    and by the suffix of the parameter name; every parameter must land in exactly one group."""
+    from vrdone_amd.models.maskvrd import MaskVRD
+    from vrdone_amd.models.blocks import MaskedConv1D, Scale, AffineDropPath, LayerNorm
+    mc, _, _ = load_case("vidvrd")
+    model = MaskVRD(mc, device="cpu")
+    decay, no_decay = set(), set()
+    for mn, m in model.named_modules():
+        for pn, _ in m.named_parameters():
+            full = f"{mn}.{pn}" if mn else pn
+            if pn.endswith("bias"):
+                no_decay.add(full)
+            elif pn.endswith("weight") and isinstance(m, (torch.nn.Linear, torch.nn.Conv1d, MaskedConv1D)):
+                decay.add(full)
+            elif pn.endswith("weight") and isinstance(m, (LayerNorm, torch.nn.GroupNorm)):
+                no_decay.add(full)
+            elif pn.endswith("scale") and isinstance(m, (Scale, AffineDropPath)):
+                no_decay.add(full)
+    params = dict(model.named_parameters())
+    assert not (decay & no_decay)
+    left = params.keys() - (decay | no_decay)
+    assert left == {"predictor.query_embed.weight"}      # the reference's only leftover (nn.Embedding)
+    # initial values the training recipe relies on
+    assert float(model.backbone.stem[0].drop_path_attn.scale.detach().mean()) == pytest.approx(1e-4)
+    assert float(model.predictor.class_embed.bias.detach().mean()) == pytest.approx(-4.59512, abs=1e-4)
+    assert all(float(p.detach().abs().sum()) == 0.0 for n, p in params.items()
+               if n.endswith("bias") and p.dim() == 1 and "class_embed" not in n)
+
+
+def test_no_cpu_fallback_and_no_oracle_import():
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, ic, _ = load_case("vidvrd")
+    model = MaskVRD(mc, device="cpu").eval()
+    x, m = O.synth_pairs(1, 2069, 96)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        model._mask_vrd(x, m)
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model({"so_features_list": [x[0]]})
+    # the product never imports the oracle
+    for root, _, files in os.walk(os.path.join(REPO, "vrdone_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "vrdone_hip.h")).read()
+    declared = set(re.findall(r"\b(vrd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"vrd_act", "vrd_kernel_id"}
+    assert len(declared) >= 14
+    path = os.path.join(REPO, "vrdone_amd", "csrc", "libvrdone_hip.so")
+    assert os.path.exists(path), "build the extension first (python -c 'import __graft_entry__ as g; g.build()')"
+    lib = ctypes.CDLL(path)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/vrdone_hip.h but not exported"
+    from vrdone_amd import _hip
+    assert set(_hip._SIGNATURES) == declared
+    assert _hip.lib.vrd_abi_version() == _hip.ABI_VERSION
+
+
+def test_ctypes_struct_layout_matches_header():
+    """Field order of the ctypes mirrors vs the C structs in the header."""
+    from vrdone_amd import _hip
+    header = open(os.path.join(REPO, "include", "vrdone_hip.h")).read()
+    for cname, cls in (("vrd_gemm_args", _hip.GemmArgs), ("vrd_dwconv_ln_args", _hip.DwconvLnArgs)):
+        body = re.search(r"typedef struct \{([^}]*)\} " + cname, header).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.sub(r"\[\d+\]", "", part.strip().split()[-1].lstrip("*")))
+        assert names == [f[0] for f in cls._fields_], cname
+
+
+def test_validation_errors_are_reported_without_a_gpu():
+    from vrdone_amd import _hip
+    a = _hip.GemmArgs()
+    a.taps = 2
+    rc = _hip.lib.vrd_gemm(ctypes.byref(a), None)
+    assert rc != 0 and b"vrd_gemm" in _hip.lib.vrd_last_error()
+
+
+@pytest.mark.parametrize("name", ["vidvrd", "vidor_x", "vidor_local"])
+def test_python_configs_equal_the_reference_yaml(name):
+    from vrdone_amd import configs
+    mc, ic, _ = load_case(name)
+    assert configs.model_config(name) == mc
+    assert configs.inference_config(name) == ic
+    assert configs.input_channels(mc) == {"vidvrd": 2069, "vidor_x": 3093, "vidor_local": 2069}[name]
+
+
+def test_synthetic_weights_match_the_oracle_recipe():
+    from vrdone_amd import configs, synth
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, _, keys = load_case("vidvrd")
+    model = synth.load_synthetic_weights(MaskVRD(configs.model_config("vidvrd"), device="cpu"))
+    want = O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"])
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, want[k]), k
+    x1, m1 = synth.synth_pairs(3, 7, 12, [12, 5, 1], seed=9)
+    x2, m2 = O.synth_pairs(3, 7, 12, [12, 5, 1], seed=9)
+    assert torch.equal(x1, x2) and torch.equal(m1, m2)

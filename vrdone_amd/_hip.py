@@ -1,0 +1,113 @@
+"""ctypes binding of libvrdone_hip.so (C ABI declared in include/vrdone_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or calling an
+op on a non-HIP tensor, raises.  Build with ``make -C vrdone_amd/csrc`` (or
+``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvrdone_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+(K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
+ K_TRANSPOSE, K_POSTPROC, K_COUNT) = range(11)
+KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
+                "maxpool_mask", "mask_head", "transpose", "postprocess"]
+
+c_f32p = C.c_void_p      # device pointers travel as plain integers
+c_u8p = C.c_void_p
+c_i32p = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_f32p), ("lda", C.c_int64), ("W", c_f32p), ("bias", c_f32p),
+                ("C", c_f32p), ("ldc", C.c_int64),
+                ("M", C.c_int64), ("N", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("T", C.c_int32),
+                ("act", C.c_int32), ("row_mask", c_u8p), ("scale", c_f32p),
+                ("res", c_f32p), ("ldres", C.c_int64), ("res_masked", C.c_int32),
+                ("res2", c_f32p), ("ldres2", C.c_int64)]
+
+
+class DwconvLnArgs(C.Structure):
+    _fields_ = [("x", c_f32p), ("ldx", C.c_int64), ("x_up", c_f32p), ("ldx_up", C.c_int64),
+                ("B", C.c_int32), ("Tin", C.c_int32), ("C", C.c_int32), ("ksize", C.c_int32),
+                ("stride", C.c_int32), ("group_in", C.c_int32),
+                ("mask_out", c_u8p), ("n_out", C.c_int32),
+                ("w", c_f32p * 3), ("bias", c_f32p * 3), ("gamma", c_f32p * 3), ("beta", c_f32p * 3),
+                ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3)]
+
+
+_SIGNATURES = {
+    "vrd_abi_version": (C.c_int, []),
+    "vrd_last_error": (C.c_char_p, []),
+    "vrd_prof_enable": (C.c_int, [C.c_int]),
+    "vrd_prof_reset": (C.c_int, []),
+    "vrd_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double)]),
+    "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "vrd_layernorm": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int,
+                                c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+    "vrd_dwconv_ln": (C.c_int, [C.POINTER(DwconvLnArgs), C.c_void_p]),
+    "vrd_local_attn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 c_f32p, C.c_int64, C.c_void_p]),
+    "vrd_attention": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+    "vrd_maxpool_mask": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p, C.c_int64, c_u8p,
+                                   C.c_void_p]),
+    "vrd_mask_head": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_float, c_f32p, C.c_void_p]),
+    "vrd_postprocess": (C.c_int, [c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p,
+                                  c_i32p, c_i32p, C.c_void_p]),
+}
+
+ABI_VERSION = 1
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: the HIP extension was not built "
+            "(run `make -C vrdone_amd/csrc`); there is no CPU fallback for this path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.vrd_abi_version()
+    if got != ABI_VERSION:
+        raise HipLibraryError(f"libvrdone_hip.so ABI {got} != expected {ABI_VERSION}: rebuild it")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {lib.vrd_last_error().decode()}")
+
+
+def prof_enable(on=True):
+    check(lib.vrd_prof_enable(1 if on else 0), "vrd_prof_enable")
+
+
+def prof_reset():
+    check(lib.vrd_prof_reset(), "vrd_prof_reset")
+
+
+def prof_read():
+    """{family: dict(ms=, launches=, flops=, bytes=)} of everything recorded since the last reset."""
+    out = {}
+    for kid, name in enumerate(KERNEL_NAMES):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(lib.vrd_prof_read(kid, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "vrd_prof_read")
+        out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+    return out

@@ -1,0 +1,225 @@
+// Dense 1-D convolution (k = 1 or 3) as an implicit GEMM on the gfx950 f32 MFMA
+// (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate).
+//
+//   C[r, n] = epilogue( sum_k A'[r, k] * W[n, k] ),  A'[r, tap*Cin + ci] = A[r + tap - taps/2, ci]
+//
+// rows r = b*T + t are channels-last activations; the tap shift stays inside one length-T
+// sequence (zero padding), which is the reference's Conv1d(padding=k//2) per sample.
+//
+// Tiling: 128 x 128 output tile per 256-thread workgroup, K step 16, four waves in a 2 x 2
+// grid, each owning a 64 x 64 sub-tile = 2 x 2 MFMA accumulators of 32 x 32 (64 VGPRs).
+// Operand tiles are staged global -> registers -> LDS (double buffered, one barrier per K
+// step) in k-major order [k][row] so every ds_read_b32 of a fragment is conflict free:
+// lane l reads row (l & 31) of k = 2*step + (l >> 5), which is exactly the A/B operand
+// map of the 32x32x2 instruction.  The f32 MFMA issues once per 64 cycles per SIMD, so
+// four LDS reads per four MFMAs leave the LDS idle; the kernel is bound by the MFMA pipe.
+//
+// Workgroups are renumbered so that the ones dealt to one XCD (blockIdx % 8) walk
+// consecutive output tiles: the N-tiles of one 128-row activation panel then share that
+// XCD's L2 instead of each XCD fetching the panel from HBM.
+#include "vrd_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDM = 132;   // LDS row pitch (floats): 128 + 4 keeps rows 16-B aligned; 2-way write conflicts are free
+
+struct Tile {
+    float a[2][BK][LDM];
+    float b[2][BK][LDM];
+};
+
+template <bool VEC, int TAPS>
+__device__ __forceinline__ void load_a(const vrd_gemm_args& p, int64_t r, int t_in_seq, int k, int K, float (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (r >= p.M) return;
+    if (VEC) {
+        if (k >= K) return;
+        int tap = 0, ci = k;
+        if (TAPS == 3) {
+            tap = (k >= p.Cin) + (k >= 2 * p.Cin);
+            ci = k - tap * p.Cin;
+            int tt = t_in_seq + tap - 1;
+            if (tt < 0 || tt >= p.T) return;
+        }
+        const float4 x = *reinterpret_cast<const float4*>(p.A + (r + tap - (TAPS == 3 ? 1 : 0)) * p.lda + ci);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int kk = k + j;
+            if (kk >= K) continue;
+            int tap = 0, ci = kk;
+            if (TAPS == 3) {
+                tap = kk / p.Cin;
+                ci = kk - tap * p.Cin;
+                int tt = t_in_seq + tap - 1;
+                if (tt < 0 || tt >= p.T) continue;
+            }
+            v[j] = p.A[(r + tap - (TAPS == 3 ? 1 : 0)) * p.lda + ci];
+        }
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void load_w(const vrd_gemm_args& p, int n, int k, int K, float (&v)[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (n >= p.N) return;
+    if (VEC) {
+        if (k >= K) return;
+        const float4 x = *reinterpret_cast<const float4*>(p.W + (int64_t)n * K + k);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j < K) v[j] = p.W[(int64_t)n * K + k + j];
+    }
+}
+
+template <bool VEC, int TAPS>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+    __shared__ Tile lds;
+
+    // XCD-aware (bijective) renumbering of the workgroup id
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = p.Cin * TAPS;
+    const int nkt = (K + BK - 1) / BK;
+
+    // staging assignment: two (row, 4-wide k chunk) pieces of each operand per thread
+    int srow[2], skq[2], st[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int f = tid + 256 * i;
+        srow[i] = f >> 2;
+        skq[i] = (f & 3) * 4;
+        int64_t r = m0 + srow[i];
+        st[i] = (TAPS == 3 && r < p.M) ? (int)(r % p.T) : 0;
+    }
+
+    float ra[2][4], rb[2][4];
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            load_a<VEC, TAPS>(p, m0 + srow[i], st[i], kt * BK + skq[i], K, ra[i]);
+            load_w<VEC>(p, n0 + srow[i], kt * BK + skq[i], K, rb[i]);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lds.a[buf][skq[i] + j][srow[i]] = ra[i][j];
+                lds.b[buf][skq[i] + j][srow[i]] = rb[i][j];
+            }
+    };
+
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) fetch(kt + 1);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const float a0 = lds.a[cur][2 * s + lh][wm * 64 + li];
+            const float a1 = lds.a[cur][2 * s + lh][wm * 64 + 32 + li];
+            const float b0 = lds.b[cur][2 * s + lh][wn * 64 + li];
+            const float b1 = lds.b[cur][2 * s + lh][wn * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: accumulator element e of lane (li, lh) is C[row (e&3) + 8*(e>>2) + 4*lh][col li]
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int n = n0 + wn * 64 + nj * 32 + li;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float scale = p.scale ? p.scale[n] : 1.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[mi][nj][e] + bias;
+                if (p.act == VRD_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == VRD_ACT_GELU) v = vrd::gelu_erf(v);
+                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
+                v *= mk;
+                v *= scale;
+                if (p.res) v += p.res[m * p.ldres + n] * (p.res_masked ? mk : 1.f);
+                if (p.res2) v += p.res2[m * p.ldres2 + n];
+                p.C[m * p.ldc + n] = v;
+            }
+        }
+    }
+}
+
+inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
+    VRD_CHECK_ARG(a != nullptr, "vrd_gemm: null args");
+    VRD_CHECK_ARG(a->A && a->W && a->C, "vrd_gemm: null operand");
+    VRD_CHECK_ARG(a->M >= 0 && a->N > 0 && a->Cin > 0, "vrd_gemm: bad sizes M=%lld N=%d Cin=%d",
+                  (long long)a->M, a->N, a->Cin);
+    VRD_CHECK_ARG(a->taps == 1 || a->taps == 3, "vrd_gemm: taps must be 1 or 3 (got %d)", a->taps);
+    VRD_CHECK_ARG(a->taps == 1 || (a->T > 0 && a->M % a->T == 0),
+                  "vrd_gemm: k=3 conv needs M (%lld) to be a multiple of T (%d)", (long long)a->M, a->T);
+    VRD_CHECK_ARG(a->lda >= a->Cin && a->ldc >= a->N, "vrd_gemm: leading dimension too small");
+    VRD_CHECK_ARG(a->act >= 0 && a->act <= 2, "vrd_gemm: bad activation %d", a->act);
+    VRD_CHECK_ARG(!a->res || a->ldres >= a->N, "vrd_gemm: ldres too small");
+    VRD_CHECK_ARG(!a->res2 || a->ldres2 >= a->N, "vrd_gemm: ldres2 too small");
+    if (a->M == 0) return 0;
+    const int64_t tiles_m64 = (a->M + BM - 1) / BM;
+    const int tiles_n = (a->N + BN - 1) / BN;
+    VRD_CHECK_ARG(tiles_m64 * tiles_n < (int64_t)1 << 31, "vrd_gemm: grid too large");
+    const int tiles_m = (int)tiles_m64;
+    const int K = a->Cin * a->taps;
+    const bool vec = (a->Cin % 4 == 0) && (a->lda % 4 == 0) && aligned16(a->A) && aligned16(a->W);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double flops = 2.0 * (double)a->M * a->N * K;
+    const double bytes = 4.0 * ((double)a->M * a->Cin + (double)a->N * K + (double)a->M * a->N *
+                                (1.0 + (a->res ? 1.0 : 0.0) + (a->res2 ? 1.0 : 0.0)));
+    vrd::ProfScope prof(VRD_K_GEMM, s, flops, bytes);
+    dim3 grid(tiles_m * tiles_n), block(256);
+    if (a->taps == 1) {
+        if (vec) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, 1>), grid, block, 0, s, *a, tiles_m, tiles_n);
+        else     hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, 1>), grid, block, 0, s, *a, tiles_m, tiles_n);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_f32_mfma_kernel<true, 3>), grid, block, 0, s, *a, tiles_m, tiles_n);
+        else     hipLaunchKernelGGL((gemm_f32_mfma_kernel<false, 3>), grid, block, 0, s, *a, tiles_m, tiles_n);
+    }
+    VRD_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,356 @@
+// HBM-bound row kernels of the relation-encoding path: layout change at the boundary,
+// channel LayerNorm, fused depthwise-conv * mask -> LayerNorm, max-pool skip, mask head.
+//
+// All of them keep one activation row (C = 256 or 512 contiguous floats) per wavefront:
+// lane l owns channels [256*i + 4*l, 256*i + 4*l + 4) for i < C/256, so every global
+// access is a full-wave 1 KiB float4 transaction and the per-row statistics are one
+// 64-lane butterfly.
+#include "vrd_common.h"
+#include <cmath>
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ------------------------------------------------------------------------------------------
+// (B, C_total, T) slab -> channels-last rows, 64 x 64 tiles through LDS
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict__ src, int C_total, int T, int c0,
+                                                         int count, float* __restrict__ dst, int64_t ld_dst) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* s = src + ((int64_t)b * C_total + c0) * T;
+    for (int c = ty; c < 64; c += 4)
+        tile[c][tx] = (ct + c < count && tt + tx < T) ? s[(int64_t)(ct + c) * T + tt + tx] : 0.f;
+    __syncthreads();
+    for (int t = ty; t < 64; t += 4)
+        if (tt + t < T && ct + tx < count) dst[((int64_t)b * T + tt + t) * ld_dst + ct + tx] = tile[tx][t];
+}
+
+__global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict__ src, int64_t ld_src, int C, int T,
+                                                         float* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int t = ty; t < 64; t += 4)
+        tile[t][tx] = (tt + t < T && ct + tx < C) ? src[((int64_t)b * T + tt + t) * ld_src + ct + tx] : 0.f;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (ct + c < C && tt + tx < T) dst[((int64_t)b * C + ct + c) * T + tt + tx] = tile[tx][c];
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over channels; NV = C / 256
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ void ln_rows(float4 (&v)[NV], const float* gamma, const float* beta, int lane, bool relu) {
+    constexpr float inv_c = 1.0f / (256.0f * NV);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = vrd::wave_sum(s) * inv_c;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float denom = sqrtf(vrd::wave_sum(ss) * inv_c + LN_EPS);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g = ld4(gamma + i * 256 + lane * 4), bb = ld4(beta + i * 256 + lane * 4);
+        v[i].x = v[i].x / denom * g.x + bb.x;
+        v[i].y = v[i].y / denom * g.y + bb.y;
+        v[i].z = v[i].z / denom * g.z + bb.z;
+        v[i].w = v[i].w / denom * g.w + bb.w;
+        if (relu) {
+            v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f);
+            v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
+        }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                        int64_t ldy, int64_t rows, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int relu,
+                                                        const float* __restrict__ post_add, int64_t ld_add, int period) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = ld4(x + row * ldx + i * 256 + lane * 4);
+    ln_rows<NV>(v, gamma, beta, lane, relu != 0);
+    if (post_add) {
+        const float* a = post_add + (row % period) * ld_add;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = f4add(v[i], ld4(a + i * 256 + lane * 4));
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) st4(y + row * ldy + i * 256 + lane * 4, v[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise (or 2-in-per-group) conv along t, * mask, -> LayerNorm, up to three weight sets
+// sharing the input rows (the q/k/v branches of the conv-attention modules)
+// ------------------------------------------------------------------------------------------
+template <int NV, int KS, int GIN>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // output row b*Tout + t'
+    if (row >= (int64_t)p.B * Tout) return;
+    const int b = (int)(row / Tout), to = (int)(row - (int64_t)b * Tout);
+
+    float4 in[KS][NV][GIN];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        const int ti = p.stride * to + k - KS / 2;
+        const bool ok = ti >= 0 && ti < p.Tin;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int g = 0; g < GIN; ++g) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) {
+                    const int64_t coff = (int64_t)GIN * (i * 256 + lane * 4) + 4 * g;
+                    v = ld4(p.x + ((int64_t)b * p.Tin + ti) * p.ldx + coff);
+                    if (p.x_up) v = f4add(v, ld4(p.x_up + ((int64_t)b * (p.Tin / 2) + (ti >> 1)) * p.ldx_up + coff));
+                }
+                in[k][i][g] = v;
+            }
+    }
+    const float mk = p.mask_out ? (float)p.mask_out[row] : 1.f;
+
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        if (o >= p.n_out) break;
+        float4 acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            // weights of this lane's 4 output channels: [4][GIN][KS] contiguous floats
+            float w[4 * GIN * KS];
+            const float* wp = p.w[o] + (int64_t)(i * 256 + lane * 4) * GIN * KS;
+#pragma unroll
+            for (int j = 0; j < GIN * KS; ++j) {
+                const float4 t = ld4(wp + 4 * j);
+                w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w;
+            }
+            float r[4];
+            if (p.bias[o]) {
+                const float4 bb = ld4(p.bias[o] + i * 256 + lane * 4);
+                r[0] = bb.x; r[1] = bb.y; r[2] = bb.z; r[3] = bb.w;
+            } else {
+                r[0] = r[1] = r[2] = r[3] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                if (GIN == 1) {
+                    const float4 v = in[k][i][0];
+                    r[0] += w[0 * KS + k] * v.x;
+                    r[1] += w[1 * KS + k] * v.y;
+                    r[2] += w[2 * KS + k] * v.z;
+                    r[3] += w[3 * KS + k] * v.w;
+                } else {
+                    // out channel c reads in channels 2c, 2c+1: lane's 8 inputs = in[k][i][0..1]
+                    const float4 v0 = in[k][i][0], v1 = in[k][i][GIN - 1];
+                    r[0] += w[(0 * 2 + 0) * KS + k] * v0.x + w[(0 * 2 + 1) * KS + k] * v0.y;
+                    r[1] += w[(1 * 2 + 0) * KS + k] * v0.z + w[(1 * 2 + 1) * KS + k] * v0.w;
+                    r[2] += w[(2 * 2 + 0) * KS + k] * v1.x + w[(2 * 2 + 1) * KS + k] * v1.y;
+                    r[3] += w[(3 * 2 + 0) * KS + k] * v1.z + w[(3 * 2 + 1) * KS + k] * v1.w;
+                }
+            }
+            acc[i] = make_float4(r[0] * mk, r[1] * mk, r[2] * mk, r[3] * mk);
+        }
+        if (p.gamma[o]) {
+            ln_rows<NV>(acc, p.gamma[o], p.beta[o], lane, p.relu[o] != 0);
+        } else if (p.relu[o]) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                acc[i].x = fmaxf(acc[i].x, 0.f); acc[i].y = fmaxf(acc[i].y, 0.f);
+                acc[i].z = fmaxf(acc[i].z, 0.f); acc[i].w = fmaxf(acc[i].w, 0.f);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) st4(p.y[o] + row * p.ldy[o] + i * 256 + lane * 4, acc[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool1d(kernel 3, stride 2, padding 1 with -inf) * downsampled mask
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_mask_kernel(const float* __restrict__ x, int64_t ldx, int B, int Tin, int C,
+                                                           const uint8_t* __restrict__ mask_in, float* __restrict__ y,
+                                                           int64_t ldy, uint8_t* __restrict__ mask_out) {
+    const int c4 = C / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int Tout = Tin / 2;
+    if (idx >= (int64_t)B * Tout * c4) return;
+    const int c = (int)(idx % c4) * 4;
+    const int64_t row = idx / c4;
+    const int b = (int)(row / Tout), to = (int)(row - (int64_t)b * Tout);
+    const float* base = x + ((int64_t)b * Tin + 2 * to) * ldx + c;
+    float4 m = ld4(base);
+    const float4 r = ld4(base + ldx);          // 2*to + 1 < Tin always (Tin even)
+    m.x = fmaxf(m.x, r.x); m.y = fmaxf(m.y, r.y); m.z = fmaxf(m.z, r.z); m.w = fmaxf(m.w, r.w);
+    if (to > 0) {
+        const float4 l = ld4(base - ldx);
+        m.x = fmaxf(m.x, l.x); m.y = fmaxf(m.y, l.y); m.z = fmaxf(m.z, l.z); m.w = fmaxf(m.w, l.w);
+    }
+    const uint8_t mk = mask_in[(int64_t)b * Tin + 2 * to];
+    const float f = (float)mk;
+    st4(y + row * ldy + c, make_float4(m.x * f, m.y * f, m.z * f, m.w * f));
+    if (c == 0 && mask_out) mask_out[row] = mk;
+}
+
+// ------------------------------------------------------------------------------------------
+// mask head: seg[b,q,t] = <emb[b,q,:], feat[b,t,:]>, fill where the output mask is 0
+// ------------------------------------------------------------------------------------------
+constexpr int MH_D = 256, MH_TT = 32, MH_QMAX = 16;
+
+__global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict__ emb, int64_t ld_emb,
+                                                        const float* __restrict__ feat, int64_t ld_feat,
+                                                        const uint8_t* __restrict__ out_mask, int Q, int T, float fill,
+                                                        float* __restrict__ seg) {
+    __shared__ float fs[MH_TT][MH_D + 1];
+    __shared__ float es[MH_QMAX][MH_D];
+    const int b = blockIdx.y, t0 = blockIdx.x * MH_TT, tid = threadIdx.x;
+    for (int i = tid; i < MH_TT * (MH_D / 4); i += 256) {
+        const int r = i / (MH_D / 4), c = (i % (MH_D / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t0 + r < T) v = ld4(feat + ((int64_t)b * T + t0 + r) * ld_feat + c);
+        fs[r][c] = v.x; fs[r][c + 1] = v.y; fs[r][c + 2] = v.z; fs[r][c + 3] = v.w;
+    }
+    for (int i = tid; i < Q * (MH_D / 4); i += 256) {
+        const int r = i / (MH_D / 4), c = (i % (MH_D / 4)) * 4;
+        st4(&es[r][c], ld4(emb + ((int64_t)b * Q + r) * ld_emb + c));
+    }
+    __syncthreads();
+    const int tt = tid & 31, qg = tid >> 5;
+    if (t0 + tt >= T) return;
+    const bool on = out_mask[(int64_t)b * T + t0 + tt] != 0;
+    for (int q = qg; q < Q; q += 8) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < MH_D; ++c) s = fmaf(es[q][c], fs[tt][c], s);
+        seg[((int64_t)b * Q + q) * T + t0 + tt] = on ? s : fill;
+    }
+}
+
+inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count, float* dst, int64_t ld_dst,
+                   void* stream) {
+    VRD_CHECK_ARG(src && dst, "vrd_bct_to_btc: null pointer");
+    VRD_CHECK_ARG(B > 0 && T > 0 && count > 0 && c0 >= 0 && c0 + count <= C_total && ld_dst >= count,
+                  "vrd_bct_to_btc: bad slab c0=%d count=%d C=%d ld=%lld", c0, count, C_total, (long long)ld_dst);
+    VRD_CHECK_ARG(B <= 65535, "vrd_bct_to_btc: B too large for one launch (%d)", B);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * B * (double)count * T);
+    dim3 grid((T + 63) / 64, (count + 63) / 64, B);
+    hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float* dst, void* stream) {
+    VRD_CHECK_ARG(src && dst, "vrd_btc_to_bct: null pointer");
+    VRD_CHECK_ARG(B > 0 && B <= 65535 && T > 0 && C > 0 && ld_src >= C, "vrd_btc_to_bct: bad shape");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * B * (double)C * T);
+    dim3 grid((T + 63) / 64, (C + 63) / 64, B);
+    hipLaunchKernelGGL(btc_to_bct_kernel, grid, dim3(256), 0, s, src, ld_src, C, T, dst);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, const float* gamma,
+                  const float* beta, int relu, const float* post_add, int64_t ld_add, int add_period, void* stream) {
+    VRD_CHECK_ARG(x && y && gamma && beta, "vrd_layernorm: null pointer");
+    VRD_CHECK_ARG(C == 256 || C == 512, "vrd_layernorm: C must be 256 or 512 (got %d)", C);
+    VRD_CHECK_ARG(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) &&
+                      aligned16(gamma) && aligned16(beta),
+                  "vrd_layernorm: rows must be 16-byte aligned");
+    VRD_CHECK_ARG(!post_add || (add_period > 0 && ld_add % 4 == 0 && aligned16(post_add)), "vrd_layernorm: bad post_add");
+    if (rows <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_LAYERNORM, s, 0.0, 8.0 * (double)rows * C);
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (C == 256)
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
+    VRD_CHECK_ARG(a && a->x, "vrd_dwconv_ln: null args");
+    VRD_CHECK_ARG(a->C == 256 || a->C == 512, "vrd_dwconv_ln: C must be 256 or 512 (got %d)", a->C);
+    VRD_CHECK_ARG(a->ksize == 1 || a->ksize == 3, "vrd_dwconv_ln: ksize must be 1 or 3");
+    VRD_CHECK_ARG(a->stride == 1 || a->stride == 2, "vrd_dwconv_ln: stride must be 1 or 2");
+    VRD_CHECK_ARG(a->group_in == 1 || (a->group_in == 2 && a->C == 256 && a->ksize == 3),
+                  "vrd_dwconv_ln: group_in=2 is only built for C=256, ksize=3");
+    VRD_CHECK_ARG(a->B > 0 && a->Tin > 0 && a->Tin % a->stride == 0, "vrd_dwconv_ln: Tin %% stride != 0");
+    VRD_CHECK_ARG(a->n_out >= 1 && a->n_out <= 3, "vrd_dwconv_ln: n_out must be 1..3");
+    VRD_CHECK_ARG(a->ldx >= (int64_t)a->C * a->group_in && a->ldx % 4 == 0 && aligned16(a->x), "vrd_dwconv_ln: bad x layout");
+    VRD_CHECK_ARG(!a->x_up || (a->Tin % 2 == 0 && a->ldx_up % 4 == 0 && aligned16(a->x_up)), "vrd_dwconv_ln: bad x_up layout");
+    for (int o = 0; o < a->n_out; ++o) {
+        VRD_CHECK_ARG(a->w[o] && a->y[o] && aligned16(a->w[o]) && aligned16(a->y[o]) && a->ldy[o] % 4 == 0 && a->ldy[o] >= a->C,
+                      "vrd_dwconv_ln: bad output set %d", o);
+        VRD_CHECK_ARG((a->gamma[o] == nullptr) == (a->beta[o] == nullptr), "vrd_dwconv_ln: gamma/beta mismatch");
+    }
+    const int Tout = a->Tin / a->stride;
+    const int64_t rows = (int64_t)a->B * Tout;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_DWCONV_LN, s, 0.0,
+                        4.0 * ((double)a->B * a->Tin * a->C * a->group_in * (a->x_up ? 1.5 : 1.0) + (double)rows * a->C * a->n_out));
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, 0, s, *a, Tout)
+    if (a->group_in == 2) VRD_DW(1, 3, 2);
+    else if (a->C == 256 && a->ksize == 3) VRD_DW(1, 3, 1);
+    else if (a->C == 256) VRD_DW(1, 1, 1);
+    else if (a->ksize == 3) VRD_DW(2, 3, 1);
+    else VRD_DW(2, 1, 1);
+#undef VRD_DW
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_maxpool_mask(const float* x, int64_t ldx, int B, int Tin, int C, const uint8_t* mask_in, float* y, int64_t ldy,
+                     uint8_t* mask_out, void* stream) {
+    VRD_CHECK_ARG(x && y && mask_in, "vrd_maxpool_mask: null pointer");
+    VRD_CHECK_ARG(B > 0 && Tin > 0 && Tin % 2 == 0 && C % 4 == 0, "vrd_maxpool_mask: Tin must be even, C %% 4 == 0");
+    VRD_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C && aligned16(x) && aligned16(y), "vrd_maxpool_mask: bad layout");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)B * (Tin / 2) * (C / 4);
+    vrd::ProfScope prof(VRD_K_POOL, s, 0.0, 4.0 * (double)B * Tin * C * 1.5);
+    hipLaunchKernelGGL(maxpool_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, B, Tin, C, mask_in, y, ldy, mask_out);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_mask_head(const float* emb, int64_t ld_emb, const float* feat, int64_t ld_feat, const uint8_t* out_mask, int B,
+                  int Q, int T, int Dp, float fill, float* seg, void* stream) {
+    VRD_CHECK_ARG(emb && feat && out_mask && seg, "vrd_mask_head: null pointer");
+    VRD_CHECK_ARG(Dp == MH_D, "vrd_mask_head: mask dim must be %d (got %d)", MH_D, Dp);
+    VRD_CHECK_ARG(Q >= 1 && Q <= MH_QMAX, "vrd_mask_head: num queries must be 1..%d (got %d)", MH_QMAX, Q);
+    VRD_CHECK_ARG(B > 0 && B <= 65535 && T > 0, "vrd_mask_head: bad B/T");
+    VRD_CHECK_ARG(ld_emb % 4 == 0 && ld_feat % 4 == 0 && aligned16(emb) && aligned16(feat), "vrd_mask_head: bad layout");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_MASK_HEAD, s, 2.0 * B * (double)Q * T * Dp, 4.0 * B * ((double)T * Dp + (double)Q * Dp + (double)Q * T));
+    hipLaunchKernelGGL(mask_head_kernel, dim3((T + MH_TT - 1) / MH_TT, B), dim3(256), 0, s, emb, ld_emb, feat, ld_feat, out_mask, Q, T, fill, seg);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// Error string + event-based per-family profiling for libvrdone_hip.so.
+#include "vrd_common.h"
+#include <mutex>
+#include <vector>
+#include <cstring>
+
+namespace vrd {
+
+static thread_local char g_err[512] = "";
+static std::mutex g_mu;
+static bool g_prof_on = false;
+
+struct ProfRec {
+    int id;
+    hipEvent_t e0, e1;
+    double flops, bytes;
+};
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_free_events;
+static double g_ms[VRD_K_COUNT], g_flops[VRD_K_COUNT], g_bytes[VRD_K_COUNT];
+static int64_t g_launches[VRD_K_COUNT];
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static hipEvent_t get_event() {
+    if (!g_free_events.empty()) {
+        hipEvent_t e = g_free_events.back();
+        g_free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(int kernel_id, hipStream_t s, double flops, double bytes)
+    : id(kernel_id), stream(s), slot(nullptr) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    ProfRec r;
+    r.id = kernel_id;
+    r.e0 = get_event();
+    r.e1 = get_event();
+    r.flops = flops;
+    r.bytes = bytes;
+    if (!r.e0 || !r.e1) return;
+    (void)hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+    slot = reinterpret_cast<void*>(g_recs.size());   // index + 1
+}
+
+ProfScope::~ProfScope() {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t idx = reinterpret_cast<size_t>(slot) - 1;
+    if (idx < g_recs.size()) (void)hipEventRecord(g_recs[idx].e1, stream);
+}
+
+// fold finished records into the per-family totals (synchronises their events)
+static void drain() {
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            g_ms[r.id] += ms;
+            g_flops[r.id] += r.flops;
+            g_bytes[r.id] += r.bytes;
+            g_launches[r.id] += 1;
+        }
+        g_free_events.push_back(r.e0);
+        g_free_events.push_back(r.e1);
+    }
+    g_recs.clear();
+}
+
+}  // namespace vrd
+
+extern "C" {
+
+int vrd_abi_version(void) { return VRD_ABI_VERSION; }
+const char* vrd_last_error(void) { return vrd::g_err; }
+
+int vrd_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(vrd::g_mu);
+    vrd::g_prof_on = on != 0;
+    return 0;
+}
+
+int vrd_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(vrd::g_mu);
+    vrd::drain();
+    memset(vrd::g_ms, 0, sizeof(vrd::g_ms));
+    memset(vrd::g_flops, 0, sizeof(vrd::g_flops));
+    memset(vrd::g_bytes, 0, sizeof(vrd::g_bytes));
+    memset(vrd::g_launches, 0, sizeof(vrd::g_launches));
+    return 0;
+}
+
+int vrd_prof_read(int kernel_id, double* ms, int64_t* launches, double* flops, double* bytes) {
+    VRD_CHECK_ARG(kernel_id >= 0 && kernel_id < VRD_K_COUNT, "vrd_prof_read: bad kernel id %d", kernel_id);
+    std::lock_guard<std::mutex> lk(vrd::g_mu);
+    vrd::drain();
+    if (ms) *ms = vrd::g_ms[kernel_id];
+    if (launches) *launches = vrd::g_launches[kernel_id];
+    if (flops) *flops = vrd::g_flops[kernel_id];
+    if (bytes) *bytes = vrd::g_bytes[kernel_id];
+    return 0;
+}
+
+}  // extern "C"

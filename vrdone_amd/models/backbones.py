@@ -1,0 +1,169 @@
+"""Backbone of the relation encoder: embedding convs, entity-box fusion, stem (local-window
+transformer on subject and object) interleaved with subject<->object mutual attention, s/o
+fusion and the stride-2 pyramid branch.  Same constructor and parameter tree as the reference's
+models/backbones.py; the forward chains HIP kernels on channels-last buffers.
+
+Subject and object share the embedding / stem weights (reference backbones.py:172-177,
+213-214), so both streams run as ONE batch of 2B sequences; concatenations are never
+materialised -- producers write into column slabs of the consumer's input buffer.
+"""
+import torch
+from torch import nn
+
+from .blocks import ConvMLP, LayerNorm, MaskedConv1D, TransformerBlock, _from_cl, _mask2d, _no_autograd, _ops
+from .local_transformer import MaskedConvTransformerDecoderLayer
+
+
+class MaskConvTransformerBackbone(nn.Module):
+    def __init__(self, n_visual, n_bbox_entity, n_bbox_so, n_embd, n_head, n_embd_ks, fuse_ks, n_fuse_head,
+                 fuse_path_drop, fuse_qx_stride, fuse_kv_stride, max_len, arch=(2, 2, 3), mha_win_size=[-1] * 4,
+                 scale_factor=2, with_ln=False, attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, use_abs_pe=False,
+                 use_rel_pe=False, use_local=True):
+        super().__init__()
+        assert len(arch) == 3 and len(mha_win_size) == 1 + arch[-1]
+        assert with_ln and not use_abs_pe and not use_rel_pe, \
+            "built for the shipped configs: embd_with_ln=True, no absolute/relative position encodings"
+        assert scale_factor == 2 and n_embd_ks == 3
+        self.n_visual, self.n_bbox_entity, self.n_bbox_so = n_visual, n_bbox_entity, n_bbox_so
+        self.n_clip = 0
+        self.arch, self.mha_win_size, self.max_len = arch, mha_win_size, max_len
+        self.relu = nn.ReLU(inplace=True)
+        self.scale_factor, self.use_abs_pe, self.use_rel_pe = scale_factor, use_abs_pe, use_rel_pe
+
+        self.visual_embd, self.visual_embd_norm = self._embedding(n_visual, n_embd, n_embd_ks, arch[0])
+        self.bbox_entity_embd = MaskedConv1D(n_bbox_entity, n_embd, n_embd_ks, stride=1, padding=n_embd_ks // 2)
+        self.bbox_entity_norm = LayerNorm(n_embd)
+        self.visual_bbox_fuse = ConvMLP(n_embd * 2, n_embd, n_embd, kernel_size=fuse_ks, num_layers=2)
+
+        self.stem = nn.ModuleList()
+        self.s_attn = nn.ModuleList()
+        self.o_attn = nn.ModuleList()
+        for _ in range(arch[1]):
+            self.stem.append(TransformerBlock(n_embd, n_head, n_ds_strides=(1, 1), attn_pdrop=attn_pdrop,
+                                              proj_pdrop=proj_pdrop, path_pdrop=path_pdrop,
+                                              mha_win_size=mha_win_size[0], use_rel_pe=use_rel_pe))
+            for mutual in (self.s_attn, self.o_attn):
+                mutual.append(MaskedConvTransformerDecoderLayer(
+                    n_embd=n_embd, n_head=n_fuse_head, path_pdrop=fuse_path_drop, n_qx_stride=fuse_qx_stride,
+                    n_kv_stride=fuse_kv_stride, with_ffn=False, use_local=use_local,
+                    win_size=mha_win_size[0] if use_local else None))
+        self.s_fuse_norm = LayerNorm(n_embd)
+        self.o_fuse_norm = LayerNorm(n_embd)
+        self.so_fuse = ConvMLP(n_embd * 2, n_embd, n_embd, kernel_size=fuse_ks, num_layers=2)
+        self.bbox_so_embd = MaskedConv1D(n_bbox_so, n_embd, n_embd_ks, stride=1, padding=n_embd_ks // 2)
+        self.so_visual_bbox_fuse = ConvMLP(n_embd * 2, n_embd, n_embd, kernel_size=fuse_ks, num_layers=2)
+
+        self.branch = nn.ModuleList(
+            TransformerBlock(n_embd, n_head, n_ds_strides=(scale_factor, scale_factor), attn_pdrop=attn_pdrop,
+                             proj_pdrop=proj_pdrop, path_pdrop=path_pdrop, mha_win_size=mha_win_size[1 + i],
+                             use_rel_pe=use_rel_pe)
+            for i in range(arch[2]))
+        self._zero_biases()
+
+    @staticmethod
+    def _embedding(n_in, n_embd, ks, depth):
+        convs, norms = nn.ModuleList(), nn.ModuleList()
+        for i in range(depth):
+            convs.append(MaskedConv1D(n_in if i == 0 else n_embd, n_embd, ks, stride=1, padding=ks // 2, bias=False))
+            norms.append(LayerNorm(n_embd))
+        return convs, norms
+
+    def _zero_biases(self):
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Conv1d)) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+    def in_channels(self):
+        return 2 * self.n_visual + 2 * self.n_clip + self.n_bbox_so + 2 * self.n_bbox_entity
+
+    # -------------------------------------------------------------------------------------
+    def _embed_into(self, x, c0, width, convs, norms, mask2, out):
+        """k=3 conv * mask -> LN -> ReLU stack on the stacked (subject, object) slabs
+        [c0, c0+width) and [c0+width, c0+2*width) of x (B, C, T); result into `out` (2B, T, D)."""
+        ops = _ops()
+        B, _, T = x.shape
+        h = torch.empty(2, B, T, width, device=x.device, dtype=torch.float32)
+        ops.bct_to_btc(x, c0, width, h[0])
+        ops.bct_to_btc(x, c0 + width, width, h[1])
+        h = h.view(2 * B, T, width)
+        last = len(convs) - 1
+        for i, (conv, norm) in enumerate(zip(convs, norms)):
+            h = ops.conv_gemm(h, conv.conv.weight, conv.conv.bias, row_mask=mask2)
+            h = norm.cl(h, relu=True, out=out if i == last else None)
+        return h
+
+    def cl(self, x, mask):
+        """x: (B, C_in, T) contiguous fp32 (the boundary layout), mask: (B, T) bool.
+        Returns channels-last feats [(B, T/2^l, D)] and masks [(B, T/2^l)]."""
+        ops = _ops()
+        B, Cin, T = x.shape
+        assert Cin == self.in_channels(), f"expected {self.in_channels()} input channels, got {Cin}"
+        x = x.contiguous()
+        V, Cc, S, E = self.n_visual, self.n_clip, self.n_bbox_so, self.n_bbox_entity
+        D = self.s_fuse_norm.num_channels
+        dev = x.device
+        mask2 = torch.cat([mask, mask], dim=0)
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
+
+        # [visual (+clip) | entity box] -> visual_bbox_fuse
+        fuse_in = new(2 * B, T, 2 * D)
+        if Cc:
+            vc = new(2 * B, T, 2 * D)
+            self._embed_into(x, 0, V, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
+            self._embed_into(x, 2 * V, Cc, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
+            self.visual_clip_fuse.cl(vc, row_mask=mask2, out=fuse_in[..., :D])
+        else:
+            self._embed_into(x, 0, V, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
+        o0 = 2 * V + 2 * Cc
+        self._embed_into(x, o0 + S, E, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
+        so = self.visual_bbox_fuse.cl(fuse_in, row_mask=mask2)              # (2B, T, D): subject rows then object rows
+
+        for stem, s_attn, o_attn in zip(self.stem, self.s_attn, self.o_attn):
+            so, _ = stem.cl(so, mask2)
+            s, o = so[:B], so[B:]
+            nxt = new(2 * B, T, D)
+            s_attn.cl(s, o, mask, mask, stream_add=s, out=nxt[:B])         # s + s_attn(s, o)
+            o_attn.cl(o, s, mask, mask, stream_add=o, out=nxt[B:])         # uses the pre-update s
+            so = nxt
+
+        pair_in = new(B, T, 2 * D)
+        self.s_fuse_norm.cl(so[:B], out=pair_in[..., :D])
+        self.o_fuse_norm.cl(so[B:], out=pair_in[..., D:])
+        pair_box = new(B, T, 2 * D)
+        self.so_fuse.cl(pair_in, row_mask=mask, out=pair_box[..., :D])
+        box = new(B, T, S)
+        ops.bct_to_btc(x, o0, S, box)
+        conv = self.bbox_so_embd.conv
+        ops.conv_gemm(box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:])
+        e = self.so_visual_bbox_fuse.cl(pair_box, row_mask=mask)
+
+        feats, masks = [e], [mask]
+        for blk in self.branch:
+            e, mask = blk.cl(e, mask)
+            feats.append(e)
+            masks.append(mask)
+        return feats, masks
+
+    def forward(self, x, mask):
+        _no_autograd(self)
+        feats, masks = self.cl(x, _mask2d(mask))
+        return tuple(_from_cl(f) for f in feats), tuple(m[:, None, :] for m in masks)
+
+
+class MaskConvTransformerBackboneWithCLIP(MaskConvTransformerBackbone):
+    """Adds the CLIP-feature embedding and its fusion MLP (reference models/backbones.py:250-436)."""
+
+    def __init__(self, n_visual, n_clip, n_bbox_entity, n_bbox_so, n_embd, n_head, n_embd_ks, fuse_ks, n_fuse_head,
+                 fuse_path_drop, fuse_qx_stride, fuse_kv_stride, max_len, arch=(2, 2, 3), mha_win_size=[-1] * 4,
+                 scale_factor=2, with_ln=False, attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, use_abs_pe=False,
+                 use_rel_pe=False, use_local=True):
+        super().__init__(n_visual=n_visual, n_bbox_entity=n_bbox_entity, n_bbox_so=n_bbox_so, n_embd=n_embd,
+                         n_head=n_head, n_embd_ks=n_embd_ks, fuse_ks=fuse_ks, n_fuse_head=n_fuse_head,
+                         fuse_path_drop=fuse_path_drop, fuse_qx_stride=fuse_qx_stride, fuse_kv_stride=fuse_kv_stride,
+                         max_len=max_len, arch=arch, mha_win_size=mha_win_size, scale_factor=scale_factor,
+                         with_ln=with_ln, attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop, path_pdrop=path_pdrop,
+                         use_abs_pe=use_abs_pe, use_rel_pe=use_rel_pe, use_local=use_local)
+        self.n_clip = n_clip
+        self.clip_embd, self.clip_embd_norm = self._embedding(n_clip, n_embd, n_embd_ks, arch[0])
+        self.visual_clip_fuse = ConvMLP(n_embd * 2, n_embd, n_embd, kernel_size=fuse_ks, num_layers=2)
+        self._zero_biases()

@@ -1,0 +1,320 @@
+"""Operators of the relation-encoding path: same class names, constructor arguments and
+parameter trees as the reference's models/blocks.py (so checkpoints, ModelEma and the
+optimizer's weight-decay grouping in utils/train_utils.py:44-65 work unchanged), with the
+forward of every module running HIP kernels (vrdone_amd.ops -> libvrdone_hip.so).
+
+Two call forms per module:
+  * ``forward(...)``  the reference's signature on ``(B, C, T)`` tensors / ``(B, 1, T)`` bool
+    masks (a layout change is done around the channels-last core; used by module-level tests),
+  * ``cl(...)``       the channels-last core on ``(B, T, C)`` tensors / ``(B, T)`` masks that
+    MaskVRD chains end to end without any transposes.
+Eval only for now: the kernels have no backward, so a forward under autograd in training mode
+raises instead of silently detaching.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .transformer import _get_activation_fn  # noqa: F401  (re-exported like the reference)
+
+
+def _ops():
+    from .. import ops      # deferred: constructing / loading a model needs no GPU
+    return ops
+
+
+def _no_autograd(module):
+    if module.training and torch.is_grad_enabled():
+        raise NotImplementedError(
+            f"{type(module).__name__}: the HIP path is forward-only for now (call .eval() / no_grad)")
+
+
+def _mask2d(mask):
+    """(B, 1, T) bool -> contiguous (B, T) bool."""
+    return mask.reshape(mask.shape[0], mask.shape[-1]).contiguous()
+
+
+def _from_cl(x_cl):
+    return _ops().btc_to_bct(x_cl)
+
+
+def _to_cl(x):
+    return _ops().to_channels_last(x)
+
+
+class MaskedConv1D(nn.Module):
+    """Conv1d followed by the (down-sampled) mask; reference models/blocks.py:63-113."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, padding_mode='zeros'):
+        super().__init__()
+        assert kernel_size % 2 == 1 and kernel_size // 2 == padding
+        self.stride = stride
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                              padding_mode)
+        if bias:
+            nn.init.zeros_(self.conv.bias)
+
+    def cl(self, x, mask, out=None):
+        """x (B, T, Cin), mask (B, T) -> (y (B, T/stride, Cout), mask_out)."""
+        ops = _ops()
+        conv = self.conv
+        assert x.shape[1] % self.stride == 0
+        m_out = mask if self.stride == 1 else mask[:, ::self.stride].contiguous()
+        if conv.groups == 1:
+            assert self.stride == 1, "dense strided conv is not on the path"
+            y = ops.conv_gemm(x, conv.weight, conv.bias, row_mask=m_out, out=out)
+        else:
+            assert conv.groups == conv.out_channels, "only depthwise / 2-in-per-group convs are on the path"
+            y, = ops.dwconv_ln(x, [dict(weight=conv.weight, bias=conv.bias, out=out)], mask_out=m_out,
+                               stride=self.stride)
+        return y, m_out
+
+    def forward(self, x, mask, downsample=True):
+        _no_autograd(self)
+        assert downsample or self.stride == 1
+        y, m = self.cl(_to_cl(x), _mask2d(mask))
+        return _from_cl(y), m[:, None, :]
+
+
+class LayerNorm(nn.Module):
+    """LayerNorm over the channel axis of (B, C, T); reference models/blocks.py:116-158."""
+
+    def __init__(self, num_channels, eps=1e-5, affine=True, device=None, dtype=None):
+        super().__init__()
+        assert affine and eps == 1e-5, "the fused kernels implement the affine, eps=1e-5 form used on the path"
+        self.num_channels, self.eps, self.affine = num_channels, eps, affine
+        kw = {'device': device, 'dtype': dtype}
+        self.weight = nn.Parameter(torch.ones(1, num_channels, 1, **kw))
+        self.bias = nn.Parameter(torch.zeros(1, num_channels, 1, **kw))
+
+    def cl(self, x, relu=False, post_add=None, out=None):
+        return _ops().layernorm(x, self.weight, self.bias, relu=relu, post_add=post_add, out=out)
+
+    def forward(self, x):
+        _no_autograd(self)
+        assert x.dim() == 3 and x.shape[1] == self.num_channels
+        return _from_cl(self.cl(_to_cl(x)))
+
+
+class ConvMLP(nn.Module):
+    """1x1-conv MLP with GELU between layers; reference models/blocks.py:37-61."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers, kernel_size=1, act_layer='gelu', drop=0.0,
+                 with_bias=True):
+        super().__init__()
+        assert kernel_size == 1 and act_layer == 'gelu' and drop == 0.0
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Conv1d(a, b, 1, bias=with_bias) for a, b in zip(dims[:-1], dims[1:]))
+        for layer in self.layers:
+            if layer.bias is not None:
+                nn.init.zeros_(layer.bias)
+
+    def cl(self, x, row_mask=None, out=None):
+        ops = _ops()
+        last = self.num_layers - 1
+        for i, layer in enumerate(self.layers):
+            if i < last:
+                x = ops.conv_gemm(x, layer.weight, layer.bias, act=ops.ACT_GELU)
+            else:
+                x = ops.conv_gemm(x, layer.weight, layer.bias, row_mask=row_mask, out=out)
+        return x
+
+    def forward(self, x):
+        _no_autograd(self)
+        return _from_cl(self.cl(_to_cl(x)))
+
+
+class AffineDropPath(nn.Module):
+    """Per-channel scale (+ stochastic depth when training); reference models/blocks.py:1134-1149.
+    In eval it is a channel scale, which the GEMM epilogue applies (``scale`` argument)."""
+
+    def __init__(self, num_dim, drop_prob=0.0, init_scale_value=1e-4):
+        super().__init__()
+        self.scale = nn.Parameter(init_scale_value * torch.ones(1, num_dim, 1))
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        _no_autograd(self)
+        return x * self.scale
+
+
+class Scale(nn.Module):
+    """Learnable scalar (reference models/blocks.py:1084-1102); not on the hot path, kept because
+    utils/train_utils.py:8 imports it."""
+
+    def __init__(self, init_value=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.tensor(init_value, dtype=torch.float32))
+
+    def forward(self, x):
+        return x * self.scale
+
+
+class _ConvAttention(nn.Module):
+    """Parameter tree shared by the conv-attention modules: depthwise conv + LayerNorm per
+    q/k/v branch, then 1x1 projections (creation order = reference state_dict order)."""
+
+    def _build(self, n_embd, n_head, q_kernel, kv_kernel, stride):
+        assert n_embd % n_head == 0
+        self.n_embd, self.n_head = n_embd, n_head
+        self.n_channels = n_embd // n_head
+        self.scale = 1.0 / math.sqrt(self.n_channels)
+        for name, ks in (("query", q_kernel), ("key", kv_kernel), ("value", kv_kernel)):
+            setattr(self, f"{name}_conv", MaskedConv1D(n_embd, n_embd, ks, stride=stride, padding=ks // 2,
+                                                        groups=n_embd, bias=False))
+            setattr(self, f"{name}_norm", LayerNorm(n_embd))
+        self.key = nn.Conv1d(n_embd, n_embd, 1)
+        self.query = nn.Conv1d(n_embd, n_embd, 1)
+        self.value = nn.Conv1d(n_embd, n_embd, 1)
+        self.attn_drop, self.proj_drop = nn.Dropout(0.0), nn.Dropout(0.0)
+        self.proj = nn.Conv1d(n_embd, n_embd, 1)
+
+    def _branch_set(self, name):
+        conv, norm = getattr(self, f"{name}_conv"), getattr(self, f"{name}_norm")
+        return dict(weight=conv.conv.weight, gamma=norm.weight, beta=norm.bias)
+
+    def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1):
+        """dwconv * mask -> LN for the three branches, sharing kernel launches when inputs coincide."""
+        ops = _ops()
+        same_ks = self.query_conv.conv.kernel_size == self.key_conv.conv.kernel_size
+        if q_in is k_in and k_in is v_in and same_ks and q_mask is kv_mask:
+            return ops.dwconv_ln(q_in, [self._branch_set(n) for n in ("query", "key", "value")], mask_out=q_mask,
+                                 stride=stride)
+        if q_in is k_in and same_ks and q_mask is kv_mask:
+            q, k = ops.dwconv_ln(q_in, [self._branch_set("query"), self._branch_set("key")], mask_out=q_mask, stride=stride)
+            v, = ops.dwconv_ln(v_in, [self._branch_set("value")], mask_out=kv_mask, stride=stride)
+            return q, k, v
+        q, = ops.dwconv_ln(q_in, [self._branch_set("query")], mask_out=q_mask, stride=stride)
+        if k_in is v_in:
+            k, v = ops.dwconv_ln(k_in, [self._branch_set("key"), self._branch_set("value")], mask_out=kv_mask, stride=stride)
+        else:
+            k, = ops.dwconv_ln(k_in, [self._branch_set("key")], mask_out=kv_mask, stride=stride)
+            v, = ops.dwconv_ln(v_in, [self._branch_set("value")], mask_out=kv_mask, stride=stride)
+        return q, k, v
+
+    def _project(self, q, k, v):
+        ops = _ops()
+        return (ops.conv_gemm(q, self.query.weight, self.query.bias),
+                ops.conv_gemm(k, self.key.weight, self.key.bias),
+                ops.conv_gemm(v, self.value.weight, self.value.bias))
+
+
+class LocalMaskedMHCA(_ConvAttention):
+    """Banded-window conv attention; reference models/blocks.py:656-989."""
+
+    def __init__(self, n_embd, n_head, window_size, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0,
+                 use_rel_pe=False):
+        super().__init__()
+        assert window_size > 1 and window_size % 2 == 1 and not use_rel_pe
+        assert n_qx_stride == n_kv_stride and n_kv_stride in (1, 2)
+        assert attn_pdrop == 0.0 and proj_pdrop == 0.0
+        self.window_size, self.window_overlap = window_size, window_size // 2
+        self.use_rel_pe = use_rel_pe
+        self.n_qx_stride, self.n_kv_stride = n_qx_stride, n_kv_stride
+        ks = n_kv_stride + 1 if n_kv_stride > 1 else 3
+        self._build(n_embd, n_head, ks, ks, n_kv_stride)
+
+    def cl(self, x, mask, mask_out=None, **epilogue):
+        """x = LN1 output (B, T, C); epilogue kwargs go to the output-projection GEMM."""
+        ops = _ops()
+        s = self.n_kv_stride
+        if mask_out is None:
+            mask_out = mask if s == 1 else mask[:, ::s].contiguous()
+        assert (x.shape[1] // s) % (2 * self.window_overlap) == 0      # reference blocks.py:828
+        q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s)
+        q, k, v = self._project(q, k, v)
+        att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap)
+        return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
+
+    def forward(self, x, mask):
+        _no_autograd(self)
+        y, m = self.cl(_to_cl(x), _mask2d(mask))
+        return _from_cl(y), m[:, None, :]
+
+
+class MaskedMHA(nn.Module):
+    """Plain masked multi-head attention parameters; reference models/blocks.py:177-242."""
+
+    def __init__(self, n_embd, n_head, attn_pdrop=0.0, proj_pdrop=0.0):
+        super().__init__()
+        assert n_embd % n_head == 0 and attn_pdrop == 0.0 and proj_pdrop == 0.0
+        self.n_embd, self.n_head = n_embd, n_head
+        self.n_channels = n_embd // n_head
+        self.scale = 1.0 / math.sqrt(self.n_channels)
+        self.key = nn.Conv1d(n_embd, n_embd, 1)
+        self.query = nn.Conv1d(n_embd, n_embd, 1)
+        self.value = nn.Conv1d(n_embd, n_embd, 1)
+        self.attn_drop, self.proj_drop = nn.Dropout(0.0), nn.Dropout(0.0)
+        self.proj = nn.Conv1d(n_embd, n_embd, 1)
+
+    def cl_qkv(self, q_in, k_in, v_in, q_mask, kv_mask, **epilogue):
+        ops = _ops()
+        q = ops.conv_gemm(q_in, self.query.weight, self.query.bias)
+        k = ops.conv_gemm(k_in, self.key.weight, self.key.bias)
+        v = ops.conv_gemm(v_in, self.value.weight, self.value.bias)
+        att = ops.attention(q, k, v, kv_mask, self.n_head)
+        return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=q_mask, **epilogue), q_mask
+
+    def forward(self, x, mask):
+        _no_autograd(self)
+        m = _mask2d(mask)
+        xc = _to_cl(x)
+        y, _ = self.cl_qkv(xc, xc, xc, m, m)
+        return _from_cl(y), mask
+
+
+class TransformerBlock(nn.Module):
+    """LN -> local conv attention -> (max-pool) skip, LN -> MLP; reference models/blocks.py:992-1080."""
+
+    def __init__(self, n_embd, n_head, n_ds_strides=(1, 1), n_out=None, n_hidden=None, act_layer=nn.GELU,
+                 attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, mha_win_size=-1, use_rel_pe=False):
+        super().__init__()
+        assert len(n_ds_strides) == 2 and act_layer is nn.GELU
+        if mha_win_size <= 1:
+            raise NotImplementedError("global-attention TransformerBlock (n_mha_win_size <= 1) is not used by any "
+                                      "shipped config and is not built")
+        self.ln1 = LayerNorm(n_embd)
+        self.ln2 = LayerNorm(n_embd)
+        self.attn = LocalMaskedMHCA(n_embd, n_head, window_size=mha_win_size, n_qx_stride=n_ds_strides[0],
+                                    n_kv_stride=n_ds_strides[1], attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop,
+                                    use_rel_pe=use_rel_pe)
+        s = n_ds_strides[0]
+        self.pool_skip = nn.MaxPool1d(s + 1, stride=s, padding=(s + 1) // 2) if s > 1 else nn.Identity()
+        n_hidden = n_hidden or 4 * n_embd
+        n_out = n_out or n_embd
+        assert n_out == n_embd
+        self.mlp = nn.Sequential(nn.Conv1d(n_embd, n_hidden, 1), act_layer(), nn.Dropout(proj_pdrop, inplace=True),
+                                 nn.Conv1d(n_hidden, n_out, 1), nn.Dropout(proj_pdrop, inplace=True))
+        if path_pdrop > 0.0:
+            self.drop_path_attn = AffineDropPath(n_embd, drop_prob=path_pdrop)
+            self.drop_path_mlp = AffineDropPath(n_out, drop_prob=path_pdrop)
+        else:
+            self.drop_path_attn = nn.Identity()
+            self.drop_path_mlp = nn.Identity()
+
+    @staticmethod
+    def _scale(dp):
+        return dp.scale if isinstance(dp, AffineDropPath) else None
+
+    def cl(self, x, mask, out=None):
+        ops = _ops()
+        h = self.ln1.cl(x)
+        if self.attn.n_kv_stride > 1:
+            skip, m_out = ops.maxpool_mask(x, mask)
+        else:
+            skip, m_out = x, mask
+        y, _ = self.attn.cl(h, mask, m_out, scale=self._scale(self.drop_path_attn), res=skip, res_masked=True)
+        h = self.ln2.cl(y)
+        h = ops.conv_gemm(h, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU)
+        y = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=m_out,
+                          scale=self._scale(self.drop_path_mlp), res=y, out=out)
+        return y, m_out
+
+    def forward(self, x, mask, pos_embd=None):
+        _no_autograd(self)
+        assert pos_embd is None
+        y, m = self.cl(_to_cl(x), _mask2d(mask))
+        return _from_cl(y), m[:, None, :]

@@ -1,0 +1,244 @@
+"""Tensor-level wrappers over the C ABI (include/vrdone_hip.h).
+
+Activations are fp32 HIP tensors in channels-last form, shape ``(B, T, C)`` (or any
+``(..., C)``) whose last stride is 1 and whose rows are uniformly strided, so a column slab of a
+wider buffer (``buf[..., 512:1024]``) is a legal operand: that is how concatenations are built
+without copies.  Masks are ``torch.bool``/``uint8`` tensors of shape ``(B, T)``.
+
+PyTorch is used for device memory and the current stream only; every op below runs one
+hand-written HIP kernel.  Nothing here works on CPU tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, lib  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rows(t):
+    """(data_ptr, n_rows, n_cols, leading dimension) of a channels-last operand."""
+    if not t.is_cuda:
+        raise RuntimeError("vrdone_amd ops need HIP tensors (no CPU path exists for the hot path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise ValueError("channels-last operand must have unit stride along channels")
+    cols = t.shape[-1]
+    rows = t.numel() // cols
+    if t.dim() == 1 or rows == 1:
+        return t.data_ptr(), rows, cols, cols
+    ld = t.stride(-2)
+    for d in range(t.dim() - 3, -1, -1):       # outer dims must collapse onto the row index
+        if t.shape[d] != 1 and t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+            raise ValueError(f"rows are not uniformly strided: shape {tuple(t.shape)} strides {t.stride()}")
+    return t.data_ptr(), rows, cols, ld
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _mask_ptr(m, rows):
+    if m is None:
+        return None
+    if m.dtype not in (torch.bool, torch.uint8) or not m.is_contiguous() or m.numel() != rows:
+        raise ValueError(f"mask must be a contiguous bool/uint8 tensor with one byte per row ({m.numel()} vs {rows})")
+    return m.data_ptr()
+
+
+# weight re-packing cache: Conv1d (N, Cin, 3) -> (N, 3*Cin) tap-major, keyed on the parameter version
+_pack_cache = {}
+
+
+def packed_conv_weight(w):
+    if w.shape[-1] == 1:
+        return w
+    key = (w.data_ptr(), w._version, tuple(w.shape))
+    hit = _pack_cache.get(id(w))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    packed = w.detach().permute(0, 2, 1).contiguous()
+    _pack_cache[id(w)] = (key, packed)
+    return packed
+
+
+def bct_to_btc(x, c0, count, out):
+    """channels [c0, c0+count) of x (B, C, T) -> out (B, T, count-wide slab)."""
+    B, Ct, T = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
+    p, rows, cols, ld = _rows(out)
+    assert rows == B * T and cols == count
+    _hip.check(lib.vrd_bct_to_btc(x.data_ptr(), B, Ct, T, c0, count, p, ld, _stream()), "vrd_bct_to_btc")
+    return out
+
+
+def btc_to_bct(x):
+    """(B, T, C) channels-last -> new (B, C, T) tensor."""
+    B, T, Cc = x.shape
+    p, rows, cols, ld = _rows(x)
+    out = torch.empty(B, Cc, T, device=x.device, dtype=torch.float32)
+    _hip.check(lib.vrd_btc_to_bct(p, ld, B, Cc, T, out.data_ptr(), _stream()), "vrd_btc_to_bct")
+    return out
+
+
+def to_channels_last(x):
+    """(B, C, T) -> (B, T, C)."""
+    B, Cc, T = x.shape
+    out = torch.empty(B, T, Cc, device=x.device, dtype=torch.float32)
+    return bct_to_btc(x.contiguous(), 0, Cc, out)
+
+
+def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
+              res2=None, out=None):
+    """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
+    vrd_gemm.  x: (B, T, Cin); weight: the Conv1d parameter (N, Cin, k)."""
+    N, Cin, k = weight.shape
+    pa, rows, cols, lda = _rows(x)
+    assert cols == Cin, f"input has {cols} channels, weight expects {Cin}"
+    T = x.shape[-2]
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    pc, rows_c, cols_c, ldc = _rows(out)
+    assert rows_c == rows and cols_c == N
+    w = packed_conv_weight(weight)
+    a = _hip.GemmArgs()
+    a.A, a.lda, a.W, a.bias = pa, lda, w.data_ptr(), _ptr(bias)
+    a.C, a.ldc = pc, ldc
+    a.M, a.N, a.Cin, a.taps, a.T = rows, N, Cin, k, T
+    a.act = act
+    a.row_mask = _mask_ptr(row_mask, rows)
+    a.scale = _ptr(scale)
+    if res is not None:
+        pr, rr, rc, ldr = _rows(res)
+        assert rr == rows and rc == N
+        a.res, a.ldres, a.res_masked = pr, ldr, 1 if res_masked else 0
+    if res2 is not None:
+        pr, rr, rc, ldr = _rows(res2)
+        assert rr == rows and rc == N
+        a.res2, a.ldres2 = pr, ldr
+    _hip.check(lib.vrd_gemm(C.byref(a), _stream()), "vrd_gemm")
+    return out
+
+
+def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None):
+    """Channel LayerNorm.  post_add: (period, C) rows added after the affine, row r gets
+    post_add[r % period]."""
+    px, rows, cols, ldx = _rows(x)
+    if out is None:
+        out = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
+    py, rows_y, cols_y, ldy = _rows(out)
+    assert rows_y == rows and cols_y == cols
+    pa, lda, period = None, 0, 0
+    if post_add is not None:
+        pa, period, ca, lda = _rows(post_add)
+        assert ca == cols
+    _hip.check(lib.vrd_layernorm(px, ldx, py, ldy, rows, cols, gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0,
+                                 pa, lda, period, _stream()), "vrd_layernorm")
+    return out
+
+
+def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None):
+    """Fused depthwise conv * mask -> LayerNorm for up to three weight sets sharing x.
+    sets: list of dicts(weight=(C, g, k) Conv1d weight, bias=None, gamma=None, beta=None, relu=False, out=None).
+    Returns the list of outputs, each (B, T/stride, C)."""
+    B, Tin, Cx = x.shape
+    w0 = sets[0]["weight"]
+    Cout, g, k = w0.shape
+    px, rows, cols, ldx = _rows(x)
+    assert cols == Cout * g
+    Tout = Tin // stride
+    a = _hip.DwconvLnArgs()
+    a.x, a.ldx = px, ldx
+    if x_up is not None:
+        pu, ru, cu, ldu = _rows(x_up)
+        assert cu == cols and ru * 2 == rows
+        a.x_up, a.ldx_up = pu, ldu
+    a.B, a.Tin, a.C, a.ksize, a.stride, a.group_in = B, Tin, Cout, k, stride, g
+    a.mask_out = _mask_ptr(mask_out, B * Tout)
+    a.n_out = len(sets)
+    outs = []
+    for i, s in enumerate(sets):
+        assert tuple(s["weight"].shape) == (Cout, g, k) and s["weight"].is_contiguous()
+        o = s.get("out")
+        if o is None:
+            o = torch.empty(B, Tout, Cout, device=x.device, dtype=torch.float32)
+        po, ro, co, ldo = _rows(o)
+        assert ro == B * Tout and co == Cout
+        a.w[i], a.bias[i] = s["weight"].data_ptr(), _ptr(s.get("bias"))
+        a.gamma[i], a.beta[i] = _ptr(s.get("gamma")), _ptr(s.get("beta"))
+        a.relu[i] = 1 if s.get("relu") else 0
+        a.y[i], a.ldy[i] = po, ldo
+        outs.append(o)
+    _hip.check(lib.vrd_dwconv_ln(C.byref(a), _stream()), "vrd_dwconv_ln")
+    return outs
+
+
+def local_attention(q, k, v, mask, n_head, half_win):
+    B, T, Cc = q.shape
+    pq, rows, cols, ld = _rows(q)
+    pk, _, _, ldk = _rows(k)
+    pv, _, _, ldv = _rows(v)
+    assert ld == ldk == ldv
+    out = torch.empty(B, T, Cc, device=q.device, dtype=torch.float32)
+    _hip.check(lib.vrd_local_attn(pq, pk, pv, ld, _mask_ptr(mask, rows), B, T, Cc, n_head, half_win,
+                                  out.data_ptr(), Cc, _stream()), "vrd_local_attn")
+    return out
+
+
+def attention(q, k, v, kv_mask, n_head, algo=0):
+    """Global masked attention; q: (B, Tq, C), k/v: (B, Tk, C); kv_mask (B, Tk) or None."""
+    B, Tq, Cc = q.shape
+    Tk = k.shape[1]
+    pq, _, _, ldq = _rows(q)
+    pk, rows_k, _, ldk = _rows(k)
+    pv, _, _, ldv = _rows(v)
+    assert ldk == ldv
+    out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
+    _hip.check(lib.vrd_attention(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), B, Tq, Tk, n_head, Cc // n_head,
+                                 out.data_ptr(), Cc, algo, _stream()), "vrd_attention")
+    return out
+
+
+def maxpool_mask(x, mask_in):
+    """MaxPool1d(3, 2, 1)(x) * mask[::2]; returns (pooled (B, T/2, C), mask_out (B, T/2) bool)."""
+    B, T, Cc = x.shape
+    px, rows, cols, ldx = _rows(x)
+    y = torch.empty(B, T // 2, Cc, device=x.device, dtype=torch.float32)
+    m_out = torch.empty(B, T // 2, device=x.device, dtype=torch.bool)
+    _hip.check(lib.vrd_maxpool_mask(px, ldx, B, T, Cc, _mask_ptr(mask_in, rows), y.data_ptr(), Cc, m_out.data_ptr(),
+                                    _stream()), "vrd_maxpool_mask")
+    return y, m_out
+
+
+def mask_head(emb, feat, out_mask, fill=-10.0):
+    """emb (B, Q, Dp), feat (B, T, Dp), out_mask (B, T) -> (B, Q, T)."""
+    B, Q, Dp = emb.shape
+    T = feat.shape[1]
+    pe, _, _, lde = _rows(emb)
+    pf, rows_f, _, ldf = _rows(feat)
+    seg = torch.empty(B, Q, T, device=emb.device, dtype=torch.float32)
+    _hip.check(lib.vrd_mask_head(pe, lde, pf, ldf, _mask_ptr(out_mask, rows_f), B, Q, T, Dp, fill, seg.data_ptr(),
+                                 _stream()), "vrd_mask_head")
+    return seg
+
+
+def postprocess(logits, masks, valid_len, topk):
+    """logits (P, Q, K1), masks (P, Q, T), valid_len (P,) int32 ->
+    (top_score (P,Q,k) f32, top_cat (P,Q,k) i32, seg_first (P,Q) i32, seg_last (P,Q) i32)."""
+    P, Q, K1 = logits.shape
+    T = masks.shape[-1]
+    assert logits.is_contiguous() and masks.is_contiguous() and valid_len.dtype == torch.int32
+    dev = logits.device
+    ts = torch.empty(P, Q, topk, device=dev, dtype=torch.float32)
+    tc = torch.empty(P, Q, topk, device=dev, dtype=torch.int32)
+    sf = torch.empty(P, Q, device=dev, dtype=torch.int32)
+    sl = torch.empty(P, Q, device=dev, dtype=torch.int32)
+    _hip.check(lib.vrd_postprocess(logits.data_ptr(), masks.data_ptr(), valid_len.data_ptr(), P, Q, K1, T, topk,
+                                   ts.data_ptr(), tc.data_ptr(), sf.data_ptr(), sl.data_ptr(), _stream()),
+               "vrd_postprocess")
+    return ts, tc, sf, sl
