@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--pair-chunk", type=int, default=0, help="pairs per launch wave inside _mask_vrd (0 = model default)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=16)
+    ap.add_argument("--cpu-pairs", type=int, default=128)
     return ap.parse_args()
 
 
@@ -54,12 +54,40 @@ def padded_len(cfg, frames, div):
     return (frames + div - 1) // div * div
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and would oversubscribe a container share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, quota // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(model_cfg, sd_cpu, c_in, frames, t_pad, n_pairs):
     """The oracle (CPU restatement of the reference, plain PyTorch fp32) on a bounded sample of the
     same workload, on this box's host cores."""
     from oracle import vrd_oracle as O
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
+    log(f"cpu baseline: {n_pairs} pairs on {threads} threads (os.cpu_count() = {os.cpu_count()})")
     x, m = O.synth_pairs(n_pairs, c_in, t_pad, [frames] * n_pairs, seed=1234)
     with torch.no_grad():
         O.mask_vrd(sd_cpu, model_cfg, x[:2], m[:2], with_aux=True)        # warm-up
@@ -68,6 +96,7 @@ def cpu_baseline(model_cfg, sd_cpu, c_in, frames, t_pad, n_pairs):
             t0 = time.perf_counter()
             O.mask_vrd(sd_cpu, model_cfg, x, m, with_aux=True)            # the reference computes the aux heads too
             times.append(time.perf_counter() - t0)
+            log(f"cpu baseline run: {times[-1]:.2f} s")
     med = sorted(times)[1]
     return {"value": n_pairs / med, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{n_pairs} pairs x {frames} frames (T_pad {t_pad}), oracle.mask_vrd, median of 3 runs, "
@@ -97,6 +126,7 @@ def main():
         model.pair_chunk = args.pair_chunk
     t_pad = padded_len(cfg, args.frames, model.max_div_factor)
 
+    log(f"model ready (T_pad {t_pad}, pair_chunk {model.pair_chunk}); generating inputs")
     lo, hi = shard_range(args.pairs, rank, world)
     # every rank generates only its own shard, already in HBM
     x, m = synth.synth_pairs(hi - lo, c_in, t_pad, [args.frames] * (hi - lo), seed=1234 + rank, device=dev)
@@ -113,8 +143,10 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for i in range(args.warmup):
             step()
+            torch.cuda.synchronize()
+            log(f"warmup step {i} done")
         fence()
         _hip.prof_enable(not args.no_prof)
         _hip.prof_reset()
@@ -124,6 +156,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         _hip.prof_enable(False)
+        log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
