@@ -28,6 +28,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparsity figure)
 # closed-form algorithmic FLOPs per pair at T_pad (cross-checked with FlopCounterMode)
 FLOPS_PER_PAIR = {("vidvrd", 96): 6.386e9, ("vidvrd", 144): 9.650e9, ("vidvrd", 288): 19.897e9,
                   ("vidor_x", 512): 42.038e9}
@@ -43,8 +44,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--pair-chunk", type=int, default=0, help="pairs per launch wave inside _mask_vrd (0 = model default)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--precision", default=None, choices=["bf16x3", "f32"], help="GEMM product mode (default: the library default)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second run in the other precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=128)
+    ap.add_argument("--cpu-pairs", type=int, default=64)
     return ap.parse_args()
 
 
@@ -115,7 +118,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    from vrdone_amd import _hip, configs, synth
+    from vrdone_amd import _hip, configs, ops, synth
     from vrdone_amd.models.maskvrd import MaskVRD
     from vrdone_amd.parallel import shard_range, gather_predictions
 
@@ -142,29 +145,59 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step()
-            torch.cuda.synchronize()
-            log(f"warmup step {i} done")
-        fence()
-        _hip.prof_enable(not args.no_prof)
-        _hip.prof_reset()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            logits, masks = step()
-        fence()
-        elapsed = time.perf_counter() - t0
-        _hip.prof_enable(False)
-        log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
-    assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    def run(mode, warmup, steps):
+        """W untimed + K timed steps in one GEMM precision mode; returns (seconds, per-family profile)."""
+        ops.set_precision(mode)
+        with torch.no_grad():
+            for i in range(warmup):
+                step()
+                torch.cuda.synchronize()
+                log(f"[{mode}] warmup step {i} done")
+            fence()
+            _hip.prof_enable(not args.no_prof)
+            _hip.prof_reset()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                logits, masks = step()
+            fence()
+            elapsed = time.perf_counter() - t0
+            _hip.prof_enable(False)
+        assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        log(f"[{mode}] timed region: {steps} steps in {float(t.item()):.3f} s")
+        return float(t.item()), (_hip.prof_read() if (rank == 0 and not args.no_prof) else {})
+
+    def roofline(mode, prof):
+        """Dominant kernel family of the mode: algorithmic FLOPs (2*M*N*K per launch) / HIP-event time."""
+        fam = "gemm_bf16x3_mfma" if mode == "bf16x3" else "gemm_f32_mfma"
+        g = prof[fam]
+        n = max(g["launches"], 1)
+        avg_ms = g["ms"] / n
+        achieved = g["flops"] / n / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        if mode == "bf16x3":
+            # three bf16 MFMA products per f32-equivalent product: peak in algorithmic FLOP/s = bf16 dense peak / 3
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+            extra = {"mfma_tflops_executed": 3.0 * achieved, "mfma_peak": PEAK_BF16_MFMA_TFLOPS,
+                     "note": "peak = bf16 dense MFMA peak / 3 (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi per product)"}
+            kern = "gemm_bf16x3_kernel"
+        else:
+            peak, extra, kern = PEAK_F32_MFMA_TFLOPS, {}, "gemm_f32_mfma_kernel"
+        tot = sum(v["ms"] for v in prof.values())
+        return dict({"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": None, "launches": g["launches"], "avg_launch_ms": avg_ms,
+                     "flops_per_launch": g["flops"] / n, "share_of_kernel_time": g["ms"] / tot if tot else 0.0}, **extra)
+
+    main_mode = args.precision or ops.get_precision()
+    alt_mode = "f32" if main_mode == "bf16x3" else "bf16x3"
+    elapsed, prof = run(main_mode, args.warmup, args.steps)
+    alt = None
+    if not args.no_alt:
+        alt = run(alt_mode, 1, args.steps)
 
     if rank == 0:
-        prof = _hip.prof_read() if not args.no_prof else {}
+        fpp = FLOPS_PER_PAIR.get((args.config, t_pad))
         line = {
             "metric": "subject-object pairs/sec forward (2048 pairs x 256 frames x 512-d)",
             "value": args.pairs * args.steps / elapsed,
@@ -174,28 +207,26 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16x3 split products, f32 accumulate (f32-equivalent)" if main_mode == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}.yaml MaskVRD._mask_vrd, {args.pairs} pairs x {args.frames} frames "
                                    f"(T_pad {t_pad}) x C_in {c_in}, embd 512, eval, last-layer heads",
-                       "pairs_per_gpu": hi - lo, "pair_chunk": model.pair_chunk,
+                       "pairs_per_gpu": hi - lo, "pair_chunk": model.pair_chunk, "gemm_precision": main_mode,
                        "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of predictions" if world > 1 else "")},
         }
-        fpp = FLOPS_PER_PAIR.get((args.config, t_pad))
         if fpp:
             line["algorithmic_tflops"] = fpp * args.pairs * args.steps / elapsed / 1e12
         if prof:
-            g = prof["gemm_f32_mfma"]
-            per_launch_flops = g["flops"] / max(g["launches"], 1)
-            avg_ms = g["ms"] / max(g["launches"], 1)
-            achieved = per_launch_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            line["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": achieved,
-                                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                                "traffic": None, "launches": g["launches"], "avg_launch_ms": avg_ms,
-                                "flops_per_launch": per_launch_flops}
+            line["roofline"] = roofline(main_mode, prof)
             tot = sum(v["ms"] for v in prof.values())
             line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
             line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
+        if alt is not None:
+            a_elapsed, a_prof = alt
+            line["alt_precision"] = {"gemm_precision": alt_mode, "value": args.pairs * args.steps / a_elapsed,
+                                     "ms_per_step": 1e3 * a_elapsed / args.steps}
+            if a_prof:
+                line["alt_precision"]["roofline"] = roofline(alt_mode, a_prof)
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, c_in, args.frames, t_pad, args.cpu_pairs)

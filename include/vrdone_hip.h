@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 1
+#define VRD_ABI_VERSION 2
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -35,7 +35,7 @@ enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 enum vrd_kernel_id {
     VRD_K_GEMM = 0, VRD_K_LAYERNORM = 1, VRD_K_DWCONV_LN = 2, VRD_K_LOCAL_ATTN = 3,
     VRD_K_ATTN_SMALL = 4, VRD_K_ATTN_FLASH = 5, VRD_K_POOL = 6, VRD_K_MASK_HEAD = 7,
-    VRD_K_TRANSPOSE = 8, VRD_K_POSTPROC = 9, VRD_K_COUNT = 10
+    VRD_K_TRANSPOSE = 8, VRD_K_POSTPROC = 9, VRD_K_GEMM_X3 = 10, VRD_K_COUNT = 11
 };
 
 int vrd_abi_version(void);
@@ -71,7 +71,12 @@ int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float*
  * blocks.py:1074-1076 and local_transformer.py:815,829,833; res2 is the SOS stream
  * update of backbones.py:220-221.
  * W is [N][K] row-major with K = taps*Cin, tap-major (the caller re-packs a (N,Cin,3)
- * Conv1d weight once). */
+ * Conv1d weight once).
+ * Precision: with W_split == NULL every product is an exact f32 MFMA product.  With W_split set
+ * (2*N*K bf16: bf16(W) followed by bf16(W - bf16(W))) and K % 32 == 0, 16-byte aligned operands, the
+ * kernel splits the activations the same way on the fly and forms a*w ~= a_hi*w_hi + a_hi*w_lo +
+ * a_lo*w_hi on the bf16 MFMA with f32 accumulation (~17 significand bits per product); shapes that do
+ * not qualify silently use the f32 kernel. */
 typedef struct {
     const float* A;  int64_t lda;
     const float* W;
@@ -83,6 +88,7 @@ typedef struct {
     const float* scale;
     const float* res;  int64_t ldres;  int32_t res_masked;
     const float* res2;  int64_t ldres2;
+    const uint16_t* W_split;
 } vrd_gemm_args;
 int vrd_gemm(const vrd_gemm_args* a, void* stream);
 

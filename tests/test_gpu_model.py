@@ -3,7 +3,9 @@ against (a) outputs of the real reference stored in tests/golden/ and (b) the CP
 fresh inputs, plus size-independent properties at the benchmark shape.
 
 Stated tolerance (BASELINE north star): predicate logits within 1e-3 of the reference.  Measured
-fp32 differences are ~1e-5; the asserts below use 2e-4 (logits) / 2e-3 (mask logits, range +-25)."""
+max differences vs the reference: f32 mode ~6e-6 (logits) / 6e-5 (mask logits, range +-25); bf16x3 mode
+(the default: split-bf16 MFMA products, f32 accumulate) ~7e-5 / 5e-4.  The asserts use 2e-4 / 2e-3 for
+both modes."""
 import json
 import os
 
@@ -49,9 +51,18 @@ def close(got, want, atol):
     np.testing.assert_allclose(got, want, atol=atol, rtol=0)
 
 
+@pytest.fixture(params=["bf16x3", "f32"])
+def precision(request):
+    from vrdone_amd import ops
+    old = ops.get_precision()
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(old)
+
+
 @pytest.mark.parametrize("name,T", [("vidvrd", 96), ("vidvrd", 144), ("vidvrd", 288),
                                     ("vidor_x", 512), ("vidor_local", 512)])
-def test_mask_vrd_matches_reference_golden(name, T):
+def test_mask_vrd_matches_reference_golden(name, T, precision):
     model, mc, _, _ = get_model(name)
     g = np.load(os.path.join(GOLDEN, f"mask_vrd_{name}.npz"))
     lens = g[f"T{T}_lengths"].tolist()
@@ -77,7 +88,7 @@ def test_mask_vrd_matches_reference_golden(name, T):
     assert torch.equal(fast["pred_logits"], out["pred_logits"]) and torch.equal(fast["pred_masks"], out["pred_masks"])
 
 
-def test_mask_vrd_matches_oracle_on_a_ragged_batch():
+def test_mask_vrd_matches_oracle_on_a_ragged_batch(precision):
     """BASELINE config 1 shape (64 pairs x 64 frames -> T_pad 96), ragged lengths, vs the oracle."""
     model, mc, _, sd = get_model("vidvrd")
     gen = torch.Generator().manual_seed(1235)
@@ -116,7 +127,7 @@ def test_chunking_and_batch_independence():
     close(pad["pred_masks"][..., :50], whole["pred_masks"][1:2, :, :50], 5e-4)
 
 
-def test_forward_test_matches_reference_golden():
+def test_forward_test_matches_reference_golden(precision):
     model, mc, ic, _ = get_model("vidvrd")
     with open(os.path.join(GOLDEN, "forward_test_vidvrd.json")) as f:
         ref = json.load(f)
@@ -124,8 +135,8 @@ def test_forward_test_matches_reference_golden():
     dev_data = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in data.items()}
     res = model(dev_data)
     assert len(res["triplets"]) == len(ref["triplets"]) == ic["n_max_pair"]
-    np.testing.assert_allclose(res["triple_scores_avg"], ref["triple_scores_avg"], atol=2e-5, rtol=0)
-    # the ranking can only differ where two scores are closer than the fp32 noise
+    np.testing.assert_allclose(res["triple_scores_avg"], ref["triple_scores_avg"], atol=5e-5, rtol=0)
+    # the ranking can only differ where two scores are closer than the arithmetic noise
     same = [a == b for a, b in zip(res["triplets"], ref["triplets"])]
     assert sum(same) >= len(same) - 4
     key = lambda r, i: (tuple(r["triplets"][i]), tuple(r["so_tids"][i]), tuple(r["pred_durations"][i]))   # noqa: E731
@@ -180,6 +191,6 @@ def test_extension_is_loaded_and_profiled():
     torch.cuda.synchronize()
     prof = _hip.prof_read()
     _hip.prof_enable(False)
-    assert prof["gemm_f32_mfma"]["launches"] > 50 and prof["gemm_f32_mfma"]["ms"] > 0
+    gemm = {k: prof["gemm_f32_mfma"][k] + prof["gemm_bf16x3_mfma"][k] for k in ("launches", "ms", "flops")}
+    assert gemm["launches"] > 50 and gemm["ms"] > 0 and gemm["flops"] > 1e9
     assert prof["attn_flash"]["launches"] == 8 and prof["local_attn"]["launches"] == 5
-    assert prof["gemm_f32_mfma"]["flops"] > 1e9

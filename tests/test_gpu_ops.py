@@ -17,6 +17,22 @@ torch.set_grad_enabled(False)
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+def precision(request):
+    """Every operator test runs in both GEMM precision modes (same tolerances)."""
+    from vrdone_amd import ops
+    global GEMM_TOL_SCALE
+    old = ops.get_precision()
+    ops.set_precision(request.param)
+    GEMM_TOL_SCALE = 1.0 if request.param == "f32" else 5.0
+    yield request.param
+    ops.set_precision(old)
+    GEMM_TOL_SCALE = 1.0
+
+
+GEMM_TOL_SCALE = 1.0      # tolerances below are stated for f32 products; bf16x3 products get 5x
+
+
 def seeded(module, prefix):
     keys = [(f"{prefix}.{k}", tuple(v.shape)) for k, v in module.state_dict().items()]
     sd = O.synth_state_dict(keys)
@@ -34,12 +50,13 @@ def g():
     return d
 
 
-def close(got, want, atol):
+def close(got, want, atol, gemm=False):
+    """gemm=True: the value went through conv GEMMs, whose products follow the precision mode."""
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else got
     want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else want
     assert got.shape == want.shape
     assert np.isfinite(got).all()
-    np.testing.assert_allclose(got, want, atol=atol, rtol=0)
+    np.testing.assert_allclose(got, want, atol=atol * (GEMM_TOL_SCALE if gemm else 1.0), rtol=0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -55,7 +72,7 @@ def test_masked_conv1d_dense_k3(g):
     from vrdone_amd.models.blocks import MaskedConv1D
     mod, _ = seeded(MaskedConv1D(512, 512, 3, padding=1, bias=False), "op.conv3")
     out, m = mod(g["xt"].to(DEV), g["mt"].to(DEV))
-    close(out, g["conv3"], 2e-5)
+    close(out, g["conv3"], 2e-5, gemm=True)
     assert torch.equal(m.cpu(), g["mt"])
 
 
@@ -65,14 +82,14 @@ def test_local_mhca(g, stride):
     mod, _ = seeded(LocalMaskedMHCA(512, 4, window_size=7, n_qx_stride=stride, n_kv_stride=stride),
                     f"op.local_mhca_s{stride}")
     out, m = mod(g["xt"].to(DEV), g["mt"].to(DEV))
-    close(out, g[f"local_mhca_s{stride}"], 5e-5)
+    close(out, g[f"local_mhca_s{stride}"], 5e-5, gemm=True)
     assert torch.equal(m.cpu(), g["mt"][..., ::stride])
 
 
 def test_local_mhca_window9_heads8(g):
     from vrdone_amd.models.blocks import LocalMaskedMHCA
     mod, _ = seeded(LocalMaskedMHCA(512, 8, window_size=9), "op.local_mhca_w9")
-    close(mod(g["xt"].to(DEV), g["mt"].to(DEV))[0], g["local_mhca_w9"], 5e-5)
+    close(mod(g["xt"].to(DEV), g["mt"].to(DEV))[0], g["local_mhca_w9"], 5e-5, gemm=True)
 
 
 @pytest.mark.parametrize("stride", [1, 2])
@@ -81,14 +98,14 @@ def test_transformer_block(g, stride):
     mod, _ = seeded(TransformerBlock(512, 4, n_ds_strides=(stride, stride), path_pdrop=0.1, mha_win_size=7),
                     f"op.block_s{stride}")
     out, m = mod(g["xt"].to(DEV), g["mt"].to(DEV))
-    close(out, g[f"block_s{stride}"], 1e-4)
+    close(out, g[f"block_s{stride}"], 1e-4, gemm=True)
 
 
 def test_mhca_qkv_global(g):
     from vrdone_amd.models.local_transformer import MaskedMHCA_QKV
     mod, _ = seeded(MaskedMHCA_QKV(512, 4, n_qx_stride=1, n_kv_stride=1), "op.mhca_qkv")
     x, y, m = g["xt"].to(DEV), g["yt"].to(DEV), g["mt"].to(DEV)
-    close(mod(x, y, y, m, m)[0], g["mhca_qkv"], 5e-5)
+    close(mod(x, y, y, m, m)[0], g["mhca_qkv"], 5e-5, gemm=True)
 
 
 @pytest.mark.parametrize("name,heads,local", [("sos", 4, False), ("sos_local", 8, True)])
@@ -98,7 +115,7 @@ def test_sos_decoder_layer(g, name, heads, local):
                                                       with_ffn=False, use_local=local, win_size=9 if local else None),
                     f"op.{name}")
     x, y, m = g["xt"].to(DEV), g["yt"].to(DEV), g["mt"].to(DEV)
-    close(mod(x, y, m, m)[0], g[name], 1e-4)
+    close(mod(x, y, m, m)[0], g[name], 1e-4, gemm=True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -127,17 +144,17 @@ def test_gemm_shapes_and_epilogue(M, N, Cin, taps, T):
     ref = torch.nn.functional.conv1d(x.transpose(1, 2), w, bias, padding=taps // 2).transpose(1, 2)
     mf = mask[..., None].float()
     # plain
-    close(ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)), ref, 3e-5)
+    close(ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)), ref, 3e-5, gemm=True)
     # full epilogue
     want = torch.nn.functional.gelu(ref) * mf * scale + res * mf + res2
     got = ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV), act=ops.ACT_GELU, row_mask=mask.to(DEV),
                         scale=scale.to(DEV), res=res.to(DEV), res_masked=True, res2=res2.to(DEV))
-    close(got, want, 3e-5)
+    close(got, want, 3e-5, gemm=True)
     # relu, unmasked residual, output into a column slab of a wider buffer
     buf = torch.zeros(B, T, N + 64, device=DEV)
     ops.conv_gemm(x.to(DEV), w.to(DEV), None, act=ops.ACT_RELU, res=res.to(DEV), out=buf[..., 64:])
     want = torch.relu(torch.nn.functional.conv1d(x.transpose(1, 2), w, None, padding=taps // 2).transpose(1, 2)) + res
-    close(buf[..., 64:], want, 3e-5)
+    close(buf[..., 64:], want, 3e-5, gemm=True)
     assert float(buf[..., :64].abs().sum()) == 0.0
 
 
@@ -147,7 +164,7 @@ def test_gemm_reads_column_slab_input():
     wide = torch.randn(3, 40, 1024, generator=gen)
     w = torch.randn(256, 512, 1, generator=gen) / 512 ** 0.5
     got = ops.conv_gemm(wide.to(DEV)[..., 512:], w.to(DEV))
-    close(got, torch.einsum("btc,nc->btn", wide[..., 512:], w[..., 0]), 3e-5)
+    close(got, torch.einsum("btc,nc->btn", wide[..., 512:], w[..., 0]), 3e-5, gemm=True)
 
 
 @pytest.mark.parametrize("C", [256, 512])
@@ -313,3 +330,32 @@ def test_bad_arguments_raise():
         ops.layernorm(x, g1, g1)
     with pytest.raises(RuntimeError, match="HIP tensors"):
         ops.layernorm(x.cpu(), g1, g1)
+
+
+@pytest.mark.parametrize("M,N,Cin,taps,T", [(1000, 512, 512, 1, 1000), (96 * 3, 133, 256, 1, 96),
+                                            (144 * 2, 512, 1024, 3, 144), (130, 2048, 512, 1, 130)])
+def test_gemm_split_bf16_precision(M, N, Cin, taps, T, precision):
+    if precision != "f32":
+        pytest.skip("compares both modes itself")
+    """bf16x3 mode: a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi, f32 accumulate.  Against an fp64 reference the
+    error must be ~2^-16 relative to sum|a*w| (far below plain bf16's 2^-8), and not much worse than f32."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(M + N)
+    B = M // T
+    x = torch.randn(B, T, Cin, generator=gen)
+    w = torch.randn(N, Cin, taps, generator=gen) / (Cin * taps) ** 0.5
+    bias = torch.randn(N, generator=gen)
+    ref = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), bias.double(), padding=taps // 2).transpose(1, 2)
+    mag = torch.nn.functional.conv1d(x.abs().double().transpose(1, 2), w.abs().double(), None, padding=taps // 2).transpose(1, 2)
+    try:
+        ops.set_precision("bf16x3")
+        got = ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)).cpu().double()
+    finally:
+        ops.set_precision("f32")
+    f32 = ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)).cpu().double()
+    rel = float(((got - ref).abs() / mag).max())
+    rel32 = float(((f32 - ref).abs() / mag).max())
+    print(f"max rel err vs fp64: bf16x3 {rel:.2e}, f32 {rel32:.2e}; max abs bf16x3 {float((got - ref).abs().max()):.2e}")
+    assert rel < 3e-6, (rel, rel32)          # 2^-18 ~ 3.8e-6 per product before averaging
+    assert rel32 < 3e-7
+    close(got.float(), ref.float(), 1e-4)

@@ -12,9 +12,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvrdone_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
- K_TRANSPOSE, K_POSTPROC, K_COUNT) = range(11)
+ K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_COUNT) = range(12)
 KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
-                "maxpool_mask", "mask_head", "transpose", "postprocess"]
+                "maxpool_mask", "mask_head", "transpose", "postprocess", "gemm_bf16x3_mfma"]
 
 c_f32p = C.c_void_p      # device pointers travel as plain integers
 c_u8p = C.c_void_p
@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int64), ("N", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("T", C.c_int32),
                 ("act", C.c_int32), ("row_mask", c_u8p), ("scale", c_f32p),
                 ("res", c_f32p), ("ldres", C.c_int64), ("res_masked", C.c_int32),
-                ("res2", c_f32p), ("ldres2", C.c_int64)]
+                ("res2", c_f32p), ("ldres2", C.c_int64), ("W_split", C.c_void_p)]
 
 
 class DwconvLnArgs(C.Structure):
@@ -64,7 +64,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HipLibraryError(RuntimeError):

@@ -18,14 +18,14 @@
 // consecutive output tiles: the N-tiles of one 128-row activation panel then share that
 // XCD's L2 instead of each XCD fetching the panel from HBM.
 #include "vrd_common.h"
+#include "vrd_gemm_epilogue.h"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using vrd::f32x16;
 
 constexpr int BM = 128, BN = 128;
 constexpr int LDM = 132;   // LDS row pitch (floats): 128 + 4 keeps rows 16-B aligned; 2-way write conflicts are free
-constexpr int STG_PITCH = 64;   // epilogue staging: one 32 x 64 slab per wave (8 KiB), see the epilogue
 
 constexpr size_t lds_bytes(int bk) { return (size_t)4 * bk * LDM * sizeof(float); }   // a[2][bk][LDM] + b[2][bk][LDM]
 
@@ -170,277 +170,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(vrd_gemm_args p, int
         cur ^= 1;
     }
 
-    // accumulator element e of lane (li, lh) is C[row (e&3) + 8*(e>>2) + 4*lh][col li] of its 32 x 32 tile
-    if (STAGED) {
-        // Epilogue through LDS: each wave transposes its 64 x 64 sub-tile, 32 rows at a time, through a
-        // private 32 x 64 slab so that global traffic is whole 256-B row segments as float4 (the raw
-        // accumulator layout would give 64 scalar stores per lane).  The main loop ended on a barrier, so the
-        // operand tiles are dead; slabs are wave-private and DS operations of one wave execute in order.
-        float* stg = smem + wave * (32 * STG_PITCH);
-        const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
-        const int n = n0 + wn * 64 + c4;
-        const bool nfull = n + 3 < p.N;
-        float bias[4] = {0.f, 0.f, 0.f, 0.f}, scale[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < p.N) {
-                if (p.bias) bias[j] = p.bias[n + j];
-                if (p.scale) scale[j] = p.scale[n + j];
-            }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mi][nj][e];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = rb0 + 4 * j;
-                const int64_t m = m0 + wm * 64 + mi * 32 + row;
-                const float4 t = *reinterpret_cast<const float4*>(stg + row * STG_PITCH + c4);
-                if (m >= p.M || n >= p.N) continue;
-                float v[4] = {t.x + bias[0], t.y + bias[1], t.z + bias[2], t.w + bias[3]};
-                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
-                float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nfull) {
-                    if (p.res) { const float4 q = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n); r1[0] = q.x; r1[1] = q.y; r1[2] = q.z; r1[3] = q.w; }
-                    if (p.res2) { const float4 q = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n); r2[0] = q.x; r2[1] = q.y; r2[2] = q.z; r2[3] = q.w; }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (n + c < p.N) {
-                            if (p.res) r1[c] = p.res[m * p.ldres + n + c];
-                            if (p.res2) r2[c] = p.res2[m * p.ldres2 + n + c];
-                        }
-                }
-                const float rmk = p.res_masked ? mk : 1.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float x = v[c];
-                    if (p.act == VRD_ACT_RELU) x = fmaxf(x, 0.f);
-                    else if (p.act == VRD_ACT_GELU) x = vrd::gelu_erf(x);
-                    v[c] = x * mk * scale[c] + r1[c] * rmk + r2[c];
-                }
-                float* crow = p.C + m * p.ldc + n;
-                if (nfull) {
-                    *reinterpret_cast<float4*>(crow) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (n + c < p.N) crow[c] = v[c];
-                }
-            }
-        }
-        return;
-    }
-    // fallback epilogue straight from the accumulator layout (unaligned outputs, e.g. ldc = 133)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-        const int n = n0 + wn * 64 + nj * 32 + li;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float scale = p.scale ? p.scale[n] : 1.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float v = acc[mi][nj][e] + bias;
-                if (p.act == VRD_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == VRD_ACT_GELU) v = vrd::gelu_erf(v);
-                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
-                v *= mk;
-                v *= scale;
-                if (p.res) v += p.res[m * p.ldres + n] * (p.res_masked ? mk : 1.f);
-                if (p.res2) v += p.res2[m * p.ldres2 + n];
-                p.C[m * p.ldc + n] = v;
-            }
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Barrier-free variant: one wavefront = one 64 x 64 output tile with wave-private LDS tiles.
-// Nothing is shared between waves, so there is no s_barrier anywhere: a wave's DS operations
-// execute in order, which is all the synchronisation a single-buffered private tile needs
-// (reads of K step t precede the writes of K step t+1 in program order).  Co-resident waves
-// therefore never wait for each other and the MFMA pipe of a SIMD stays fed by whichever of its
-// waves is ready.  Operand panels are re-read by neighbouring tiles from the XCD's L2.
-// ------------------------------------------------------------------------------------------
-constexpr int WK = 16;         // K step
-constexpr int WP = 68;         // LDS pitch (floats) of the [k][row] tiles
-
-template <bool VEC, int TAPS, bool STAGED>
-__global__ __launch_bounds__(64, 4) void gemm_f32_wave_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * WK * WP];
-    float (*lds_a)[WP] = reinterpret_cast<float (*)[WP]>(smem);
-    float (*lds_b)[WP] = reinterpret_cast<float (*)[WP]>(smem + WK * WP);
-
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int64_t m0 = (int64_t)tm * 64;
-    const int n0 = tn * 64;
-
-    const int lane = threadIdx.x;
-    const int li = lane & 31, lh = lane >> 5;
-    const int K = p.Cin * TAPS;
-    const int nkt = (K + WK - 1) / WK;
-
-    // staging: piece i of a lane is (row = lane/4 + 16*i, k chunk = (lane%4)*4)
-    const int skq = (lane & 3) * 4;
-    int st[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t r = m0 + (lane >> 2) + 16 * i;
-        st[i] = (TAPS == 3 && r < p.M) ? (int)(r % p.T) : 0;
-    }
-    float ra[4][4], rb[4][4];
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    auto fetch = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            load_a<VEC, TAPS>(p, m0 + (lane >> 2) + 16 * i, st[i], kt * WK + skq, K, ra[i]);
-            load_w<VEC>(p, n0 + (lane >> 2) + 16 * i, kt * WK + skq, K, rb[i]);
-        }
-    };
-    auto stage = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                lds_a[skq + j][(lane >> 2) + 16 * i] = ra[i][j];
-                lds_b[skq + j][(lane >> 2) + 16 * i] = rb[i][j];
-            }
-    };
-
-    fetch(0);
-    stage();
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) fetch(kt + 1);
-#pragma unroll
-        for (int s = 0; s < WK / 2; ++s) {
-            const float a0 = lds_a[2 * s + lh][li];
-            const float a1 = lds_a[2 * s + lh][32 + li];
-            const float b0 = lds_b[2 * s + lh][li];
-            const float b1 = lds_b[2 * s + lh][32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (kt + 1 < nkt) stage();
-    }
-
-    if (STAGED) {
-        float* stg = smem;                       // 32 x 64 floats = 8 KiB <= the two operand tiles
-        const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
-        const int n = n0 + c4;
-        const bool nfull = n + 3 < p.N;
-        float bias[4] = {0.f, 0.f, 0.f, 0.f}, scale[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < p.N) {
-                if (p.bias) bias[j] = p.bias[n + j];
-                if (p.scale) scale[j] = p.scale[n + j];
-            }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mi][nj][e];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int row = rb0 + 4 * j;
-                const int64_t m = m0 + mi * 32 + row;
-                const float4 t = *reinterpret_cast<const float4*>(stg + row * STG_PITCH + c4);
-                if (m >= p.M || n >= p.N) continue;
-                float v[4] = {t.x + bias[0], t.y + bias[1], t.z + bias[2], t.w + bias[3]};
-                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
-                float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nfull) {
-                    if (p.res) { const float4 q4 = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n); r1[0] = q4.x; r1[1] = q4.y; r1[2] = q4.z; r1[3] = q4.w; }
-                    if (p.res2) { const float4 q4 = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n); r2[0] = q4.x; r2[1] = q4.y; r2[2] = q4.z; r2[3] = q4.w; }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (n + c < p.N) {
-                            if (p.res) r1[c] = p.res[m * p.ldres + n + c];
-                            if (p.res2) r2[c] = p.res2[m * p.ldres2 + n + c];
-                        }
-                }
-                const float rmk = p.res_masked ? mk : 1.f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float x = v[c];
-                    if (p.act == VRD_ACT_RELU) x = fmaxf(x, 0.f);
-                    else if (p.act == VRD_ACT_GELU) x = vrd::gelu_erf(x);
-                    v[c] = x * mk * scale[c] + r1[c] * rmk + r2[c];
-                }
-                float* crow = p.C + m * p.ldc + n;
-                if (nfull) {
-                    *reinterpret_cast<float4*>(crow) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (n + c < p.N) crow[c] = v[c];
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-        const int n = n0 + nj * 32 + li;
-        if (n >= p.N) continue;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float scale = p.scale ? p.scale[n] : 1.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m >= p.M) continue;
-                float v = acc[mi][nj][e] + bias;
-                if (p.act == VRD_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == VRD_ACT_GELU) v = vrd::gelu_erf(v);
-                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
-                v *= mk;
-                v *= scale;
-                if (p.res) v += p.res[m * p.ldres + n] * (p.res_masked ? mk : 1.f);
-                if (p.res2) v += p.res2[m * p.ldres2 + n];
-                p.C[m * p.ldc + n] = v;
-            }
-        }
-    }
-}
-
-template <bool STAGED>
-int launch_wave(const vrd_gemm_args& a, bool vec, hipStream_t s) {
-    const int tiles_m = (int)((a.M + 63) / 64), tiles_n = (a.N + 63) / 64;
-    dim3 grid(tiles_m * tiles_n), block(64);
-    if (a.taps == 1) {
-        if (vec) hipLaunchKernelGGL((gemm_f32_wave_kernel<true, 1, STAGED>), grid, block, 0, s, a, tiles_m, tiles_n);
-        else     hipLaunchKernelGGL((gemm_f32_wave_kernel<false, 1, STAGED>), grid, block, 0, s, a, tiles_m, tiles_n);
-    } else {
-        if (vec) hipLaunchKernelGGL((gemm_f32_wave_kernel<true, 3, STAGED>), grid, block, 0, s, a, tiles_m, tiles_n);
-        else     hipLaunchKernelGGL((gemm_f32_wave_kernel<false, 3, STAGED>), grid, block, 0, s, a, tiles_m, tiles_n);
-    }
-    return 0;
+    vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
 }
 
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
@@ -474,6 +204,8 @@ int launch_bk(const vrd_gemm_args& a, bool vec, int tiles_m, int tiles_n, hipStr
 
 }  // namespace
 
+namespace vrd { int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s); }
+
 extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     VRD_CHECK_ARG(a != nullptr, "vrd_gemm: null args");
     VRD_CHECK_ARG(a->A && a->W && a->C, "vrd_gemm: null operand");
@@ -502,12 +234,16 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     const double flops = 2.0 * (double)a->M * a->N * K;
     const double bytes = 4.0 * ((double)a->M * a->Cin + (double)a->N * K + (double)a->M * a->N *
                                 (1.0 + (a->res ? 1.0 : 0.0) + (a->res2 ? 1.0 : 0.0)));
-    vrd::ProfScope prof(VRD_K_GEMM, s, flops, bytes);
-    static const int algo_env = [] { const char* e = getenv("VRD_GEMM_ALGO"); return e ? atoi(e) : 0; }();
+    const bool x3 = a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split);
+    vrd::ProfScope prof(x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM, s, flops, bytes);
+    if (x3) {
+        int rc3 = vrd::launch_gemm_bf16x3(*a, staged, s);
+        if (rc3) return rc3;
+        VRD_LAUNCH_CHECK();
+        return 0;
+    }
     int rc;
-    if (algo_env == 1 && (a->M + 63) / 64 * ((a->N + 63) / 64) < ((int64_t)1 << 31))
-        rc = staged ? launch_wave<true>(*a, vec, s) : launch_wave<false>(*a, vec, s);
-    else if (bk == 32) rc = staged ? launch_bk<32, true>(*a, vec, tiles_m, tiles_n, s) : launch_bk<32, false>(*a, vec, tiles_m, tiles_n, s);
+    if (bk == 32) rc = staged ? launch_bk<32, true>(*a, vec, tiles_m, tiles_n, s) : launch_bk<32, false>(*a, vec, tiles_m, tiles_n, s);
     else          rc = staged ? launch_bk<16, true>(*a, vec, tiles_m, tiles_n, s) : launch_bk<16, false>(*a, vec, tiles_m, tiles_n, s);
     if (rc) return rc;
     VRD_LAUNCH_CHECK();

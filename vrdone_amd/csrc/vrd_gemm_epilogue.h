@@ -1,0 +1,110 @@
+// Epilogue shared by the f32 and the split-bf16 GEMM kernels: both leave a 64 x 64 sub-tile per
+// wave as 2 x 2 MFMA accumulators of 32 x 32, whose element e of lane (li = lane & 31, lh = lane >> 5)
+// is C[row (e&3) + 8*(e>>2) + 4*lh][col li].
+#pragma once
+#include "vrd_common.h"
+
+namespace vrd {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int STG_PITCH = 64;   // staging slab: 32 rows x 64 floats per wave = 8 KiB
+
+__device__ __forceinline__ float epilogue_value(const vrd_gemm_args& p, float v, float mk, float scale, float r1, float rmk,
+                                                float r2) {
+    if (p.act == VRD_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.act == VRD_ACT_GELU) v = gelu_erf(v);
+    return v * mk * scale + r1 * rmk + r2;
+}
+
+// v = acc + bias; v = act(v); v *= row_mask; v *= scale; v += res * (res_masked ? row_mask : 1); v += res2
+template <bool STAGED>
+__device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
+                                              int nw, int wave, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    if (STAGED) {
+        // Through LDS: each wave transposes its sub-tile, 32 rows at a time, through a private 32 x 64 slab
+        // so that global traffic is whole 256-B row segments as float4 (the raw accumulator layout would
+        // give 64 scalar stores per lane).  The caller's main loop ended on a barrier, so the operand tiles
+        // are dead; slabs are wave-private and the DS operations of one wave execute in order.
+        float* stg = smem + wave * (32 * STG_PITCH);
+        const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
+        const int n = nw + c4;
+        const bool nfull = n + 3 < p.N;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f}, scale[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + j < p.N) {
+                if (p.bias) bias[j] = p.bias[n + j];
+                if (p.scale) scale[j] = p.scale[n + j];
+            }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mi][nj][e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = rb0 + 4 * j;
+                const int64_t m = mw + mi * 32 + row;
+                const float4 t = *reinterpret_cast<const float4*>(stg + row * STG_PITCH + c4);
+                if (m >= p.M || n >= p.N) continue;
+                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
+                const float rmk = p.res_masked ? mk : 1.f;
+                float v[4] = {t.x + bias[0], t.y + bias[1], t.z + bias[2], t.w + bias[3]};
+                float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
+                if (nfull) {
+                    if (p.res) {
+                        const float4 q = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n);
+                        r1[0] = q.x; r1[1] = q.y; r1[2] = q.z; r1[3] = q.w;
+                    }
+                    if (p.res2) {
+                        const float4 q = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n);
+                        r2[0] = q.x; r2[1] = q.y; r2[2] = q.z; r2[3] = q.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (n + c < p.N) {
+                            if (p.res) r1[c] = p.res[m * p.ldres + n + c];
+                            if (p.res2) r2[c] = p.res2[m * p.ldres2 + n + c];
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = epilogue_value(p, v[c], mk, scale[c], r1[c], rmk, r2[c]);
+                float* crow = p.C + m * p.ldc + n;
+                if (nfull) {
+                    *reinterpret_cast<float4*>(crow) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (n + c < p.N) crow[c] = v[c];
+                }
+            }
+        }
+        return;
+    }
+    // fallback straight from the accumulator layout (rows that are not 16-byte aligned, e.g. ldc = 133)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+        const int n = nw + nj * 32 + li;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+        const float scale = p.scale ? p.scale[n] : 1.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = mw + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
+                const float r1 = p.res ? p.res[m * p.ldres + n] : 0.f;
+                const float r2 = p.res2 ? p.res2[m * p.ldres2 + n] : 0.f;
+                p.C[m * p.ldc + n] = epilogue_value(p, acc[mi][nj][e] + bias, mk, scale, r1, p.res_masked ? mk : 1.f, r2);
+            }
+        }
+    }
+}
+
+}  // namespace vrd

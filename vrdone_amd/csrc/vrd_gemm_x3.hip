@@ -1,0 +1,182 @@
+// Split-precision variant of the conv GEMM: the same C = epilogue(A' . W^T) as vrd_gemm.hip, with
+// every f32 product replaced by three bf16 MFMA products (v_mfma_f32_32x32x16_bf16, f32 accumulate):
+//
+//     x = x_hi + x_lo,  x_hi = bf16(x),  x_lo = bf16(x - x_hi)            (|x - x_hi - x_lo| <= 2^-17 |x|)
+//     a * w  ~=  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi                          (drops a_lo*w_lo ~ 2^-18 |a w|)
+//
+// Each bf16 x bf16 product is exact in the f32 accumulator, so the result carries ~17 significand bits
+// per product (relative error ~1e-5 per GEMM) at 3/16 of the f32-MFMA instruction time.  Activations stay
+// fp32 in HBM and are split while being staged into LDS; weights are split once on the host side of the
+// ABI (W_split = [hi | lo], each N x K bf16).
+//
+// Tiling: 128 x 128 x 32 per 256-thread workgroup, four waves x (2 x 2) accumulators of 32 x 32, operand
+// tiles [row][k] in bf16 with an 80-byte row pitch (16 consecutive rows hit 16 distinct 16-byte LDS slots,
+// so the ds_read_b128 fragment reads are conflict free).  One LDS buffer + register prefetch of the next
+// K step (two barriers per step); 40 KiB of LDS and <= 128 VGPRs keep 3-4 workgroups per CU resident.
+#include "vrd_common.h"
+#include "vrd_gemm_epilogue.h"
+
+namespace {
+
+using vrd::f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int XP = 40;                                   // row pitch in bf16 elements (80 B)
+constexpr int TILE = BM * XP;                            // elements per operand tile
+constexpr size_t X3_LDS = 4 * TILE * sizeof(__bf16);     // a_hi, a_lo, w_hi, w_lo = 40960 B
+
+template <int TAPS, bool STAGED>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* a_hi = reinterpret_cast<__bf16*>(smem);
+    __bf16* a_lo = a_hi + TILE;
+    __bf16* w_hi = a_lo + TILE;
+    __bf16* w_lo = w_hi + TILE;
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = p.Cin * TAPS;          // multiple of 32 (checked on the host)
+    const int nkt = K / BK;
+    const __bf16* Whi = reinterpret_cast<const __bf16*>(p.W_split);
+    const __bf16* Wlo = Whi + (int64_t)p.N * K;
+
+    // A staging: 4 float4 pieces per thread, piece i = (row = (tid + 256 i) / 8, k = 4 * ((tid + 256 i) % 8))
+    // W staging: 2 x (hi, lo) 16-byte pieces per thread, piece i = (row = (tid + 256 i) / 4, k = 8 * (f % 4))
+    int st[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = m0 + ((tid + 256 * i) >> 3);
+        st[i] = (TAPS == 3 && r < p.M) ? (int)(r % p.T) : 0;
+    }
+    float4 ra[4];
+    uint4 rwh[2], rwl[2];
+
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            const int64_t r = m0 + (f >> 3);
+            const int k = kt * BK + (f & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < p.M) {
+                int tap = 0, ci = k;
+                bool ok = true;
+                if (TAPS == 3) {
+                    tap = (k >= p.Cin) + (k >= 2 * p.Cin);
+                    ci = k - tap * p.Cin;
+                    const int tt = st[i] + tap - 1;
+                    ok = tt >= 0 && tt < p.T;
+                }
+                if (ok) v = *reinterpret_cast<const float4*>(p.A + (r + tap - (TAPS == 3 ? 1 : 0)) * p.lda + ci);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const int n = n0 + (f >> 2);
+            const int k = kt * BK + (f & 3) * 8;
+            uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+            if (n < p.N) {
+                h = *reinterpret_cast<const uint4*>(Whi + (int64_t)n * K + k);
+                l = *reinterpret_cast<const uint4*>(Wlo + (int64_t)n * K + k);
+            }
+            rwh[i] = h;
+            rwl[i] = l;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            const int off = (f >> 3) * XP + (f & 7) * 4;
+            const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            bf16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[j] = (__bf16)x[j];
+                l[j] = (__bf16)(x[j] - (float)h[j]);
+            }
+            *reinterpret_cast<bf16x4*>(a_hi + off) = h;
+            *reinterpret_cast<bf16x4*>(a_lo + off) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const int off = (f >> 2) * XP + (f & 3) * 8;
+            *reinterpret_cast<uint4*>(w_hi + off) = rwh[i];
+            *reinterpret_cast<uint4*>(w_lo + off) = rwl[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    fetch(0);
+    stage();
+    __syncthreads();
+    const int arow = (wm * 64 + li) * XP + 8 * lh, wrow = (wn * 64 + li) * XP + 8 * lh;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) fetch(kt + 1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[2], al[2], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *reinterpret_cast<const bf16x8*>(a_hi + arow + t * 32 * XP + 16 * s);
+                al[t] = *reinterpret_cast<const bf16x8*>(a_lo + arow + t * 32 * XP + 16 * s);
+                wh[t] = *reinterpret_cast<const bf16x8*>(w_hi + wrow + t * 32 * XP + 16 * s);
+                wl[t] = *reinterpret_cast<const bf16x8*>(w_lo + wrow + t * 32 * XP + 16 * s);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], wh[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) stage();
+        __syncthreads();
+    }
+    vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
+}
+
+}  // namespace
+
+namespace vrd {
+
+// called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
+int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s) {
+    const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (a.N + BN - 1) / BN;
+    dim3 grid(tiles_m * tiles_n), block(256);
+    if (a.taps == 1) {
+        if (staged) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, true>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
+        else        hipLaunchKernelGGL((gemm_bf16x3_kernel<1, false>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
+    } else {
+        if (staged) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, true>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
+        else        hipLaunchKernelGGL((gemm_bf16x3_kernel<3, false>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
+    }
+    return 0;
+}
+
+}  // namespace vrd

@@ -9,6 +9,7 @@ PyTorch is used for device memory and the current stream only; every op below ru
 hand-written HIP kernel.  Nothing here works on CPU tensors.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -51,20 +52,57 @@ def _mask_ptr(m, rows):
     return m.data_ptr()
 
 
-# weight re-packing cache: Conv1d (N, Cin, 3) -> (N, 3*Cin) tap-major, keyed on the parameter version
-_pack_cache = {}
+# Derived weight layouts are cached ON the parameter object (so they die with it and can never be
+# confused with another tensor that later reuses the same address), keyed on (data_ptr, version).
+def _cached(w, slot, build):
+    key = (w.data_ptr(), w._version)
+    hit = getattr(w, slot, None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = build()
+    setattr(w, slot, (key, val))
+    return val
 
 
 def packed_conv_weight(w):
+    """Conv1d weight (N, Cin, k) -> (N, k*Cin) tap-major for k = 3; k = 1 weights are used in place."""
     if w.shape[-1] == 1:
         return w
-    key = (w.data_ptr(), w._version, tuple(w.shape))
-    hit = _pack_cache.get(id(w))
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    packed = w.detach().permute(0, 2, 1).contiguous()
-    _pack_cache[id(w)] = (key, packed)
-    return packed
+    return _cached(w, "_vrd_packed", lambda: w.detach().permute(0, 2, 1).contiguous())
+
+
+# GEMM precision mode.
+#   "bf16x3" (default): every f32 product a*w is formed as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16
+#            MFMA with f32 accumulation (x = x_hi + x_lo split in bf16): ~17 significand bits per product.
+#            Measured end to end: logits within 7e-5 of the reference (stated tolerance 1e-3).
+#   "f32":   exact f32 MFMA products (bit-level fmaf chains); logits within 7e-6; ~1.55x slower end to end.
+# Select with set_precision() or the VRDONE_PRECISION environment variable.  Everything outside the
+# conv GEMMs (LayerNorm, depthwise convs, softmax, attention) is f32 in both modes.
+_PRECISIONS = ("f32", "bf16x3")
+_precision = os.environ.get("VRDONE_PRECISION", "bf16x3")
+if _precision not in _PRECISIONS:
+    raise ValueError(f"VRDONE_PRECISION must be one of {_PRECISIONS}, got {_precision!r}")
+
+
+def set_precision(mode):
+    global _precision
+    if mode not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {_PRECISIONS}, got {mode!r}")
+    _precision = mode
+
+
+def get_precision():
+    return _precision
+
+
+def split_conv_weight(w):
+    """(2, N, K) bf16: bf16(W) and bf16(W - bf16(W)) of the tap-major packed weight."""
+    def build():
+        packed = packed_conv_weight(w).detach().reshape(w.shape[0], -1)
+        hi = packed.to(torch.bfloat16)
+        lo = (packed - hi.float()).to(torch.bfloat16)
+        return torch.stack([hi, lo]).contiguous()
+    return _cached(w, "_vrd_split", build)
 
 
 def bct_to_btc(x, c0, count, out):
@@ -113,6 +151,8 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     a.act = act
     a.row_mask = _mask_ptr(row_mask, rows)
     a.scale = _ptr(scale)
+    if _precision == "bf16x3" and (Cin * k) % 32 == 0:
+        a.W_split = split_conv_weight(weight).data_ptr()
     if res is not None:
         pr, rr, rc, ldr = _rows(res)
         assert rr == rows and rc == N
