@@ -221,6 +221,9 @@ def main():
             tot = sum(v["ms"] for v in prof.values())
             line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
             line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
+            # algorithmic HBM bytes of each family / its time (how close each family runs to the ~6.3 TB/s roof)
+            line["kernel_algorithmic_gbps"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+                                               for k, v in prof.items() if v["launches"] and v["ms"] > 0}
         if alt is not None:
             a_elapsed, a_prof = alt
             line["alt_precision"] = {"gemm_precision": alt_mode, "value": args.pairs * args.steps / a_elapsed,

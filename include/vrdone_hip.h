@@ -11,6 +11,10 @@
  *  - every activation tensor is fp32, channels-last: a matrix of `rows` x `C` with an
  *    explicit leading dimension `ld*` (floats between consecutive rows); row r = b*T + t.
  *    Leading dimensions let producers write straight into concatenation buffers.
+ *  - "pair" rows (bf16x3 mode only): a tensor whose only consumer is a GEMM may be produced in the
+ *    GEMM-operand format instead of f32: the 4*W bytes of a W-channel row hold [W x bf16 hi | W x bf16 lo]
+ *    with hi = bf16(x), lo = bf16(x - hi) (same leading dimension as the f32 row).  Producers take an
+ *    `out_pair` flag; vrd_gemm takes `a_pair_width` (= W of the producer, 0 for f32 input).
  *  - masks are uint8 (0/1), one byte per row (the reference's (B,1,T) bool mask).
  *  - all pointers are device pointers owned by the caller; the library allocates no
  *    device memory and keeps no state besides the optional profiling event list.
@@ -27,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 2
+#define VRD_ABI_VERSION 3
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -53,7 +57,7 @@ int vrd_prof_read(int kernel_id, double* ms, int64_t* launches, double* flops, d
  * Replaces the channel slicing of models/backbones.py:161-166 / :329-341 and the
  * transposing copy of models/maskvrd.py:382-385. */
 int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count,
-                   float* dst, int64_t ld_dst, void* stream);
+                   float* dst, int64_t ld_dst, int out_pair, void* stream);
 /* rows (b*T+t) x C (leading dim ld_src) -> (B, C, T) contiguous. */
 int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float* dst, void* stream);
 
@@ -89,6 +93,8 @@ typedef struct {
     const float* res;  int64_t ldres;  int32_t res_masked;
     const float* res2;  int64_t ldres2;
     const uint16_t* W_split;
+    int32_t a_pair_width;   /* > 0: A rows are pair rows produced with this width (needs W_split) */
+    int32_t c_pair;         /* 1: write C as pair rows of width N */
 } vrd_gemm_args;
 int vrd_gemm(const vrd_gemm_args* a, void* stream);
 
@@ -98,7 +104,7 @@ int vrd_gemm(const vrd_gemm_args* a, void* stream);
  * models/local_transformer.py:809,820). */
 int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C,
                   const float* gamma, const float* beta, int relu,
-                  const float* post_add, int64_t ld_add, int add_period, void* stream);
+                  const float* post_add, int64_t ld_add, int add_period, int out_pair, void* stream);
 
 /* ---- depthwise conv (+ nearest-upsample add) * mask -> LayerNorm, fused -----------------
  * for o in [0, n_out): y_o[b,t',:] = LN_o( mask_out[b,t'] * (bias_o + sum_k w_o[c,g,k] *
@@ -120,6 +126,7 @@ typedef struct {
     int32_t relu[3];
     float* y[3];
     int64_t ldy[3];
+    int32_t out_pair[3];
 } vrd_dwconv_ln_args;
 int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
 
@@ -128,15 +135,16 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
  * masked query rows give 0.  q is scaled by head_dim^-0.5 inside.  C = n_head*head_dim = 512. */
 int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld,
                    const uint8_t* mask, int B, int T, int C, int n_head, int half_win,
-                   float* out, int64_t ldo, void* stream);
+                   float* out, int64_t ldo, int out_pair, void* stream);
 
 /* ---- global masked attention, models/local_transformer.py:163-183 and :44-63 -------------
  * out[b,tq,h,:] = softmax_j(q.k_j / sqrt(hd) | kv_mask[b,j]) . v_j ; keys with mask 0 get
  * -inf.  kv_mask may be NULL (all keys valid).  `algo`: 0 = auto, 1 = generic VALU kernel
- * (any shape; the predictor's 9-query attention), 2 = f32-MFMA flash kernel (hd in {64,128}). */
+ * (any shape; the predictor's 9-query attention), 2 = f32-MFMA flash kernel (hd in {64,128}).
+ * out_pair is honoured by the flash kernel only (row width n_head*head_dim). */
 int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                   const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim,
-                  float* out, int64_t ldo, int algo, void* stream);
+                  float* out, int64_t ldo, int algo, int out_pair, void* stream);
 
 /* ---- MaxPool1d(3,2,1) skip * mask (models/blocks.py:1040-1046,1074) and mask[::2] ------- */
 int vrd_maxpool_mask(const float* x, int64_t ldx, int B, int Tin, int C, const uint8_t* mask_in,

@@ -359,3 +359,35 @@ def test_gemm_split_bf16_precision(M, N, Cin, taps, T, precision):
     assert rel < 3e-6, (rel, rel32)          # 2^-18 ~ 3.8e-6 per product before averaging
     assert rel32 < 3e-7
     close(got.float(), ref.float(), 1e-4)
+
+
+def test_pair_row_format_round_trip(precision):
+    """Producers' pair rows decode to the f32 value within 2^-16 relative; a GEMM fed with pair rows equals the
+    GEMM fed with the f32 tensor (same split, done by the producer instead of the GEMM's staging)."""
+    if precision != "bf16x3":
+        pytest.skip("pair rows exist in bf16x3 mode only")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(123)
+    x = torch.randn(3, 40, 512, generator=gen) * 3
+    gam, bet = torch.randn(1, 512, 1, generator=gen), torch.randn(1, 512, 1, generator=gen)
+    plain = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), relu=True)
+    pr = ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), relu=True, pair=True)
+    assert isinstance(pr, ops.Pair) and pr.width == 512
+    dec = pr.float()
+    assert float(((dec - plain).abs() / plain.abs().clamp_min(1e-3)).max()) < 2 ** -15
+    w = torch.randn(256, 512, 1, generator=gen) / 512 ** 0.5
+    b = torch.randn(256, generator=gen)
+    a = ops.conv_gemm(plain, w.to(DEV), b.to(DEV))
+    c = ops.conv_gemm(pr, w.to(DEV), b.to(DEV))
+    assert torch.equal(a, c)
+    # k = 3 conv over pair rows, two slabs of a concatenation buffer, pair output
+    cat = torch.zeros(3, 40, 1024, device=DEV)
+    ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), out=cat[..., :512], pair=True)
+    ops.layernorm((x * 0.5 + 1).to(DEV), gam.to(DEV), bet.to(DEV), out=cat[..., 512:], pair=True)
+    cat_f = torch.cat([ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV)),
+                       ops.layernorm((x * 0.5 + 1).to(DEV), gam.to(DEV), bet.to(DEV))], dim=-1)
+    w3 = torch.randn(512, 1024, 3, generator=gen) / 3072 ** 0.5
+    want = ops.conv_gemm(cat_f, w3.to(DEV), None, act=ops.ACT_GELU)
+    got = ops.conv_gemm(ops.Pair(cat, 512), w3.to(DEV), None, act=ops.ACT_GELU, out_pair=True)
+    assert torch.equal(ops.conv_gemm(ops.Pair(cat, 512), w3.to(DEV), None, act=ops.ACT_GELU), want)
+    assert float(((got.float() - want).abs() / want.abs().clamp_min(1e-2)).max()) < 2 ** -15

@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int64), ("N", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("T", C.c_int32),
                 ("act", C.c_int32), ("row_mask", c_u8p), ("scale", c_f32p),
                 ("res", c_f32p), ("ldres", C.c_int64), ("res_masked", C.c_int32),
-                ("res2", c_f32p), ("ldres2", C.c_int64), ("W_split", C.c_void_p)]
+                ("res2", c_f32p), ("ldres2", C.c_int64), ("W_split", C.c_void_p),
+                ("a_pair_width", C.c_int32), ("c_pair", C.c_int32)]
 
 
 class DwconvLnArgs(C.Structure):
@@ -36,7 +37,7 @@ class DwconvLnArgs(C.Structure):
                 ("stride", C.c_int32), ("group_in", C.c_int32),
                 ("mask_out", c_u8p), ("n_out", C.c_int32),
                 ("w", c_f32p * 3), ("bias", c_f32p * 3), ("gamma", c_f32p * 3), ("beta", c_f32p * 3),
-                ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3)]
+                ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3), ("out_pair", C.c_int32 * 3)]
 
 
 _SIGNATURES = {
@@ -46,16 +47,16 @@ _SIGNATURES = {
     "vrd_prof_reset": (C.c_int, []),
     "vrd_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
-    "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_layernorm": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int,
-                                c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+                                c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_dwconv_ln": (C.c_int, [C.POINTER(DwconvLnArgs), C.c_void_p]),
     "vrd_local_attn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 c_f32p, C.c_int64, C.c_void_p]),
+                                 c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_attention": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
-                                C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+                                C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_maxpool_mask": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p, C.c_int64, c_u8p,
                                    C.c_void_p]),
     "vrd_mask_head": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -64,7 +65,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryError(RuntimeError):

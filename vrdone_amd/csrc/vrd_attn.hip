@@ -26,14 +26,14 @@ template <int W, int GROUP>
 __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int64_t ld,
                                                          const uint8_t* __restrict__ mask, int B, int T, float scale,
-                                                         float* __restrict__ out, int64_t ldo) {
+                                                         float* __restrict__ out, int64_t ldo, int pair) {
     constexpr int HW = W / 2;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)B * T) return;
     const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
     float* o = out + row * ldo + lane * 8;
-    if (!mask[row]) {      // masked query rows are zeroed after the softmax (blocks.py:977-978)
+    if (!mask[row]) {      // masked query rows are zeroed after the softmax (blocks.py:977-978); 0 is 0 in pair rows too
         st4(o, make_float4(0.f, 0.f, 0.f, 0.f));
         st4(o + 4, make_float4(0.f, 0.f, 0.f, 0.f));
         return;
@@ -69,8 +69,13 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
         a0.x += pj * v0.x; a0.y += pj * v0.y; a0.z += pj * v0.z; a0.w += pj * v0.w;
         a1.x += pj * v1.x; a1.y += pj * v1.y; a1.z += pj * v1.z; a1.w += pj * v1.w;
     }
-    st4(o, a0);
-    st4(o + 4, a1);
+    if (pair) {
+        vrd::store_pair4(out + row * ldo, lane * 8, 512, a0);
+        vrd::store_pair4(out + row * ldo, lane * 8 + 4, 512, a1);
+    } else {
+        st4(o, a0);
+        st4(o + 4, a1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -146,7 +151,8 @@ template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_flash_kernel(const float* __restrict__ q, int64_t ldq,
                                                              const float* __restrict__ k, const float* __restrict__ v,
                                                              int64_t ldkv, const uint8_t* __restrict__ kv_mask, int Tq,
-                                                             int Tk, float scale, float* __restrict__ out, int64_t ldo) {
+                                                             int Tk, float scale, float* __restrict__ out, int64_t ldo,
+                                                             int pair) {
     constexpr int NT = NW * 64;
     constexpr int KP = HD + 1;                    // K tile pitch: conflict-free b32 fragment reads
     constexpr int PIECES = 32 * HD / 4;           // float4 pieces per 32-key tile
@@ -279,14 +285,18 @@ __global__ __launch_bounds__(NW * 64) void attn_flash_kernel(const float* __rest
     const float inv = 1.0f / l_tot;
     const int tq = q0 + li;
     if (tq < Tq) {
-        float* orow = out + ((int64_t)b * Tq + tq) * ldo + h * HD;
+        float* orow = out + ((int64_t)b * Tq + tq) * ldo;
+        const int width = gridDim.y * HD;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 // registers 4g..4g+3 are d = 32*d + 8g + 4*lh + 0..3
-                st4(orow + 32 * d + 8 * g + 4 * lh,
-                    make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv));
+                const int c = h * HD + 32 * d + 8 * g + 4 * lh;
+                const float4 v = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv,
+                                             oacc[d][4 * g + 3] * inv);
+                if (pair) vrd::store_pair4(orow, c, width, v);
+                else st4(orow + c, v);
             }
     }
 }
@@ -298,7 +308,7 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 extern "C" {
 
 int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, const uint8_t* mask, int B, int T, int C,
-                   int n_head, int half_win, float* out, int64_t ldo, void* stream) {
+                   int n_head, int half_win, float* out, int64_t ldo, int out_pair, void* stream) {
     VRD_CHECK_ARG(q && k && v && mask && out, "vrd_local_attn: null pointer");
     VRD_CHECK_ARG(C == 512, "vrd_local_attn: built for C = 512 (got %d)", C);
     VRD_CHECK_ARG(n_head == 4 || n_head == 8, "vrd_local_attn: n_head must be 4 or 8 (got %d)", n_head);
@@ -311,7 +321,7 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
     vrd::ProfScope prof(VRD_K_LOCAL_ATTN, s, 4.0 * (double)rows * W * C, 16.0 * (double)rows * C);
     const float scale = 1.0f / sqrtf((float)(C / n_head));
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define VRD_LA(Wn, G) hipLaunchKernelGGL((local_attn_kernel<Wn, G>), grid, block, 0, s, q, k, v, ld, mask, B, T, scale, out, ldo)
+#define VRD_LA(Wn, G) hipLaunchKernelGGL((local_attn_kernel<Wn, G>), grid, block, 0, s, q, k, v, ld, mask, B, T, scale, out, ldo, out_pair)
     if (half_win == 3 && n_head == 4) VRD_LA(7, 16);
     else if (half_win == 3) VRD_LA(7, 8);
     else if (n_head == 4) VRD_LA(9, 16);
@@ -322,7 +332,8 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
 }
 
 int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask,
-                  int B, int Tq, int Tk, int n_head, int head_dim, float* out, int64_t ldo, int algo, void* stream) {
+                  int B, int Tq, int Tk, int n_head, int head_dim, float* out, int64_t ldo, int algo, int out_pair,
+                  void* stream) {
     VRD_CHECK_ARG(q && k && v && out, "vrd_attention: null pointer");
     VRD_CHECK_ARG(B > 0 && B <= 65535 && Tq > 0 && Tk > 0 && n_head > 0 && n_head <= 65535, "vrd_attention: bad sizes");
     VRD_CHECK_ARG(head_dim % 4 == 0 && head_dim <= SM_MAX_HD, "vrd_attention: head_dim must be a multiple of 4, <= %d", SM_MAX_HD);
@@ -333,6 +344,7 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
     const bool flash_ok = head_dim == 64 || head_dim == 128;
     if (algo == 0) algo = (flash_ok && Tq >= 32) ? 2 : 1;
     VRD_CHECK_ARG(algo != 2 || flash_ok, "vrd_attention: flash kernel needs head_dim 64 or 128");
+    VRD_CHECK_ARG(!out_pair || algo == 2, "vrd_attention: pair output is only built for the flash kernel");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float scale = 1.0f / sqrtf((float)head_dim);
     const double flops = 4.0 * B * (double)n_head * Tq * Tk * head_dim;
@@ -351,7 +363,7 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
         const int waste3 = ((tiles + 2) / 3) * 3 - tiles, waste4 = ((tiles + 3) / 4) * 4 - tiles;
         const int nw = (waste3 < waste4) ? 3 : 4;
         dim3 grid((tiles + nw - 1) / nw, n_head, B);
-#define VRD_FA(HD, NW) hipLaunchKernelGGL((attn_flash_kernel<HD, NW>), grid, dim3(NW * 64), 0, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk, scale, out, ldo)
+#define VRD_FA(HD, NW) hipLaunchKernelGGL((attn_flash_kernel<HD, NW>), grid, dim3(NW * 64), 0, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk, scale, out, ldo, out_pair)
         if (head_dim == 128 && nw == 3) VRD_FA(128, 3);
         else if (head_dim == 128) VRD_FA(128, 4);
         else if (nw == 3) VRD_FA(64, 3);

@@ -44,6 +44,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// "Pair" rows (GEMM-input format of the bf16x3 mode): a row of W logical channels stored in the 4*W bytes
+// an f32 row would occupy as [W x bf16 hi | W x bf16 lo] with hi = bf16(x), lo = bf16(x - hi).  Producers
+// whose output is consumed only as a GEMM operand write this directly, so the GEMM stages pure bf16.
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+__device__ __forceinline__ void store_pair4(float* row, int c, int W, float4 v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    bf16x4_t h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (__bf16)x[j];
+        l[j] = (__bf16)(x[j] - (float)h[j]);
+    }
+    __bf16* r = reinterpret_cast<__bf16*>(row);
+    *reinterpret_cast<bf16x4_t*>(r + c) = h;
+    *reinterpret_cast<bf16x4_t*>(r + W + c) = l;
+}
+
+__device__ __forceinline__ void store_pair1(float* row, int c, int W, float x) {
+    __bf16* r = reinterpret_cast<__bf16*>(row);
+    const __bf16 h = (__bf16)x;
+    r[c] = h;
+    r[W + c] = (__bf16)(x - (float)h);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -218,6 +218,12 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     VRD_CHECK_ARG(a->act >= 0 && a->act <= 2, "vrd_gemm: bad activation %d", a->act);
     VRD_CHECK_ARG(!a->res || a->ldres >= a->N, "vrd_gemm: ldres too small");
     VRD_CHECK_ARG(!a->res2 || a->ldres2 >= a->N, "vrd_gemm: ldres2 too small");
+    VRD_CHECK_ARG(!a->c_pair || (a->N % 8 == 0 && a->ldc % 4 == 0 && aligned16(a->C)),
+                  "vrd_gemm: pair output needs N %% 8 == 0 and 16-byte aligned rows");
+    VRD_CHECK_ARG(a->a_pair_width == 0 || (a->W_split && a->a_pair_width % 8 == 0 && a->Cin % a->a_pair_width == 0 &&
+                                           a->Cin % 8 == 0 && (a->Cin * a->taps) % 32 == 0 && a->lda % 4 == 0 &&
+                                           aligned16(a->A) && aligned16(a->W_split)),
+                  "vrd_gemm: pair-row A needs W_split, K %% 32 == 0 and Cin a multiple of the pair width");
     if (a->M == 0) return 0;
     const int64_t tiles_m64 = (a->M + BM - 1) / BM;
     const int tiles_n = (a->N + BN - 1) / BN;
@@ -234,7 +240,7 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     const double flops = 2.0 * (double)a->M * a->N * K;
     const double bytes = 4.0 * ((double)a->M * a->Cin + (double)a->N * K + (double)a->M * a->N *
                                 (1.0 + (a->res ? 1.0 : 0.0) + (a->res2 ? 1.0 : 0.0)));
-    const bool x3 = a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split);
+    const bool x3 = a->a_pair_width > 0 || (a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split));
     vrd::ProfScope prof(x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM, s, flops, bytes);
     if (x3) {
         int rc3 = vrd::launch_gemm_bf16x3(*a, staged, s);

@@ -74,7 +74,9 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = epilogue_value(p, v[c], mk, scale[c], r1[c], rmk, r2[c]);
                 float* crow = p.C + m * p.ldc + n;
-                if (nfull) {
+                if (p.c_pair) {          // pair rows of width N (host checks N % 8 == 0, so a float4 group is whole)
+                    store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[0], v[1], v[2], v[3]));
+                } else if (nfull) {
                     *reinterpret_cast<float4*>(crow) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
@@ -101,7 +103,9 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
                 const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
                 const float r1 = p.res ? p.res[m * p.ldres + n] : 0.f;
                 const float r2 = p.res2 ? p.res2[m * p.ldres2 + n] : 0.f;
-                p.C[m * p.ldc + n] = epilogue_value(p, acc[mi][nj][e] + bias, mk, scale, r1, p.res_masked ? mk : 1.f, r2);
+                const float v = epilogue_value(p, acc[mi][nj][e] + bias, mk, scale, r1, p.res_masked ? mk : 1.f, r2);
+                if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v);
+                else p.C[m * p.ldc + n] = v;
             }
         }
     }

@@ -5,14 +5,17 @@
 //     a * w  ~=  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi                          (drops a_lo*w_lo ~ 2^-18 |a w|)
 //
 // Each bf16 x bf16 product is exact in the f32 accumulator, so the result carries ~17 significand bits
-// per product (relative error ~1e-5 per GEMM) at 3/16 of the f32-MFMA instruction time.  Activations stay
-// fp32 in HBM and are split while being staged into LDS; weights are split once on the host side of the
-// ABI (W_split = [hi | lo], each N x K bf16).
+// per product (relative error ~1e-5 per GEMM) at 3/16 of the f32-MFMA instruction time.  Weights are
+// split once on the host side of the ABI (W_split = [hi | lo], each N x K bf16).  Activations come either
+// as f32 rows, split while being staged into LDS, or (APAIR) as "pair" rows already holding [hi | lo]
+// bf16 planes written by the producing kernel, staged as plain 16-byte copies.
 //
 // Tiling: 128 x 128 x 32 per 256-thread workgroup, four waves x (2 x 2) accumulators of 32 x 32, operand
 // tiles [row][k] in bf16 with an 80-byte row pitch (16 consecutive rows hit 16 distinct 16-byte LDS slots,
-// so the ds_read_b128 fragment reads are conflict free).  One LDS buffer + register prefetch of the next
-// K step (two barriers per step); 40 KiB of LDS and <= 128 VGPRs keep 3-4 workgroups per CU resident.
+// so the ds_read_b128 fragment reads are conflict free).  Two LDS buffers (80 KiB, two workgroups per CU)
+// and a register prefetch two K steps ahead: while the MFMAs of step t run, the registers holding step
+// t+1 are split and written to the other buffer and the global loads of step t+2 are issued; one barrier
+// per step.
 #include "vrd_common.h"
 #include "vrd_gemm_epilogue.h"
 
@@ -25,15 +28,12 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int XP = 40;                                   // row pitch in bf16 elements (80 B)
 constexpr int TILE = BM * XP;                            // elements per operand tile
-constexpr size_t X3_LDS = 4 * TILE * sizeof(__bf16);     // a_hi, a_lo, w_hi, w_lo = 40960 B
+constexpr size_t X3_LDS = 2 * 4 * TILE * sizeof(__bf16); // 2 buffers x (a_hi, a_lo, w_hi, w_lo) = 81920 B
 
-template <int TAPS, bool STAGED>
+template <int TAPS, bool STAGED, bool APAIR>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* a_hi = reinterpret_cast<__bf16*>(smem);
-    __bf16* a_lo = a_hi + TILE;
-    __bf16* w_hi = a_lo + TILE;
-    __bf16* w_lo = w_hi + TILE;
+    __bf16* const lds = reinterpret_cast<__bf16*>(smem);      // buffer b: lds + b*4*TILE; tiles a_hi, a_lo, w_hi, w_lo
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -60,10 +60,40 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
         const int64_t r = m0 + ((tid + 256 * i) >> 3);
         st[i] = (TAPS == 3 && r < p.M) ? (int)(r % p.T) : 0;
     }
-    float4 ra[4];
+    float4 ra[4];                   // f32 A pieces (APAIR: reinterpreted as hi[2] | lo[2] 16-byte pieces)
     uint4 rwh[2], rwl[2];
 
     auto fetch = [&](int kt) {
+        if (APAIR) {
+            // piece i = (row = (tid + 256 i) / 4, 8 consecutive k): one 16-byte load from each plane
+            const int PW = p.a_pair_width;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = tid + 256 * i;
+                const int64_t r = m0 + (f >> 2);
+                const int k = kt * BK + (f & 3) * 8;
+                uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+                if (r < p.M) {
+                    int tap = 0, ci = k;
+                    bool ok = true;
+                    if (TAPS == 3) {
+                        tap = (k >= p.Cin) + (k >= 2 * p.Cin);
+                        ci = k - tap * p.Cin;
+                        const int tt = (int)(r % p.T) + tap - 1;
+                        ok = tt >= 0 && tt < p.T;
+                    }
+                    if (ok) {
+                        const int slab = ci / PW, j = ci - slab * PW;
+                        const __bf16* row = reinterpret_cast<const __bf16*>(p.A + (r + tap - (TAPS == 3 ? 1 : 0)) * p.lda) +
+                                            2 * slab * PW + j;
+                        h = *reinterpret_cast<const uint4*>(row);
+                        l = *reinterpret_cast<const uint4*>(row + PW);
+                    }
+                }
+                ra[i] = *reinterpret_cast<float4*>(&h);
+                ra[2 + i] = *reinterpret_cast<float4*>(&l);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i;
@@ -97,7 +127,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             rwl[i] = l;
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int buf) {
+        __bf16* a_hi = lds + buf * 4 * TILE;
+        __bf16* a_lo = a_hi + TILE;
+        __bf16* w_hi = a_lo + TILE;
+        __bf16* w_lo = w_hi + TILE;
+        if (APAIR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = tid + 256 * i;
+                const int off = (f >> 2) * XP + (f & 3) * 8;
+                *reinterpret_cast<float4*>(a_hi + off) = ra[i];
+                *reinterpret_cast<float4*>(a_lo + off) = ra[2 + i];
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i;
@@ -130,11 +173,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     fetch(0);
-    stage();
+    stage(0);
+    if (nkt > 1) fetch(1);
     __syncthreads();
     const int arow = (wm * 64 + li) * XP + 8 * lh, wrow = (wn * 64 + li) * XP + 8 * lh;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) fetch(kt + 1);
+        const int cur = kt & 1;
+        const __bf16* a_hi = lds + cur * 4 * TILE;
+        const __bf16* a_lo = a_hi + TILE;
+        const __bf16* w_hi = a_lo + TILE;
+        const __bf16* w_lo = w_hi + TILE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 ah[2], al[2], wh[2], wl[2];
@@ -153,9 +201,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
                 }
+            if (s == 0 && kt + 1 < nkt) {
+                // the registers hold step kt+1 (loaded one iteration ago): split + write them into the
+                // other buffer under this step's MFMAs, then reuse them for the loads of step kt+2
+                stage(cur ^ 1);
+                if (kt + 2 < nkt) fetch(kt + 2);
+            }
         }
-        __syncthreads();
-        if (kt + 1 < nkt) stage();
         __syncthreads();
     }
     vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
@@ -166,17 +218,33 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
 namespace vrd {
 
 // called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
+template <int TAPS, bool STAGED, bool APAIR>
+static int launch_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t s) {
+    auto kern = gemm_bf16x3_kernel<TAPS, STAGED, APAIR>;
+    static bool reserved = false;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS);
+        if (e != hipSuccess) {
+            set_error("vrd_gemm(bf16x3): cannot reserve %zu B of LDS: %s", X3_LDS, hipGetErrorString(e));
+            return -2;
+        }
+        reserved = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), X3_LDS, s, a, tiles_m, tiles_n);
+    return 0;
+}
+
+template <int TAPS>
+static int launch_taps(const vrd_gemm_args& a, bool staged, int tiles_m, int tiles_n, hipStream_t s) {
+    const bool apair = a.a_pair_width > 0;
+    if (staged) return apair ? launch_one<TAPS, true, true>(a, tiles_m, tiles_n, s) : launch_one<TAPS, true, false>(a, tiles_m, tiles_n, s);
+    return apair ? launch_one<TAPS, false, true>(a, tiles_m, tiles_n, s) : launch_one<TAPS, false, false>(a, tiles_m, tiles_n, s);
+}
+
+// called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
 int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s) {
     const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (a.N + BN - 1) / BN;
-    dim3 grid(tiles_m * tiles_n), block(256);
-    if (a.taps == 1) {
-        if (staged) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, true>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
-        else        hipLaunchKernelGGL((gemm_bf16x3_kernel<1, false>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
-    } else {
-        if (staged) hipLaunchKernelGGL((gemm_bf16x3_kernel<3, true>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
-        else        hipLaunchKernelGGL((gemm_bf16x3_kernel<3, false>), grid, block, X3_LDS, s, a, tiles_m, tiles_n);
-    }
-    return 0;
+    return a.taps == 1 ? launch_taps<1>(a, staged, tiles_m, tiles_n, s) : launch_taps<3>(a, staged, tiles_m, tiles_n, s);
 }
 
 }  // namespace vrd

@@ -20,7 +20,7 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // (B, C_total, T) slab -> channels-last rows, 64 x 64 tiles through LDS
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict__ src, int C_total, int T, int c0,
-                                                         int count, float* __restrict__ dst, int64_t ld_dst) {
+                                                         int count, float* __restrict__ dst, int64_t ld_dst, int pair) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict
         tile[c][tx] = (ct + c < count && tt + tx < T) ? s[(int64_t)(ct + c) * T + tt + tx] : 0.f;
     __syncthreads();
     for (int t = ty; t < 64; t += 4)
-        if (tt + t < T && ct + tx < count) dst[((int64_t)b * T + tt + t) * ld_dst + ct + tx] = tile[tx][t];
+        if (tt + t < T && ct + tx < count) {
+            float* row = dst + ((int64_t)b * T + tt + t) * ld_dst;
+            if (pair) vrd::store_pair1(row, ct + tx, count, tile[tx][t]);
+            else row[ct + tx] = tile[tx][t];
+        }
 }
 
 __global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict__ src, int64_t ld_src, int C, int T,
@@ -79,7 +83,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                         int64_t ldy, int64_t rows, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int relu,
-                                                        const float* __restrict__ post_add, int64_t ld_add, int period) {
+                                                        const float* __restrict__ post_add, int64_t ld_add, int period,
+                                                        int pair) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -93,7 +98,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         for (int i = 0; i < NV; ++i) v[i] = f4add(v[i], ld4(a + i * 256 + lane * 4));
     }
 #pragma unroll
-    for (int i = 0; i < NV; ++i) st4(y + row * ldy + i * 256 + lane * 4, v[i]);
+    for (int i = 0; i < NV; ++i) {
+        if (pair) vrd::store_pair4(y + row * ldy, i * 256 + lane * 4, 256 * NV, v[i]);
+        else st4(y + row * ldy + i * 256 + lane * 4, v[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -177,7 +185,10 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             }
         }
 #pragma unroll
-        for (int i = 0; i < NV; ++i) st4(p.y[o] + row * p.ldy[o] + i * 256 + lane * 4, acc[i]);
+        for (int i = 0; i < NV; ++i) {
+            if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], i * 256 + lane * 4, 256 * NV, acc[i]);
+            else st4(p.y[o] + row * p.ldy[o] + i * 256 + lane * 4, acc[i]);
+        }
     }
 }
 
@@ -249,7 +260,7 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 extern "C" {
 
 int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count, float* dst, int64_t ld_dst,
-                   void* stream) {
+                   int out_pair, void* stream) {
     VRD_CHECK_ARG(src && dst, "vrd_bct_to_btc: null pointer");
     VRD_CHECK_ARG(B > 0 && T > 0 && count > 0 && c0 >= 0 && c0 + count <= C_total && ld_dst >= count,
                   "vrd_bct_to_btc: bad slab c0=%d count=%d C=%d ld=%lld", c0, count, C_total, (long long)ld_dst);
@@ -257,7 +268,8 @@ int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int coun
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * B * (double)count * T);
     dim3 grid((T + 63) / 64, (count + 63) / 64, B);
-    hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst);
+    VRD_CHECK_ARG(!out_pair || (count % 8 == 0 && ld_dst % 4 == 0 && aligned16(dst)), "vrd_bct_to_btc: pair rows need count %% 8 == 0");
+    hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
     VRD_LAUNCH_CHECK();
     return 0;
 }
@@ -274,7 +286,8 @@ int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float*
 }
 
 int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, const float* gamma,
-                  const float* beta, int relu, const float* post_add, int64_t ld_add, int add_period, void* stream) {
+                  const float* beta, int relu, const float* post_add, int64_t ld_add, int add_period, int out_pair,
+                  void* stream) {
     VRD_CHECK_ARG(x && y && gamma && beta, "vrd_layernorm: null pointer");
     VRD_CHECK_ARG(C == 256 || C == 512, "vrd_layernorm: C must be 256 or 512 (got %d)", C);
     VRD_CHECK_ARG(ldx >= C && ldy >= C && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y) &&
@@ -286,9 +299,9 @@ int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t ro
     vrd::ProfScope prof(VRD_K_LAYERNORM, s, 0.0, 8.0 * (double)rows * C);
     dim3 grid((unsigned)((rows + 3) / 4));
     if (C == 256)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair);
     else
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair);
     VRD_LAUNCH_CHECK();
     return 0;
 }

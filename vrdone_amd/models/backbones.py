@@ -82,14 +82,20 @@ class MaskConvTransformerBackbone(nn.Module):
         [c0, c0+width) and [c0+width, c0+2*width) of x (B, C, T); result into `out` (2B, T, D)."""
         ops = _ops()
         B, _, T = x.shape
+        # every tensor here is consumed by a GEMM only: pair rows in bf16x3 mode (3*width must be a
+        # multiple of 32 for the split-precision kernel; the 8-channel box features stay f32)
+        pair = ops.pair_mode()
+        pair_in = pair and (3 * width) % 32 == 0 and width % 8 == 0
         h = torch.empty(2, B, T, width, device=x.device, dtype=torch.float32)
-        ops.bct_to_btc(x, c0, width, h[0])
-        ops.bct_to_btc(x, c0 + width, width, h[1])
+        ops.bct_to_btc(x, c0, width, h[0], pair=pair_in)
+        ops.bct_to_btc(x, c0 + width, width, h[1], pair=pair_in)
         h = h.view(2 * B, T, width)
+        if pair_in:
+            h = ops.Pair(h, width)
         last = len(convs) - 1
         for i, (conv, norm) in enumerate(zip(convs, norms)):
             h = ops.conv_gemm(h, conv.conv.weight, conv.conv.bias, row_mask=mask2)
-            h = norm.cl(h, relu=True, out=out if i == last else None)
+            h = norm.cl(h, relu=True, out=out if i == last else None, pair=pair)
         return h
 
     def cl(self, x, mask):
@@ -105,18 +111,22 @@ class MaskConvTransformerBackbone(nn.Module):
         mask2 = torch.cat([mask, mask], dim=0)
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
 
+        # concatenation buffers hold two D-wide slabs; in bf16x3 mode both slabs are pair rows (width D)
+        pair = ops.pair_mode()
+        cat = (lambda t: ops.Pair(t, D)) if pair else (lambda t: t)          # noqa: E731
+
         # [visual (+clip) | entity box] -> visual_bbox_fuse
         fuse_in = new(2 * B, T, 2 * D)
         if Cc:
             vc = new(2 * B, T, 2 * D)
             self._embed_into(x, 0, V, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
             self._embed_into(x, 2 * V, Cc, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
-            self.visual_clip_fuse.cl(vc, row_mask=mask2, out=fuse_in[..., :D])
+            self.visual_clip_fuse.cl(cat(vc), row_mask=mask2, out=fuse_in[..., :D], out_pair=pair)
         else:
             self._embed_into(x, 0, V, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
         o0 = 2 * V + 2 * Cc
         self._embed_into(x, o0 + S, E, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
-        so = self.visual_bbox_fuse.cl(fuse_in, row_mask=mask2)              # (2B, T, D): subject rows then object rows
+        so = self.visual_bbox_fuse.cl(cat(fuse_in), row_mask=mask2)         # (2B, T, D): subject rows then object rows
 
         for stem, s_attn, o_attn in zip(self.stem, self.s_attn, self.o_attn):
             so, _ = stem.cl(so, mask2)
@@ -126,16 +136,16 @@ class MaskConvTransformerBackbone(nn.Module):
             o_attn.cl(o, s, mask, mask, stream_add=o, out=nxt[B:])         # uses the pre-update s
             so = nxt
 
-        pair_in = new(B, T, 2 * D)
-        self.s_fuse_norm.cl(so[:B], out=pair_in[..., :D])
-        self.o_fuse_norm.cl(so[B:], out=pair_in[..., D:])
-        pair_box = new(B, T, 2 * D)
-        self.so_fuse.cl(pair_in, row_mask=mask, out=pair_box[..., :D])
+        so_in = new(B, T, 2 * D)
+        self.s_fuse_norm.cl(so[:B], out=so_in[..., :D], pair=pair)
+        self.o_fuse_norm.cl(so[B:], out=so_in[..., D:], pair=pair)
+        so_box = new(B, T, 2 * D)
+        self.so_fuse.cl(cat(so_in), row_mask=mask, out=so_box[..., :D], out_pair=pair)
         box = new(B, T, S)
         ops.bct_to_btc(x, o0, S, box)
         conv = self.bbox_so_embd.conv
-        ops.conv_gemm(box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:])
-        e = self.so_visual_bbox_fuse.cl(pair_box, row_mask=mask)
+        ops.conv_gemm(box, conv.weight, conv.bias, row_mask=mask, out=so_box[..., D:], out_pair=pair)
+        e = self.so_visual_bbox_fuse.cl(cat(so_box), row_mask=mask)
 
         feats, masks = [e], [mask]
         for blk in self.branch:

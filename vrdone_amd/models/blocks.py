@@ -89,8 +89,9 @@ class LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(1, num_channels, 1, **kw))
         self.bias = nn.Parameter(torch.zeros(1, num_channels, 1, **kw))
 
-    def cl(self, x, relu=False, post_add=None, out=None):
-        return _ops().layernorm(x, self.weight, self.bias, relu=relu, post_add=post_add, out=out)
+    def cl(self, x, relu=False, post_add=None, out=None, pair=False):
+        """pair=True: emit GEMM-operand pair rows (only when the sole consumer is a conv GEMM)."""
+        return _ops().layernorm(x, self.weight, self.bias, relu=relu, post_add=post_add, out=out, pair=pair)
 
     def forward(self, x):
         _no_autograd(self)
@@ -112,14 +113,15 @@ class ConvMLP(nn.Module):
             if layer.bias is not None:
                 nn.init.zeros_(layer.bias)
 
-    def cl(self, x, row_mask=None, out=None):
+    def cl(self, x, row_mask=None, out=None, out_pair=False):
+        """x: tensor or ops.Pair.  Hidden activations only feed the next GEMM, so they travel as pair rows."""
         ops = _ops()
         last = self.num_layers - 1
         for i, layer in enumerate(self.layers):
             if i < last:
-                x = ops.conv_gemm(x, layer.weight, layer.bias, act=ops.ACT_GELU)
+                x = ops.conv_gemm(x, layer.weight, layer.bias, act=ops.ACT_GELU, out_pair=ops.pair_mode())
             else:
-                x = ops.conv_gemm(x, layer.weight, layer.bias, row_mask=row_mask, out=out)
+                x = ops.conv_gemm(x, layer.weight, layer.bias, row_mask=row_mask, out=out, out_pair=out_pair)
         return x
 
     def forward(self, x):
@@ -174,7 +176,8 @@ class _ConvAttention(nn.Module):
 
     def _branch_set(self, name):
         conv, norm = getattr(self, f"{name}_conv"), getattr(self, f"{name}_norm")
-        return dict(weight=conv.conv.weight, gamma=norm.weight, beta=norm.bias)
+        # the branch output feeds only its 1x1 projection GEMM
+        return dict(weight=conv.conv.weight, gamma=norm.weight, beta=norm.bias, pair=_ops().pair_mode())
 
     def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1):
         """dwconv * mask -> LN for the three branches, sharing kernel launches when inputs coincide."""
@@ -226,7 +229,7 @@ class LocalMaskedMHCA(_ConvAttention):
         assert (x.shape[1] // s) % (2 * self.window_overlap) == 0      # reference blocks.py:828
         q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s)
         q, k, v = self._project(q, k, v)
-        att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap)
+        att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap, pair=ops.pair_mode())
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
 
     def forward(self, x, mask):
@@ -307,8 +310,8 @@ class TransformerBlock(nn.Module):
         else:
             skip, m_out = x, mask
         y, _ = self.attn.cl(h, mask, m_out, scale=self._scale(self.drop_path_attn), res=skip, res_masked=True)
-        h = self.ln2.cl(y)
-        h = ops.conv_gemm(h, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU)
+        h = self.ln2.cl(y, pair=ops.pair_mode())
+        h = ops.conv_gemm(h, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU, out_pair=ops.pair_mode())
         y = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=m_out,
                           scale=self._scale(self.drop_path_mlp), res=y, out=out)
         return y, m_out

@@ -42,7 +42,8 @@ class FPN1D_Fuse(nn.Module):
         ops = _ops()
         y = None
         for l in range(len(self.lateral_convs) - 1, -1, -1):
-            x = self.input_norms[l].cl(feats[l])
+            # below the top level the normalised input feeds only the lateral 1x1 GEMM
+            x = self.input_norms[l].cl(feats[l], pair=ops.pair_mode() and self.lateral_convs[l] is not None)
             fpn = dict(weight=self.fpn_convs[l].conv.weight, gamma=self.fpn_norms[l].weight, beta=self.fpn_norms[l].bias)
             if self.lateral_convs[l] is None:
                 y, = ops.dwconv_ln(x, [fpn], mask_out=masks[l])

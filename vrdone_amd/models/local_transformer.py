@@ -43,10 +43,10 @@ class MaskedMHCA_QKV(_ConvAttention):
         q, k, v = self._prep(q_in, k_in, v_in, q_mask, kv_mask)
         q, k, v = self._project(q, k, v)
         if self._half_win is None:
-            att = ops.attention(q, k, v, kv_mask, self.n_head)
+            att = ops.attention(q, k, v, kv_mask, self.n_head, pair=ops.pair_mode())
         else:
             assert q.shape[1] == k.shape[1]
-            att = ops.local_attention(q, k, v, kv_mask, self.n_head, self._half_win)
+            att = ops.local_attention(q, k, v, kv_mask, self.n_head, self._half_win, pair=ops.pair_mode())
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=q_mask, **epilogue), q_mask
 
     def forward(self, q, k, v, _qx_mask, _kv_mask, _attn_mask=None):

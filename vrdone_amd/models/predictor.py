@@ -43,7 +43,7 @@ class MaskedTransformerPredictor(nn.Module):
         ops = _ops()
         if with_aux is None:
             with_aux = self.aux_loss
-        src = self.input_norm.cl(x)
+        src = self.input_norm.cl(x, pair=ops.pair_mode() and self.input_proj is not None)
         if self.input_proj is not None:
             src = ops.conv_gemm(src, self.input_proj.weight, self.input_proj.bias, row_mask=mask)
         hs = self.transformer.cl(src, mask, self.query_embed.weight, all_layers=with_aux and self.aux_loss)

@@ -44,6 +44,40 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+class Pair:
+    """A channels-last tensor stored in the GEMM-operand "pair" format of the bf16x3 mode: the 4*W bytes of
+    each W-channel slab of a row hold [W x bf16 hi | W x bf16 lo] (hi = bf16(x), lo = bf16(x - hi)) instead
+    of W floats.  `t` is the f32-typed buffer (same shape / strides as the f32 tensor would have), `width`
+    the slab width W the producers used.  Only conv_gemm() consumes a Pair."""
+    __slots__ = ("t", "width")
+
+    def __init__(self, t, width):
+        self.t, self.width = t, width
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def __getitem__(self, idx):      # batch slicing (rows) keeps the format
+        return Pair(self.t[idx], self.width)
+
+    def float(self):
+        """Decode to f32 (hi + lo); for tests."""
+        W = self.width
+        raw = self.t.contiguous().view(torch.bfloat16)                 # (..., 2*C)
+        slabs = raw.reshape(*raw.shape[:-1], -1, 2, W).float()
+        return (slabs[..., 0, :] + slabs[..., 1, :]).reshape(*self.t.shape)
+
+
+def pair_mode():
+    """True when producers should emit pair rows for GEMM-only consumers (bf16x3 precision)."""
+    return _precision == "bf16x3"
+
+
+def _unwrap(x):
+    return (x.t, x.width) if isinstance(x, Pair) else (x, 0)
+
+
 def _mask_ptr(m, rows):
     if m is None:
         return None
@@ -105,14 +139,14 @@ def split_conv_weight(w):
     return _cached(w, "_vrd_split", build)
 
 
-def bct_to_btc(x, c0, count, out):
+def bct_to_btc(x, c0, count, out, pair=False):
     """channels [c0, c0+count) of x (B, C, T) -> out (B, T, count-wide slab)."""
     B, Ct, T = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
     p, rows, cols, ld = _rows(out)
     assert rows == B * T and cols == count
-    _hip.check(lib.vrd_bct_to_btc(x.data_ptr(), B, Ct, T, c0, count, p, ld, _stream()), "vrd_bct_to_btc")
-    return out
+    _hip.check(lib.vrd_bct_to_btc(x.data_ptr(), B, Ct, T, c0, count, p, ld, 1 if pair else 0, _stream()), "vrd_bct_to_btc")
+    return Pair(out, count) if pair else out
 
 
 def btc_to_bct(x):
@@ -132,10 +166,12 @@ def to_channels_last(x):
 
 
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
-              res2=None, out=None):
+              res2=None, out=None, out_pair=False):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
-    vrd_gemm.  x: (B, T, Cin); weight: the Conv1d parameter (N, Cin, k)."""
+    vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
+    out_pair: write the result as pair rows of width N (returns a Pair)."""
     N, Cin, k = weight.shape
+    x, a_width = _unwrap(x)
     pa, rows, cols, lda = _rows(x)
     assert cols == Cin, f"input has {cols} channels, weight expects {Cin}"
     T = x.shape[-2]
@@ -151,8 +187,12 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     a.act = act
     a.row_mask = _mask_ptr(row_mask, rows)
     a.scale = _ptr(scale)
+    if a_width:
+        assert _precision == "bf16x3" and (Cin * k) % 32 == 0 and Cin % a_width == 0, "pair input needs an eligible bf16x3 GEMM"
     if _precision == "bf16x3" and (Cin * k) % 32 == 0:
         a.W_split = split_conv_weight(weight).data_ptr()
+    a.a_pair_width = a_width
+    a.c_pair = 1 if out_pair else 0
     if res is not None:
         pr, rr, rc, ldr = _rows(res)
         assert rr == rows and rc == N
@@ -162,12 +202,12 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
         assert rr == rows and rc == N
         a.res2, a.ldres2 = pr, ldr
     _hip.check(lib.vrd_gemm(C.byref(a), _stream()), "vrd_gemm")
-    return out
+    return Pair(out, N) if out_pair else out
 
 
-def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None):
+def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False):
     """Channel LayerNorm.  post_add: (period, C) rows added after the affine, row r gets
-    post_add[r % period]."""
+    post_add[r % period].  pair: write pair rows (returns a Pair)."""
     px, rows, cols, ldx = _rows(x)
     if out is None:
         out = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
@@ -178,8 +218,8 @@ def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None):
         pa, period, ca, lda = _rows(post_add)
         assert ca == cols
     _hip.check(lib.vrd_layernorm(px, ldx, py, ldy, rows, cols, gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0,
-                                 pa, lda, period, _stream()), "vrd_layernorm")
-    return out
+                                 pa, lda, period, 1 if pair else 0, _stream()), "vrd_layernorm")
+    return Pair(out, cols) if pair else out
 
 
 def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None):
@@ -213,12 +253,13 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None):
         a.gamma[i], a.beta[i] = _ptr(s.get("gamma")), _ptr(s.get("beta"))
         a.relu[i] = 1 if s.get("relu") else 0
         a.y[i], a.ldy[i] = po, ldo
-        outs.append(o)
+        a.out_pair[i] = 1 if s.get("pair") else 0
+        outs.append(Pair(o, Cout) if s.get("pair") else o)
     _hip.check(lib.vrd_dwconv_ln(C.byref(a), _stream()), "vrd_dwconv_ln")
     return outs
 
 
-def local_attention(q, k, v, mask, n_head, half_win):
+def local_attention(q, k, v, mask, n_head, half_win, pair=False):
     B, T, Cc = q.shape
     pq, rows, cols, ld = _rows(q)
     pk, _, _, ldk = _rows(k)
@@ -226,12 +267,13 @@ def local_attention(q, k, v, mask, n_head, half_win):
     assert ld == ldk == ldv
     out = torch.empty(B, T, Cc, device=q.device, dtype=torch.float32)
     _hip.check(lib.vrd_local_attn(pq, pk, pv, ld, _mask_ptr(mask, rows), B, T, Cc, n_head, half_win,
-                                  out.data_ptr(), Cc, _stream()), "vrd_local_attn")
-    return out
+                                  out.data_ptr(), Cc, 1 if pair else 0, _stream()), "vrd_local_attn")
+    return Pair(out, Cc) if pair else out
 
 
-def attention(q, k, v, kv_mask, n_head, algo=0):
-    """Global masked attention; q: (B, Tq, C), k/v: (B, Tk, C); kv_mask (B, Tk) or None."""
+def attention(q, k, v, kv_mask, n_head, algo=0, pair=False):
+    """Global masked attention; q: (B, Tq, C), k/v: (B, Tk, C); kv_mask (B, Tk) or None.
+    pair: pair-row output when the flash kernel runs (otherwise a plain tensor is returned)."""
     B, Tq, Cc = q.shape
     Tk = k.shape[1]
     pq, _, _, ldq = _rows(q)
@@ -239,9 +281,12 @@ def attention(q, k, v, kv_mask, n_head, algo=0):
     pv, _, _, ldv = _rows(v)
     assert ldk == ldv
     out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
-    _hip.check(lib.vrd_attention(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), B, Tq, Tk, n_head, Cc // n_head,
-                                 out.data_ptr(), Cc, algo, _stream()), "vrd_attention")
-    return out
+    hd = Cc // n_head
+    flash = algo == 2 or (algo == 0 and hd in (64, 128) and Tq >= 32)      # mirrors vrd_attention's auto choice
+    pair = bool(pair and flash)
+    _hip.check(lib.vrd_attention(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), B, Tq, Tk, n_head, hd,
+                                 out.data_ptr(), Cc, algo, 1 if pair else 0, _stream()), "vrd_attention")
+    return Pair(out, Cc) if pair else out
 
 
 def maxpool_mask(x, mask_in):
