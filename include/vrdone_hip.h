@@ -146,6 +146,12 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
                   const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim,
                   float* out, int64_t ldo, int algo, int out_pair, void* stream);
 
+/* Same attention for pair-row q, k, v (bf16x3 mode; rows of width n_head*head_dim written by the projection
+ * GEMMs with c_pair): both contractions as split-bf16 MFMA products, f32 softmax.  head_dim in {64, 128}. */
+int vrd_attention_pair(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                       const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim,
+                       float* out, int64_t ldo, int out_pair, void* stream);
+
 /* ---- MaxPool1d(3,2,1) skip * mask (models/blocks.py:1040-1046,1074) and mask[::2] ------- */
 int vrd_maxpool_mask(const float* x, int64_t ldx, int B, int Tin, int C, const uint8_t* mask_in,
                      float* y, int64_t ldy, uint8_t* mask_out, void* stream);

@@ -28,6 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=int, default=-1)
+    ap.add_argument("--pair", action="store_true", help="feed pair-row activations (bf16x3 mode)")
     args = ap.parse_args()
     dev = "cuda"
     for i, (M, N, Cin, taps, label) in enumerate(SHAPES):
@@ -35,6 +36,8 @@ def main():
             continue
         T = 288
         x = torch.randn(M // T, T, Cin, device=dev)
+        if args.pair and ops.pair_mode() and (Cin * taps) % 32 == 0 and Cin % 32 == 0:
+            x = ops.Pair(x, Cin)      # timing only: the bit pattern is arbitrary bf16 data
         w = torch.randn(N, Cin, taps, device=dev) / (Cin * taps) ** 0.5
         b = torch.randn(N, device=dev)
         mask = torch.ones(M // T, T, dtype=torch.bool, device=dev)

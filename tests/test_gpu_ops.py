@@ -391,3 +391,38 @@ def test_pair_row_format_round_trip(precision):
     got = ops.conv_gemm(ops.Pair(cat, 512), w3.to(DEV), None, act=ops.ACT_GELU, out_pair=True)
     assert torch.equal(ops.conv_gemm(ops.Pair(cat, 512), w3.to(DEV), None, act=ops.ACT_GELU), want)
     assert float(((got.float() - want).abs() / want.abs().clamp_min(1e-2)).max()) < 2 ** -15
+
+
+def _to_pair(t):
+    """Encode an f32 (B, T, C) tensor as pair rows (test helper; mirrors vrd::store_pair4)."""
+    from vrdone_amd import ops
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.float()).to(torch.bfloat16)
+    raw = torch.cat([hi, lo], dim=-1).contiguous()                  # (..., 2C) bf16 = 4C bytes per row
+    return ops.Pair(raw.view(torch.float32), t.shape[-1])
+
+
+@pytest.mark.parametrize("H,hd,Tq,Tk", [(4, 128, 96, 96), (8, 64, 144, 144), (4, 128, 288, 288), (8, 64, 512, 512),
+                                        (4, 128, 40, 77)])
+def test_flash_attention_pair_rows(H, hd, Tq, Tk, precision):
+    if precision != "bf16x3":
+        pytest.skip("pair rows exist in bf16x3 mode only")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(H + hd + Tq + Tk)
+    B, C = 3, H * hd
+    q = torch.randn(B, Tq, C, generator=gen) * 2.0
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    k[:, min(70, Tk - 1), :hd] = q[:, 5, :hd] * 2.0          # a dominant late key: forces the running-max rescale
+    lens = torch.tensor([Tk, max(1, Tk // 3), 1])
+    mask = torch.arange(Tk)[None] < lens[:, None]
+    want = O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H).transpose(1, 2)
+    qp, kp, vp = (_to_pair(t.to(DEV)) for t in (q, k, v))
+    got = ops.attention(qp, kp, vp, mask.to(DEV), H)
+    close(got, want, 2e-4)
+    got_pair = ops.attention(qp, kp, vp, mask.to(DEV), H, pair=True)
+    assert isinstance(got_pair, ops.Pair)
+    close(got_pair.float(), want, 2e-4)
+    close(ops.attention(qp, kp, vp, None, H),
+          O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                           torch.ones(B, 1, Tk, dtype=torch.bool), H).transpose(1, 2), 2e-4)

@@ -204,7 +204,11 @@ int launch_bk(const vrd_gemm_args& a, bool vec, int tiles_m, int tiles_n, hipStr
 
 }  // namespace
 
-namespace vrd { int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s); }
+namespace vrd {
+int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s);
+bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged);
+int launch_gemm_bf16x3_dma(const vrd_gemm_args& a, hipStream_t s);
+}  // namespace vrd
 
 extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     VRD_CHECK_ARG(a != nullptr, "vrd_gemm: null args");
@@ -243,7 +247,9 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     const bool x3 = a->a_pair_width > 0 || (a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split));
     vrd::ProfScope prof(x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM, s, flops, bytes);
     if (x3) {
-        int rc3 = vrd::launch_gemm_bf16x3(*a, staged, s);
+        static const int dma_env = [] { const char* e = getenv("VRD_X3_DMA"); return e ? atoi(e) : 1; }();
+        int rc3 = (dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged)) ? vrd::launch_gemm_bf16x3_dma(*a, s)
+                                                                   : vrd::launch_gemm_bf16x3(*a, staged, s);
         if (rc3) return rc3;
         VRD_LAUNCH_CHECK();
         return 0;

@@ -198,11 +198,11 @@ class _ConvAttention(nn.Module):
             v, = ops.dwconv_ln(v_in, [self._branch_set("value")], mask_out=kv_mask, stride=stride)
         return q, k, v
 
-    def _project(self, q, k, v):
+    def _project(self, q, k, v, out_pair=False):
         ops = _ops()
-        return (ops.conv_gemm(q, self.query.weight, self.query.bias),
-                ops.conv_gemm(k, self.key.weight, self.key.bias),
-                ops.conv_gemm(v, self.value.weight, self.value.bias))
+        return (ops.conv_gemm(q, self.query.weight, self.query.bias, out_pair=out_pair),
+                ops.conv_gemm(k, self.key.weight, self.key.bias, out_pair=out_pair),
+                ops.conv_gemm(v, self.value.weight, self.value.bias, out_pair=out_pair))
 
 
 class LocalMaskedMHCA(_ConvAttention):

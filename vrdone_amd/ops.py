@@ -69,6 +69,11 @@ class Pair:
         return (slabs[..., 0, :] + slabs[..., 1, :]).reshape(*self.t.shape)
 
 
+def flash_pair_ok(n_head, channels, Tq):
+    """True when global attention of this shape runs the split-precision flash kernel on pair-row q/k/v."""
+    return _precision == "bf16x3" and channels // n_head in (64, 128) and Tq >= 32
+
+
 def pair_mode():
     """True when producers should emit pair rows for GEMM-only consumers (bf16x3 precision)."""
     return _precision == "bf16x3"
@@ -274,6 +279,20 @@ def local_attention(q, k, v, mask, n_head, half_win, pair=False):
 def attention(q, k, v, kv_mask, n_head, algo=0, pair=False):
     """Global masked attention; q: (B, Tq, C), k/v: (B, Tk, C); kv_mask (B, Tk) or None.
     pair: pair-row output when the flash kernel runs (otherwise a plain tensor is returned)."""
+    if isinstance(q, Pair):
+        assert isinstance(k, Pair) and isinstance(v, Pair) and q.width == k.width == v.width == q.shape[-1]
+        q, k, v = q.t, k.t, v.t
+        B, Tq, Cc = q.shape
+        Tk = k.shape[1]
+        pq, _, _, ldq = _rows(q)
+        pk, rows_k, _, ldk = _rows(k)
+        pv, _, _, ldv = _rows(v)
+        assert ldk == ldv
+        out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
+        _hip.check(lib.vrd_attention_pair(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), B, Tq, Tk, n_head,
+                                          Cc // n_head, out.data_ptr(), Cc, 1 if pair else 0, _stream()),
+                   "vrd_attention_pair")
+        return Pair(out, Cc) if pair else out
     B, Tq, Cc = q.shape
     Tk = k.shape[1]
     pq, _, _, ldq = _rows(q)
