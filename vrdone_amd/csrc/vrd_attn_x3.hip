@@ -50,7 +50,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
 }
 
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_flash_x3_kernel(const float* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* __restrict__ q, int64_t ldq,
                                                                 const float* __restrict__ k, const float* __restrict__ v,
                                                                 int64_t ldkv, const uint8_t* __restrict__ kv_mask, int Tq,
                                                                 int Tk, int width, float scale, float* __restrict__ out,

@@ -39,6 +39,32 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
             }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            // Row-wise inputs of this round (mask bytes, residual rows) are requested up front, all eight rows
+            // at once, so their latency is paid once per round instead of once per row.
+            float mk[8];
+            float4 r1[8], r2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t m = mw + mi * 32 + rb0 + 4 * j;
+                const bool ok = m < p.M && n < p.N;
+                mk[j] = (p.row_mask && ok) ? (float)p.row_mask[m] : 1.f;
+                r1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                r2[j] = r1[j];
+                if (ok && nfull) {
+                    if (p.res) r1[j] = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n);
+                    if (p.res2) r2[j] = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n);
+                } else if (ok) {
+                    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (n + c < p.N) {
+                            if (p.res) a1[c] = p.res[m * p.ldres + n + c];
+                            if (p.res2) a2[c] = p.res2[m * p.ldres2 + n + c];
+                        }
+                    r1[j] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                    r2[j] = make_float4(a2[0], a2[1], a2[2], a2[3]);
+                }
+            }
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
@@ -50,29 +76,11 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
                 const int64_t m = mw + mi * 32 + row;
                 const float4 t = *reinterpret_cast<const float4*>(stg + row * STG_PITCH + c4);
                 if (m >= p.M || n >= p.N) continue;
-                const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
-                const float rmk = p.res_masked ? mk : 1.f;
+                const float rmk = p.res_masked ? mk[j] : 1.f;
+                const float a1[4] = {r1[j].x, r1[j].y, r1[j].z, r1[j].w}, a2[4] = {r2[j].x, r2[j].y, r2[j].z, r2[j].w};
                 float v[4] = {t.x + bias[0], t.y + bias[1], t.z + bias[2], t.w + bias[3]};
-                float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
-                if (nfull) {
-                    if (p.res) {
-                        const float4 q = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n);
-                        r1[0] = q.x; r1[1] = q.y; r1[2] = q.z; r1[3] = q.w;
-                    }
-                    if (p.res2) {
-                        const float4 q = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n);
-                        r2[0] = q.x; r2[1] = q.y; r2[2] = q.z; r2[3] = q.w;
-                    }
-                } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (n + c < p.N) {
-                            if (p.res) r1[c] = p.res[m * p.ldres + n + c];
-                            if (p.res2) r2[c] = p.res2[m * p.ldres2 + n + c];
-                        }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = epilogue_value(p, v[c], mk, scale[c], r1[c], rmk, r2[c]);
+                for (int c = 0; c < 4; ++c) v[c] = epilogue_value(p, v[c], mk[j], scale[c], a1[c], rmk, a2[c]);
                 float* crow = p.C + m * p.ldc + n;
                 if (p.c_pair) {          // pair rows of width N (host checks N % 8 == 0, so a float4 group is whole)
                     store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[0], v[1], v[2], v[3]));

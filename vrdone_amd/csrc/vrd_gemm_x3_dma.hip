@@ -24,10 +24,10 @@ using vrd::f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int DBM = 128, DBN = 256, NSTG = 3;
+constexpr int DBN = 256;
 
-// geometry of one K step of DBK bf16 elements
-template <int DBK>
+// geometry of one K step of DBK bf16 elements for a DBM x 256 tile and an NSTG-stage ring
+template <int DBK, int DBM, int NSTG>
 struct Geo {
     static constexpr int ROWB = DBK * 2;                      // bytes per tile row
     static constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row (4 or 2)
@@ -38,15 +38,18 @@ struct Geo {
     static constexpr int STAGE = 2 * A_PLANE + 2 * W_PLANE;   // a_hi | a_lo | w_hi | w_lo
     static constexpr int A_INSTR = DBM / RPI, W_INSTR = DBN / RPI;
     static constexpr int DMA_PER_WAVE = (2 * A_INSTR + 2 * W_INSTR) / 8;
+    static constexpr int WM = DBM / 64, WN = 8 / WM;          // 8 waves as WM x WN, each 64 rows x (256/WN) columns
+    static constexpr int NJ = (DBN / WN) / 32;                // 32-wide accumulator columns per wave (2 or 4)
     static constexpr size_t LDS = (size_t)NSTG * STAGE;
     __device__ static constexpr int swz(int row) { return (row / RB) % CPR; }
 };
 
 __device__ uint4 g_zero_block[4];                     // 64 zero bytes: source of padded taps
 
-template <int TAPS, int DBK>
+template <int TAPS, int DBK, int DBM, int NSTG>
 __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
-    using G = Geo<DBK>;
+    using G = Geo<DBK, DBM, NSTG>;
+    constexpr int NJ = G::NJ;
     constexpr int ROWB = G::ROWB, A_PLANE = G::A_PLANE, W_PLANE = G::W_PLANE, STAGE = G::STAGE;
     constexpr int DMA_PER_WAVE = G::DMA_PER_WAVE, KSUB = DBK / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / G::WN, wn = wave % G::WN;
     const int li = lane & 31, lh = lane >> 5;
     const int K = p.Cin * TAPS;
     const int nkt = K / DBK;      // K is a multiple of 32 (host check)
@@ -134,48 +137,57 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
     };
 
     // ---- fragment read offsets (bytes inside a stage) for the k16 sub-steps
-    int a_rd[2][KSUB], w_rd[2][KSUB];    // [mi | nj][s]
+    int a_rd[2][KSUB], w_rd[NJ][KSUB];   // [mi | nj][s]
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int ra = wm * 64 + t * 32 + li, rw = wn * 64 + t * 32 + li;
+    for (int s = 0; s < KSUB; ++s) {
 #pragma unroll
-        for (int s = 0; s < KSUB; ++s) {
+        for (int t = 0; t < 2; ++t) {
+            const int ra = wm * 64 + t * 32 + li;
             a_rd[t][s] = ra * ROWB + (((2 * s + lh) ^ G::swz(ra)) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) {
+            const int rw = wn * (32 * NJ) + t * 32 + li;
             w_rd[t][s] = 2 * A_PLANE + rw * ROWB + (((2 * s + lh) ^ G::swz(rw)) * 16);
         }
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    issue(0);
-    if (nkt > 1) issue(1);
+    // NSTG - 1 stages are kept in flight behind the one being consumed
+#pragma unroll
+    for (int t = 0; t < NSTG - 1; ++t)
+        if (t < nkt) issue(t);
     for (int kt = 0; kt < nkt; ++kt) {
-        // stage kt has landed once at most the DMAs of stage kt+1 are still outstanding
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+        // stage kt has landed once at most the DMAs of the NSTG-2 newer stages are still outstanding
+        if (NSTG > 2 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * DMA_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) issue(kt + 2);
+        if (kt + NSTG - 1 < nkt) issue(kt + NSTG - 1);
         const char* st = lds + (kt % NSTG) * STAGE;
 #pragma unroll
         for (int s = 0; s < KSUB; ++s) {
-            bf16x8 ah[2], al[2], wh[2], wl[2];
+            bf16x8 ah[2], al[2], wh[NJ], wl[NJ];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 ah[t] = *reinterpret_cast<const bf16x8*>(st + a_rd[t][s]);
                 al[t] = *reinterpret_cast<const bf16x8*>(st + A_PLANE + a_rd[t][s]);
+            }
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
                 wh[t] = *reinterpret_cast<const bf16x8*>(st + w_rd[t][s]);
                 wl[t] = *reinterpret_cast<const bf16x8*>(st + W_PLANE + w_rd[t][s]);
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 2; ++nj) {
+                for (int nj = 0; nj < NJ; ++nj) {
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], wh[nj], acc[mi][nj], 0, 0, 0);
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
@@ -185,17 +197,26 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
     // every wave must be done with the ring before it is reused as epilogue staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    vrd::gemm_epilogue<true>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
+#pragma unroll
+    for (int hn = 0; hn < NJ / 2; ++hn) {      // the epilogue works on 64 x 64 halves of the wave's sub-tile
+        f32x16 part[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) part[i][j] = acc[i][2 * hn + j];
+        vrd::gemm_epilogue<true>(p, part, smem, m0 + wm * 64, n0 + wn * (32 * NJ) + hn * 64, wave, lane);
+    }
 }
 
 }  // namespace
 
 namespace vrd {
 
-template <int TAPS, int DBK>
-static int launch_dma_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t s) {
-    auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK>;
-    constexpr size_t lds = Geo<DBK>::LDS;
+template <int TAPS, int DBK, int DBM, int NSTG>
+static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
+    auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK, DBM, NSTG>;
+    constexpr size_t lds = Geo<DBK, DBM, NSTG>::LDS;
+    static_assert(lds >= 8 * 8192 && lds <= 160 * 1024, "ring must hold the epilogue slabs and fit the CU");
     static bool reserved = false;
     if (!reserved) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -205,6 +226,7 @@ static int launch_dma_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipS
         }
         reserved = true;
     }
+    const int tiles_m = (int)((a.M + DBM - 1) / DBM), tiles_n = (a.N + DBN - 1) / DBN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
     return 0;
 }
@@ -215,15 +237,21 @@ bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged) {
 }
 
 int launch_gemm_bf16x3_dma(const vrd_gemm_args& a, hipStream_t s) {
-    const int tiles_m = (int)((a.M + DBM - 1) / DBM), tiles_n = (a.N + DBN - 1) / DBN;
-    // K step 32 (144 KiB of LDS, one workgroup per CU) streams best; short-K GEMMs with a residual read in
-    // the epilogue do better with K step 16 (72 KiB, two workgroups per CU: one's epilogue hides under the
-    // other's main loop).  Measured on the path's shapes (scripts/gemm_bench.py --pair).
-    static const int bk_env = [] { const char* e = getenv("VRD_X3_DMA_BK"); return e ? atoi(e) : 0; }();
-    const int bk = bk_env ? bk_env : ((a.Cin * a.taps <= 512 && (a.res || a.res2)) ? 16 : 32);
-    if (bk == 32)
-        return a.taps == 1 ? launch_dma_one<1, 32>(a, tiles_m, tiles_n, s) : launch_dma_one<3, 32>(a, tiles_m, tiles_n, s);
-    return a.taps == 1 ? launch_dma_one<1, 16>(a, tiles_m, tiles_n, s) : launch_dma_one<3, 16>(a, tiles_m, tiles_n, s);
+    // variants (measured with scripts/gemm_bench.py --pair on the path's shapes):
+    //   0: 128 x 256 tile, K step 32, 3-stage ring (144 KiB)          -- default for small row counts
+    //   1: 128 x 256 tile, K step 16, 3-stage ring (72 KiB, two workgroups per CU)
+    //   2: 256 x 256 tile, K step 32, 2-stage ring (128 KiB): a third fewer operand bytes per FLOP
+    static const int var_env = [] { const char* e = getenv("VRD_X3_DMA_VARIANT"); return e ? atoi(e) : -1; }();
+    int var = var_env;
+    if (var < 0) var = 0;
+    if (a.taps == 1) {
+        if (var == 2) return launch_dma_one<1, 32, 256, 2>(a, s);
+        if (var == 1) return launch_dma_one<1, 16, 128, 3>(a, s);
+        return launch_dma_one<1, 32, 128, 3>(a, s);
+    }
+    if (var == 2) return launch_dma_one<3, 32, 256, 2>(a, s);
+    if (var == 1) return launch_dma_one<3, 16, 128, 3>(a, s);
+    return launch_dma_one<3, 32, 128, 3>(a, s);
 }
 
 }  // namespace vrd

@@ -74,7 +74,7 @@ class MaskVRD(nn.Module):
         self.device = device
         # pairs per launch wave inside _mask_vrd: bounds the live intermediates (the 4x MLP hidden is
         # 2*chunk*T*2048 floats) and keeps producer->consumer tensors close to the 256 MiB Infinity Cache
-        self.pair_chunk = 256
+        self.pair_chunk = 1024
 
     @torch.no_grad()
     def _config_eval(self, infer_config):
