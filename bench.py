@@ -84,6 +84,21 @@ def usable_cores():
     return max(1, n)
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_hbm_traffic.json, made by
+    scripts/collect_profiles.sh + scripts/summarize_traffic.py: counters cannot be read inside this process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    k = d.get("kernels", {}).get(kernel)
+    if not k:
+        return None, None
+    return k["hbm_bytes_per_launch"], f"{os.path.basename(files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)"
+
+
 def cpu_baseline(model_cfg, sd_cpu, c_in, frames, t_pad, n_pairs):
     """The oracle (CPU restatement of the reference, plain PyTorch fp32) on a bounded sample of the
     same workload, on this box's host cores."""
@@ -171,7 +186,7 @@ def main():
 
     def roofline(mode, prof):
         """Dominant kernel family of the mode: algorithmic FLOPs (2*M*N*K per launch) / HIP-event time."""
-        fam = "gemm_bf16x3_mfma" if mode == "bf16x3" else "gemm_f32_mfma"
+        fam = "gemm_bf16x3_dma" if mode == "bf16x3" else "gemm_f32_mfma"
         g = prof[fam]
         n = max(g["launches"], 1)
         avg_ms = g["ms"] / n
@@ -181,13 +196,17 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             extra = {"mfma_tflops_executed": 3.0 * achieved, "mfma_peak": PEAK_BF16_MFMA_TFLOPS,
                      "note": "peak = bf16 dense MFMA peak / 3 (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi per product)"}
-            kern = "gemm_bf16x3_kernel"
+            kern = "gemm_bf16x3_dma_kernel"
         else:
             peak, extra, kern = PEAK_F32_MFMA_TFLOPS, {}, "gemm_f32_mfma_kernel"
         tot = sum(v["ms"] for v in prof.values())
+        traffic, src = hbm_traffic(kern)
+        if src:
+            extra = dict(extra, traffic_source=src)
         return dict({"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": None, "launches": g["launches"], "avg_launch_ms": avg_ms,
-                     "flops_per_launch": g["flops"] / n, "share_of_kernel_time": g["ms"] / tot if tot else 0.0}, **extra)
+                     "frac": achieved / peak, "traffic": traffic, "launches": g["launches"], "avg_launch_ms": avg_ms,
+                     "flops_per_launch": g["flops"] / n, "algorithmic_bytes_per_launch": g["bytes"] / n,
+                     "share_of_kernel_time": g["ms"] / tot if tot else 0.0}, **extra)
 
     main_mode = args.precision or ops.get_precision()
     alt_mode = "f32" if main_mode == "bf16x3" else "bf16x3"

@@ -191,6 +191,7 @@ def test_extension_is_loaded_and_profiled():
     torch.cuda.synchronize()
     prof = _hip.prof_read()
     _hip.prof_enable(False)
-    gemm = {k: prof["gemm_f32_mfma"][k] + prof["gemm_bf16x3_mfma"][k] for k in ("launches", "ms", "flops")}
+    gemm = {k: sum(prof[f][k] for f in ("gemm_f32_mfma", "gemm_bf16x3_mfma", "gemm_bf16x3_dma"))
+            for k in ("launches", "ms", "flops")}
     assert gemm["launches"] > 50 and gemm["ms"] > 0 and gemm["flops"] > 1e9
     assert prof["attn_flash"]["launches"] == 8 and prof["local_attn"]["launches"] == 5

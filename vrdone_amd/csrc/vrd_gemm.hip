@@ -245,11 +245,11 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     const double bytes = 4.0 * ((double)a->M * a->Cin + (double)a->N * K + (double)a->M * a->N *
                                 (1.0 + (a->res ? 1.0 : 0.0) + (a->res2 ? 1.0 : 0.0)));
     const bool x3 = a->a_pair_width > 0 || (a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split));
-    vrd::ProfScope prof(x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM, s, flops, bytes);
+    static const int dma_env = [] { const char* e = getenv("VRD_X3_DMA"); return e ? atoi(e) : 1; }();
+    const bool dma = x3 && dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged);
+    vrd::ProfScope prof(dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
     if (x3) {
-        static const int dma_env = [] { const char* e = getenv("VRD_X3_DMA"); return e ? atoi(e) : 1; }();
-        int rc3 = (dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged)) ? vrd::launch_gemm_bf16x3_dma(*a, s)
-                                                                   : vrd::launch_gemm_bf16x3(*a, staged, s);
+        int rc3 = dma ? vrd::launch_gemm_bf16x3_dma(*a, s) : vrd::launch_gemm_bf16x3(*a, staged, s);
         if (rc3) return rc3;
         VRD_LAUNCH_CHECK();
         return 0;
