@@ -58,6 +58,26 @@ int vrd_prof_read(int kernel_id, double* ms, int64_t* launches, double* flops, d
  * transposing copy of models/maskvrd.py:382-385. */
 int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count,
                    float* dst, int64_t ld_dst, int out_pair, void* stream);
+/* Eval batching (models/maskvrd.py:363-414 + backbones.py:161-166) without the (B, C_in, T) intermediate: pair p
+ * is an (L_p, C_in) frame-major matrix src[p] (how dataloaders/vidvrd.py:693 builds it, before its permute view)
+ * laid out [s_vis V | o_vis V | (s_clip Cc | o_clip Cc) | so_box S | s_box E | o_box E].  Writes the backbone's
+ * channels-last operand buffers, zero rows for t >= lens[p]:
+ *   vis  (2, P, T, V)   subject rows then object rows (pair rows when pair_wide)
+ *   clip (2, P, T, Cc)  only when Cc > 0 (pair rows when pair_wide)
+ *   so_box (P, T, S), ent (2, P, T, E)   f32
+ * `src` is a device array of P device pointers. */
+typedef struct {
+    const float* const* src;
+    const int32_t* lens;
+    int32_t P, C_in, T, V, Cc, S, E;
+    float* vis;
+    float* clip;
+    float* so_box;
+    float* ent;
+    int32_t pair_wide;
+} vrd_pack_args;
+int vrd_pack_pairs(const vrd_pack_args* a, void* stream);
+
 /* rows (b*T+t) x C (leading dim ld_src) -> (B, C, T) contiguous. */
 int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float* dst, void* stream);
 

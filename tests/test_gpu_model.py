@@ -195,3 +195,23 @@ def test_extension_is_loaded_and_profiled():
             for k in ("launches", "ms", "flops")}
     assert gemm["launches"] > 50 and gemm["ms"] > 0 and gemm["flops"] > 1e9
     assert prof["attn_flash"]["launches"] == 8 and prof["local_attn"]["launches"] == 5
+
+
+def test_pack_pairs_equals_padded_batch(precision):
+    """Batching straight from the frame-major per-pair matrices == zero-padded (B, C_in, T) batch + unpack."""
+    from vrdone_amd import ops
+    model, mc, _, _ = get_model("vidvrd")
+    data = synth_proposal(4, c_in(mc), 10, 110, seed=5)
+    feats = [f.to(DEV) for f in data["so_features_list"]]
+    feats = [f.t().contiguous().t() for f in feats]              # (C, L) views of contiguous (L, C) matrices
+    ids = list(range(len(feats)))
+    T = 144
+    bb = model.backbone
+    table, lens = ops.pair_table(feats)
+    *parts, m2 = ops.pack_pairs(table, lens, T, bb.n_visual, bb.n_clip, bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+    assert ops.pair_table([f.contiguous() for f in feats]) is None          # not frame-major -> generic batching path
+    got = model._heads(*bb.cl_parts(*parts, m2), False)
+    x, m = model._batch(feats, ids, T)
+    want = model._mask_vrd(x, m, with_aux=False)
+    assert torch.equal(m2, m[:, 0])
+    assert torch.equal(got["pred_logits"], want["pred_logits"]) and torch.equal(got["pred_masks"], want["pred_masks"])

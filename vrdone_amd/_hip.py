@@ -40,6 +40,13 @@ class DwconvLnArgs(C.Structure):
                 ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3), ("out_pair", C.c_int32 * 3)]
 
 
+class PackArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("lens", C.c_void_p),
+                ("P", C.c_int32), ("C_in", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("Cc", C.c_int32),
+                ("S", C.c_int32), ("E", C.c_int32),
+                ("vis", c_f32p), ("clip", c_f32p), ("so_box", c_f32p), ("ent", c_f32p), ("pair_wide", C.c_int32)]
+
+
 _SIGNATURES = {
     "vrd_abi_version": (C.c_int, []),
     "vrd_last_error": (C.c_char_p, []),
@@ -49,6 +56,7 @@ _SIGNATURES = {
                                 C.POINTER(C.c_double)]),
     "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_layernorm": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int,
                                 c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

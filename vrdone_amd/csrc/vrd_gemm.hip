@@ -246,7 +246,11 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
                                 (1.0 + (a->res ? 1.0 : 0.0) + (a->res2 ? 1.0 : 0.0)));
     const bool x3 = a->a_pair_width > 0 || (a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split));
     static const int dma_env = [] { const char* e = getenv("VRD_X3_DMA"); return e ? atoi(e) : 1; }();
-    const bool dma = x3 && dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged);
+    // the 128 x 256 DMA kernel runs one workgroup per CU: below ~2 rounds of tiles the 128 x 128 kernel (two
+    // workgroups per CU, four times the tiles) fills the chip better
+    static const int64_t dma_min_tiles = [] { const char* e = getenv("VRD_X3_DMA_MIN_TILES"); return e ? atoll(e) : 512; }();
+    const bool dma = x3 && dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged) &&
+                     ((a->M + 127) / 128) * ((a->N + 255) / 256) >= dma_min_tiles;
     vrd::ProfScope prof(dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
     if (x3) {
         int rc3 = dma ? vrd::launch_gemm_bf16x3_dma(*a, s) : vrd::launch_gemm_bf16x3(*a, staged, s);

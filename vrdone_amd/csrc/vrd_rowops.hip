@@ -49,6 +49,41 @@ __global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// eval batching straight from the dataloader's per-pair matrices: pair p is an (L_p, C_in) frame-major
+// matrix [s_vis | o_vis | (s_clip | o_clip) | so_box | s_box | o_box]; one wave copies one (pair, frame) row
+// into the channels-last operand buffers of the backbone (zero rows past L_p), in pair-row format for the
+// wide visual / clip slabs when requested.  Replaces the zero-padded (B, C_in, T) batch of
+// models/maskvrd.py:382-385 and the channel slicing of models/backbones.py:161-166.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack_segment(const float* src, bool live, int lane, int width, float* dst, int pair) {
+    for (int c = lane; c < width; c += 64) {
+        const float v = live ? src[c] : 0.f;
+        if (pair) vrd::store_pair1(dst, c, width, v);
+        else dst[c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_pairs_kernel(vrd_pack_args a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)a.P * a.T) return;
+    const int p = (int)(row / a.T), t = (int)(row - (int64_t)p * a.T);
+    const bool live = t < a.lens[p];
+    const float* src = a.src[p] + (int64_t)t * a.C_in;
+    const int64_t half = (int64_t)a.P * a.T;             // rows per (subject | object) half of the stacked buffers
+    int c0 = 0;
+    pack_segment(src + c0, live, lane, a.V, a.vis + row * a.V, a.pair_wide);              c0 += a.V;
+    pack_segment(src + c0, live, lane, a.V, a.vis + (half + row) * a.V, a.pair_wide);     c0 += a.V;
+    if (a.Cc) {
+        pack_segment(src + c0, live, lane, a.Cc, a.clip + row * a.Cc, a.pair_wide);          c0 += a.Cc;
+        pack_segment(src + c0, live, lane, a.Cc, a.clip + (half + row) * a.Cc, a.pair_wide); c0 += a.Cc;
+    }
+    pack_segment(src + c0, live, lane, a.S, a.so_box + row * a.S, 0);                     c0 += a.S;
+    pack_segment(src + c0, live, lane, a.E, a.ent + row * a.E, 0);                        c0 += a.E;
+    pack_segment(src + c0, live, lane, a.E, a.ent + (half + row) * a.E, 0);
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm over channels; NV = C / 256
 // ------------------------------------------------------------------------------------------
 template <int NV>
@@ -270,6 +305,20 @@ int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int coun
     dim3 grid((T + 63) / 64, (count + 63) / 64, B);
     VRD_CHECK_ARG(!out_pair || (count % 8 == 0 && ld_dst % 4 == 0 && aligned16(dst)), "vrd_bct_to_btc: pair rows need count %% 8 == 0");
     hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_pack_pairs(const vrd_pack_args* a, void* stream) {
+    VRD_CHECK_ARG(a && a->src && a->lens && a->vis && a->so_box && a->ent, "vrd_pack_pairs: null pointer");
+    VRD_CHECK_ARG(a->P > 0 && a->T > 0 && a->V > 0 && a->S > 0 && a->E > 0 && a->Cc >= 0, "vrd_pack_pairs: bad sizes");
+    VRD_CHECK_ARG(a->C_in == 2 * a->V + 2 * a->Cc + a->S + 2 * a->E, "vrd_pack_pairs: C_in %d does not match the slab widths", a->C_in);
+    VRD_CHECK_ARG(a->Cc == 0 || a->clip, "vrd_pack_pairs: clip buffer missing");
+    VRD_CHECK_ARG(!a->pair_wide || (a->V % 8 == 0 && a->Cc % 8 == 0), "vrd_pack_pairs: pair rows need widths %% 8 == 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t rows = (int64_t)a->P * a->T;
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * a->C_in);
+    hipLaunchKernelGGL(pack_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
     VRD_LAUNCH_CHECK();
     return 0;
 }

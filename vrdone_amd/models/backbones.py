@@ -77,37 +77,52 @@ class MaskConvTransformerBackbone(nn.Module):
         return 2 * self.n_visual + 2 * self.n_clip + self.n_bbox_so + 2 * self.n_bbox_entity
 
     # -------------------------------------------------------------------------------------
-    def _embed_into(self, x, c0, width, convs, norms, mask2, out):
-        """k=3 conv * mask -> LN -> ReLU stack on the stacked (subject, object) slabs
-        [c0, c0+width) and [c0+width, c0+2*width) of x (B, C, T); result into `out` (2B, T, D)."""
+    def _unpack(self, x):
+        """Boundary layout (B, C_in, T) -> the channels-last operand buffers of cl_parts: the subject and
+        object slabs of every shared-weight stage are stacked on the batch axis (2B sequences); the wide
+        visual / clip slabs feed GEMMs only, so they are pair rows in bf16x3 mode."""
         ops = _ops()
         B, _, T = x.shape
-        # every tensor here is consumed by a GEMM only: pair rows in bf16x3 mode (3*width must be a
-        # multiple of 32 for the split-precision kernel; the 8-channel box features stay f32)
+        V, Cc, S, E = self.n_visual, self.n_clip, self.n_bbox_so, self.n_bbox_entity
         pair = ops.pair_mode()
-        pair_in = pair and (3 * width) % 32 == 0 and width % 8 == 0
-        h = torch.empty(2, B, T, width, device=x.device, dtype=torch.float32)
-        ops.bct_to_btc(x, c0, width, h[0], pair=pair_in)
-        ops.bct_to_btc(x, c0 + width, width, h[1], pair=pair_in)
-        h = h.view(2 * B, T, width)
-        if pair_in:
-            h = ops.Pair(h, width)
+
+        def stacked(c0, width, as_pair):
+            h = torch.empty(2, B, T, width, device=x.device, dtype=torch.float32)
+            ops.bct_to_btc(x, c0, width, h[0], pair=as_pair)
+            ops.bct_to_btc(x, c0 + width, width, h[1], pair=as_pair)
+            h = h.view(2 * B, T, width)
+            return ops.Pair(h, width) if as_pair else h
+
+        o0 = 2 * V + 2 * Cc
+        so_box = torch.empty(B, T, S, device=x.device, dtype=torch.float32)
+        ops.bct_to_btc(x, o0, S, so_box)
+        return (stacked(0, V, pair), stacked(2 * V, Cc, pair) if Cc else None, so_box, stacked(o0 + S, E, False))
+
+    @staticmethod
+    def _embed(h, convs, norms, mask2, out):
+        """k=3 conv * mask -> LN -> ReLU stack on 2B stacked sequences; the last LN writes into `out`, a column
+        slab of the consumer GEMM's input buffer (pair rows in bf16x3 mode)."""
+        ops = _ops()
         last = len(convs) - 1
         for i, (conv, norm) in enumerate(zip(convs, norms)):
             h = ops.conv_gemm(h, conv.conv.weight, conv.conv.bias, row_mask=mask2)
-            h = norm.cl(h, relu=True, out=out if i == last else None, pair=pair)
+            h = norm.cl(h, relu=True, out=out if i == last else None, pair=ops.pair_mode())
         return h
 
     def cl(self, x, mask):
         """x: (B, C_in, T) contiguous fp32 (the boundary layout), mask: (B, T) bool.
         Returns channels-last feats [(B, T/2^l, D)] and masks [(B, T/2^l)]."""
+        assert x.shape[1] == self.in_channels(), f"expected {self.in_channels()} input channels, got {x.shape[1]}"
+        return self.cl_parts(*self._unpack(x.contiguous()), mask)
+
+    def cl_parts(self, vis, clip, so_box, ent, mask):
+        """vis (2B, T, V), clip (2B, T, Cc) or None, so_box (B, T, S), ent (2B, T, E): channels-last operand
+        buffers (from _unpack or ops.pack_pairs); mask (B, T) bool."""
         ops = _ops()
-        B, Cin, T = x.shape
-        assert Cin == self.in_channels(), f"expected {self.in_channels()} input channels, got {Cin}"
-        x = x.contiguous()
-        V, Cc, S, E = self.n_visual, self.n_clip, self.n_bbox_so, self.n_bbox_entity
+        B, T = mask.shape
+        Cc = self.n_clip
         D = self.s_fuse_norm.num_channels
-        dev = x.device
+        dev = mask.device
         mask2 = torch.cat([mask, mask], dim=0)
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
 
@@ -119,13 +134,12 @@ class MaskConvTransformerBackbone(nn.Module):
         fuse_in = new(2 * B, T, 2 * D)
         if Cc:
             vc = new(2 * B, T, 2 * D)
-            self._embed_into(x, 0, V, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
-            self._embed_into(x, 2 * V, Cc, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
+            self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
+            self._embed(clip, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
             self.visual_clip_fuse.cl(cat(vc), row_mask=mask2, out=fuse_in[..., :D], out_pair=pair)
         else:
-            self._embed_into(x, 0, V, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
-        o0 = 2 * V + 2 * Cc
-        self._embed_into(x, o0 + S, E, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
+            self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
+        self._embed(ent, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
         so = self.visual_bbox_fuse.cl(cat(fuse_in), row_mask=mask2)         # (2B, T, D): subject rows then object rows
 
         for stem, s_attn, o_attn in zip(self.stem, self.s_attn, self.o_attn):
@@ -139,13 +153,11 @@ class MaskConvTransformerBackbone(nn.Module):
         so_in = new(B, T, 2 * D)
         self.s_fuse_norm.cl(so[:B], out=so_in[..., :D], pair=pair)
         self.o_fuse_norm.cl(so[B:], out=so_in[..., D:], pair=pair)
-        so_box = new(B, T, 2 * D)
-        self.so_fuse.cl(cat(so_in), row_mask=mask, out=so_box[..., :D], out_pair=pair)
-        box = new(B, T, S)
-        ops.bct_to_btc(x, o0, S, box)
+        pair_box = new(B, T, 2 * D)
+        self.so_fuse.cl(cat(so_in), row_mask=mask, out=pair_box[..., :D], out_pair=pair)
         conv = self.bbox_so_embd.conv
-        ops.conv_gemm(box, conv.weight, conv.bias, row_mask=mask, out=so_box[..., D:], out_pair=pair)
-        e = self.so_visual_bbox_fuse.cl(cat(so_box), row_mask=mask)
+        ops.conv_gemm(so_box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:], out_pair=pair)
+        e = self.so_visual_bbox_fuse.cl(cat(pair_box), row_mask=mask)
 
         feats, masks = [e], [mask]
         for blk in self.branch:

@@ -100,9 +100,15 @@ class MaskVRD(nn.Module):
         for b0 in range(0, B, self.pair_chunk):
             x = batched_inputs[b0:b0 + self.pair_chunk]
             m = masks2d[b0:b0 + self.pair_chunk]
-            feats, masks = self.backbone.cl(x, m)
-            fpn_feat, _ = self.neck.cl(feats, masks)
-            outs.append(self.predictor.cl(feats[-1], fpn_feat, masks[-1], masks[0], with_aux=with_aux))
+            outs.append(self._heads(*self.backbone.cl(x, m), with_aux))
+        return self._merge(outs)
+
+    def _heads(self, feats, masks, with_aux):
+        fpn_feat, _ = self.neck.cl(feats, masks)
+        return self.predictor.cl(feats[-1], fpn_feat, masks[-1], masks[0], with_aux=with_aux)
+
+    @staticmethod
+    def _merge(outs):
         if len(outs) == 1:
             return outs[0]
         merged = {k: torch.cat([o[k] for o in outs], dim=0) for k in ("pred_logits", "pred_masks", "output_mask")}
@@ -133,17 +139,19 @@ class MaskVRD(nn.Module):
         t_pad = (self.max_seq_len, (max(lens + [self.max_seq_len]) + d - 1) // d * d)
         inputs, masks = [], []
         for part_ids, T in zip(ids, t_pad):
-            if not part_ids:
-                inputs.append(None)
-                masks.append(None)
-                continue
-            x = torch.zeros(len(part_ids), feats_list[0].shape[0], T, device=dev, dtype=torch.float32)
-            for r, i in enumerate(part_ids):
-                x[r, :, :lens[i]].copy_(feats_list[i], non_blocking=True)
-            n = torch.tensor([lens[i] for i in part_ids], device=dev)
-            masks.append((torch.arange(T, device=dev)[None, :] < n[:, None])[:, None, :])
+            x, m = self._batch(feats_list, part_ids, T) if part_ids else (None, None)
             inputs.append(x)
+            masks.append(m)
         return tuple(inputs), tuple(masks), ids
+
+    def _batch(self, feats_list, ids, T):
+        """Zero-padded (len(ids), C_in, T) batch and its (len(ids), 1, T) validity mask on the device."""
+        dev = self.device
+        x = torch.zeros(len(ids), feats_list[0].shape[0], T, device=dev, dtype=torch.float32)
+        for r, i in enumerate(ids):
+            x[r, :, :feats_list[i].shape[1]].copy_(feats_list[i], non_blocking=True)
+        n = torch.tensor([feats_list[i].shape[1] for i in ids], device=dev)
+        return x, (torch.arange(T, device=dev)[None, :] < n[:, None])[:, None, :]
 
     @torch.no_grad()
     def forward_test(self, input_data):
@@ -160,17 +168,43 @@ class MaskVRD(nn.Module):
         top_cat = torch.empty(P, Q, k, device=dev, dtype=torch.int32)
         first = torch.empty(P, Q, device=dev, dtype=torch.int32)
         last = torch.empty(P, Q, device=dev, dtype=torch.int32)
+        # The reference walks the pairs in slices of max_so_pair and pads the long pairs of a slice to that
+        # slice's longest (maskvrd.py:208-227, :373-379).  A pair's result depends only on its own padded
+        # length, so pairs are bucketed by the padded length their slice gives them and every bucket runs as
+        # ONE batch (short pairs of all slices share max_seq_len).
+        lens = [int(f.shape[1]) for f in feats]
+        d = self.max_div_factor
+        buckets = {}
         for s0 in range(0, P, self.max_so_pair):
-            inputs, masks, ids = self.preprocessing(feats[s0:s0 + self.max_so_pair])
-            assert len(ids[0]) + len(ids[1]) == len(feats[s0:s0 + self.max_so_pair])
-            for x, m, part_ids in zip(inputs, masks, ids):
-                if x is None:
-                    continue
+            sl = range(s0, min(s0 + self.max_so_pair, P))
+            t_long = (max([lens[i] for i in sl] + [self.max_seq_len]) + d - 1) // d * d
+            for i in sl:
+                buckets.setdefault(self.max_seq_len if lens[i] <= self.max_seq_len else t_long, []).append(i)
+        buckets = sorted(buckets.items())
+        # every host->device table goes up before the first kernel is queued (such a copy waits for the queue)
+        order = torch.tensor([i for _, ids in buckets for i in ids], device=dev)
+        lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
+        tables = ops.pair_table(feats)          # None unless the features are the dataloader's frame-major matrices
+        bb = self.backbone
+        at = 0
+        for T, ids in buckets:
+            rows = order[at:at + len(ids)]
+            at += len(ids)
+            if tables is not None:
+                # the dataloader's (L, C_in) matrices go straight into the backbone's operand buffers
+                outs = []
+                for c0 in range(0, len(ids), self.pair_chunk):
+                    sel = rows[c0:c0 + self.pair_chunk]
+                    *parts, m2 = ops.pack_pairs(tables[0][sel], tables[1][sel], T, bb.n_visual, bb.n_clip,
+                                                bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+                    outs.append(self._heads(*bb.cl_parts(*parts, m2), False))
+                out = self._merge(outs)
+            else:
+                x, m = self._batch(feats, ids, T)
                 out = self._mask_vrd(x, m, with_aux=False)
-                valid = m.sum(dim=(1, 2)).to(torch.int32)
-                ts, tc, sf, sl = ops.postprocess(out["pred_logits"].contiguous(), out["pred_masks"].contiguous(), valid, k)
-                rows = torch.tensor(part_ids, device=dev) + s0
-                top_score[rows], top_cat[rows], first[rows], last[rows] = ts, tc, sf, sl
+            ts, tc, sf, sl_ = ops.postprocess(out["pred_logits"].contiguous(), out["pred_masks"].contiguous(),
+                                              lens_dev[rows], k)
+            top_score[rows], top_cat[rows], first[rows], last[rows] = ts, tc, sf, sl_
 
         to = lambda t: torch.as_tensor(t).to(dev)     # noqa: E731
         sids, oids = to(input_data['sids']).long(), to(input_data['oids']).long()
@@ -201,13 +235,22 @@ class MaskVRD(nn.Module):
                             so_start[pp] + st, so_start[pp] + en,
                             so_start[pp] - durs[sel_s, 0] + st, so_start[pp] - durs[sel_o, 0] + st, en - st],
                            dim=1).cpu().tolist()
+        # box tracks of the winners: every tracklet that appears is copied to the host and turned into Python rows
+        # ONCE (one concatenation, one copy); each triplet then slices those rows.  The reference slices and
+        # .tolist()s two device tensors per triplet (maskvrd.py:302-306), converting shared frames many times.
         boxes = input_data['bboxes_list']
+        used = sorted({r[0] for r in host} | {r[1] for r in host})
+        flat = torch.cat([boxes[t] for t in used], dim=0).cpu().numpy().tolist()
+        rows_of, at = {}, 0
+        for t in used:
+            rows_of[t] = flat[at:at + len(boxes[t])]
+            at += len(boxes[t])
         so_trajs = []
         for r in host:
-            s_box = boxes[r[0]][r[7]:r[7] + r[9]]
-            o_box = boxes[r[1]][r[8]:r[8] + r[9]]
-            assert len(s_box) == len(o_box)
-            so_trajs.append([s_box.tolist(), o_box.tolist()])
+            s_rows = [row[:] for row in rows_of[r[0]][r[7]:r[7] + r[9]]]
+            o_rows = [row[:] for row in rows_of[r[1]][r[8]:r[8] + r[9]]]
+            assert len(s_rows) == len(o_rows)
+            so_trajs.append([s_rows, o_rows])
         return {
             "triplets": [r[2:5] for r in host],
             "triple_scores": tri[order].cpu().tolist(),

@@ -154,6 +154,43 @@ def bct_to_btc(x, c0, count, out, pair=False):
     return Pair(out, count) if pair else out
 
 
+def pair_table(feats):
+    """Device pointer table + lengths of the dataloader's per-pair feature list (one upload for the whole video,
+    done before any kernel is queued: a host->device copy waits for everything already queued on the GPU).
+    Every feats[i] must be the (C_in, L) view of a contiguous (L, C_in) float32 matrix on the device."""
+    dev = feats[0].device
+    C_in = feats[0].shape[0]
+    for f in feats:
+        if not (f.is_cuda and f.dtype == torch.float32 and f.shape[0] == C_in and f.stride(0) == 1 and
+                (f.shape[1] == 1 or f.stride(1) == C_in)):
+            return None
+    return (torch.tensor([f.data_ptr() for f in feats], dtype=torch.int64, device=dev),
+            torch.tensor([f.shape[1] for f in feats], dtype=torch.int32, device=dev))
+
+
+def pack_pairs(table, lens, T, V, Cc, S, E, pair_wide):
+    """Batch the pairs described by `table` (B device pointers) / `lens` (B) straight into the backbone's
+    channels-last operand buffers (see vrd_pack_pairs).
+    Returns (vis (2B,T,V) tensor|Pair, clip or None, so_box (B,T,S), ent (2B,T,E), mask (B,T) bool)."""
+    B = table.shape[0]
+    dev = table.device
+    assert table.dtype == torch.int64 and lens.dtype == torch.int32 and table.is_contiguous() and lens.is_contiguous()
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)      # noqa: E731
+    vis, so_box, ent = new(2 * B, T, V), new(B, T, S), new(2 * B, T, E)
+    clip = new(2 * B, T, Cc) if Cc else None
+    a = _hip.PackArgs()
+    a.src, a.lens = table.data_ptr(), lens.data_ptr()
+    a.P, a.C_in, a.T, a.V, a.Cc, a.S, a.E = B, 2 * V + 2 * Cc + S + 2 * E, T, V, Cc, S, E
+    a.vis, a.clip, a.so_box, a.ent = vis.data_ptr(), _ptr(clip), so_box.data_ptr(), ent.data_ptr()
+    a.pair_wide = 1 if pair_wide else 0
+    _hip.check(lib.vrd_pack_pairs(C.byref(a), _stream()), "vrd_pack_pairs")
+    mask = torch.arange(T, device=dev)[None, :] < lens[:, None]
+    if pair_wide:
+        vis = Pair(vis, V)
+        clip = Pair(clip, Cc) if Cc else None
+    return vis, clip, so_box, ent, mask
+
+
 def btc_to_bct(x):
     """(B, T, C) channels-last -> new (B, C, T) tensor."""
     B, T, Cc = x.shape
