@@ -69,8 +69,37 @@ __device__ __forceinline__ void store_pair1(float* row, int c, int W, float x) {
     r[W + c] = (__bf16)(x - (float)h);
 }
 
+// Branch-free erf (the library erff branches on |z| < 1 per lane, and both sides run under exec masks in any
+// wave that straddles it).  |z| <= 1: z * P(z^2); |z| > 1: sign(z) * (1 - 2^-G(|z|)), G = -log2(erfc) on [1, 4]
+// (erf rounds to 1 beyond).  Coefficients and error (max 1.6e-7 absolute) from scripts/fit_erf.py.
+__device__ __forceinline__ float erf_f32(float z) {
+    const float t = z * z;
+    float a = -9.673590184e-06f;
+    a = fmaf(a, t, 1.126825367e-04f);
+    a = fmaf(a, t, -8.484396520e-04f);
+    a = fmaf(a, t, 5.221053410e-03f);
+    a = fmaf(a, t, -2.686543831e-02f);
+    a = fmaf(a, t, 1.128378262e-01f);
+    a = fmaf(a, t, -3.761263848e-01f);
+    a = fmaf(a, t, 1.128379167e+00f);
+    a *= z;
+    const float u = fminf(fabsf(z), 4.0f);
+    float g = 9.497056197e-08f;
+    g = fmaf(g, u, -4.465436315e-06f);
+    g = fmaf(g, u, 8.666095290e-05f);
+    g = fmaf(g, u, -9.714207371e-04f);
+    g = fmaf(g, u, 7.243836344e-03f);
+    g = fmaf(g, u, -3.895204052e-02f);
+    g = fmaf(g, u, 1.600055804e-01f);
+    g = fmaf(g, u, 9.104687804e-01f);
+    g = fmaf(g, u, 1.631117461e+00f);
+    g = fmaf(g, u, -5.778000722e-04f);
+    const float b = copysignf(1.0f - __builtin_amdgcn_exp2f(-g), z);
+    return fabsf(z) <= 1.0f ? a : b;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752440f));
 }
 
 }  // namespace vrd

@@ -26,70 +26,136 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
         // so that global traffic is whole 256-B row segments as float4 (the raw accumulator layout would
         // give 64 scalar stores per lane).  The caller's main loop ended on a barrier, so the operand tiles
         // are dead; slabs are wave-private and the DS operations of one wave execute in order.
+        // Each round is written as whole-array passes (row inputs, transpose, read-back, arithmetic, stores)
+        // with the activation chosen once per pass, so the 8 rows of a lane are in flight together instead
+        // of one load -> wait -> compute -> store chain per row.
         float* stg = smem + wave * (32 * STG_PITCH);
         const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
         const int n = nw + c4;
         const bool nfull = n + 3 < p.N;
         float bias[4] = {0.f, 0.f, 0.f, 0.f}, scale[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < p.N) {
-                if (p.bias) bias[j] = p.bias[n + j];
-                if (p.scale) scale[j] = p.scale[n + j];
+        if (nfull && ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.scale)) & 15) == 0) {
+            if (p.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                bias[0] = b.x, bias[1] = b.y, bias[2] = b.z, bias[3] = b.w;
             }
+            if (p.scale) {
+                const float4 b = *reinterpret_cast<const float4*>(p.scale + n);
+                scale[0] = b.x, scale[1] = b.y, scale[2] = b.z, scale[3] = b.w;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < p.N) {
+                    if (p.bias) bias[j] = p.bias[n + j];
+                    if (p.scale) scale[j] = p.scale[n + j];
+                }
+        }
+        const bool row_inputs = p.row_mask || p.res || p.res2;
+        const bool ragged = __any(n < p.N && !nfull);          // wave-uniform
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            // Row-wise inputs of this round (mask bytes, residual rows) are requested up front, all eight rows
-            // at once, so their latency is paid once per round instead of once per row.
+            const int64_t mr = mw + mi * 32 + rb0;        // this lane's rows are mr + 4*j
+            // ---- row-wise inputs (mask bytes, residual rows): all eight rows requested together.  Unless the
+            // wave holds a ragged column group (N % 4 != 0 in the last tile column) the loads are unpredicated:
+            // rows past M and column groups past N read a clamped, valid address and are dropped at the store.
             float mk[8];
             float4 r1[8], r2[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int64_t m = mw + mi * 32 + rb0 + 4 * j;
-                const bool ok = m < p.M && n < p.N;
-                mk[j] = (p.row_mask && ok) ? (float)p.row_mask[m] : 1.f;
+                mk[j] = 1.f;
                 r1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 r2[j] = r1[j];
-                if (ok && nfull) {
-                    if (p.res) r1[j] = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n);
-                    if (p.res2) r2[j] = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n);
-                } else if (ok) {
-                    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+            }
+            if (row_inputs && !ragged) {
+                const int nc = n < p.N ? n : 0;
+                unsigned char mb[8];
+                int64_t mc[8];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (n + c < p.N) {
-                            if (p.res) a1[c] = p.res[m * p.ldres + n + c];
-                            if (p.res2) a2[c] = p.res2[m * p.ldres2 + n + c];
-                        }
-                    r1[j] = make_float4(a1[0], a1[1], a1[2], a1[3]);
-                    r2[j] = make_float4(a2[0], a2[1], a2[2], a2[3]);
+                for (int j = 0; j < 8; ++j) mc[j] = (mr + 4 * j < p.M) ? mr + 4 * j : p.M - 1;
+                if (p.row_mask) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mb[j] = p.row_mask[mc[j]];
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r1[j] = *reinterpret_cast<const float4*>(p.res + mc[j] * p.ldres + nc);
+                }
+                if (p.res2) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r2[j] = *reinterpret_cast<const float4*>(p.res2 + mc[j] * p.ldres2 + nc);
+                }
+                if (p.row_mask) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mk[j] = (float)mb[j];
+                }
+            } else if (row_inputs) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t m = mr + 4 * j;
+                    const bool ok = m < p.M && n < p.N;
+                    if (p.row_mask && ok) mk[j] = (float)p.row_mask[m];
+                    if (ok && nfull) {
+                        if (p.res) r1[j] = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n);
+                        if (p.res2) r2[j] = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n);
+                    } else if (ok) {
+                        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (n + c < p.N) {
+                                if (p.res) a1[c] = p.res[m * p.ldres + n + c];
+                                if (p.res2) a2[c] = p.res2[m * p.ldres2 + n + c];
+                            }
+                        r1[j] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                        r2[j] = make_float4(a2[0], a2[1], a2[2], a2[3]);
+                    }
                 }
             }
+            // ---- transpose: accumulator layout -> slab -> eight float4 row pieces per lane
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mi][nj][e];
+            float v[8][4];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int row = rb0 + 4 * j;
-                const int64_t m = mw + mi * 32 + row;
-                const float4 t = *reinterpret_cast<const float4*>(stg + row * STG_PITCH + c4);
-                if (m >= p.M || n >= p.N) continue;
+                const float4 t = *reinterpret_cast<const float4*>(stg + (rb0 + 4 * j) * STG_PITCH + c4);
+                v[j][0] = t.x + bias[0], v[j][1] = t.y + bias[1], v[j][2] = t.z + bias[2], v[j][3] = t.w + bias[3];
+            }
+            // ---- activation (one wave-uniform choice per round), then mask * scale + residuals
+            if (p.act == VRD_ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[j][c] = gelu_erf(v[j][c]);
+            } else if (p.act == VRD_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[j][c] = fmaxf(v[j][c], 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
                 const float rmk = p.res_masked ? mk[j] : 1.f;
                 const float a1[4] = {r1[j].x, r1[j].y, r1[j].z, r1[j].w}, a2[4] = {r2[j].x, r2[j].y, r2[j].z, r2[j].w};
-                float v[4] = {t.x + bias[0], t.y + bias[1], t.z + bias[2], t.w + bias[3]};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = epilogue_value(p, v[c], mk[j], scale[c], a1[c], rmk, a2[c]);
+                for (int c = 0; c < 4; ++c) v[j][c] = v[j][c] * mk[j] * scale[c] + a1[c] * rmk + a2[c];
+            }
+            // ---- stores
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t m = mr + 4 * j;
+                if (m >= p.M || n >= p.N) continue;
                 float* crow = p.C + m * p.ldc + n;
                 if (p.c_pair) {          // pair rows of width N (host checks N % 8 == 0, so a float4 group is whole)
-                    store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[0], v[1], v[2], v[3]));
+                    store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
                 } else if (nfull) {
-                    *reinterpret_cast<float4*>(crow) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(crow) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        if (n + c < p.N) crow[c] = v[c];
+                        if (n + c < p.N) crow[c] = v[j][c];
                 }
             }
         }

@@ -27,33 +27,74 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int DBN = 256;
 
 // geometry of one K step of DBK bf16 elements for a DBM x 256 tile and an NSTG-stage ring
-template <int DBK, int DBM, int NSTG>
+template <int DBK, int DBM, int NSTG, bool BLK = false>
 struct Geo {
-    static constexpr int ROWB = DBK * 2;                      // bytes per tile row
+    static constexpr int ROWB = BLK ? DBK * 4 : DBK * 2;      // bytes per tile row (blocked: hi and lo of a K step side by side)
     static constexpr int CPR = ROWB / 16;                     // 16-byte chunks per row (4 or 2)
     static constexpr int RPI = 1024 / ROWB;                   // rows covered by one wave DMA instruction
     static constexpr int RB = 16 / CPR;                       // rows per 256-byte LDS bank row
     static constexpr int A_PLANE = DBM * ROWB;
     static constexpr int W_PLANE = DBN * ROWB;
-    static constexpr int STAGE = 2 * A_PLANE + 2 * W_PLANE;   // a_hi | a_lo | w_hi | w_lo
+    static constexpr int NPL = BLK ? 1 : 2;                   // LDS images per operand
+    static constexpr int STAGE = NPL * (A_PLANE + W_PLANE);   // a_hi | a_lo | w_hi | w_lo   (blocked: a | w)
     static constexpr int A_INSTR = DBM / RPI, W_INSTR = DBN / RPI;
-    static constexpr int DMA_PER_WAVE = (2 * A_INSTR + 2 * W_INSTR) / 8;
+    static constexpr int DMA_PER_WAVE = NPL * (A_INSTR + W_INSTR) / 8;
     static constexpr int WM = DBM / 64, WN = 8 / WM;          // 8 waves as WM x WN, each 64 rows x (256/WN) columns
     static constexpr int NJ = (DBN / WN) / 32;                // 32-wide accumulator columns per wave (2 or 4)
     static constexpr size_t LDS = (size_t)NSTG * STAGE;
     __device__ static constexpr int swz(int row) { return (row / RB) % CPR; }
 };
 
-__device__ uint4 g_zero_block[4];                     // 64 zero bytes: source of padded taps
+__device__ uint4 g_zero_block[8];                     // 128 zero bytes: source of padded taps
 
-template <int TAPS, int DBK, int DBM, int NSTG>
-__global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
-    using G = Geo<DBK, DBM, NSTG>;
+#ifdef VRD_LAB_STAMP   // scripts/lab/gemm_lab.hip only: per-workgroup cycle stamps (never compiled into the library)
+__device__ unsigned long long g_lab[8 * 65536];
+__device__ unsigned long long g_lab_phase[16 * 4096];   // [wg][group][5 phase accumulators]
+#define LAB_STAMP(slot)                                                                            \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 65536) g_lab[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define LAB_REAL(slot)                                                                             \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 65536) g_lab[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define LAB_PHASE_DECL unsigned long long lab_prev = __builtin_amdgcn_s_memtime(), lab_acc[5] = {0, 0, 0, 0, 0}
+#define LAB_PHASE(i)                                                  \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        lab_acc[i] += now_ - lab_prev;                                \
+        lab_prev = now_;                                              \
+    } while (0)
+#define LAB_PHASE_FLUSH(grp)                                                                  \
+    do {                                                                                      \
+        if ((threadIdx.x & 255) == 0 && blockIdx.x < 4096)                                    \
+            for (int i_ = 0; i_ < 5; ++i_) g_lab_phase[blockIdx.x * 16 + (grp) * 8 + i_] = lab_acc[i_]; \
+    } while (0)
+#else
+#define LAB_STAMP(slot)
+#define LAB_REAL(slot)
+#define LAB_PHASE_DECL
+#define LAB_PHASE(i)
+#define LAB_PHASE_FLUSH(grp)
+#endif
+
+template <int TAPS, int DBK, int DBM, int NSTG, bool PP, bool BLK>
+__global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, int stagger) {
+    using G = Geo<DBK, DBM, NSTG, BLK>;
     constexpr int NJ = G::NJ;
     constexpr int ROWB = G::ROWB, A_PLANE = G::A_PLANE, W_PLANE = G::W_PLANE, STAGE = G::STAGE;
     constexpr int DMA_PER_WAVE = G::DMA_PER_WAVE, KSUB = DBK / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
+    // The workgroups of the first round start together and would all reach their store tail together, where
+    // the whole chip is bound by HBM writes while the MFMAs idle (and the other way round in the main loop).
+    // Spreading the first round's start over one tile time keeps the rounds out of step for the whole launch.
+    if (stagger > 0 && blockIdx.x < 256) {
+        const int slots = (blockIdx.x >> 3) & 7;       // blocks b, b+8, ... share an XCD: stagger inside the XCD
+        for (int i = 0; i < slots * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    LAB_STAMP(0);
+    LAB_REAL(4);
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -79,36 +120,38 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
     int ldst[DMA_PER_WAVE];              // wave-uniform LDS offset inside a stage
     int tseq[DMA_PER_WAVE];              // A rows: position inside the sequence (k=3 padding)
     bool is_a[DMA_PER_WAVE];
-    int lchunk;                          // this lane's logical chunk (bytes) after the source-side swizzle
+    int lchunk[DMA_PER_WAVE];            // this lane's logical chunk (bytes) after the source-side swizzle
     {
         const int rin = lane / G::CPR, pch = lane % G::CPR;
-        // row blocks start at multiples of RPI (a multiple of RB*CPR), so swz(row) == swz(rin)
-        lchunk = (pch ^ G::swz(rin)) * 16;
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
             const int j = wave * DMA_PER_WAVE + i;
-            if (j < 2 * G::A_INSTR) {                      // activation planes
+            if (j < G::NPL * G::A_INSTR) {                 // activation planes
                 const int lo = j / G::A_INSTR, rb = j % G::A_INSTR;
                 int64_t r = m0 + rb * G::RPI + rin;
                 if (r >= p.M) r = p.M - 1;                 // rows past M are computed on duplicates and dropped
-                gsrc[i] = reinterpret_cast<const char*>(p.A + r * p.lda) + (lo ? PW * 2 : 0);
+                gsrc[i] = reinterpret_cast<const char*>(p.A + r * p.lda) + (lo ? PW * 2 : 0);   // (blocked: lo == 0)
                 tseq[i] = (TAPS == 3) ? (int)(r % p.T) : 0;
                 ldst[i] = lo * A_PLANE + rb * 1024;
+                lchunk[i] = (pch ^ G::swz(rb * G::RPI + rin)) * 16;
                 is_a[i] = true;
             } else {                                       // weight planes
-                const int lo = (j - 2 * G::A_INSTR) / G::W_INSTR, rb = (j - 2 * G::A_INSTR) % G::W_INSTR;
+                const int jw = j - G::NPL * G::A_INSTR;
+                const int lo = jw / G::W_INSTR, rb = jw % G::W_INSTR;
                 int n = n0 + rb * G::RPI + rin;
                 if (n >= p.N) n = p.N - 1;
-                gsrc[i] = (lo ? Wlo : Whi) + (int64_t)n * K * 2;
+                gsrc[i] = BLK ? Whi + (int64_t)n * K * 4 : (lo ? Wlo : Whi) + (int64_t)n * K * 2;
                 tseq[i] = 0;
-                ldst[i] = 2 * A_PLANE + lo * W_PLANE + rb * 1024;
+                ldst[i] = G::NPL * A_PLANE + lo * W_PLANE + rb * 1024;
+                lchunk[i] = (pch ^ G::swz(rb * G::RPI + rin)) * 16;
                 is_a[i] = false;
             }
         }
     }
     const char* zero_src = reinterpret_cast<const char*>(g_zero_block);
 
-    auto issue = [&](int kt) {
+    // DMA instructions [i0, i1) of this wave's share of stage kt
+    auto issue_part = [&](int kt, int i0, int i1) {
         const int buf = kt % NSTG;
         const int k0 = kt * DBK;
         int tap = 0, ci0 = k0;
@@ -118,37 +161,45 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
         }
         const int slab = ci0 / PW;
         // byte offset of this K step inside an activation row (pair rows: slab base + hi-plane offset)
-        const int64_t a_off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 + (int64_t)(2 * slab * PW + (ci0 - slab * PW)) * 2;
-        const int64_t w_off = (int64_t)k0 * 2;
+        const int64_t a_off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 +
+                              (BLK ? (int64_t)ci0 * 4 : (int64_t)(2 * slab * PW + (ci0 - slab * PW)) * 2);
+        const int64_t w_off = BLK ? (int64_t)k0 * 4 : (int64_t)k0 * 2;
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            if (i < i0 || i >= i1) continue;
             const char* src;
             if (is_a[i]) {
-                src = gsrc[i] + a_off + lchunk;
+                src = gsrc[i] + a_off + lchunk[i];
                 if (TAPS == 3) {
                     const int tt = tseq[i] + tap - 1;
-                    if (tt < 0 || tt >= p.T) src = zero_src + lchunk;
+                    if (tt < 0 || tt >= p.T) src = zero_src + lchunk[i];
                 }
             } else {
-                src = gsrc[i] + w_off + lchunk;
+                src = gsrc[i] + w_off + lchunk[i];
             }
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + buf * STAGE + ldst[i]), 16, 0, 0);
         }
     };
+    auto issue = [&](int kt) { issue_part(kt, 0, DMA_PER_WAVE); };
 
     // ---- fragment read offsets (bytes inside a stage) for the k16 sub-steps
+    // blocked rows hold the hi half of the K step in chunks 0 .. DBK/8-1 and the lo half behind it
+    constexpr int LO_A = BLK ? 0 : A_PLANE, LO_W = BLK ? 0 : W_PLANE, LO_CH = BLK ? DBK / 8 : 0;
     int a_rd[2][KSUB], w_rd[NJ][KSUB];   // [mi | nj][s]
+    int a_rl[2][KSUB], w_rl[NJ][KSUB];   // the lo halves
 #pragma unroll
     for (int s = 0; s < KSUB; ++s) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int ra = wm * 64 + t * 32 + li;
             a_rd[t][s] = ra * ROWB + (((2 * s + lh) ^ G::swz(ra)) * 16);
+            a_rl[t][s] = LO_A + ra * ROWB + (((LO_CH + 2 * s + lh) ^ G::swz(ra)) * 16);
         }
 #pragma unroll
         for (int t = 0; t < NJ; ++t) {
             const int rw = wn * (32 * NJ) + t * 32 + li;
-            w_rd[t][s] = 2 * A_PLANE + rw * ROWB + (((2 * s + lh) ^ G::swz(rw)) * 16);
+            w_rd[t][s] = G::NPL * A_PLANE + rw * ROWB + (((2 * s + lh) ^ G::swz(rw)) * 16);
+            w_rl[t][s] = G::NPL * A_PLANE + LO_W + rw * ROWB + (((LO_CH + 2 * s + lh) ^ G::swz(rw)) * 16);
         }
     }
 
@@ -164,6 +215,102 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
 #pragma unroll
     for (int t = 0; t < NSTG - 1; ++t)
         if (t < nkt) issue(t);
+    LAB_STAMP(1);
+    if constexpr (PP) {
+        // Ping-pong schedule (NSTG == 3).  Waves w and w+4 share a SIMD; group g = wave >> 2 runs one barrier
+        // phase behind group 0, so in every phase one wave of each SIMD issues MFMAs at priority while its
+        // partner refills its fragment registers from LDS:
+        //     phase 2t   : g0 LOAD(t)     | g1 MFMA(t-1)
+        //     phase 2t+1 : g0 MFMA(t)     | g1 LOAD(t)
+        // The buffer of stage t-1 is free once both groups' reads of it are retired (lgkmcnt(0)) ahead of the
+        // barrier that opens phase 2t, and stage t+2 must have landed by the barrier that opens phase 2t+4.
+        // Every wave issues the first half of its DMA share of stage t+2 in phase 2t and the second half in
+        // phase 2t+1 (g0: LOAD(t) / MFMA(t); g1: MFMA(t-1) / LOAD(t)), so each phase carries half a stage of
+        // DMA issue, split between a loading and a computing wave of every SIMD; inside an MFMA phase the
+        // DMA instructions sit between MFMAs, whose execution hides their issue.
+        // Every wave waits (counted vmcnt: the six newer DMAs stay in flight) for its share of stage t+1
+        // before the barrier that opens phase 2t+2; the first reader starts after that barrier.
+        // Both groups execute 2*nkt + 1 barriers.
+        static_assert(!PP || (NSTG == 3 && DMA_PER_WAVE % 2 == 0), "ping-pong schedule is written for a 3-stage ring");
+        constexpr int H = DMA_PER_WAVE / 2;
+        constexpr int NT = KSUB * 2 * NJ;           // MFMA triples per K step
+        const int grp = wave >> 2;
+        if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp) {
+            if (2 < nkt) issue_part(2, 0, H);
+            __builtin_amdgcn_s_barrier();
+        }
+        LAB_PHASE_DECL;
+        for (int kt = 0; kt < nkt; ++kt) {
+            // ---- LOAD(kt)
+            if (kt + 2 < nkt) {
+                if (grp) issue_part(kt + 2, H, DMA_PER_WAVE);
+                else issue_part(kt + 2, 0, H);
+            }
+            const char* st = lds + (kt % NSTG) * STAGE;
+            bf16x8 ah[KSUB][2], al[KSUB][2], wh[KSUB][NJ], wl[KSUB][NJ];
+#pragma unroll
+            for (int s = 0; s < KSUB; ++s) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    ah[s][t] = *reinterpret_cast<const bf16x8*>(st + a_rd[t][s]);
+                    al[s][t] = *reinterpret_cast<const bf16x8*>(st + a_rl[t][s]);
+                }
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) {
+                    wh[s][t] = *reinterpret_cast<const bf16x8*>(st + w_rd[t][s]);
+                    wl[s][t] = *reinterpret_cast<const bf16x8*>(st + w_rl[t][s]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            LAB_PHASE(0);
+            if (grp) {
+                if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                LAB_PHASE(3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            LAB_PHASE(1);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA(kt), with this phase's half stage of DMA between the MFMAs
+            const int dkt = grp ? kt + 3 : kt + 2;
+            const bool dma = dkt < nkt;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int s = u / (2 * NJ), mi = (u / NJ) % 2, nj = u % NJ;
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mi], wh[s][nj], acc[mi][nj], 0, 0, 0);
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi], wl[s][nj], acc[mi][nj], 0, 0, 0);
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi], wh[s][nj], acc[mi][nj], 0, 0, 0);
+                if (u % 2 == 0 && u / 2 < H) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (dma) {
+                        if (grp) issue_part(dkt, u / 2, u / 2 + 1);
+                        else issue_part(dkt, H + u / 2, H + u / 2 + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            LAB_PHASE(2);
+            if (!grp) {
+                if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_WAVE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                LAB_PHASE(3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // group 1 skips its last barrier (group 0 ran one fewer up front): group 0's epilogue then overlaps
+            // group 1's last MFMA phase.  The staging slabs are wave-private and every LDS read and DMA of
+            // the ring was retired before the barrier group 0 passed last.
+            if (!(grp && kt + 1 == nkt)) __builtin_amdgcn_s_barrier();
+            LAB_PHASE(4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        LAB_PHASE_FLUSH(grp);
+    } else {
     for (int kt = 0; kt < nkt; ++kt) {
         // stage kt has landed once at most the DMAs of the NSTG-2 newer stages are still outstanding
         if (NSTG > 2 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * DMA_PER_WAVE) : "memory");
@@ -177,12 +324,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 ah[t] = *reinterpret_cast<const bf16x8*>(st + a_rd[t][s]);
-                al[t] = *reinterpret_cast<const bf16x8*>(st + A_PLANE + a_rd[t][s]);
+                al[t] = *reinterpret_cast<const bf16x8*>(st + a_rl[t][s]);
             }
 #pragma unroll
             for (int t = 0; t < NJ; ++t) {
                 wh[t] = *reinterpret_cast<const bf16x8*>(st + w_rd[t][s]);
-                wl[t] = *reinterpret_cast<const bf16x8*>(st + W_PLANE + w_rd[t][s]);
+                wl[t] = *reinterpret_cast<const bf16x8*>(st + w_rl[t][s]);
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
@@ -197,6 +344,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
     // every wave must be done with the ring before it is reused as epilogue staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    }
+    LAB_STAMP(2);
 #pragma unroll
     for (int hn = 0; hn < NJ / 2; ++hn) {      // the epilogue works on 64 x 64 halves of the wave's sub-tile
         f32x16 part[2][2];
@@ -206,16 +355,18 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
             for (int j = 0; j < 2; ++j) part[i][j] = acc[i][2 * hn + j];
         vrd::gemm_epilogue<true>(p, part, smem, m0 + wm * 64, n0 + wn * (32 * NJ) + hn * 64, wave, lane);
     }
+    LAB_STAMP(3);
+    LAB_REAL(5);
 }
 
 }  // namespace
 
 namespace vrd {
 
-template <int TAPS, int DBK, int DBM, int NSTG>
+template <int TAPS, int DBK, int DBM, int NSTG, bool PP = false, bool BLK = false>
 static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
-    auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK, DBM, NSTG>;
-    constexpr size_t lds = Geo<DBK, DBM, NSTG>::LDS;
+    auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK, DBM, NSTG, PP, BLK>;
+    constexpr size_t lds = Geo<DBK, DBM, NSTG, BLK>::LDS;
     static_assert(lds >= 8 * 8192 && lds <= 160 * 1024, "ring must hold the epilogue slabs and fit the CU");
     static bool reserved = false;
     if (!reserved) {
@@ -227,7 +378,8 @@ static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
         reserved = true;
     }
     const int tiles_m = (int)((a.M + DBM - 1) / DBM), tiles_n = (a.N + DBN - 1) / DBN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
+    static const int stagger_env = [] { const char* e = getenv("VRD_X3_DMA_STAGGER"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n, stagger_env);
     return 0;
 }
 
@@ -236,19 +388,30 @@ bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged) {
     return staged && a.a_pair_width > 0 && a.a_pair_width % 32 == 0 && a.Cin % 32 == 0 && a.N >= 192;
 }
 
+int launch_gemm_bf16x3_dma_variant(const vrd_gemm_args& a, hipStream_t s, int var);
+
 int launch_gemm_bf16x3_dma(const vrd_gemm_args& a, hipStream_t s) {
+    static const int var_env = [] { const char* e = getenv("VRD_X3_DMA_VARIANT"); return e ? atoi(e) : -1; }();
+    return launch_gemm_bf16x3_dma_variant(a, s, var_env < 0 ? 0 : var_env);
+}
+
+int launch_gemm_bf16x3_dma_variant(const vrd_gemm_args& a, hipStream_t s, int var) {
     // variants (measured with scripts/gemm_bench.py --pair on the path's shapes):
     //   0: 128 x 256 tile, K step 32, 3-stage ring (144 KiB)          -- default for small row counts
     //   1: 128 x 256 tile, K step 16, 3-stage ring (72 KiB, two workgroups per CU)
     //   2: 256 x 256 tile, K step 32, 2-stage ring (128 KiB): a third fewer operand bytes per FLOP
-    static const int var_env = [] { const char* e = getenv("VRD_X3_DMA_VARIANT"); return e ? atoi(e) : -1; }();
-    int var = var_env;
-    if (var < 0) var = 0;
+    //   3: variant 0 with the ping-pong schedule (two wave groups one barrier phase apart)
     if (a.taps == 1) {
+        if (var == 5) return launch_dma_one<1, 32, 128, 3, true, true>(a, s);
+        if (var == 4) return launch_dma_one<1, 32, 128, 3, false, true>(a, s);
+        if (var == 3) return launch_dma_one<1, 32, 128, 3, true>(a, s);
         if (var == 2) return launch_dma_one<1, 32, 256, 2>(a, s);
         if (var == 1) return launch_dma_one<1, 16, 128, 3>(a, s);
         return launch_dma_one<1, 32, 128, 3>(a, s);
     }
+    if (var == 5) return launch_dma_one<3, 32, 128, 3, true, true>(a, s);
+    if (var == 4) return launch_dma_one<3, 32, 128, 3, false, true>(a, s);
+    if (var == 3) return launch_dma_one<3, 32, 128, 3, true>(a, s);
     if (var == 2) return launch_dma_one<3, 32, 256, 2>(a, s);
     if (var == 1) return launch_dma_one<3, 16, 128, 3>(a, s);
     return launch_dma_one<3, 32, 128, 3>(a, s);
