@@ -3,6 +3,7 @@
 // Timing only: operands are arbitrary bf16 bit patterns.
 #include "../../vrdone_amd/csrc/vrd_runtime.hip"
 #include "../../vrdone_amd/csrc/vrd_gemm_x3_dma.hip"
+#include "../../vrdone_amd/csrc/vrd_gemm_x3_big.hip"
 #include <algorithm>
 #include <vector>
 
@@ -12,6 +13,9 @@ static double median(std::vector<double> v) {
 }
 
 int main(int argc, char** argv) {
+    const int lab_mode = argc > 1 ? atoi(argv[1]) : 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_lab_mode), &lab_mode, sizeof lab_mode);
+    printf("lab mode %d\n", lab_mode);
     struct Shape { int64_t M; int N, Cin, taps; const char* label; };
     const Shape shapes[] = {{147456, 512, 512, 1, "qkv/proj"}, {147456, 2048, 512, 1, "mlp up"}, {147456, 512, 2048, 1, "mlp down"},
                             {147456, 512, 1024, 3, "embd k3"}, {589824, 512, 512, 1, "qkv/proj chunk1024"}};
@@ -30,7 +34,7 @@ int main(int argc, char** argv) {
         vrd_gemm_args a = {};
         a.A = A; a.lda = sh.Cin; a.W = nullptr; a.bias = bias; a.C = C; a.ldc = sh.N; a.M = sh.M; a.N = sh.N; a.Cin = sh.Cin;
         a.taps = sh.taps; a.T = T; a.act = 0; a.W_split = (const uint16_t*)W; a.a_pair_width = sh.Cin; a.c_pair = 0;
-        for (int var : {0, 3, 4, 5}) {
+        for (int var : {0, 11}) {
             char env[8];
             snprintf(env, sizeof env, "%d", var);
             hipEvent_t e0, e1;
@@ -39,13 +43,13 @@ int main(int argc, char** argv) {
             float ms = 0;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
-                int rc = vrd::launch_gemm_bf16x3_dma_variant(a, 0, var);
+                int rc = var == 11 ? vrd::launch_gemm_bf16x3_big(a, 0) : vrd::launch_gemm_bf16x3_dma_variant(a, 0, var);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 if (rc) { printf("launch failed: %s\n", vrd_last_error()); return 1; }
                 hipEventElapsedTime(&ms, e0, e1);
             }
-            const int tiles = (int)((sh.M + 127) / 128) * ((sh.N + 255) / 256);
+            const int tiles = (int)((sh.M + (var == 11 ? 255 : 127)) / (var == 11 ? 256 : 128)) * ((sh.N + 255) / 256);
             const int n = std::min(tiles, 65536);
             std::vector<unsigned long long> st((size_t)n * 8);
             hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_lab), st.size() * 8);
@@ -62,7 +66,35 @@ int main(int argc, char** argv) {
             printf("%-20s K=%5d N=%4d var %d: %7.3f ms  %6.1f TF/s | per tile (wave 0): setup %6.0f  loop %7.0f (%5.0f/kstep)  epilogue %6.0f  total %7.0f cyc @ %.2f GHz | tiles/CU %.1f -> busy %.3f ms\n",
                    sh.label, K, sh.N, var, ms, 2.0 * sh.M * sh.N * K / ms / 1e9, median(pro), median(loop), median(loop) / nkt, median(epi),
                    median(tot), ghz, tiles / 256.0, tiles / 256.0 * median(tot) / ghz * 1e-6);
-            if (var == 3 || var == 5) {
+            if (var == 0 || var == 11) {
+                std::vector<unsigned long long> ph((size_t)4096 * 16);
+                hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(g_lab_phase), ph.size() * 8);
+                const char* names[4] = {"vmwait", "barrier", "dma issue", "reads+mfma"};
+                for (int g = 0; g < 2; ++g) {
+                    printf("      waves %d per kstep:", g * 4);
+                    for (int i = 0; i < 4; ++i) {
+                        std::vector<double> v;
+                        for (int w = 0; w < std::min(tiles, 4096); ++w) v.push_back((double)ph[(size_t)w * 16 + g * 8 + i] / nkt);
+                        printf("  %s %5.0f", names[i], median(v));
+                    }
+                    printf("\n");
+                }
+            }
+            if (var >= 6) {
+                std::vector<unsigned long long> ph((size_t)4096 * 16);
+                hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(g_lab_phase), ph.size() * 8);
+                const char* names[2][3] = {{"half0+wait", "barrier", "half1"}, {"vmwait", "barrier", "issue"}};
+                for (int g = 0; g < 2; ++g) {
+                    printf("      %s per kstep:", g ? "producer 0" : "consumer 0");
+                    for (int i = 0; i < 3; ++i) {
+                        std::vector<double> v;
+                        for (int w = 0; w < std::min(tiles, 4096); ++w) v.push_back((double)ph[(size_t)w * 16 + g * 8 + i] / nkt);
+                        printf("  %s %5.0f", names[g][i], median(v));
+                    }
+                    printf("\n");
+                }
+            }
+            if (var == 3) {
                 std::vector<unsigned long long> ph((size_t)4096 * 16);
                 hipMemcpyFromSymbol(ph.data(), HIP_SYMBOL(g_lab_phase), ph.size() * 8);
                 const char* names[5] = {"load", "bar1", "mfma", "vmwait", "bar2"};

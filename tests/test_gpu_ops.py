@@ -398,8 +398,10 @@ def _to_pair(t):
     from vrdone_amd import ops
     hi = t.to(torch.bfloat16)
     lo = (t - hi.float()).to(torch.bfloat16)
-    raw = torch.cat([hi, lo], dim=-1).contiguous()                  # (..., 2C) bf16 = 4C bytes per row
-    return ops.Pair(raw.view(torch.float32), t.shape[-1])
+    C = t.shape[-1]
+    raw = torch.stack([hi.reshape(*t.shape[:-1], C // 32, 32), lo.reshape(*t.shape[:-1], C // 32, 32)], dim=-2)
+    raw = raw.reshape(*t.shape[:-1], 2 * C).contiguous()            # blocks of [32 hi | 32 lo]: 4C bytes per row
+    return ops.Pair(raw.view(torch.float32), C)
 
 
 @pytest.mark.parametrize("H,hd,Tq,Tk", [(4, 128, 96, 96), (8, 64, 144, 144), (4, 128, 288, 288), (8, 64, 512, 512),

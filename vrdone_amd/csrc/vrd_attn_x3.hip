@@ -68,20 +68,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int q0 = (blockIdx.x * NW + wave) * 32;
-    const char* kb = reinterpret_cast<const char*>(k + (int64_t)b * Tk * ldkv) + h * HD * 2;   // hi plane of this head
-    const char* vb = reinterpret_cast<const char*>(v + (int64_t)b * Tk * ldkv) + h * HD * 2;
-    const int lo_off = width * 2;                                                             // bytes to the lo plane
+    // pair rows are blocks of [32 hi | 32 lo] bf16 (vrd_common.h), so a head's HD channels are HD*4 contiguous
+    // bytes; 16-byte chunk lc of the head's logical hi (lo) plane is at block lc/4, +64 bytes for lo
+    const char* kb = reinterpret_cast<const char*>(k + (int64_t)b * Tk * ldkv) + h * HD * 4;
+    const char* vb = reinterpret_cast<const char*>(v + (int64_t)b * Tk * ldkv) + h * HD * 4;
     const char* zero_src = reinterpret_cast<const char*>(g_attn_zero);
 
     // Q^T fragments: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo
     bf16x8 qh[KS], ql[KS];
     {
         const int tq = q0 + li;
-        const char* qr = reinterpret_cast<const char*>(q + ((int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)) * ldq) + h * HD * 2;
+        const char* qr = reinterpret_cast<const char*>(q + ((int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)) * ldq) + h * HD * 4;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            qh[s] = *reinterpret_cast<const bf16x8*>(qr + (16 * s + 8 * lh) * 2);
-            ql[s] = *reinterpret_cast<const bf16x8*>(qr + lo_off + (16 * s + 8 * lh) * 2);
+            const int off = vrd::pair_index(16 * s + 8 * lh) * 2;
+            qh[s] = *reinterpret_cast<const bf16x8*>(qr + off);
+            ql[s] = *reinterpret_cast<const bf16x8*>(qr + off + 64);
         }
     }
 
@@ -97,8 +99,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 const int row = rb * G::RPI + rin;                 // key inside the tile
                 const int key = kt * 32 + row;
                 const int sw = plane < 2 ? G::kswz(row) : G::vswz(row);
-                const char* base = (plane < 2 ? kb : vb) + (int64_t)key * ldkv * 4 + ((plane & 1) ? lo_off : 0);
-                const char* src = (key < Tk ? base : zero_src) + ((pch ^ sw) * 16);
+                const int lc = pch ^ sw;                           // logical 16-byte chunk of the plane row
+                const char* base = (plane < 2 ? kb : vb) + (int64_t)key * ldkv * 4 + ((plane & 1) ? 64 : 0);
+                const char* src = key < Tk ? base + (lc >> 2) * 128 + (lc & 3) * 16 : zero_src + lc * 16;
                 __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + buf * G::STAGE + plane * G::PLANE + rb * 1024), 16, 0, 0);
             }
         }

@@ -44,12 +44,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// "Pair" rows (GEMM-input format of the bf16x3 mode): a row of W logical channels stored in the 4*W bytes
-// an f32 row would occupy as [W x bf16 hi | W x bf16 lo] with hi = bf16(x), lo = bf16(x - hi).  Producers
-// whose output is consumed only as a GEMM operand write this directly, so the GEMM stages pure bf16.
+// "Pair" rows (GEMM-operand format of the bf16x3 mode): a row of W logical channels (W % 32 == 0) stored in the
+// 4*W bytes an f32 row would occupy, as blocks of 32 channels: [32 x bf16 hi | 32 x bf16 lo] per block, with
+// hi = bf16(x), lo = bf16(x - hi).  One 128-byte line therefore holds everything a K step of 32 needs from a
+// row, which is what the GEMM's LDS-DMA wants (whole lines per request).  Producers whose output is consumed
+// only as a GEMM / attention operand write this directly.  Rows concatenated from several producers need no
+// bookkeeping: the block structure does not depend on where a slab starts (slab widths are multiples of 32).
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
-__device__ __forceinline__ void store_pair4(float* row, int c, int W, float4 v) {
+// bf16 index of the hi half of channel c inside a pair row (the lo half is 32 further)
+__device__ __forceinline__ int pair_index(int c) { return ((c >> 5) << 6) + (c & 31); }
+
+__device__ __forceinline__ void store_pair4(float* row, int c, int /*W*/, float4 v) {      // c % 4 == 0
     const float x[4] = {v.x, v.y, v.z, v.w};
     bf16x4_t h, l;
 #pragma unroll
@@ -57,16 +63,16 @@ __device__ __forceinline__ void store_pair4(float* row, int c, int W, float4 v) 
         h[j] = (__bf16)x[j];
         l[j] = (__bf16)(x[j] - (float)h[j]);
     }
-    __bf16* r = reinterpret_cast<__bf16*>(row);
-    *reinterpret_cast<bf16x4_t*>(r + c) = h;
-    *reinterpret_cast<bf16x4_t*>(r + W + c) = l;
+    __bf16* r = reinterpret_cast<__bf16*>(row) + pair_index(c);
+    *reinterpret_cast<bf16x4_t*>(r) = h;
+    *reinterpret_cast<bf16x4_t*>(r + 32) = l;
 }
 
-__device__ __forceinline__ void store_pair1(float* row, int c, int W, float x) {
-    __bf16* r = reinterpret_cast<__bf16*>(row);
+__device__ __forceinline__ void store_pair1(float* row, int c, int /*W*/, float x) {
+    __bf16* r = reinterpret_cast<__bf16*>(row) + pair_index(c);
     const __bf16 h = (__bf16)x;
-    r[c] = h;
-    r[W + c] = (__bf16)(x - (float)h);
+    r[0] = h;
+    r[32] = (__bf16)(x - (float)h);
 }
 
 // Branch-free erf (the library erff branches on |z| < 1 per lane, and both sides run under exec masks in any

@@ -208,6 +208,7 @@ namespace vrd {
 int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s);
 bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged);
 int launch_gemm_bf16x3_dma(const vrd_gemm_args& a, hipStream_t s);
+int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s);
 }  // namespace vrd
 
 extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
@@ -222,12 +223,11 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     VRD_CHECK_ARG(a->act >= 0 && a->act <= 2, "vrd_gemm: bad activation %d", a->act);
     VRD_CHECK_ARG(!a->res || a->ldres >= a->N, "vrd_gemm: ldres too small");
     VRD_CHECK_ARG(!a->res2 || a->ldres2 >= a->N, "vrd_gemm: ldres2 too small");
-    VRD_CHECK_ARG(!a->c_pair || (a->N % 8 == 0 && a->ldc % 4 == 0 && aligned16(a->C)),
-                  "vrd_gemm: pair output needs N %% 8 == 0 and 16-byte aligned rows");
-    VRD_CHECK_ARG(a->a_pair_width == 0 || (a->W_split && a->a_pair_width % 8 == 0 && a->Cin % a->a_pair_width == 0 &&
-                                           a->Cin % 8 == 0 && (a->Cin * a->taps) % 32 == 0 && a->lda % 4 == 0 &&
+    VRD_CHECK_ARG(!a->c_pair || (a->N % 32 == 0 && a->ldc % 32 == 0 && aligned16(a->C)),
+                  "vrd_gemm: pair output needs N %% 32 == 0 and rows that start on a 128-byte block");
+    VRD_CHECK_ARG(a->a_pair_width == 0 || (a->W_split && a->Cin % 32 == 0 && a->lda % 32 == 0 &&
                                            aligned16(a->A) && aligned16(a->W_split)),
-                  "vrd_gemm: pair-row A needs W_split, K %% 32 == 0 and Cin a multiple of the pair width");
+                  "vrd_gemm: pair-row A needs W_split, Cin %% 32 == 0 and rows that start on a 128-byte block");
     if (a->M == 0) return 0;
     const int64_t tiles_m64 = (a->M + BM - 1) / BM;
     const int tiles_n = (a->N + BN - 1) / BN;
@@ -251,9 +251,13 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     static const int64_t dma_min_tiles = [] { const char* e = getenv("VRD_X3_DMA_MIN_TILES"); return e ? atoll(e) : 512; }();
     const bool dma = x3 && dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged) &&
                      ((a->M + 127) / 128) * ((a->N + 255) / 256) >= dma_min_tiles;
+    // the 256 x 256 kernel (DMA-issue cost per MFMA a third lower) once there are about two rounds of its tiles
+    static const int64_t big_min_tiles = [] { const char* e = getenv("VRD_X3_BIG_MIN_TILES"); return e ? atoll(e) : 512; }();
+    const bool big = dma && a->N >= 256 && ((a->M + 255) / 256) * ((a->N + 255) / 256) >= big_min_tiles;
     vrd::ProfScope prof(dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
     if (x3) {
-        int rc3 = dma ? vrd::launch_gemm_bf16x3_dma(*a, s) : vrd::launch_gemm_bf16x3(*a, staged, s);
+        int rc3 = big ? vrd::launch_gemm_bf16x3_big(*a, s)
+                      : dma ? vrd::launch_gemm_bf16x3_dma(*a, s) : vrd::launch_gemm_bf16x3(*a, staged, s);
         if (rc3) return rc3;
         VRD_LAUNCH_CHECK();
         return 0;

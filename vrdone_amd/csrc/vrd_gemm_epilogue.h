@@ -17,7 +17,9 @@ __device__ __forceinline__ float epilogue_value(const vrd_gemm_args& p, float v,
 }
 
 // v = acc + bias; v = act(v); v *= row_mask; v *= scale; v += res * (res_masked ? row_mask : 1); v += res2
-template <bool STAGED>
+// SLAB_ROWS: rows of the wave's private staging slab.  64 (16 KiB per wave) lets both accumulator halves be
+// transposed up front so their registers are dead for the rest of the epilogue; 32 for kernels with less LDS.
+template <bool STAGED, int SLAB_ROWS = 32>
 __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
                                               int nw, int wave, int lane) {
     const int li = lane & 31, lh = lane >> 5;
@@ -29,7 +31,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
         // Each round is written as whole-array passes (row inputs, transpose, read-back, arithmetic, stores)
         // with the activation chosen once per pass, so the 8 rows of a lane are in flight together instead
         // of one load -> wait -> compute -> store chain per row.
-        float* stg = smem + wave * (32 * STG_PITCH);
+        float* stg = smem + wave * (SLAB_ROWS * STG_PITCH);
         const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
         const int n = nw + c4;
         const bool nfull = n + 3 < p.N;
@@ -53,99 +55,120 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
         }
         const bool row_inputs = p.row_mask || p.res || p.res2;
         const bool ragged = __any(n < p.N && !nfull);          // wave-uniform
+        // A 64 x 64 sub-tile is written in four passes of 16 rows (accumulator half mi, row group h): the row
+        // inputs of the next pass are requested before the current one is worked on.
+        struct RowIn {
+            float mk[4];
+            float4 r1[4], r2[4];
+        };
+        auto fetch = [&](int pass) {
+            RowIn in;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int64_t mr = mw + mi * 32 + rb0;        // this lane's rows are mr + 4*j
-            // ---- row-wise inputs (mask bytes, residual rows): all eight rows requested together.  Unless the
-            // wave holds a ragged column group (N % 4 != 0 in the last tile column) the loads are unpredicated:
-            // rows past M and column groups past N read a clamped, valid address and are dropped at the store.
-            float mk[8];
-            float4 r1[8], r2[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                mk[j] = 1.f;
-                r1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                r2[j] = r1[j];
+            for (int j = 0; j < 4; ++j) {
+                in.mk[j] = 1.f;
+                in.r1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                in.r2[j] = in.r1[j];
             }
-            if (row_inputs && !ragged) {
+            if (!row_inputs) return in;
+            const int64_t mr = mw + (pass >> 1) * 32 + rb0 + (pass & 1) * 16;     // rows mr + 4*j
+            if (!ragged) {
+                // unpredicated: rows past M and column groups past N read a clamped, valid address and are
+                // dropped at the store
                 const int nc = n < p.N ? n : 0;
-                unsigned char mb[8];
-                int64_t mc[8];
+                unsigned char mb[4];
+                int64_t mc[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) mc[j] = (mr + 4 * j < p.M) ? mr + 4 * j : p.M - 1;
+                for (int j = 0; j < 4; ++j) mc[j] = (mr + 4 * j < p.M) ? mr + 4 * j : p.M - 1;
                 if (p.row_mask) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) mb[j] = p.row_mask[mc[j]];
+                    for (int j = 0; j < 4; ++j) mb[j] = p.row_mask[mc[j]];
                 }
                 if (p.res) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) r1[j] = *reinterpret_cast<const float4*>(p.res + mc[j] * p.ldres + nc);
+                    for (int j = 0; j < 4; ++j) in.r1[j] = *reinterpret_cast<const float4*>(p.res + mc[j] * p.ldres + nc);
                 }
                 if (p.res2) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) r2[j] = *reinterpret_cast<const float4*>(p.res2 + mc[j] * p.ldres2 + nc);
+                    for (int j = 0; j < 4; ++j) in.r2[j] = *reinterpret_cast<const float4*>(p.res2 + mc[j] * p.ldres2 + nc);
                 }
                 if (p.row_mask) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) mk[j] = (float)mb[j];
+                    for (int j = 0; j < 4; ++j) in.mk[j] = (float)mb[j];
                 }
-            } else if (row_inputs) {
+                return in;
+            }
+            // ragged column group in this wave (N % 4 != 0): guarded element loads
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int64_t m = mr + 4 * j;
-                    const bool ok = m < p.M && n < p.N;
-                    if (p.row_mask && ok) mk[j] = (float)p.row_mask[m];
-                    if (ok && nfull) {
-                        if (p.res) r1[j] = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n);
-                        if (p.res2) r2[j] = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n);
-                    } else if (ok) {
-                        float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = mr + 4 * j;
+                const bool ok = m < p.M && n < p.N;
+                if (p.row_mask && ok) in.mk[j] = (float)p.row_mask[m];
+                if (ok && nfull) {
+                    if (p.res) in.r1[j] = *reinterpret_cast<const float4*>(p.res + m * p.ldres + n);
+                    if (p.res2) in.r2[j] = *reinterpret_cast<const float4*>(p.res2 + m * p.ldres2 + n);
+                } else if (ok) {
+                    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (n + c < p.N) {
-                                if (p.res) a1[c] = p.res[m * p.ldres + n + c];
-                                if (p.res2) a2[c] = p.res2[m * p.ldres2 + n + c];
-                            }
-                        r1[j] = make_float4(a1[0], a1[1], a1[2], a1[3]);
-                        r2[j] = make_float4(a2[0], a2[1], a2[2], a2[3]);
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (n + c < p.N) {
+                            if (p.res) a1[c] = p.res[m * p.ldres + n + c];
+                            if (p.res2) a2[c] = p.res2[m * p.ldres2 + n + c];
+                        }
+                    in.r1[j] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                    in.r2[j] = make_float4(a2[0], a2[1], a2[2], a2[3]);
                 }
             }
-            // ---- transpose: accumulator layout -> slab -> eight float4 row pieces per lane
+            return in;
+        };
+        RowIn cur = fetch(0);
 #pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
+        for (int pass = 0; pass < 4; ++pass) {
+            const int mi = pass >> 1, h = pass & 1;
+            const int slab_row0 = SLAB_ROWS == 64 ? mi * 32 : 0;
+            if (SLAB_ROWS == 64 ? pass == 0 : h == 0) {
+                // transpose: accumulator layout -> slab (32 rows x 64 columns per accumulator half)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mi][nj][e];
-            float v[8][4];
+                for (int mt = 0; mt < 2; ++mt) {
+                    if (SLAB_ROWS == 64 ? false : mt != mi) continue;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 t = *reinterpret_cast<const float4*>(stg + (rb0 + 4 * j) * STG_PITCH + c4);
+                    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e)
+                            stg[((SLAB_ROWS == 64 ? mt * 32 : 0) + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] =
+                                acc[mt][nj][e];
+                }
+            }
+            RowIn nxt = cur;
+            if (pass + 1 < 4) nxt = fetch(pass + 1);
+            float v[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 t = *reinterpret_cast<const float4*>(stg + (slab_row0 + rb0 + h * 16 + 4 * j) * STG_PITCH + c4);
                 v[j][0] = t.x + bias[0], v[j][1] = t.y + bias[1], v[j][2] = t.z + bias[2], v[j][3] = t.w + bias[3];
             }
-            // ---- activation (one wave-uniform choice per round), then mask * scale + residuals
+            // activation (one wave-uniform choice per pass), then mask * scale + residuals
             if (p.act == VRD_ACT_GELU) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[j][c] = gelu_erf(v[j][c]);
             } else if (p.act == VRD_ACT_RELU) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[j][c] = fmaxf(v[j][c], 0.f);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float rmk = p.res_masked ? mk[j] : 1.f;
-                const float a1[4] = {r1[j].x, r1[j].y, r1[j].z, r1[j].w}, a2[4] = {r2[j].x, r2[j].y, r2[j].z, r2[j].w};
+            for (int j = 0; j < 4; ++j) {
+                const float rmk = p.res_masked ? cur.mk[j] : 1.f;
+                const float a1[4] = {cur.r1[j].x, cur.r1[j].y, cur.r1[j].z, cur.r1[j].w};
+                const float a2[4] = {cur.r2[j].x, cur.r2[j].y, cur.r2[j].z, cur.r2[j].w};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[j][c] = v[j][c] * mk[j] * scale[c] + a1[c] * rmk + a2[c];
+                for (int c = 0; c < 4; ++c) v[j][c] = v[j][c] * cur.mk[j] * scale[c] + a1[c] * rmk + a2[c];
             }
-            // ---- stores
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t m = mr + 4 * j;
+            for (int j = 0; j < 4; ++j) {
+                const int64_t m = mw + mi * 32 + rb0 + h * 16 + 4 * j;
                 if (m >= p.M || n >= p.N) continue;
                 float* crow = p.C + m * p.ldc + n;
                 if (p.c_pair) {          // pair rows of width N (host checks N % 8 == 0, so a float4 group is whole)
@@ -158,6 +181,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
                         if (n + c < p.N) crow[c] = v[j][c];
                 }
             }
+            cur = nxt;
         }
         return;
     }

@@ -49,8 +49,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
     const int li = lane & 31, lh = lane >> 5;
     const int K = p.Cin * TAPS;          // multiple of 32 (checked on the host)
     const int nkt = K / BK;
-    const __bf16* Whi = reinterpret_cast<const __bf16*>(p.W_split);
-    const __bf16* Wlo = Whi + (int64_t)p.N * K;
+    const __bf16* Wsp = reinterpret_cast<const __bf16*>(p.W_split);      // [N][K/32][32 hi | 32 lo]
 
     // A staging: 4 float4 pieces per thread, piece i = (row = (tid + 256 i) / 8, k = 4 * ((tid + 256 i) % 8))
     // W staging: 2 x (hi, lo) 16-byte pieces per thread, piece i = (row = (tid + 256 i) / 4, k = 8 * (f % 4))
@@ -66,7 +65,6 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
     auto fetch = [&](int kt) {
         if (APAIR) {
             // piece i = (row = (tid + 256 i) / 4, 8 consecutive k): one 16-byte load from each plane
-            const int PW = p.a_pair_width;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int f = tid + 256 * i;
@@ -83,11 +81,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
                         ok = tt >= 0 && tt < p.T;
                     }
                     if (ok) {
-                        const int slab = ci / PW, j = ci - slab * PW;
                         const __bf16* row = reinterpret_cast<const __bf16*>(p.A + (r + tap - (TAPS == 3 ? 1 : 0)) * p.lda) +
-                                            2 * slab * PW + j;
+                                            vrd::pair_index(ci);
                         h = *reinterpret_cast<const uint4*>(row);
-                        l = *reinterpret_cast<const uint4*>(row + PW);
+                        l = *reinterpret_cast<const uint4*>(row + 32);
                     }
                 }
                 ra[i] = *reinterpret_cast<float4*>(&h);
@@ -120,8 +117,9 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             const int k = kt * BK + (f & 3) * 8;
             uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
             if (n < p.N) {
-                h = *reinterpret_cast<const uint4*>(Whi + (int64_t)n * K + k);
-                l = *reinterpret_cast<const uint4*>(Wlo + (int64_t)n * K + k);
+                const __bf16* wrow = Wsp + (int64_t)n * K * 2 + vrd::pair_index(k);
+                h = *reinterpret_cast<const uint4*>(wrow);
+                l = *reinterpret_cast<const uint4*>(wrow + 32);
             }
             rwh[i] = h;
             rwl[i] = l;

@@ -1,0 +1,242 @@
+// Split-precision conv GEMM, 256 x 256 tile (see vrd_gemm_x3.hip for the arithmetic and vrd_gemm_x3_dma.hip for
+// the LDS-DMA staging it shares).
+//
+// Why a second DMA kernel: measured on the 128 x 256 kernel (scripts/lab/gemm_lab.hip), a 1-KiB LDS-DMA
+// instruction costs the CU ~45 cycles while MFMAs are running -- whoever issues it and at whatever priority --
+// so a 48-KiB K step costs ~2,100 cycles of DMA issue against 1,536 cycles of MFMA: the step is DMA-issue-bound.
+// A 256 x 256 tile moves 64 KiB per K step for twice the MFMAs (3,072 cycles), which puts the MFMAs back in
+// front.  The activations stream from HBM (latency of microseconds), the weights come from L2, so the ring is
+// split: three activation stages (two in flight, ~6k cycles ahead) and two weight stages:
+//     A ring 3 x 32 KiB | W ring 2 x 32 KiB = 160 KiB, all of the CU's LDS (one workgroup per CU).
+// Per K step t every wave:  wait (counted vmcnt) until its pieces of W(t) and A(t) landed -> barrier ->
+// issue W(t+1) then A(t+2) (4 + 4 DMAs; W first so that the counted wait can leave A(t+2) in flight) ->
+// fragment reads and MFMAs of step t.  The barrier also tells everyone that stage t-1 is no longer being read,
+// which frees A buffer (t+2) % 3 and W buffer (t+1) % 2.
+// 8 waves as 2 (M) x 4 (N), each 128 x 64 = 4 x 2 accumulators of 32 x 32.
+// Operands are pair rows in 32-channel blocks [32 hi | 32 lo] (vrd_common.h): a tile row of one K step is one
+// 128-byte line; its 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the DMA source and on the reads.
+#include "vrd_common.h"
+#include "vrd_gemm_epilogue.h"
+
+namespace {
+
+using vrd::f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int TM = 256, TN = 256;
+constexpr int ROWB = 128;                      // bytes of a tile row per K step (32 hi + 32 lo bf16)
+constexpr int A_STAGE = TM * ROWB, W_STAGE = TN * ROWB;
+constexpr int NA_STG = 3, NW_STG = 2;
+constexpr int W_RING = NA_STG * A_STAGE;       // byte offset of the W ring
+constexpr size_t BIG_LDS = (size_t)NA_STG * A_STAGE + (size_t)NW_STG * W_STAGE;      // 163,840
+constexpr int PER = 4;                         // DMA instructions per wave, operand and K step (8 rows x 128 B each)
+
+__device__ uint4 g_big_zero[8];                // 128 zero bytes: source of padded taps
+
+#ifndef VRD_LAB_STAMP      // the lab harness (scripts/lab/gemm_lab.hip) defines these before including this file
+#define LAB_STAMP(slot)
+#define LAB_REAL(slot)
+#define LAB_PHASE_DECL
+#define LAB_PHASE(i)
+#define LAB_PHASE_FLUSH(grp)
+#endif
+
+__device__ constexpr int swz(int row) { return (row >> 1) & 7; }
+
+template <int TAPS>
+__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    LAB_STAMP(0);
+    LAB_REAL(4);
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * TM;
+    const int n0 = tn * TN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = p.Cin * TAPS;
+    const int nkt = K / 32;
+
+    // ---- DMA sources: this wave moves row blocks wave*4 .. wave*4+3 (8 rows each) of both operands
+    const int rin = lane >> 3, pch = lane & 7;
+    const char* asrc[PER];
+    const char* wsrc[PER];
+    int tseq[PER], chunk[PER];
+    const char* zero_src = reinterpret_cast<const char*>(g_big_zero);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int row = (wave * PER + i) * 8 + rin;                 // row inside the tile, for both operands
+        chunk[i] = (pch ^ swz(row)) * 16;
+        int64_t r = m0 + row;
+        if (r >= p.M) r = p.M - 1;                                  // rows past M are computed on duplicates and dropped
+        asrc[i] = reinterpret_cast<const char*>(p.A + r * p.lda) + chunk[i];
+        tseq[i] = (TAPS == 3) ? (int)(r % p.T) : 0;
+        int n = n0 + row;
+        if (n >= p.N) n = p.N - 1;
+        wsrc[i] = reinterpret_cast<const char*>(p.W_split) + (int64_t)n * K * 4 + chunk[i];
+    }
+    // piece i of W(kt) / A(kt): one DMA instruction each
+    auto issue_w1 = [&](int kt, int i) {
+        char* const dst = lds + W_RING + (kt % NW_STG) * W_STAGE + wave * PER * 1024;
+        __builtin_amdgcn_global_load_lds(wsrc[i] + (int64_t)kt * 128, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+    };
+    auto issue_a1 = [&](int kt, int i) {
+        char* const dst = lds + (kt % NA_STG) * A_STAGE + wave * PER * 1024;
+        const int k0 = kt * 32;
+        int tap = 0, ci0 = k0;
+        if (TAPS == 3) {
+            tap = (k0 >= p.Cin) + (k0 >= 2 * p.Cin);
+            ci0 = k0 - tap * p.Cin;
+        }
+        const int64_t off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 + (int64_t)ci0 * 4;
+        const char* src = asrc[i] + off;
+        if (TAPS == 3) {
+            const int tt = tseq[i] + tap - 1;
+            if (tt < 0 || tt >= p.T) src = zero_src + chunk[i];
+        }
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+    };
+    auto issue_w = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) issue_w1(kt, i);
+    };
+    auto issue_a = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) issue_a1(kt, i);
+    };
+
+    // ---- fragment read offsets (bytes inside a stage): hi chunks 0..3, lo chunks 4..7 of the row
+    int a_hi[4][2], a_lo[4][2], w_hi[2][2], w_lo[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = wm * 128 + t * 32 + li;
+            a_hi[t][s] = r * ROWB + (((2 * s + lh) ^ swz(r)) * 16);
+            a_lo[t][s] = r * ROWB + (((4 + 2 * s + lh) ^ swz(r)) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = wn * 64 + t * 32 + li;
+            w_hi[t][s] = W_RING + r * ROWB + (((2 * s + lh) ^ swz(r)) * 16);
+            w_lo[t][s] = W_RING + r * ROWB + (((4 + 2 * s + lh) ^ swz(r)) * 16);
+        }
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue_a(0);
+    if (nkt > 1) issue_a(1);
+    issue_w(0);
+    LAB_STAMP(1);
+    LAB_PHASE_DECL;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // in issue order this wave has outstanding at most [.. W(kt), A(kt+1)]: leave A(kt+1) in flight
+        if (kt > 0 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LAB_PHASE(0);
+        __builtin_amdgcn_s_barrier();
+        LAB_PHASE(1);
+        // The eight DMAs of this step (W(kt+1) x 4, then A(kt+2) x 4) are spread over the step, one behind every
+        // group of six MFMAs: a DMA issue stalls its wave for 100-200 cycles while MFMAs run, and the SIMD's
+        // other wave fills that gap only if it is not stalled on its own DMA at the same time.
+        const bool do_w = kt + 1 < nkt, do_a = kt + 2 < nkt;
+        LAB_PHASE(2);
+        const char* sa = lds + (kt % NA_STG) * A_STAGE;
+        const char* sw = lds + (kt % NW_STG) * W_STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[4], al[4], wh[2], wl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                wh[t] = *reinterpret_cast<const bf16x8*>(sw + w_hi[t][s]);
+                wl[t] = *reinterpret_cast<const bf16x8*>(sw + w_lo[t][s]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                ah[t] = *reinterpret_cast<const bf16x8*>(sa + a_hi[t][s]);
+                al[t] = *reinterpret_cast<const bf16x8*>(sa + a_lo[t][s]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], wh[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s == 0) {
+                    if (do_w) issue_w1(kt + 1, mi);
+                } else {
+                    if (do_a) issue_a1(kt + 2, mi);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#ifdef VRD_LAB_STAMP
+        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[3][1][15]));
+#endif
+        LAB_PHASE(3);
+    }
+    LAB_PHASE_FLUSH(wave >> 2);
+    // every wave must be done with the rings before they are reused as epilogue staging
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    LAB_STAMP(2);
+#pragma unroll
+    for (int hm = 0; hm < 2; ++hm) {          // the epilogue works on 64 x 64 halves of the wave's 128 x 64
+        f32x16 part[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) part[i][j] = acc[2 * hm + i][j];
+        vrd::gemm_epilogue<true, 64>(p, part, smem, m0 + wm * 128 + hm * 64, n0 + wn * 64, wave, lane);
+    }
+    LAB_STAMP(3);
+    LAB_REAL(5);
+}
+
+}  // namespace
+
+namespace vrd {
+
+template <int TAPS>
+static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
+    auto kern = gemm_bf16x3_big_kernel<TAPS>;
+    static bool reserved = false;
+    if (!reserved) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIG_LDS);
+        if (e != hipSuccess) {
+            set_error("vrd_gemm(bf16x3 256x256): cannot reserve %zu B of LDS: %s", BIG_LDS, hipGetErrorString(e));
+            return -2;
+        }
+        reserved = true;
+    }
+    const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n);
+    return 0;
+}
+
+// same eligibility as the 128 x 256 DMA kernel (pair-row A, staged epilogue); the caller picks by tile count
+int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s) {
+    return a.taps == 1 ? launch_big_one<1>(a, s) : launch_big_one<3>(a, s);
+}
+
+}  // namespace vrd

@@ -303,7 +303,7 @@ int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int coun
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * B * (double)count * T);
     dim3 grid((T + 63) / 64, (count + 63) / 64, B);
-    VRD_CHECK_ARG(!out_pair || (count % 8 == 0 && ld_dst % 4 == 0 && aligned16(dst)), "vrd_bct_to_btc: pair rows need count %% 8 == 0");
+    VRD_CHECK_ARG(!out_pair || (count % 32 == 0 && ld_dst % 4 == 0 && aligned16(dst)), "vrd_bct_to_btc: pair rows need count %% 32 == 0");
     hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
     VRD_LAUNCH_CHECK();
     return 0;
@@ -314,7 +314,7 @@ int vrd_pack_pairs(const vrd_pack_args* a, void* stream) {
     VRD_CHECK_ARG(a->P > 0 && a->T > 0 && a->V > 0 && a->S > 0 && a->E > 0 && a->Cc >= 0, "vrd_pack_pairs: bad sizes");
     VRD_CHECK_ARG(a->C_in == 2 * a->V + 2 * a->Cc + a->S + 2 * a->E, "vrd_pack_pairs: C_in %d does not match the slab widths", a->C_in);
     VRD_CHECK_ARG(a->Cc == 0 || a->clip, "vrd_pack_pairs: clip buffer missing");
-    VRD_CHECK_ARG(!a->pair_wide || (a->V % 8 == 0 && a->Cc % 8 == 0), "vrd_pack_pairs: pair rows need widths %% 8 == 0");
+    VRD_CHECK_ARG(!a->pair_wide || (a->V % 32 == 0 && a->Cc % 32 == 0), "vrd_pack_pairs: pair rows need widths %% 32 == 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t rows = (int64_t)a->P * a->T;
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * a->C_in);

@@ -45,10 +45,11 @@ def _ptr(t):
 
 
 class Pair:
-    """A channels-last tensor stored in the GEMM-operand "pair" format of the bf16x3 mode: the 4*W bytes of
-    each W-channel slab of a row hold [W x bf16 hi | W x bf16 lo] (hi = bf16(x), lo = bf16(x - hi)) instead
-    of W floats.  `t` is the f32-typed buffer (same shape / strides as the f32 tensor would have), `width`
-    the slab width W the producers used.  Only conv_gemm() consumes a Pair."""
+    """A channels-last tensor stored in the GEMM-operand "pair" format of the bf16x3 mode: the 4*C bytes of a
+    C-channel row (C % 32 == 0) hold, per block of 32 channels, [32 x bf16 hi | 32 x bf16 lo] (hi = bf16(x),
+    lo = bf16(x - hi)) instead of 32 floats.  `t` is the f32-typed buffer (same shape / strides as the f32
+    tensor would have); `width` records the width of the producer's slab (the format itself does not depend on
+    it).  Only conv_gemm() and attention() consume a Pair."""
     __slots__ = ("t", "width")
 
     def __init__(self, t, width):
@@ -63,10 +64,9 @@ class Pair:
 
     def float(self):
         """Decode to f32 (hi + lo); for tests."""
-        W = self.width
         raw = self.t.contiguous().view(torch.bfloat16)                 # (..., 2*C)
-        slabs = raw.reshape(*raw.shape[:-1], -1, 2, W).float()
-        return (slabs[..., 0, :] + slabs[..., 1, :]).reshape(*self.t.shape)
+        blocks = raw.reshape(*raw.shape[:-1], -1, 2, 32).float()
+        return (blocks[..., 0, :] + blocks[..., 1, :]).reshape(*self.t.shape)
 
 
 def flash_pair_ok(n_head, channels, Tq):
@@ -135,12 +135,15 @@ def get_precision():
 
 
 def split_conv_weight(w):
-    """(2, N, K) bf16: bf16(W) and bf16(W - bf16(W)) of the tap-major packed weight."""
+    """(N, K/32, 2, 32) bf16 of the tap-major packed weight (K = Cin*k, K % 32 == 0): per block of 32 K positions
+    [32 x bf16(W) | 32 x bf16(W - bf16(W))] -- the pair-row block format of vrd_common.h, so one 128-byte line
+    holds what a K step needs from a weight row."""
     def build():
         packed = packed_conv_weight(w).detach().reshape(w.shape[0], -1)
         hi = packed.to(torch.bfloat16)
         lo = (packed - hi.float()).to(torch.bfloat16)
-        return torch.stack([hi, lo]).contiguous()
+        N, K = hi.shape
+        return torch.stack([hi.reshape(N, K // 32, 32), lo.reshape(N, K // 32, 32)], dim=2).contiguous()
     return _cached(w, "_vrd_split", build)
 
 
@@ -230,7 +233,7 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     a.row_mask = _mask_ptr(row_mask, rows)
     a.scale = _ptr(scale)
     if a_width:
-        assert _precision == "bf16x3" and (Cin * k) % 32 == 0 and Cin % a_width == 0, "pair input needs an eligible bf16x3 GEMM"
+        assert _precision == "bf16x3" and Cin % 32 == 0, "pair input needs bf16x3 precision and Cin % 32 == 0"
     if _precision == "bf16x3" and (Cin * k) % 32 == 0:
         a.W_split = split_conv_weight(weight).data_ptr()
     a.a_pair_width = a_width
