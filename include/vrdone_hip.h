@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 3
+#define VRD_ABI_VERSION 4
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -39,7 +39,8 @@ enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 enum vrd_kernel_id {
     VRD_K_GEMM = 0, VRD_K_LAYERNORM = 1, VRD_K_DWCONV_LN = 2, VRD_K_LOCAL_ATTN = 3,
     VRD_K_ATTN_SMALL = 4, VRD_K_ATTN_FLASH = 5, VRD_K_POOL = 6, VRD_K_MASK_HEAD = 7,
-    VRD_K_TRANSPOSE = 8, VRD_K_POSTPROC = 9, VRD_K_GEMM_X3 = 10, VRD_K_GEMM_X3_DMA = 11, VRD_K_COUNT = 12
+    VRD_K_TRANSPOSE = 8, VRD_K_POSTPROC = 9, VRD_K_GEMM_X3 = 10, VRD_K_GEMM_X3_DMA = 11, VRD_K_GEMM_X3_BIG = 12,
+    VRD_K_COUNT = 13
 };
 
 int vrd_abi_version(void);

@@ -393,6 +393,36 @@ def test_pair_row_format_round_trip(precision):
     assert float(((got.float() - want).abs() / want.abs().clamp_min(1e-2)).max()) < 2 ** -15
 
 
+@pytest.mark.parametrize("k", [1, 3])
+def test_gemm_large_tile_kernels(k, precision):
+    """Shapes with enough tiles for the 256 x 256 (and, in the smaller call, the 128 x 256) LDS-DMA kernels:
+    pair-row input, k = 1 / 3, mask * scale + two residuals, f32 and pair output, checked per sequence against
+    an f64 reference on a sample of the sequences (rows of other sequences never enter a sequence's result)."""
+    if precision != "bf16x3":
+        pytest.skip("the LDS-DMA kernels are split-precision kernels")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(7 + k)
+    T, Cin, N = 288, 512, 512
+    for B in (256, 96):        # 576 tiles of 256x256 -> big kernel; 432 tiles of 128x256 ... -> 128x256 kernel
+        x = torch.randn(B, T, Cin, generator=gen)
+        w = torch.randn(N, Cin, k, generator=gen) / (Cin * k) ** 0.5
+        bias, scale = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5
+        mask = torch.rand(B, T, generator=gen) > 0.2
+        res, res2 = torch.randn(B, T, N, generator=gen), torch.randn(B, T, N, generator=gen)
+        xp = _to_pair(x.to(DEV))
+        kw = dict(row_mask=mask.to(DEV), scale=scale.to(DEV), res=res.to(DEV), res_masked=True, res2=res2.to(DEV))
+        got = ops.conv_gemm(xp, w.to(DEV), bias.to(DEV), **kw)
+        got_pair = ops.conv_gemm(xp, w.to(DEV), bias.to(DEV), out_pair=True, **kw)
+        sample = [0, 1, B // 2, B - 2, B - 1]
+        xs = x[sample].double().transpose(1, 2)                                   # (S, Cin, T)
+        y = torch.nn.functional.conv1d(xs, w.double(), bias.double(), padding=k // 2).transpose(1, 2)
+        mk = mask[sample].double()[..., None]
+        want = (y * mk * scale.double() + res[sample].double() * mk + res2[sample].double()).float()
+        close(got[sample], want, 2e-5, gemm=True)
+        # the pair output is the same result rounded to hi + lo (16 mantissa bits)
+        assert float(((got_pair.float() - got).abs() / got.abs().clamp_min(1e-3)).max()) < 2 ** -15
+
+
 def _to_pair(t):
     """Encode an f32 (B, T, C) tensor as pair rows (test helper; mirrors vrd::store_pair4)."""
     from vrdone_amd import ops

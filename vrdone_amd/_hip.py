@@ -14,7 +14,8 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
  K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_COUNT) = range(13)
 KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
-                "maxpool_mask", "mask_head", "transpose", "postprocess", "gemm_bf16x3_mfma", "gemm_bf16x3_dma"]
+                "maxpool_mask", "mask_head", "transpose", "postprocess", "gemm_bf16x3_mfma", "gemm_bf16x3_dma",
+                "gemm_bf16x3_big"]
 
 c_f32p = C.c_void_p      # device pointers travel as plain integers
 c_u8p = C.c_void_p
@@ -75,7 +76,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):

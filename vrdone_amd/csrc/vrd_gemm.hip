@@ -254,7 +254,7 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     // the 256 x 256 kernel (DMA-issue cost per MFMA a third lower) once there are about two rounds of its tiles
     static const int64_t big_min_tiles = [] { const char* e = getenv("VRD_X3_BIG_MIN_TILES"); return e ? atoll(e) : 512; }();
     const bool big = dma && a->N >= 256 && ((a->M + 255) / 256) * ((a->N + 255) / 256) >= big_min_tiles;
-    vrd::ProfScope prof(dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
+    vrd::ProfScope prof(big ? VRD_K_GEMM_X3_BIG : dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
     if (x3) {
         int rc3 = big ? vrd::launch_gemm_bf16x3_big(*a, s)
                       : dma ? vrd::launch_gemm_bf16x3_dma(*a, s) : vrd::launch_gemm_bf16x3(*a, staged, s);
