@@ -143,17 +143,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // depthwise (or 2-in-per-group) conv along t, * mask, -> LayerNorm, up to three weight sets
 // sharing the input rows (the q/k/v branches of the conv-attention modules)
 // ------------------------------------------------------------------------------------------
-template <int NV, int KS, int GIN>
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // output row b*Tout + t'
-    if (row >= (int64_t)p.B * Tout) return;
-    const int b = (int)(row / Tout), to = (int)(row - (int64_t)b * Tout);
+// One wave walks a strip of RW consecutive output rows of one sequence, so the input rows it shares with its
+// neighbours stay in registers (a 3-row window, the next row(s) already requested), and the per-channel
+// parameters of all output sets (taps, bias, gamma, beta: 12 KiB per 512-channel set) sit in LDS, filled once per
+// workgroup: with one row per wave they were re-read through the vector L1 for every row, 36 KiB per 8 KiB of
+// row data, and the kernel ran at the L1's rate (2.7 TB/s of HBM) instead of HBM's.
+// LDS per set o (floats): taps [GIN*KS][C] | bias [C] | gamma [C] | beta [C].
+constexpr int DW_RW = 16;                      // output rows per wave
 
-    float4 in[KS][NV][GIN];
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        const int ti = p.stride * to + k - KS / 2;
+template <int NV, int KS, int GIN>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq) {
+    constexpr int C = 256 * NV, NT = GIN * KS, SETF = (NT + 3) * C;
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- parameters -> LDS (taps transposed to tap-major so a lane's four channels are one float4)
+    for (int o = 0; o < p.n_out; ++o) {
+        float* const ls = dw_lds + o * SETF;
+        for (int idx = threadIdx.x; idx < C * NT; idx += 256) ls[(idx % NT) * C + idx / NT] = p.w[o][idx];
+        for (int c = threadIdx.x; c < C; c += 256) {
+            ls[NT * C + c] = p.bias[o] ? p.bias[o][c] : 0.f;
+            ls[(NT + 1) * C + c] = p.gamma[o] ? p.gamma[o][c] : 1.f;
+            ls[(NT + 2) * C + c] = p.gamma[o] ? p.beta[o][c] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int64_t ws = (int64_t)blockIdx.x * 4 + wave;
+    const int b = (int)(ws / strips_per_seq);
+    if (b >= p.B) return;
+    const int to0 = (int)(ws - (int64_t)b * strips_per_seq) * DW_RW;
+    const int to1 = min(to0 + DW_RW, Tout);
+
+    struct Row {
+        float4 v[NV][GIN];
+    };
+    auto load_row = [&](int ti) {
+        Row r;
         const bool ok = ti >= 0 && ti < p.Tin;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
@@ -165,64 +189,86 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                     v = ld4(p.x + ((int64_t)b * p.Tin + ti) * p.ldx + coff);
                     if (p.x_up) v = f4add(v, ld4(p.x_up + ((int64_t)b * (p.Tin / 2) + (ti >> 1)) * p.ldx_up + coff));
                 }
-                in[k][i][g] = v;
+                r.v[i][g] = v;
             }
-    }
-    const float mk = p.mask_out ? (float)p.mask_out[row] : 1.f;
-
+        return r;
+    };
+    // window win[k] = input row stride*to + k - KS/2; between consecutive output rows it moves by `stride`
+    Row win[KS];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        if (o >= p.n_out) break;
-        float4 acc[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            // weights of this lane's 4 output channels: [4][GIN][KS] contiguous floats
-            float w[4 * GIN * KS];
-            const float* wp = p.w[o] + (int64_t)(i * 256 + lane * 4) * GIN * KS;
-#pragma unroll
-            for (int j = 0; j < GIN * KS; ++j) {
-                const float4 t = ld4(wp + 4 * j);
-                w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w;
+    for (int k = 0; k < KS; ++k) win[k] = load_row(p.stride * to0 + k - KS / 2);
+    for (int to = to0; to < to1; ++to) {
+        // request what the next output row adds to the window before working on this one
+        Row nxt[2];
+        const int tn = p.stride * (to + 1) - KS / 2;            // first input row of the next window
+        const bool more = to + 1 < to1;
+        if (KS == 1) {
+            if (more) nxt[0] = load_row(tn);
+        } else if (p.stride == 1) {
+            if (more) nxt[0] = load_row(tn + 2);
+        } else {
+            if (more) {
+                nxt[0] = load_row(tn + 1);
+                nxt[1] = load_row(tn + 2);
             }
-            float r[4];
-            if (p.bias[o]) {
-                const float4 bb = ld4(p.bias[o] + i * 256 + lane * 4);
-                r[0] = bb.x; r[1] = bb.y; r[2] = bb.z; r[3] = bb.w;
-            } else {
-                r[0] = r[1] = r[2] = r[3] = 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                if (GIN == 1) {
-                    const float4 v = in[k][i][0];
-                    r[0] += w[0 * KS + k] * v.x;
-                    r[1] += w[1 * KS + k] * v.y;
-                    r[2] += w[2 * KS + k] * v.z;
-                    r[3] += w[3 * KS + k] * v.w;
-                } else {
-                    // out channel c reads in channels 2c, 2c+1: lane's 8 inputs = in[k][i][0..1]
-                    const float4 v0 = in[k][i][0], v1 = in[k][i][GIN - 1];
-                    r[0] += w[(0 * 2 + 0) * KS + k] * v0.x + w[(0 * 2 + 1) * KS + k] * v0.y;
-                    r[1] += w[(1 * 2 + 0) * KS + k] * v0.z + w[(1 * 2 + 1) * KS + k] * v0.w;
-                    r[2] += w[(2 * 2 + 0) * KS + k] * v1.x + w[(2 * 2 + 1) * KS + k] * v1.y;
-                    r[3] += w[(3 * 2 + 0) * KS + k] * v1.z + w[(3 * 2 + 1) * KS + k] * v1.w;
-                }
-            }
-            acc[i] = make_float4(r[0] * mk, r[1] * mk, r[2] * mk, r[3] * mk);
         }
-        if (p.gamma[o]) {
-            ln_rows<NV>(acc, p.gamma[o], p.beta[o], lane, p.relu[o] != 0);
-        } else if (p.relu[o]) {
+        const int64_t row = (int64_t)b * Tout + to;
+        const float mk = p.mask_out ? (float)p.mask_out[row] : 1.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            if (o >= p.n_out) break;
+            const float* const ls = dw_lds + o * SETF;
+            float4 acc[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                acc[i].x = fmaxf(acc[i].x, 0.f); acc[i].y = fmaxf(acc[i].y, 0.f);
-                acc[i].z = fmaxf(acc[i].z, 0.f); acc[i].w = fmaxf(acc[i].w, 0.f);
+                const int c = i * 256 + lane * 4;
+                float4 r = *reinterpret_cast<const float4*>(ls + NT * C + c);          // bias
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    if (GIN == 1) {
+                        const float4 w = *reinterpret_cast<const float4*>(ls + k * C + c);
+                        const float4 v = win[k].v[i][0];
+                        r.x += w.x * v.x; r.y += w.y * v.y; r.z += w.z * v.z; r.w += w.w * v.w;
+                    } else {
+                        // out channel c reads in channels 2c, 2c+1 (taps [g][k] per channel): lane's 8 inputs
+                        const float4 w0 = *reinterpret_cast<const float4*>(ls + (0 * KS + k) * C + c);
+                        const float4 w1 = *reinterpret_cast<const float4*>(ls + (1 * KS + k) * C + c);
+                        const float4 v0 = win[k].v[i][0], v1 = win[k].v[i][GIN - 1];
+                        r.x += w0.x * v0.x + w1.x * v0.y;
+                        r.y += w0.y * v0.z + w1.y * v0.w;
+                        r.z += w0.z * v1.x + w1.z * v1.y;
+                        r.w += w0.w * v1.z + w1.w * v1.w;
+                    }
+                }
+                acc[i] = make_float4(r.x * mk, r.y * mk, r.z * mk, r.w * mk);
+            }
+            if (p.gamma[o]) {
+                ln_rows<NV>(acc, ls + (NT + 1) * C, ls + (NT + 2) * C, lane, p.relu[o] != 0);
+            } else if (p.relu[o]) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    acc[i].x = fmaxf(acc[i].x, 0.f); acc[i].y = fmaxf(acc[i].y, 0.f);
+                    acc[i].z = fmaxf(acc[i].z, 0.f); acc[i].w = fmaxf(acc[i].w, 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], i * 256 + lane * 4, 256 * NV, acc[i]);
+                else st4(p.y[o] + row * p.ldy[o] + i * 256 + lane * 4, acc[i]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], i * 256 + lane * 4, 256 * NV, acc[i]);
-            else st4(p.y[o] + row * p.ldy[o] + i * 256 + lane * 4, acc[i]);
+        if (more) {
+            if (KS == 1) {
+                win[0] = nxt[0];
+            } else if (p.stride == 1) {
+                win[0] = win[1];
+                win[KS > 1 ? 1 : 0] = win[KS - 1];
+                win[KS - 1] = nxt[0];
+            } else {
+                win[0] = win[KS - 1];
+                win[KS > 1 ? 1 : 0] = nxt[0];
+                win[KS - 1] = nxt[1];
+            }
         }
     }
 }
@@ -376,8 +422,10 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_DWCONV_LN, s, 0.0,
                         4.0 * ((double)a->B * a->Tin * a->C * a->group_in * (a->x_up ? 1.5 : 1.0) + (double)rows * a->C * a->n_out));
-    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, 0, s, *a, Tout)
+    const int strips = (Tout + DW_RW - 1) / DW_RW;
+    dim3 grid((unsigned)(((int64_t)a->B * strips + 3) / 4)), block(256);
+    const size_t lds = (size_t)a->n_out * (a->group_in * a->ksize + 3) * a->C * sizeof(float);
+#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips)
     if (a->group_in == 2) VRD_DW(1, 3, 2);
     else if (a->C == 256 && a->ksize == 3) VRD_DW(1, 3, 1);
     else if (a->C == 256) VRD_DW(1, 1, 1);
