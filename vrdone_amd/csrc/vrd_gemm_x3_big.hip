@@ -141,60 +141,108 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // ---- main loop.  A K step is eight groups g = (s, mi) of six MFMAs (k16 half s, 32-row block mi, both
+    // column blocks).  Fragment reads run one group ahead of the MFMAs (A fragments of group g+1, and the W
+    // fragments of the next half two groups ahead), so no LDS latency is exposed; for that to hold across K
+    // steps the step's barrier sits BEFORE its last group: by then every fragment of the step is in registers
+    // (lgkmcnt(0)), so the barrier both publishes stage kt+1 (every wave waited for its own pieces first) and
+    // frees the buffers of stage kt, which the DMAs issued after it refill: W(kt+2), then A(kt+3), one per
+    // group over the next eight groups (a DMA issue stalls its wave for 100-200 cycles while MFMAs run; the
+    // two waves of a SIMD place theirs half a group apart).
+    struct AF { bf16x8 hi, lo; };
+    struct WF { bf16x8 hi[2], lo[2]; };
+    auto load_a = [&](const char* sa, int s2, int mi) {
+        AF f;
+        f.hi = *reinterpret_cast<const bf16x8*>(sa + a_hi[mi][s2]);
+        f.lo = *reinterpret_cast<const bf16x8*>(sa + a_lo[mi][s2]);
+        return f;
+    };
+    auto load_w = [&](const char* sw, int s2) {
+        WF f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f.hi[t] = *reinterpret_cast<const bf16x8*>(sw + w_hi[t][s2]);
+            f.lo[t] = *reinterpret_cast<const bf16x8*>(sw + w_lo[t][s2]);
+        }
+        return f;
+    };
     issue_a(0);
-    if (nkt > 1) issue_a(1);
     issue_w(0);
+    if (nkt > 1) {
+        issue_a(1);
+        issue_w(1);
+    }
     LAB_STAMP(1);
+    // stage 0: what was issued after A(0), W(0) may stay in flight (A(2) follows inside step 0, see below)
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    WF w_cur = load_w(lds, 0), w_nxt = w_cur;
+    AF a_cur = load_a(lds, 0, 0), a_nxt = a_cur;
     LAB_PHASE_DECL;
+    // DMA slot d (0..7) of the batch opened by the barrier inside step kt: W(kt+2) pieces 0..3, A(kt+3) pieces 0..3
+    auto dma_slot = [&](int kt_open, int d) {
+        if (d < PER) {
+            if (kt_open + 2 < nkt) issue_w1(kt_open + 2, d);
+        } else {
+            if (kt_open + 3 < nkt) issue_a1(kt_open + 3, d - PER);
+        }
+    };
     for (int kt = 0; kt < nkt; ++kt) {
-        // in issue order this wave has outstanding at most [.. W(kt), A(kt+1)]: leave A(kt+1) in flight
-        if (kt > 0 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        LAB_PHASE(0);
-        __builtin_amdgcn_s_barrier();
-        LAB_PHASE(1);
-        // The eight DMAs of this step (W(kt+1) x 4, then A(kt+2) x 4) are spread over the step, one behind every
-        // group of six MFMAs: a DMA issue stalls its wave for 100-200 cycles while MFMAs run, and the SIMD's
-        // other wave fills that gap only if it is not stalled on its own DMA at the same time.
-        const bool do_w = kt + 1 < nkt, do_a = kt + 2 < nkt;
-        LAB_PHASE(2);
         const char* sa = lds + (kt % NA_STG) * A_STAGE;
         const char* sw = lds + (kt % NW_STG) * W_STAGE;
+        const char* sa1 = lds + ((kt + 1) % NA_STG) * A_STAGE;
+        const char* sw1 = lds + ((kt + 1) % NW_STG) * W_STAGE;
+        const bool last = kt + 1 == nkt;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[4], al[4], wh[2], wl[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                wh[t] = *reinterpret_cast<const bf16x8*>(sw + w_hi[t][s]);
-                wl[t] = *reinterpret_cast<const bf16x8*>(sw + w_lo[t][s]);
+        for (int g = 0; g < 8; ++g) {
+            const int mi = g & 3;
+            // ---- reads for what comes next
+            if (g < 7) a_nxt = load_a(sa, (g + 1) >> 2, (g + 1) & 3);
+            if (g == 2) w_nxt = load_w(sw, 1);
+            if (g == 7 && !last) {
+                // (the barrier was passed at the end of group 6)
+                a_nxt = load_a(sa1, 0, 0);
+                w_nxt = load_w(sw1, 0);
             }
+            // ---- six MFMAs, this wave's DMA of the group in the middle or at the end
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                ah[t] = *reinterpret_cast<const bf16x8*>(sa + a_hi[t][s]);
-                al[t] = *reinterpret_cast<const bf16x8*>(sa + a_lo[t][s]);
+            for (int nj = 0; nj < 2; ++nj) {
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.lo, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.lo[nj], acc[mi][nj], 0, 0, 0);
+                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
+                if ((wave >> 2) == nj) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // groups 0..6 carry slots 1..7 of the batch opened in step kt-1, group 7 slot 0 of this step's
+                    if (g < 7) {
+                        if (kt > 0) dma_slot(kt - 1, g + 1);
+                        else if (g < PER && nkt > 2) issue_a1(2, g);          // step 0 has no batch of its own yet
+                    } else if (!last) {
+                        dma_slot(kt, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int nj = 0; nj < 2; ++nj) {
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], wh[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
-                }
+            a_cur = a_nxt;
+            if (g == 3 || g == 7) w_cur = w_nxt;
+            if (g == 6 && !last) {
+                // every fragment of stage kt is in registers or landed; stage kt+1 must be visible before group 7
+                // starts reading it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                LAB_PHASE(3);
+                if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                LAB_PHASE(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s == 0) {
-                    if (do_w) issue_w1(kt + 1, mi);
-                } else {
-                    if (do_a) issue_a1(kt + 2, mi);
-                }
+                __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                LAB_PHASE(1);
             }
         }
-#ifdef VRD_LAB_STAMP
-        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[3][1][15]));
-#endif
-        LAB_PHASE(3);
     }
+#ifdef VRD_LAB_STAMP
+    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[3][1][15]));
+#endif
     LAB_PHASE_FLUSH(wave >> 2);
     // every wave must be done with the rings before they are reused as epilogue staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
