@@ -11,10 +11,11 @@
  *  - every activation tensor is fp32, channels-last: a matrix of `rows` x `C` with an
  *    explicit leading dimension `ld*` (floats between consecutive rows); row r = b*T + t.
  *    Leading dimensions let producers write straight into concatenation buffers.
- *  - "pair" rows (bf16x3 mode only): a tensor whose only consumer is a GEMM may be produced in the
- *    GEMM-operand format instead of f32: the 4*W bytes of a W-channel row hold [W x bf16 hi | W x bf16 lo]
- *    with hi = bf16(x), lo = bf16(x - hi) (same leading dimension as the f32 row).  Producers take an
- *    `out_pair` flag; vrd_gemm takes `a_pair_width` (= W of the producer, 0 for f32 input).
+ *  - "pair" rows (bf16x3 mode only): a tensor whose only consumer is a GEMM (or the global attention) may be
+ *    produced in the operand format of the split-precision MFMA: the 4*C bytes of a C-channel row (C % 32 == 0,
+ *    row start 16-byte aligned) hold, per block of 32 channels, [32 x bf16 hi | 32 x bf16 lo], hi = bf16(x),
+ *    lo = bf16(x - hi): one 128-byte line per 32 channels.  Same leading dimension as the f32 row; producers
+ *    take an `out_pair` flag; vrd_gemm takes `a_pair_width` (> 0: A is pair rows; 0 for f32 input).
  *  - masks are uint8 (0/1), one byte per row (the reference's (B,1,T) bool mask).
  *  - all pointers are device pointers owned by the caller; the library allocates no
  *    device memory and keeps no state besides the optional profiling event list.
@@ -113,9 +114,10 @@ typedef struct {
     const float* scale;
     const float* res;  int64_t ldres;  int32_t res_masked;
     const float* res2;  int64_t ldres2;
-    const uint16_t* W_split;
-    int32_t a_pair_width;   /* > 0: A rows are pair rows produced with this width (needs W_split) */
-    int32_t c_pair;         /* 1: write C as pair rows of width N */
+    const uint16_t* W_split; /* optional bf16 split of W in pair-row blocks, (N, K/32, [32 hi | 32 lo]), K % 32 == 0:
+                                enables the split-bf16 MFMA path */
+    int32_t a_pair_width;   /* > 0: A rows are pair rows (needs W_split, Cin % 32 == 0, lda % 32 == 0) */
+    int32_t c_pair;         /* 1: write C as pair rows of width N (N % 32 == 0, ldc % 32 == 0) */
 } vrd_gemm_args;
 int vrd_gemm(const vrd_gemm_args* a, void* stream);
 
