@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 4
+#define VRD_ABI_VERSION 5
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -131,7 +131,9 @@ int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t ro
 
 /* ---- depthwise conv (+ nearest-upsample add) * mask -> LayerNorm, fused -----------------
  * for o in [0, n_out): y_o[b,t',:] = LN_o( mask_out[b,t'] * (bias_o + sum_k w_o[c,g,k] *
- *        xin[b, stride*t' + k - ksize/2, group_in*c + g]) ), xin = x (+ x_up[b, t/2, :]).
+ *        xin[b, stride*t' + k - ksize/2, group_in*c + g]) ), xin = x (+ x_up[b, t/2, :]), or, with pre_gamma set,
+ *        xin = LayerNorm(x; pre_gamma, pre_beta) (the ln1 of models/blocks.py:1064 applied to every input row as it
+ *        is read; rows outside [0, Tin) stay the zero padding of the convolution).
  * MaskedConv1D depthwise + LayerNorm pairs of models/blocks.py:927-933,
  * models/local_transformer.py:149-156, models/fpns.py:246-254 (group_in = 2 is the
  * top-level Conv1d(512,256,3,groups=256) of fpns.py:181-184), and mask_features
@@ -150,6 +152,8 @@ typedef struct {
     float* y[3];
     int64_t ldy[3];
     int32_t out_pair[3];
+    const float* pre_gamma;     /* optional LayerNorm on the input rows (needs group_in == 1, no x_up) */
+    const float* pre_beta;
 } vrd_dwconv_ln_args;
 int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
 

@@ -213,6 +213,32 @@ def test_dwconv_ln_variants(C, ks, stride, gin, up):
         close(got, want, 2e-5)
 
 
+@pytest.mark.parametrize("C,stride,T", [(512, 1, 40), (512, 2, 48), (256, 1, 33)])
+def test_dwconv_ln_input_layernorm(C, stride, T):
+    """The block's ln1 applied inside the depthwise-conv kernel (rows normalised as they enter the window; the
+    convolution's zero padding stays zero) against the oracle's LayerNorm -> conv -> LayerNorm chain, over
+    strips that are full, partial and cross the 16-row strip length."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(C + stride + T)
+    B = 3
+    x = torch.randn(B, T, C, generator=gen) * 2 + 0.5
+    lens = torch.tensor([T, T // 2 + 1, 2])
+    mask = torch.arange(T)[None] < lens[:, None]
+    m_out = mask[:, ::stride].contiguous()
+    g0, b0 = torch.randn(1, C, 1, generator=gen), torch.randn(1, C, 1, generator=gen)
+    h = O.channel_ln(x.transpose(1, 2), g0, b0)
+    sets, wants = [], []
+    for o in range(3):
+        w = torch.randn(C, 1, 3, generator=gen)
+        gam, bet = torch.randn(1, C, 1, generator=gen), torch.randn(1, C, 1, generator=gen)
+        y, _ = O.masked_conv1d(h, mask[:, None], w, None, stride=stride, groups=C)
+        wants.append(O.channel_ln(y, gam, bet).transpose(1, 2))
+        sets.append(dict(weight=w.to(DEV), gamma=gam.to(DEV), beta=bet.to(DEV)))
+    outs = ops.dwconv_ln(x.to(DEV), sets, mask_out=m_out.to(DEV), stride=stride, pre_ln=(g0.to(DEV), b0.to(DEV)))
+    for got, want in zip(outs, wants):
+        close(got, want, 3e-5)
+
+
 @pytest.mark.parametrize("H,w", [(4, 3), (8, 3), (4, 4), (8, 4)])
 def test_local_attention_kernel(H, w):
     from vrdone_amd import ops

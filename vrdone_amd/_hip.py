@@ -38,7 +38,8 @@ class DwconvLnArgs(C.Structure):
                 ("stride", C.c_int32), ("group_in", C.c_int32),
                 ("mask_out", c_u8p), ("n_out", C.c_int32),
                 ("w", c_f32p * 3), ("bias", c_f32p * 3), ("gamma", c_f32p * 3), ("beta", c_f32p * 3),
-                ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3), ("out_pair", C.c_int32 * 3)]
+                ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3), ("out_pair", C.c_int32 * 3),
+                ("pre_gamma", c_f32p), ("pre_beta", c_f32p)]
 
 
 class PackArgs(C.Structure):
@@ -76,7 +77,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // parameters of all output sets (taps, bias, gamma, beta: 12 KiB per 512-channel set) sit in LDS, filled once per
 // workgroup: with one row per wave they were re-read through the vector L1 for every row, 36 KiB per 8 KiB of
 // row data, and the kernel ran at the L1's rate (2.7 TB/s of HBM) instead of HBM's.
-// LDS per set o (floats): taps [GIN*KS][C] | bias [C] | gamma [C] | beta [C].
+// LDS per set o (floats): taps [GIN*KS][C] | bias [C] | gamma [C] | beta [C]; behind the sets the optional input
+// LayerNorm's gamma [C] | beta [C].
 constexpr int DW_RW = 16;                      // output rows per wave
 
 template <int NV, int KS, int GIN>
@@ -166,6 +167,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             ls[(NT + 2) * C + c] = p.gamma[o] ? p.beta[o][c] : 0.f;
         }
     }
+    const float* const pre = dw_lds + p.n_out * SETF;
+    if (p.pre_gamma)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            dw_lds[p.n_out * SETF + c] = p.pre_gamma[c];
+            dw_lds[p.n_out * SETF + C + c] = p.pre_beta[c];
+        }
     __syncthreads();
     const int64_t ws = (int64_t)blockIdx.x * 4 + wave;
     const int b = (int)(ws / strips_per_seq);
@@ -191,6 +198,14 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 }
                 r.v[i][g] = v;
             }
+        if (GIN == 1 && p.pre_gamma && ok) {       // the block's ln1, applied to a real row once, as it enters the window
+            float4 t[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t[i] = r.v[i][0];
+            ln_rows<NV>(t, pre, pre + C, lane, false);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) r.v[i][0] = t[i];
+        }
         return r;
     };
     // window win[k] = input row stride*to + k - KS/2; between consecutive output rows it moves by `stride`
@@ -410,6 +425,8 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
                   "vrd_dwconv_ln: group_in=2 is only built for C=256, ksize=3");
     VRD_CHECK_ARG(a->B > 0 && a->Tin > 0 && a->Tin % a->stride == 0, "vrd_dwconv_ln: Tin %% stride != 0");
     VRD_CHECK_ARG(a->n_out >= 1 && a->n_out <= 3, "vrd_dwconv_ln: n_out must be 1..3");
+    VRD_CHECK_ARG((a->pre_gamma == nullptr) == (a->pre_beta == nullptr) && (!a->pre_gamma || (a->group_in == 1 && !a->x_up)),
+                  "vrd_dwconv_ln: input LayerNorm needs gamma and beta, group_in == 1 and no x_up");
     VRD_CHECK_ARG(a->ldx >= (int64_t)a->C * a->group_in && a->ldx % 4 == 0 && aligned16(a->x), "vrd_dwconv_ln: bad x layout");
     VRD_CHECK_ARG(!a->x_up || (a->Tin % 2 == 0 && a->ldx_up % 4 == 0 && aligned16(a->x_up)), "vrd_dwconv_ln: bad x_up layout");
     for (int o = 0; o < a->n_out; ++o) {
@@ -424,7 +441,7 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
                         4.0 * ((double)a->B * a->Tin * a->C * a->group_in * (a->x_up ? 1.5 : 1.0) + (double)rows * a->C * a->n_out));
     const int strips = (Tout + DW_RW - 1) / DW_RW;
     dim3 grid((unsigned)(((int64_t)a->B * strips + 3) / 4)), block(256);
-    const size_t lds = (size_t)a->n_out * (a->group_in * a->ksize + 3) * a->C * sizeof(float);
+    const size_t lds = ((size_t)a->n_out * (a->group_in * a->ksize + 3) + (a->pre_gamma ? 2 : 0)) * a->C * sizeof(float);
 #define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips)
     if (a->group_in == 2) VRD_DW(1, 3, 2);
     else if (a->C == 256 && a->ksize == 3) VRD_DW(1, 3, 1);

@@ -179,13 +179,15 @@ class _ConvAttention(nn.Module):
         # the branch output feeds only its 1x1 projection GEMM
         return dict(weight=conv.conv.weight, gamma=norm.weight, beta=norm.bias, pair=_ops().pair_mode())
 
-    def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1):
-        """dwconv * mask -> LN for the three branches, sharing kernel launches when inputs coincide."""
+    def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1, pre_ln=None):
+        """dwconv * mask -> LN for the three branches, sharing kernel launches when inputs coincide.
+        pre_ln (gamma, beta): the inputs are LayerNorm'ed on the fly (only when all three coincide)."""
         ops = _ops()
         same_ks = self.query_conv.conv.kernel_size == self.key_conv.conv.kernel_size
         if q_in is k_in and k_in is v_in and same_ks and q_mask is kv_mask:
             return ops.dwconv_ln(q_in, [self._branch_set(n) for n in ("query", "key", "value")], mask_out=q_mask,
-                                 stride=stride)
+                                 stride=stride, pre_ln=pre_ln)
+        assert pre_ln is None
         if q_in is k_in and same_ks and q_mask is kv_mask:
             q, k = ops.dwconv_ln(q_in, [self._branch_set("query"), self._branch_set("key")], mask_out=q_mask, stride=stride)
             v, = ops.dwconv_ln(v_in, [self._branch_set("value")], mask_out=kv_mask, stride=stride)
@@ -220,14 +222,15 @@ class LocalMaskedMHCA(_ConvAttention):
         ks = n_kv_stride + 1 if n_kv_stride > 1 else 3
         self._build(n_embd, n_head, ks, ks, n_kv_stride)
 
-    def cl(self, x, mask, mask_out=None, **epilogue):
-        """x = LN1 output (B, T, C); epilogue kwargs go to the output-projection GEMM."""
+    def cl(self, x, mask, mask_out=None, pre_ln=None, **epilogue):
+        """x = LN1 output (B, T, C), or the block input with pre_ln = (ln1.weight, ln1.bias) applied inside the
+        depthwise-conv kernel; epilogue kwargs go to the output-projection GEMM."""
         ops = _ops()
         s = self.n_kv_stride
         if mask_out is None:
             mask_out = mask if s == 1 else mask[:, ::s].contiguous()
         assert (x.shape[1] // s) % (2 * self.window_overlap) == 0      # reference blocks.py:828
-        q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s)
+        q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s, pre_ln=pre_ln)
         q, k, v = self._project(q, k, v)
         att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap, pair=ops.pair_mode())
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
@@ -304,12 +307,13 @@ class TransformerBlock(nn.Module):
 
     def cl(self, x, mask, out=None):
         ops = _ops()
-        h = self.ln1.cl(x)
         if self.attn.n_kv_stride > 1:
             skip, m_out = ops.maxpool_mask(x, mask)
         else:
             skip, m_out = x, mask
-        y, _ = self.attn.cl(h, mask, m_out, scale=self._scale(self.drop_path_attn), res=skip, res_masked=True)
+        # ln1 is applied to the rows inside the depthwise-conv kernel (its only consumer)
+        y, _ = self.attn.cl(x, mask, m_out, pre_ln=(self.ln1.weight, self.ln1.bias),
+                            scale=self._scale(self.drop_path_attn), res=skip, res_masked=True)
         h = self.ln2.cl(y, pair=ops.pair_mode())
         h = ops.conv_gemm(h, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU, out_pair=ops.pair_mode())
         y = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=m_out,

@@ -267,9 +267,10 @@ def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False
     return Pair(out, cols) if pair else out
 
 
-def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None):
+def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
     """Fused depthwise conv * mask -> LayerNorm for up to three weight sets sharing x.
     sets: list of dicts(weight=(C, g, k) Conv1d weight, bias=None, gamma=None, beta=None, relu=False, out=None).
+    pre_ln = (gamma, beta): the input rows are LayerNorm'ed as they are read (the block's ln1).
     Returns the list of outputs, each (B, T/stride, C)."""
     B, Tin, Cx = x.shape
     w0 = sets[0]["weight"]
@@ -284,6 +285,9 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None):
         assert cu == cols and ru * 2 == rows
         a.x_up, a.ldx_up = pu, ldu
     a.B, a.Tin, a.C, a.ksize, a.stride, a.group_in = B, Tin, Cout, k, stride, g
+    if pre_ln is not None:
+        assert g == 1 and x_up is None
+        a.pre_gamma, a.pre_beta = pre_ln[0].data_ptr(), pre_ln[1].data_ptr()
     a.mask_out = _mask_ptr(mask_out, B * Tout)
     a.n_out = len(sets)
     outs = []
