@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     constexpr int PER_WAVE = (G::N_DMA + NW - 1) / NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
-    float* const kbias = reinterpret_cast<float*>(lds + 2 * G::STAGE);      // [2][32]
+    float* const kbias = reinterpret_cast<float*>(lds + 2 * G::STAGE);      // [32 * nkt]: 0 or -inf per key
 
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -105,11 +105,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + buf * G::STAGE + plane * G::PLANE + rb * 1024), 16, 0, 0);
             }
         }
-        if (tid < 32) {
-            const int key = kt * 32 + tid;
-            const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
-            kbias[buf * 32 + tid] = ok ? 0.f : -INFINITY;
-        }
     };
 
     f32x16 oacc[DT];
@@ -126,26 +121,41 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     const int vcol0 = 16 * ((lane >> 4) & 1) + 4 * vp;          // column inside a 32-wide d tile
 
     const int nkt = (Tk + 31) / 32;
+    // key bias of the whole row of tiles, once: an ordinary global load inside the loop would make the compiler
+    // drain the LDS-DMA queue (vmcnt(0)) at its first use, every tile
+    for (int key = tid; key < nkt * 32; key += NW * 64) {
+        const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
+        kbias[key] = ok ? 0.f : -INFINITY;
+    }
     issue(0);
     for (int kt = 0; kt < nkt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of tile kt (and its key-bias writes) have landed
         __builtin_amdgcn_s_barrier();                           // ... and everybody else's; tile kt-1 is fully consumed
         if (kt + 1 < nkt) issue(kt + 1);
         const char* st = lds + (kt & 1) * G::STAGE;
-        const float* kbs = kbias + (kt & 1) * 32;
+        const float* kbs = kbias + kt * 32;
 
         // ---- S^T = K . Q^T (three products per k16 step)
         f32x16 sacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+        // the K fragments of step s+1 are requested before the three MFMAs of step s (one chain of dependent
+        // MFMAs: nothing else would hide the LDS latency)
+        bf16x8 kh = *reinterpret_cast<const bf16x8*>(st + krow + ((lh ^ G::kswz(li)) * 16));
+        bf16x8 kl = *reinterpret_cast<const bf16x8*>(st + G::PLANE + krow + ((lh ^ G::kswz(li)) * 16));
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const int off = krow + (((2 * s + lh) ^ G::kswz(li)) * 16);
-            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(st + off);
-            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(st + G::PLANE + off);
+            bf16x8 nh = kh, nl = kl;
+            if (s + 1 < KS) {
+                const int off = krow + (((2 * (s + 1) + lh) ^ G::kswz(li)) * 16);
+                nh = *reinterpret_cast<const bf16x8*>(st + off);
+                nl = *reinterpret_cast<const bf16x8*>(st + G::PLANE + off);
+            }
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sacc, 0, 0, 0);
+            kh = nh;
+            kl = nl;
         }
 
         // ---- online softmax for query column li; this lane holds keys (e&3) + 8*(e>>2) + 4*lh
@@ -239,11 +249,16 @@ template <int HD, int NW>
 int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, int B, int Tq,
            int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
     auto kern = attn_flash_x3_kernel<HD, NW>;
-    constexpr size_t lds = 2 * AG<HD>::STAGE + 2 * 32 * sizeof(float);
+    constexpr size_t lds_max = 2 * AG<HD>::STAGE + 4096 * sizeof(float);       // key bias for Tk <= 4096
+    const size_t lds = 2 * AG<HD>::STAGE + (size_t)((Tk + 31) / 32) * 32 * sizeof(float);
+    if (lds > lds_max) {
+        vrd::set_error("vrd_attention_pair: Tk = %d exceeds the 4096 keys the key-bias row is sized for", Tk);
+        return -1;
+    }
     static bool reserved = false;
     if (!reserved) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            vrd::set_error("vrd_attention_pair: cannot reserve %zu B of LDS", lds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess) {
+            vrd::set_error("vrd_attention_pair: cannot reserve %zu B of LDS", lds_max);
             return -2;
         }
         reserved = true;
