@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         vrd_gemm_args a = {};
         a.A = A; a.lda = sh.Cin; a.W = nullptr; a.bias = bias; a.C = C; a.ldc = sh.N; a.M = sh.M; a.N = sh.N; a.Cin = sh.Cin;
         a.taps = sh.taps; a.T = T; a.act = 0; a.W_split = (const uint16_t*)W; a.a_pair_width = sh.Cin; a.c_pair = 0;
-        for (int var : {0, 11}) {
+        for (int var : {11}) {
             char env[8];
             snprintf(env, sizeof env, "%d", var);
             hipEvent_t e0, e1;

@@ -17,6 +17,152 @@ __device__ __forceinline__ float epilogue_value(const vrd_gemm_args& p, float v,
 }
 
 // v = acc + bias; v = act(v); v *= row_mask; v *= scale; v += res * (res_masked ? row_mask : 1); v += res2
+// Per-column epilogue inputs of a lane's float4 column group (columns nw + 4*(lane & 15) ...), loaded by the kernel
+// before its main loop so that their latency is not paid, exposed, by the tile's epilogue.
+struct EpiCols {
+    float bias[4], scale[4];
+};
+__device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw, int lane) {
+    EpiCols c;
+    const int n = nw + (lane & 15) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c.bias[j] = 0.f, c.scale[j] = 1.f;
+    if (n + 3 < p.N) {                 // (the caller guarantees 16-byte aligned bias / scale for the lean epilogue)
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            c.bias[0] = b.x, c.bias[1] = b.y, c.bias[2] = b.z, c.bias[3] = b.w;
+        }
+        if (p.scale) {
+            const float4 b = *reinterpret_cast<const float4*>(p.scale + n);
+            c.scale[0] = b.x, c.scale[1] = b.y, c.scale[2] = b.z, c.scale[3] = b.w;
+        }
+    }
+    return c;
+}
+
+// Lean epilogue of the 256 x 256 kernel: a 64 x 64 wave sub-tile that lies fully inside C (the host sends only
+// GEMMs with M % 64 == 0 and N % 64 == 0 to that kernel, so a sub-tile is inside or entirely outside), 16-byte
+// aligned rows, bias and scale, 64-row private slab.  Which terms exist is a template parameter, so a pass is
+// straight-line code without per-row predicates or per-element selects: the epilogue is instruction-bound (two
+// waves per SIMD, ~8 cycles per instruction and wave; the general version below runs ~240 instructions per
+// 16-row pass).   ROWIN: any of row_mask / scale / res / res2 may be set;  ACT: VRD_ACT_NONE or VRD_ACT_GELU.
+template <bool ROWIN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
+                                                   int nw, int wave, int lane, const EpiCols& cols) {
+    const int li = lane & 31, lh = lane >> 5;
+    float* stg = smem + wave * (64 * STG_PITCH);
+    const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
+    const int n = nw + c4;
+    // lane base pointers (row mw + rb0, column n); the rows of the passes are wave-uniform offsets from them
+    const int64_t m_lane = mw + rb0;
+    const bool pair = p.c_pair != 0;
+    char* const c_lane = reinterpret_cast<char*>(p.C + m_lane * p.ldc) + (pair ? pair_index(n) * 2 : n * 4);
+    const float* const r1_lane = (ROWIN && p.res) ? p.res + m_lane * p.ldres + n : nullptr;
+    const float* const r2_lane = (ROWIN && p.res2) ? p.res2 + m_lane * p.ldres2 + n : nullptr;
+    const unsigned char* const mk_lane = (ROWIN && p.row_mask) ? p.row_mask + m_lane : nullptr;
+    const int64_t c_step = p.ldc * 16, r1_step = p.ldres * 4, r2_step = p.ldres2 * 4;     // bytes / floats per 4 rows
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stg[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
+    struct RowIn {
+        unsigned char mb[4];
+        float4 r1[4], r2[4];
+    };
+    auto fetch = [&](int pass) {
+        RowIn in;
+        if (ROWIN) {
+            if (p.row_mask) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) in.mb[j] = mk_lane[pass * 16 + 4 * j];
+            }
+            if (p.res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) in.r1[j] = *reinterpret_cast<const float4*>(r1_lane + (pass * 4 + j) * r1_step);
+            }
+            if (p.res2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) in.r2[j] = *reinterpret_cast<const float4*>(r2_lane + (pass * 4 + j) * r2_step);
+            }
+        }
+        return in;
+    };
+    RowIn nxt = fetch(0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const RowIn cur = nxt;
+        if (pass + 1 < 4) nxt = fetch(pass + 1);
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 t = *reinterpret_cast<const float4*>(stg + (pass * 16 + rb0 + 4 * j) * STG_PITCH + c4);
+            v[j][0] = t.x + cols.bias[0], v[j][1] = t.y + cols.bias[1], v[j][2] = t.z + cols.bias[2], v[j][3] = t.w + cols.bias[3];
+        }
+        if (ACT == VRD_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[j][c] = gelu_erf(v[j][c]);
+        }
+        if (ROWIN) {
+            float mk[4] = {1.f, 1.f, 1.f, 1.f};
+            if (p.row_mask) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mk[j] = (float)cur.mb[j];
+            }
+            if (p.row_mask || p.scale) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[j][c] *= mk[j] * cols.scale[c];
+            }
+            if (p.res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float rmk = p.res_masked ? mk[j] : 1.f;
+                    v[j][0] += cur.r1[j].x * rmk, v[j][1] += cur.r1[j].y * rmk;
+                    v[j][2] += cur.r1[j].z * rmk, v[j][3] += cur.r1[j].w * rmk;
+                }
+            }
+            if (p.res2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j][0] += cur.r2[j].x, v[j][1] += cur.r2[j].y;
+                    v[j][2] += cur.r2[j].z, v[j][3] += cur.r2[j].w;
+                }
+            }
+        }
+        if (pair) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                char* const rowp = c_lane + (pass * 4 + j) * c_step;
+                bf16x4_t h, l;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    h[c] = (__bf16)v[j][c];
+                    l[c] = (__bf16)(v[j][c] - (float)h[c]);
+                }
+                *reinterpret_cast<bf16x4_t*>(rowp) = h;
+                *reinterpret_cast<bf16x4_t*>(rowp + 64) = l;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(c_lane + (pass * 4 + j) * c_step) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+        }
+    }
+}
+
+// true when vrd_gemm arguments fit the lean epilogue (checked on the host before the 256 x 256 kernel is chosen)
+inline bool gemm_epilogue_lean_ok(const vrd_gemm_args& a) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    return a.M % 64 == 0 && a.N % 64 == 0 && (a.act == VRD_ACT_NONE || a.act == VRD_ACT_GELU) &&
+           !(a.act == VRD_ACT_GELU && (a.row_mask || a.scale || a.res || a.res2)) && al16(a.bias) && al16(a.scale);
+}
+
 // SLAB_ROWS: rows of the wave's private staging slab.  64 (16 KiB per wave) lets both accumulator halves be
 // transposed up front so their registers are dead for the rest of the epilogue; 32 for kernels with less LDS.
 template <bool STAGED, int SLAB_ROWS = 32>

@@ -133,6 +133,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         }
     }
 
+    // bias / scale of this lane's columns: requested now, used by the epilogue
+    const vrd::EpiCols cols = vrd::load_epi_cols(p, n0 + wn * 64, lane);
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -255,7 +257,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) part[i][j] = acc[2 * hm + i][j];
-        vrd::gemm_epilogue<true, 64>(p, part, smem, m0 + wm * 128 + hm * 64, n0 + wn * 64, wave, lane);
+        // (M % 64 == 0 and N % 64 == 0, checked on the host: the sub-tile is inside C or entirely outside)
+        const int64_t mw = m0 + wm * 128 + hm * 64;
+        const int nw = n0 + wn * 64;
+        if (mw >= p.M || nw >= p.N) continue;
+        if (p.row_mask || p.scale || p.res || p.res2) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+        else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU>(p, part, smem, mw, nw, wave, lane, cols);
+        else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
     }
     LAB_STAMP(3);
     LAB_REAL(5);
