@@ -32,7 +32,7 @@ constexpr int W_RING = NA_STG * A_STAGE;       // byte offset of the W ring
 constexpr size_t BIG_LDS = (size_t)NA_STG * A_STAGE + (size_t)NW_STG * W_STAGE;      // 163,840
 constexpr int PER = 4;                         // DMA instructions per wave, operand and K step (8 rows x 128 B each)
 
-__device__ uint4 g_big_zero[8];                // 128 zero bytes: source of padded taps
+__device__ __attribute__((aligned(128))) uint4 g_big_zero[8];      // 128 zero bytes: source of padded taps and outside pieces
 
 #ifndef VRD_LAB_STAMP      // the lab harness (scripts/lab/gemm_lab.hip) defines these before including this file
 #define LAB_STAMP(slot)
@@ -40,6 +40,23 @@ __device__ uint4 g_big_zero[8];                // 128 zero bytes: source of padd
 #define LAB_PHASE_DECL
 #define LAB_PHASE(i)
 #define LAB_PHASE_FLUSH(grp)
+#else                      // per TILE (virtual block id vb) instead of per workgroup
+#undef LAB_STAMP
+#undef LAB_REAL
+#undef LAB_PHASE_FLUSH
+#define LAB_STAMP(slot)                                                                        \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && vb < 65536) g_lab[vb * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define LAB_REAL(slot)                                                                         \
+    do {                                                                                       \
+        if (threadIdx.x == 0 && vb < 65536) g_lab[vb * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define LAB_PHASE_FLUSH(grp)                                                                   \
+    do {                                                                                       \
+        if ((threadIdx.x & 255) == 0 && vb < 4096)                                             \
+            for (int i_ = 0; i_ < 5; ++i_) g_lab_phase[vb * 16 + (grp) * 8 + i_] = lab_acc[i_]; \
+    } while (0)
 #endif
 
 __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
@@ -48,17 +65,6 @@ template <int TAPS>
 __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
-    LAB_STAMP(0);
-    LAB_REAL(4);
-
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int64_t m0 = (int64_t)tm * TM;
-    const int n0 = tn * TN;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,29 +72,38 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     const int li = lane & 31, lh = lane >> 5;
     const int K = p.Cin * TAPS;
     const int nkt = K / 32;
+    const int nwg = tiles_m * tiles_n;
+    // (persistent workgroups -- one per CU walking its tiles -- were measured: same cycles per tile, no gain)
+    const int vb = blockIdx.x;
+    {
+    LAB_STAMP(0);
+    LAB_REAL(4);
+    const int xcd = vb & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (vb >> 3);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * TM;
+    const int n0 = tn * TN;
 
-    // ---- DMA sources: this wave moves row blocks wave*4 .. wave*4+3 (8 rows each) of both operands
+    // ---- DMA sources: this wave moves row blocks wave*4 .. wave*4+3 (8 rows each) of both operands.  Only piece 0's
+    // per-lane pointers are kept: piece i is a wave-uniform stride further, its source-side swizzle differs from
+    // piece 0's by bit 6 for odd i, and (M, N multiples of 64) a piece lies entirely inside or outside the matrix,
+    // which is a scalar test; pieces outside read the zero block.  (The bit-6 flip is applied to the pointer, which is
+    // why the host sends only 128-byte aligned A and W_split here: address bits 4..6 are then the chunk index.)
     const int rin = lane >> 3, pch = lane & 7;
-    const char* asrc[PER];
-    const char* wsrc[PER];
-    int tseq[PER], chunk[PER];
-    const char* zero_src = reinterpret_cast<const char*>(g_big_zero);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int row = (wave * PER + i) * 8 + rin;                 // row inside the tile, for both operands
-        chunk[i] = (pch ^ swz(row)) * 16;
-        int64_t r = m0 + row;
-        if (r >= p.M) r = p.M - 1;                                  // rows past M are computed on duplicates and dropped
-        asrc[i] = reinterpret_cast<const char*>(p.A + r * p.lda) + chunk[i];
-        tseq[i] = (TAPS == 3) ? (int)(r % p.T) : 0;
-        int n = n0 + row;
-        if (n >= p.N) n = p.N - 1;
-        wsrc[i] = reinterpret_cast<const char*>(p.W_split) + (int64_t)n * K * 4 + chunk[i];
-    }
+    const int row0 = wave * PER * 8 + rin;                              // row inside the tile, for both operands
+    const int chunk0 = (pch ^ swz(row0)) * 16;
+    const char* const zero_src = reinterpret_cast<const char*>(g_big_zero);
+    const char* const a0 = reinterpret_cast<const char*>(p.A + (m0 + row0) * p.lda) + chunk0;
+    const char* const w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(n0 + row0) * K * 4 + chunk0;
+    const int tseq0 = (TAPS == 3) ? (int)((m0 + row0) % p.T) : 0;
+    const int64_t a_pstride = p.lda * 32, w_pstride = (int64_t)K * 32;  // bytes between pieces (8 rows)
+    const int a_in = (int)((p.M - m0 - wave * PER * 8 + 7) / 8), w_in = (p.N - n0 - wave * PER * 8 + 7) / 8;   // pieces inside
     // piece i of W(kt) / A(kt): one DMA instruction each
     auto issue_w1 = [&](int kt, int i) {
         char* const dst = lds + W_RING + (kt % NW_STG) * W_STAGE + wave * PER * 1024;
-        __builtin_amdgcn_global_load_lds(wsrc[i] + (int64_t)kt * 128, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+        const char* src = i < w_in ? (w0 + i * w_pstride + (int64_t)kt * 128) : zero_src + chunk0;
+        if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
     };
     auto issue_a1 = [&](int kt, int i) {
         char* const dst = lds + (kt % NA_STG) * A_STAGE + wave * PER * 1024;
@@ -99,11 +114,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
             ci0 = k0 - tap * p.Cin;
         }
         const int64_t off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 + (int64_t)ci0 * 4;
-        const char* src = asrc[i] + off;
+        const char* src = i < a_in ? a0 + i * a_pstride + off : zero_src + chunk0;
         if (TAPS == 3) {
-            const int tt = tseq[i] + tap - 1;
-            if (tt < 0 || tt >= p.T) src = zero_src + chunk[i];
+            int tt = tseq0 + 8 * i;                   // position of this piece's row in its sequence (T >= 32)
+            if (tt >= p.T) tt -= p.T;
+            tt += tap - 1;
+            if (tt < 0 || tt >= p.T) src = zero_src + chunk0;
         }
+        if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
         __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
     };
     auto issue_w = [&](int kt) {
@@ -115,23 +133,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         for (int i = 0; i < PER; ++i) issue_a1(kt, i);
     };
 
-    // ---- fragment read offsets (bytes inside a stage): hi chunks 0..3, lo chunks 4..7 of the row
-    int a_hi[4][2], a_lo[4][2], w_hi[2][2], w_lo[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int r = wm * 128 + t * 32 + li;
-            a_hi[t][s] = r * ROWB + (((2 * s + lh) ^ swz(r)) * 16);
-            a_lo[t][s] = r * ROWB + (((4 + 2 * s + lh) ^ swz(r)) * 16);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int r = wn * 64 + t * 32 + li;
-            w_hi[t][s] = W_RING + r * ROWB + (((2 * s + lh) ^ swz(r)) * 16);
-            w_lo[t][s] = W_RING + r * ROWB + (((4 + 2 * s + lh) ^ swz(r)) * 16);
-        }
-    }
+    // ---- fragment read offsets (bytes inside a stage).  A tile row is 128 bytes: hi chunks 0..3, lo chunks 4..7,
+    // chunk index XOR-swizzled with (row >> 1) & 7 = (li >> 1) & 7 for every 32-row block.  Hence all fragment
+    // addresses of an operand derive from ONE per-lane base: k16 half s flips bit 5 (chunk ^ 2), lo flips bit 6
+    // (chunk ^ 4), and the 32-row blocks are constant offsets (kept out of registers: two VGPRs instead of 24).
+    const int a_base = (wm * 128 + li) * ROWB + ((lh ^ swz(li)) * 16);
+    const int w_base = W_RING + (wn * 64 + li) * ROWB + ((lh ^ swz(li)) * 16);
 
     // bias / scale of this lane's columns: requested now, used by the epilogue
     const vrd::EpiCols cols = vrd::load_epi_cols(p, n0 + wn * 64, lane);
@@ -155,16 +162,17 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     struct WF { bf16x8 hi[2], lo[2]; };
     auto load_a = [&](const char* sa, int s2, int mi) {
         AF f;
-        f.hi = *reinterpret_cast<const bf16x8*>(sa + a_hi[mi][s2]);
-        f.lo = *reinterpret_cast<const bf16x8*>(sa + a_lo[mi][s2]);
+        const char* q = sa + (a_base ^ (s2 * 32)) + mi * 32 * ROWB;
+        f.hi = *reinterpret_cast<const bf16x8*>(q);
+        f.lo = *reinterpret_cast<const bf16x8*>(sa + (a_base ^ (s2 * 32) ^ 64) + mi * 32 * ROWB);
         return f;
     };
     auto load_w = [&](const char* sw, int s2) {
         WF f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f.hi[t] = *reinterpret_cast<const bf16x8*>(sw + w_hi[t][s2]);
-            f.lo[t] = *reinterpret_cast<const bf16x8*>(sw + w_lo[t][s2]);
+            f.hi[t] = *reinterpret_cast<const bf16x8*>(sw + (w_base ^ (s2 * 32)) + t * 32 * ROWB);
+            f.lo[t] = *reinterpret_cast<const bf16x8*>(sw + (w_base ^ (s2 * 32) ^ 64) + t * 32 * ROWB);
         }
         return f;
     };
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     }
     LAB_STAMP(3);
     LAB_REAL(5);
+    }
 }
 
 }  // namespace
