@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                                                                 const float* __restrict__ k, const float* __restrict__ v,
                                                                 int64_t ldkv, const uint8_t* __restrict__ kv_mask, int Tq,
                                                                 int Tk, int width, float scale, float* __restrict__ out,
-                                                                int64_t ldo, int pair_out) {
+                                                                int64_t ldo, int pair_out, int q_blocks, int n_head_) {
     using G = AG<HD>;
     constexpr int KS = HD / 16;                   // k16 steps of the S^T contraction
     constexpr int DT = HD / 32;                   // 32-row d tiles of O^T
@@ -63,11 +63,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     char* const lds = reinterpret_cast<char*>(smem);
     float* const kbias = reinterpret_cast<float*>(lds + 2 * G::STAGE);      // [32 * nkt]: 0 or -inf per key
 
-    const int b = blockIdx.z, h = blockIdx.y;
+    // 1-D grid with the XCD-aware renumbering of the GEMM kernels: the workgroups that share one (b, h)'s K and V
+    // (consecutive logical ids) get the same XCD label, i.e. the same L2, and are dispatched close together.  With a
+    // (q-block, h, b) grid they went round-robin to different XCDs and K/V were fetched from HBM once per q-block
+    // (4.2 GB fetched per launch against 1.8 GB of q, k, v).
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    const int qblk = lid % q_blocks, h = (lid / q_blocks) % n_head_, b = lid / (q_blocks * n_head_);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int q0 = (qblk * NW + wave) * 32;
     // pair rows are blocks of [32 hi | 32 lo] bf16 (vrd_common.h), so a head's HD channels are HD*4 contiguous
     // bytes; 16-byte chunk lc of the head's logical hi (lo) plane is at block lc/4, +64 bytes for lo
     const char* kb = reinterpret_cast<const char*>(k + (int64_t)b * Tk * ldkv) + h * HD * 4;
@@ -264,8 +271,9 @@ int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t 
         reserved = true;
     }
     const int tiles = (Tq + 31) / 32;
-    hipLaunchKernelGGL(kern, dim3((tiles + NW - 1) / NW, n_head, B), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk,
-                       n_head * HD, scale, out, ldo, pair_out);
+    const int q_blocks = (tiles + NW - 1) / NW;
+    hipLaunchKernelGGL(kern, dim3((unsigned)q_blocks * n_head * B), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk,
+                       n_head * HD, scale, out, ldo, pair_out, q_blocks, n_head);
     return 0;
 }
 
