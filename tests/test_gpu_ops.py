@@ -428,8 +428,10 @@ def test_gemm_large_tile_kernels(k, precision):
         pytest.skip("the LDS-DMA kernels are split-precision kernels")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(7 + k)
-    T, Cin, N = 288, 512, 512
-    for B in (256, 96):        # 576 tiles of 256x256 -> big kernel; 432 tiles of 128x256 ... -> 128x256 kernel
+    T, Cin = 288, 512
+    # (B, N): 576 tiles of 256x256 -> 256x256 kernel; M = 72,000 leaves a 64-row last tile; N = 320 a 64-column one;
+    # 432 tiles of 128x256 -> 128x256 kernel
+    for B, N in ((256, 512), (250, 512), (256, 320), (96, 512)):
         x = torch.randn(B, T, Cin, generator=gen)
         w = torch.randn(N, Cin, k, generator=gen) / (Cin * k) ** 0.5
         bias, scale = torch.randn(N, generator=gen), torch.rand(N, generator=gen) + 0.5
