@@ -36,6 +36,35 @@ __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict
         }
 }
 
+// same, 16-byte accesses on both sides (T % 4 == 0, count % 4 == 0, 16-byte aligned rows): float4 reads along t,
+// float4 / pair-row writes of four channels
+__global__ __launch_bounds__(256) void bct_to_btc_vec_kernel(const float* __restrict__ src, int C_total, int T, int c0,
+                                                             int count, float* __restrict__ dst, int64_t ld_dst, int pair) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
+    const float* s = src + ((int64_t)b * C_total + c0) * T;
+    {
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 float4 along t, 16 channels per sweep
+#pragma unroll
+        for (int c = ty; c < 64; c += 16) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ct + c < count && tt + 4 * tx < T) v = ld4(s + (int64_t)(ct + c) * T + tt + 4 * tx);
+            tile[c][4 * tx] = v.x, tile[c][4 * tx + 1] = v.y, tile[c][4 * tx + 2] = v.z, tile[c][4 * tx + 3] = v.w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int id = threadIdx.x + 256 * k;
+        const int cg = id & 15, t = id >> 4;
+        if (tt + t >= T || ct + 4 * cg >= count) continue;
+        const float4 v = make_float4(tile[4 * cg][t], tile[4 * cg + 1][t], tile[4 * cg + 2][t], tile[4 * cg + 3][t]);
+        float* row = dst + ((int64_t)b * T + tt + t) * ld_dst;
+        if (pair) vrd::store_pair4(row, ct + 4 * cg, count, v);
+        else st4(row + ct + 4 * cg, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict__ src, int64_t ld_src, int C, int T,
                                                          float* __restrict__ dst) {
     __shared__ float tile[64][65];
@@ -365,7 +394,9 @@ int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int coun
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * B * (double)count * T);
     dim3 grid((T + 63) / 64, (count + 63) / 64, B);
     VRD_CHECK_ARG(!out_pair || (count % 32 == 0 && ld_dst % 4 == 0 && aligned16(dst)), "vrd_bct_to_btc: pair rows need count %% 32 == 0");
-    hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
+    const bool vec = T % 4 == 0 && count % 4 == 0 && ld_dst % 4 == 0 && aligned16(dst) && aligned16(src) && ((int64_t)c0 * T) % 4 == 0;
+    if (vec) hipLaunchKernelGGL(bct_to_btc_vec_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
+    else hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
     VRD_LAUNCH_CHECK();
     return 0;
 }
