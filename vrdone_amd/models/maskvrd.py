@@ -73,8 +73,9 @@ class MaskVRD(nn.Module):
         self.deep_supervision = config['predictor']['deep_supervision']
         self.device = device
         # pairs per launch wave inside _mask_vrd: bounds the live intermediates (the 4x MLP hidden is
-        # 2*chunk*T*2048 floats) and keeps producer->consumer tensors close to the 256 MiB Infinity Cache
-        self.pair_chunk = 1024
+        # 2*chunk*T*2048 floats = 9.7 GB at 2048 pairs x 288 frames, of 288 GB).  Measured: 256 -> 1024 pairs +15 %,
+        # 1024 -> 2048 +2.5 % (fewer launches of the small predictor / pyramid GEMMs, longer tile runs)
+        self.pair_chunk = 2048
 
     @torch.no_grad()
     def _config_eval(self, infer_config):
