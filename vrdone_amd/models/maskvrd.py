@@ -236,20 +236,20 @@ class MaskVRD(nn.Module):
                             so_start[pp] + st, so_start[pp] + en,
                             so_start[pp] - durs[sel_s, 0] + st, so_start[pp] - durs[sel_o, 0] + st, en - st],
                            dim=1).cpu().tolist()
-        # box tracks of the winners: every tracklet that appears is copied to the host and turned into Python rows
-        # ONCE (one concatenation, one copy); each triplet then slices those rows.  The reference slices and
-        # .tolist()s two device tensors per triplet (maskvrd.py:302-306), converting shared frames many times.
+        # box tracks of the winners: every tracklet that appears is copied to the host ONCE (one concatenation, one
+        # copy); each triplet then converts its slice of the host array to fresh Python lists.  The reference slices
+        # and .tolist()s two device tensors per triplet (maskvrd.py:302-306): 400 device round trips.
         boxes = input_data['bboxes_list']
         used = sorted({r[0] for r in host} | {r[1] for r in host})
-        flat = torch.cat([boxes[t] for t in used], dim=0).cpu().numpy().tolist()
+        flat = torch.cat([boxes[t] for t in used], dim=0).cpu().numpy()
         rows_of, at = {}, 0
         for t in used:
             rows_of[t] = flat[at:at + len(boxes[t])]
             at += len(boxes[t])
         so_trajs = []
         for r in host:
-            s_rows = [row[:] for row in rows_of[r[0]][r[7]:r[7] + r[9]]]
-            o_rows = [row[:] for row in rows_of[r[1]][r[8]:r[8] + r[9]]]
+            s_rows = rows_of[r[0]][r[7]:r[7] + r[9]].tolist()
+            o_rows = rows_of[r[1]][r[8]:r[8] + r[9]].tolist()
             assert len(s_rows) == len(o_rows)
             so_trajs.append([s_rows, o_rows])
         return {
