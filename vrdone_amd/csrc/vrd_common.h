@@ -68,6 +68,22 @@ __device__ __forceinline__ void store_pair4(float* row, int c, int /*W*/, float4
     *reinterpret_cast<bf16x4_t*>(r + 32) = l;
 }
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+// eight consecutive channels c .. c+7 (c % 8 == 0): one 16-byte store per half
+__device__ __forceinline__ void store_pair8(float* row, int c, float4 v0, float4 v1) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    bf16x8_t h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = (__bf16)x[j];
+        l[j] = (__bf16)(x[j] - (float)h[j]);
+    }
+    __bf16* r = reinterpret_cast<__bf16*>(row) + pair_index(c);
+    *reinterpret_cast<bf16x8_t*>(r) = h;
+    *reinterpret_cast<bf16x8_t*>(r + 32) = l;
+}
+
 __device__ __forceinline__ void store_pair1(float* row, int c, int /*W*/, float x) {
     __bf16* r = reinterpret_cast<__bf16*>(row) + pair_index(c);
     const __bf16 h = (__bf16)x;

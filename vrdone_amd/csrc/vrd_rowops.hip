@@ -115,7 +115,12 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(vrd_pack_args a) {
 // ------------------------------------------------------------------------------------------
 // LayerNorm over channels; NV = C / 256
 // ------------------------------------------------------------------------------------------
-template <int NV>
+// lane's channels: WIDE (NV == 2): 8 consecutive channels lane*8 .. lane*8+7 (v[0], v[1]), so that pair rows are
+// written with 16-byte stores; otherwise 4 channels in each 256-channel half
+template <int NV, bool WIDE>
+__device__ __forceinline__ int lane_chan(int i, int lane) { return WIDE ? lane * 8 + i * 4 : i * 256 + lane * 4; }
+
+template <int NV, bool WIDE = false>
 __device__ __forceinline__ void ln_rows(float4 (&v)[NV], const float* gamma, const float* beta, int lane, bool relu) {
     constexpr float inv_c = 1.0f / (256.0f * NV);
     float s = 0.f;
@@ -131,7 +136,7 @@ __device__ __forceinline__ void ln_rows(float4 (&v)[NV], const float* gamma, con
     const float denom = sqrtf(vrd::wave_sum(ss) * inv_c + LN_EPS);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const float4 g = ld4(gamma + i * 256 + lane * 4), bb = ld4(beta + i * 256 + lane * 4);
+        const float4 g = ld4(gamma + lane_chan<NV, WIDE>(i, lane)), bb = ld4(beta + lane_chan<NV, WIDE>(i, lane));
         v[i].x = v[i].x / denom * g.x + bb.x;
         v[i].y = v[i].y / denom * g.y + bb.y;
         v[i].z = v[i].z / denom * g.z + bb.z;
@@ -184,6 +189,7 @@ constexpr int DW_RW = 16;                      // output rows per wave
 template <int NV, int KS, int GIN>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq) {
     constexpr int C = 256 * NV, NT = GIN * KS, SETF = (NT + 3) * C;
+    constexpr bool WIDE = NV == 2 && GIN == 1;
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- parameters -> LDS (taps transposed to tap-major so a lane's four channels are one float4)
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             for (int g = 0; g < GIN; ++g) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok) {
-                    const int64_t coff = (int64_t)GIN * (i * 256 + lane * 4) + 4 * g;
+                    const int64_t coff = (int64_t)GIN * lane_chan<NV, WIDE>(i, lane) + 4 * g;
                     v = ld4(p.x + ((int64_t)b * p.Tin + ti) * p.ldx + coff);
                     if (p.x_up) v = f4add(v, ld4(p.x_up + ((int64_t)b * (p.Tin / 2) + (ti >> 1)) * p.ldx_up + coff));
                 }
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             float4 t[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) t[i] = r.v[i][0];
-            ln_rows<NV>(t, pre, pre + C, lane, false);
+            ln_rows<NV, WIDE>(t, pre, pre + C, lane, false);
 #pragma unroll
             for (int i = 0; i < NV; ++i) r.v[i][0] = t[i];
         }
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             float4 acc[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int c = i * 256 + lane * 4;
+                const int c = lane_chan<NV, WIDE>(i, lane);
                 float4 r = *reinterpret_cast<const float4*>(ls + NT * C + c);          // bias
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 acc[i] = make_float4(r.x * mk, r.y * mk, r.z * mk, r.w * mk);
             }
             if (p.gamma[o]) {
-                ln_rows<NV>(acc, ls + (NT + 1) * C, ls + (NT + 2) * C, lane, p.relu[o] != 0);
+                ln_rows<NV, WIDE>(acc, ls + (NT + 1) * C, ls + (NT + 2) * C, lane, p.relu[o] != 0);
             } else if (p.relu[o]) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
@@ -295,10 +301,15 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                     acc[i].z = fmaxf(acc[i].z, 0.f); acc[i].w = fmaxf(acc[i].w, 0.f);
                 }
             }
+            if (WIDE && p.out_pair[o]) {
+                vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, acc[0], acc[NV - 1]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], i * 256 + lane * 4, 256 * NV, acc[i]);
-                else st4(p.y[o] + row * p.ldy[o] + i * 256 + lane * 4, acc[i]);
+                for (int i = 0; i < NV; ++i) {
+                    const int c = lane_chan<NV, WIDE>(i, lane);
+                    if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, acc[i]);
+                    else st4(p.y[o] + row * p.ldy[o] + c, acc[i]);
+                }
             }
         }
         if (more) {
