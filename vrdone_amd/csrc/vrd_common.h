@@ -91,37 +91,47 @@ __device__ __forceinline__ void store_pair1(float* row, int c, int /*W*/, float 
     r[32] = (__bf16)(x - (float)h);
 }
 
-// Branch-free erf (the library erff branches on |z| < 1 per lane, and both sides run under exec masks in any
-// wave that straddles it).  |z| <= 1: z * P(z^2); |z| > 1: sign(z) * (1 - 2^-G(|z|)), G = -log2(erfc) on [1, 4]
-// (erf rounds to 1 beyond).  Coefficients and error (max 1.6e-7 absolute) from scripts/fit_erf.py.
+// Branch-free, single-path erf (the library erff branches on |z| < 1 per lane, and both sides run under exec masks in
+// any wave that straddles it):  erf(z) = sign(z) * (1 - 2^-G(min(|z|, 4))),  G = -log2(erfc) as a degree-11 polynomial.
+// Near 0 the form keeps the ABSOLUTE error at one rounding of 1 (what GELU needs), not the relative one.
+// Coefficients and error (max 9.8e-8 absolute; GELU 8.3e-8) from scripts/fit_erf.py.
+#define VRD_ERF_G(FMA, u, T)                                   \
+    T g = T(-1.133601083e-07f);                                \
+    g = FMA(g, u, T(2.984484956e-06f));                        \
+    g = FMA(g, u, T(-3.493388466e-05f));                       \
+    g = FMA(g, u, T(2.373710733e-04f));                        \
+    g = FMA(g, u, T(-1.004358838e-03f));                       \
+    g = FMA(g, u, T(2.405994177e-03f));                        \
+    g = FMA(g, u, T(-7.954030742e-05f));                       \
+    g = FMA(g, u, T(-2.782256332e-02f));                       \
+    g = FMA(g, u, T(1.483803001e-01f));                        \
+    g = FMA(g, u, T(9.184222287e-01f));                        \
+    g = FMA(g, u, T(1.627909324e+00f));                        \
+    g = FMA(g, u, T(-3.292586530e-08f));
+
 __device__ __forceinline__ float erf_f32(float z) {
-    const float t = z * z;
-    float a = -9.673590184e-06f;
-    a = fmaf(a, t, 1.126825367e-04f);
-    a = fmaf(a, t, -8.484396520e-04f);
-    a = fmaf(a, t, 5.221053410e-03f);
-    a = fmaf(a, t, -2.686543831e-02f);
-    a = fmaf(a, t, 1.128378262e-01f);
-    a = fmaf(a, t, -3.761263848e-01f);
-    a = fmaf(a, t, 1.128379167e+00f);
-    a *= z;
     const float u = fminf(fabsf(z), 4.0f);
-    float g = 9.497056197e-08f;
-    g = fmaf(g, u, -4.465436315e-06f);
-    g = fmaf(g, u, 8.666095290e-05f);
-    g = fmaf(g, u, -9.714207371e-04f);
-    g = fmaf(g, u, 7.243836344e-03f);
-    g = fmaf(g, u, -3.895204052e-02f);
-    g = fmaf(g, u, 1.600055804e-01f);
-    g = fmaf(g, u, 9.104687804e-01f);
-    g = fmaf(g, u, 1.631117461e+00f);
-    g = fmaf(g, u, -5.778000722e-04f);
-    const float b = copysignf(1.0f - __builtin_amdgcn_exp2f(-g), z);
-    return fabsf(z) <= 1.0f ? a : b;
+    VRD_ERF_G(fmaf, u, float)
+    return copysignf(1.0f - __builtin_amdgcn_exp2f(-g), z);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_f32(x * 0.70710678118654752440f));
+}
+
+// two elements at a time on packed f32 math (v_pk_fma_f32 / v_pk_mul_f32: half the instructions; the GEMM epilogue is
+// instruction-bound and GELU is most of the mlp-up epilogue).  Same arithmetic per element as gelu_erf.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+    const f32x2_t z = x * 0.70710678118654752440f;
+    f32x2_t u;
+    u.x = fminf(fabsf(z.x), 4.0f);
+    u.y = fminf(fabsf(z.y), 4.0f);
+    VRD_ERF_G(__builtin_elementwise_fma, u, f32x2_t)
+    f32x2_t e;
+    e.x = copysignf(1.0f - __builtin_amdgcn_exp2f(-g.x), z.x);
+    e.y = copysignf(1.0f - __builtin_amdgcn_exp2f(-g.y), z.y);
+    return (x * 0.5f) * (e + 1.0f);
 }
 
 }  // namespace vrd

@@ -105,7 +105,12 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[j][c] = gelu_erf(v[j][c]);
+                for (int c = 0; c < 4; c += 2) {
+                    f32x2_t t2;
+                    t2.x = v[j][c], t2.y = v[j][c + 1];
+                    t2 = gelu_erf2(t2);
+                    v[j][c] = t2.x, v[j][c + 1] = t2.y;
+                }
         }
         if (ROWIN) {
             float mk[4] = {1.f, 1.f, 1.f, 1.f};
