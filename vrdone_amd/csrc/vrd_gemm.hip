@@ -254,6 +254,7 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     // the 256 x 256 kernel (DMA-issue cost per MFMA a third lower) once there are about two rounds of its tiles
     static const int64_t big_min_tiles = [] { const char* e = getenv("VRD_X3_BIG_MIN_TILES"); return e ? atoll(e) : 512; }();
     const bool big = dma && a->N >= 256 && vrd::gemm_epilogue_lean_ok(*a) &&
+                     (a->taps == 1 || a->T >= 32) &&      // k = 3: the kernel steps its sequence position by 8 rows per piece
                      (reinterpret_cast<uintptr_t>(a->A) & 127u) == 0 && (reinterpret_cast<uintptr_t>(a->W_split) & 127u) == 0 &&
                      ((a->M + 255) / 256) * ((a->N + 255) / 256) >= big_min_tiles;
     vrd::ProfScope prof(big ? VRD_K_GEMM_X3_BIG : dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
