@@ -451,6 +451,23 @@ def test_gemm_large_tile_kernels(k, precision):
         assert float(((got_pair.float() - got).abs() / got.abs().clamp_min(1e-3)).max()) < 2 ** -15
 
 
+def test_gemm_k3_short_sequences(precision):
+    """k = 3 over many short sequences (T = 24 < 32): enough tiles for the LDS-DMA kernels; the 256 x 256 kernel
+    must decline (it advances the position inside the sequence by 8 rows per DMA piece, which needs T >= 32)."""
+    if precision != "bf16x3":
+        pytest.skip("the LDS-DMA kernels are split-precision kernels")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(99)
+    B, T, Cin, N = 4096, 24, 512, 512
+    x = torch.randn(B, T, Cin, generator=gen)
+    w = torch.randn(N, Cin, 3, generator=gen) / (Cin * 3) ** 0.5
+    bias = torch.randn(N, generator=gen)
+    got = ops.conv_gemm(_to_pair(x.to(DEV)), w.to(DEV), bias.to(DEV))
+    sample = [0, 1, 2047, 4094, 4095]
+    want = torch.nn.functional.conv1d(x[sample].double().transpose(1, 2), w.double(), bias.double(), padding=1).transpose(1, 2).float()
+    close(got[sample], want, 2e-5, gemm=True)
+
+
 def _to_pair(t):
     """Encode an f32 (B, T, C) tensor as pair rows (test helper; mirrors vrd::store_pair4)."""
     from vrdone_amd import ops
