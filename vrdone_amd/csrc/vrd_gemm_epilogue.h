@@ -61,13 +61,6 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
     const float* const r2_lane = (ROWIN && p.res2) ? p.res2 + m_lane * p.ldres2 + n : nullptr;
     const unsigned char* const mk_lane = (ROWIN && p.row_mask) ? p.row_mask + m_lane : nullptr;
     const int64_t c_step = p.ldc * 16, r1_step = p.ldres * 4, r2_step = p.ldres2 * 4;     // bytes / floats per 4 rows
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                stg[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
     struct RowIn {
         unsigned char mb[4];
         float4 r1[4], r2[4];
@@ -90,11 +83,21 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
         }
         return in;
     };
-    RowIn nxt = fetch(0);
+    // row inputs run two passes ahead (HBM latency under load is several thousand cycles, a pass ~1.5k); the first
+    // two requests go out before the transposition
+    RowIn q0 = fetch(0), q1 = fetch(1);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stg[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
-        const RowIn cur = nxt;
-        if (pass + 1 < 4) nxt = fetch(pass + 1);
+        const RowIn cur = q0;
+        q0 = q1;
+        if (pass + 2 < 4) q1 = fetch(pass + 2);
         float v[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
