@@ -16,6 +16,7 @@
 // for the transposed reads; both patterns are conflict free for head_dim 128.
 #include "vrd_common.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -184,10 +185,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
         }
         l_part = l_part * alpha + psum;
         m_run = m_new;
+        // rescale the running output only if some query's maximum moved (the kernel is instruction-bound: ~550
+        // instructions per tile and wave, 16 * DT of them this rescale; after the first tiles the maxima rarely move)
+        if (__any(alpha != 1.0f)) {
 #pragma unroll
-        for (int d = 0; d < DT; ++d)
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T
 #pragma unroll
@@ -297,7 +302,8 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
                         4.0 * B * (double)width * (2.0 * Tq + 2.0 * Tk));
     const int tiles = (Tq + 31) / 32;
     const int waste3 = ((tiles + 2) / 3) * 3 - tiles, waste4 = ((tiles + 3) / 4) * 4 - tiles;
-    const int nw = (waste3 < waste4) ? 3 : 4;
+    static const int nw_env = [] { const char* e = getenv("VRD_FLASH_NW"); return e ? atoi(e) : 0; }();
+    const int nw = nw_env == 3 || nw_env == 4 ? nw_env : ((waste3 < waste4) ? 3 : 4);
     int rc;
     if (head_dim == 128) rc = nw == 3 ? launch<128, 3>(q, ldq, k, v, ldkv, kv_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
                                       : launch<128, 4>(q, ldq, k, v, ldkv, kv_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
