@@ -133,14 +133,16 @@ __device__ __forceinline__ void ln_rows(float4 (&v)[NV], const float* gamma, con
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
         ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-    const float denom = sqrtf(vrd::wave_sum(ss) * inv_c + LN_EPS);
+    // one division per row (the reference divides every element by sqrt(var + eps); x * (1 / d) differs from x / d by
+    // at most an ulp, and an f32 division is ~10 instructions per element in kernels that are instruction-bound)
+    const float inv = 1.0f / sqrtf(vrd::wave_sum(ss) * inv_c + LN_EPS);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const float4 g = ld4(gamma + lane_chan<NV, WIDE>(i, lane)), bb = ld4(beta + lane_chan<NV, WIDE>(i, lane));
-        v[i].x = v[i].x / denom * g.x + bb.x;
-        v[i].y = v[i].y / denom * g.y + bb.y;
-        v[i].z = v[i].z / denom * g.z + bb.z;
-        v[i].w = v[i].w / denom * g.w + bb.w;
+        v[i].x = fmaf(v[i].x * inv, g.x, bb.x);
+        v[i].y = fmaf(v[i].y * inv, g.y, bb.y);
+        v[i].z = fmaf(v[i].z * inv, g.z, bb.z);
+        v[i].w = fmaf(v[i].w * inv, g.w, bb.w);
         if (relu) {
             v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f);
             v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f);
