@@ -38,10 +38,26 @@ struct ProfScope {
         }                                                                         \
     } while (0)
 
+// Sum over the 64 lanes, returned wave-uniform.  Data-parallel-primitive adds instead of six ds_bpermute shuffles
+// (each of those is an address computation, an LDS-crossbar instruction and a wait): quad swaps, half-row and row
+// mirrors give every lane its 16-lane row sum, two row broadcasts carry the running sum into lane 63, one readlane
+// returns it as a scalar.  The row kernels are instruction-bound; this is 7 instructions against ~20.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    const int iv0 = __builtin_bit_cast(int, v);
+    float t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv0, 0xB1, 0xF, 0xF, true));                              // quad_perm [1,0,3,2]
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));     // row_mirror
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));    // row_bcast:15 -> rows 1, 3
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));    // row_bcast:31 -> rows 2, 3
+    v += t;
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // "Pair" rows (GEMM-operand format of the bf16x3 mode): a row of W logical channels (W % 32 == 0) stored in the
