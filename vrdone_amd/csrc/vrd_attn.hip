@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
                                                          float* __restrict__ out, int64_t ldo, int pair) {
     constexpr int HW = W / 2;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
     if (row >= (int64_t)B * T) return;
     const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
     float* o = out + row * ldo + lane * 8;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const float* __restrict
     __shared__ float qs[4][SM_MAX_HD];
     __shared__ float ps[4][SM_MAX_TK];
     const int b = blockIdx.z, h = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float* kb = k + (int64_t)b * Tk * ldkv + h * hd;
     const float* vb = v + (int64_t)b * Tk * ldkv + h * hd;
     for (int tq = blockIdx.x * 4 + wave; tq < Tq; tq += gridDim.x * 4) {

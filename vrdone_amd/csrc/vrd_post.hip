@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
                                                           int topk, float* __restrict__ top_score, int32_t* __restrict__ top_cat,
                                                           int32_t* __restrict__ seg_first, int32_t* __restrict__ seg_last) {
     const int lane = threadIdx.x & 63;
-    const int pq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int pq = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (pq >= PQ) return;
     const int p = pq / Q;
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ void pack_segment(const float* src, bool live, int la
 
 __global__ __launch_bounds__(256) void pack_pairs_kernel(vrd_pack_args a) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
     if (row >= (int64_t)a.P * a.T) return;
     const int p = (int)(row / a.T), t = (int)(row - (int64_t)p * a.T);
     const bool live = t < a.lens[p];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ post_add, int64_t ld_add, int period,
                                                         int pair) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
     if (row >= rows) return;
     float4 v[NV];
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     constexpr int C = 256 * NV, NT = GIN * KS, SETF = (NT + 3) * C;
     constexpr bool WIDE = NV == 2 && GIN == 1;
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // ---- parameters -> LDS (taps transposed to tap-major so a lane's four channels are one float4)
     for (int o = 0; o < p.n_out; ++o) {
         float* const ls = dw_lds + o * SETF;
