@@ -109,7 +109,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 const int sw = plane < 2 ? G::kswz(row) : G::vswz(row);
                 const int lc = pch ^ sw;                           // logical 16-byte chunk of the plane row
                 const char* base = (plane < 2 ? kb : vb) + (int64_t)key * ldkv * 4 + ((plane & 1) ? 64 : 0);
-                const char* src = key < Tk ? base + (lc >> 2) * 128 + (lc & 3) * 16 : zero_src + lc * 16;
+                // branch-free select (as a ternary on pointers hipcc emits an exec-masked branch per DMA)
+                const uintptr_t pa = reinterpret_cast<uintptr_t>(base + (lc >> 2) * 128 + (lc & 3) * 16);
+                const uintptr_t pz = reinterpret_cast<uintptr_t>(zero_src + lc * 16);
+                const char* src = reinterpret_cast<const char*>(pz ^ ((pa ^ pz) & (uintptr_t)0 - (uintptr_t)(key < Tk)));
                 __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + buf * G::STAGE + plane * G::PLANE + rb * 1024), 16, 0, 0);
             }
         }
