@@ -194,7 +194,9 @@ def test_extension_is_loaded_and_profiled():
     gemm = {k: sum(prof[f][k] for f in ("gemm_f32_mfma", "gemm_bf16x3_mfma", "gemm_bf16x3_dma"))
             for k in ("launches", "ms", "flops")}
     assert gemm["launches"] > 50 and gemm["ms"] > 0 and gemm["flops"] > 1e9
-    assert prof["attn_flash"]["launches"] == 8 and prof["local_attn"]["launches"] == 5
+    # 8 SOS self/cross attentions + the predictor's 4 x (self, cross) on the MFMA kernels; 5 banded attentions
+    assert prof["attn_flash"]["launches"] == 16 and prof["attn_small"]["launches"] == 0
+    assert prof["local_attn"]["launches"] == 5
 
 
 def test_pack_pairs_equals_padded_batch(precision):

@@ -345,7 +345,7 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False):
     assert ldk == ldv
     out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
     hd = Cc // n_head
-    flash = algo == 2 or (algo == 0 and hd in (64, 128) and Tq >= 32)      # mirrors vrd_attention's auto choice
+    flash = algo == 2 or (algo == 0 and hd in (64, 128))      # mirrors vrd_attention's auto choice
     pair = bool(pair and flash)
     _hip.check(lib.vrd_attention(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), B, Tq, Tk, n_head, hd,
                                  out.data_ptr(), Cc, algo, 1 if pair else 0, _stream()), "vrd_attention")
