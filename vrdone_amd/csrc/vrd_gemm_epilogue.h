@@ -46,10 +46,9 @@ __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw,
 // straight-line code without per-row predicates or per-element selects: the epilogue is instruction-bound (two
 // waves per SIMD, ~8 cycles per instruction and wave; the general version below runs ~240 instructions per
 // 16-row pass).   ROWIN: any of row_mask / scale / res / res2 may be set;  ACT: VRD_ACT_NONE or VRD_ACT_GELU.
-template <bool ROWIN, int ACT>
-__device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
-                                                   int nw, int wave, int lane, const EpiCols& cols) {
-    const int li = lane & 31, lh = lane >> 5;
+template <bool ROWIN, int ACT, typename Transposer>
+__device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Transposer&& transpose_into, float* smem, int64_t mw,
+                                                      int nw, int wave, int lane, const EpiCols& cols) {
     float* stg = smem + wave * (64 * STG_PITCH);
     const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
     const int n = nw + c4;
@@ -86,13 +85,7 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
     // row inputs run two passes ahead (HBM latency under load is several thousand cycles, a pass ~1.5k); the first
     // two requests go out before the transposition
     RowIn q0 = fetch(0), q1 = fetch(1);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                stg[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
+    transpose_into(stg);            // the wave's 64 x 64 sub-tile, accumulator layout -> slab rows
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const RowIn cur = q0;
@@ -162,6 +155,44 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
                 *reinterpret_cast<float4*>(c_lane + (pass * 4 + j) * c_step) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
         }
     }
+}
+
+// 32 x 32 accumulators (v_mfma_f32_32x32x16): element e of lane (li, lh) is C[(e & 3) + 8 * (e >> 2) + 4 * lh][li]
+template <bool ROWIN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
+                                                   int nw, int wave, int lane, const EpiCols& cols) {
+    const int li = lane & 31, lh = lane >> 5;
+    gemm_epilogue_lean_tr<ROWIN, ACT>(
+        p,
+        [&](float* stg) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        stg[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
+        },
+        smem, mw, nw, wave, lane, cols);
+}
+
+// 16 x 16 accumulators (v_mfma_f32_16x16x32): element j of lane l is C[4 * (l >> 4) + j][l & 15]
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool ROWIN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, const f32x4_t (&acc)[4][4], float* smem, int64_t mw,
+                                                     int nw, int wave, int lane, const EpiCols& cols) {
+    const int lc = lane & 15, lq = lane >> 4;
+    gemm_epilogue_lean_tr<ROWIN, ACT>(
+        p,
+        [&](float* stg) {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) stg[(ti * 16 + 4 * lq + j) * STG_PITCH + tj * 16 + lc] = acc[ti][tj][j];
+        },
+        smem, mw, nw, wave, lane, cols);
 }
 
 // true when vrd_gemm arguments fit the lean epilogue (checked on the host before the 256 x 256 kernel is chosen)

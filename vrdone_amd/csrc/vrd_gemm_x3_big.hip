@@ -17,6 +17,7 @@
 // 128-byte line; its 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the DMA source and on the reads.
 #include "vrd_common.h"
 #include "vrd_gemm_epilogue.h"
+#include <cstdlib>
 
 namespace {
 
@@ -61,7 +62,7 @@ __device__ __attribute__((aligned(128))) uint4 g_big_zero[8];      // 128 zero b
 
 __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
 
-template <int TAPS>
+template <int TAPS, bool M16>
 __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -137,18 +138,28 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     // chunk index XOR-swizzled with (row >> 1) & 7 = (li >> 1) & 7 for every 32-row block.  Hence all fragment
     // addresses of an operand derive from ONE per-lane base: k16 half s flips bit 5 (chunk ^ 2), lo flips bit 6
     // (chunk ^ 4), and the 32-row blocks are constant offsets (kept out of registers: two VGPRs instead of 24).
-    const int a_base = (wm * 128 + li) * ROWB + ((lh ^ swz(li)) * 16);
-    const int w_base = W_RING + (wn * 64 + li) * ROWB + ((lh ^ swz(li)) * 16);
+    // (M16: v_mfma_f32_16x16x32 -- lane l holds row l & 15, k = 8 * (l >> 4) .. +7 of the whole K step, i.e. hi chunk
+    //  l >> 4; the swizzle of rows (16-row block) + (l & 15) is again that of l & 15)
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int a_base = M16 ? (wm * 128 + l15) * ROWB + ((l4 ^ swz(l15)) * 16) : (wm * 128 + li) * ROWB + ((lh ^ swz(li)) * 16);
+    const int w_base = W_RING + (M16 ? (wn * 64 + l15) * ROWB + ((l4 ^ swz(l15)) * 16) : (wn * 64 + li) * ROWB + ((lh ^ swz(li)) * 16));
 
     // bias / scale of this lane's columns: requested now, used by the epilogue
     const vrd::EpiCols cols = vrd::load_epi_cols(p, n0 + wn * 64, lane);
-    f32x16 acc[4][2];
+    f32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
+    vrd::f32x4_t acc16[M16 ? 8 : 1][M16 ? 4 : 1];        // M16: 8 x 4 tiles of 16 x 16
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < (M16 ? 1 : 4); ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < (M16 ? 1 : 2); ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (M16 ? 8 : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (M16 ? 4 : 1); ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
 
     // ---- main loop.  A K step is eight groups g = (s, mi) of six MFMAs (k16 half s, 32-row block mi, both
     // column blocks).  Fragment reads run one group ahead of the MFMAs (A fragments of group g+1, and the W
@@ -158,21 +169,24 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     // frees the buffers of stage kt, which the DMAs issued after it refill: W(kt+2), then A(kt+3), one per
     // group over the next eight groups (a DMA issue stalls its wave for 100-200 cycles while MFMAs run; the
     // two waves of a SIMD place theirs half a group apart).
+    constexpr int NWF = M16 ? 4 : 2;                 // W fragments (column blocks) held at a time
     struct AF { bf16x8 hi, lo; };
-    struct WF { bf16x8 hi[2], lo[2]; };
+    struct WF { bf16x8 hi[NWF], lo[NWF]; };
+    // 32x32x16: (s2, mi) = k16 half, 32-row block.  M16: s2 unused, mi = 16-row block 0..7 (g of the group)
     auto load_a = [&](const char* sa, int s2, int mi) {
         AF f;
-        const char* q = sa + (a_base ^ (s2 * 32)) + mi * 32 * ROWB;
-        f.hi = *reinterpret_cast<const bf16x8*>(q);
-        f.lo = *reinterpret_cast<const bf16x8*>(sa + (a_base ^ (s2 * 32) ^ 64) + mi * 32 * ROWB);
+        const int off = M16 ? a_base + mi * 16 * ROWB : (a_base ^ (s2 * 32)) + mi * 32 * ROWB;
+        f.hi = *reinterpret_cast<const bf16x8*>(sa + off);
+        f.lo = *reinterpret_cast<const bf16x8*>(sa + (off ^ 64));
         return f;
     };
     auto load_w = [&](const char* sw, int s2) {
         WF f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f.hi[t] = *reinterpret_cast<const bf16x8*>(sw + (w_base ^ (s2 * 32)) + t * 32 * ROWB);
-            f.lo[t] = *reinterpret_cast<const bf16x8*>(sw + (w_base ^ (s2 * 32) ^ 64) + t * 32 * ROWB);
+        for (int t = 0; t < NWF; ++t) {
+            const int off = M16 ? w_base + t * 16 * ROWB : (w_base ^ (s2 * 32)) + t * 32 * ROWB;
+            f.hi[t] = *reinterpret_cast<const bf16x8*>(sw + off);
+            f.lo[t] = *reinterpret_cast<const bf16x8*>(sw + (off ^ 64));
         }
         return f;
     };
@@ -208,19 +222,29 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         for (int g = 0; g < 8; ++g) {
             const int mi = g & 3;
             // ---- reads for what comes next
-            if (g < 7) a_nxt = load_a(sa, (g + 1) >> 2, (g + 1) & 3);
-            if (g == 2) w_nxt = load_w(sw, 1);
+            if (g < 7) a_nxt = M16 ? load_a(sa, 0, g + 1) : load_a(sa, (g + 1) >> 2, (g + 1) & 3);
+            if (!M16 && g == 2) w_nxt = load_w(sw, 1);
             if (g == 7 && !last) {
                 // (the barrier was passed at the end of group 6)
                 a_nxt = load_a(sa1, 0, 0);
                 w_nxt = load_w(sw1, 0);
             }
-            // ---- six MFMAs, this wave's DMA of the group in the middle or at the end
+            // ---- the group's MFMAs (six 32x32x16 or twelve 16x16x32), this wave's DMA of the group in the middle or
+            // at the end
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj) {
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.lo, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.lo[nj], acc[mi][nj], 0, 0, 0);
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
+                if (M16) {
+#pragma unroll
+                    for (int t = 2 * nj; t < 2 * nj + 2; ++t) {
+                        acc16[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur.lo, w_cur.hi[t], acc16[g][t], 0, 0, 0);
+                        acc16[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur.hi, w_cur.lo[t], acc16[g][t], 0, 0, 0);
+                        acc16[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur.hi, w_cur.hi[t], acc16[g][t], 0, 0, 0);
+                    }
+                } else {
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.lo, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.lo[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
+                }
                 if ((wave >> 2) == nj) {
                     __builtin_amdgcn_sched_barrier(0);
                     // groups 0..6 carry slots 1..7 of the batch opened in step kt-1, group 7 slot 0 of this step's
@@ -234,7 +258,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
                 }
             }
             a_cur = a_nxt;
-            if (g == 3 || g == 7) w_cur = w_nxt;
+            if ((!M16 && g == 3) || g == 7) w_cur = w_nxt;
             if (g == 6 && !last) {
                 // every fragment of stage kt is in registers or landed; stage kt+1 must be visible before group 7
                 // starts reading it
@@ -251,7 +275,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         }
     }
 #ifdef VRD_LAB_STAMP
-    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[3][1][15]));
+    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc16[0][0][0]));
 #endif
     LAB_PHASE_FLUSH(wave >> 2);
     // every wave must be done with the rings before they are reused as epilogue staging
@@ -260,18 +284,30 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     LAB_STAMP(2);
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {          // the epilogue works on 64 x 64 halves of the wave's 128 x 64
-        f32x16 part[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) part[i][j] = acc[2 * hm + i][j];
         // (M % 64 == 0 and N % 64 == 0, checked on the host: the sub-tile is inside C or entirely outside)
         const int64_t mw = m0 + wm * 128 + hm * 64;
         const int nw = n0 + wn * 64;
         if (mw >= p.M || nw >= p.N) continue;
-        if (p.row_mask || p.scale || p.res || p.res2) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
-        else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU>(p, part, smem, mw, nw, wave, lane, cols);
-        else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+        const bool rowin = p.row_mask || p.scale || p.res || p.res2;
+        if (M16) {
+            vrd::f32x4_t part[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) part[i][j] = acc16[M16 ? 4 * hm + i : 0][M16 ? j : 0];
+            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU>(p, part, smem, mw, nw, wave, lane, cols);
+            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+        } else {
+            f32x16 part[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) part[i][j] = acc[M16 ? 0 : 2 * hm + i][M16 ? 0 : j];
+            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU>(p, part, smem, mw, nw, wave, lane, cols);
+            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+        }
     }
     LAB_STAMP(3);
     LAB_REAL(5);
@@ -282,9 +318,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
 
 namespace vrd {
 
-template <int TAPS>
+template <int TAPS, bool M16>
 static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
-    auto kern = gemm_bf16x3_big_kernel<TAPS>;
+    auto kern = gemm_bf16x3_big_kernel<TAPS, M16>;
     static bool reserved = false;
     if (!reserved) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIG_LDS);
@@ -301,7 +337,12 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
 
 // same eligibility as the 128 x 256 DMA kernel (pair-row A, staged epilogue); the caller picks by tile count
 int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s) {
-    return a.taps == 1 ? launch_big_one<1>(a, s) : launch_big_one<3>(a, s);
+    // MFMA shape: 16x16x32 (default) or 32x32x16 (VRD_BIG_M16=0).  Same fragments, LDS traffic and MFMA cycles per K
+    // step; interleaved A/B runs in one process put 16x16x32 0.5-1 % ahead on the whole step (the guide's advice for
+    // MFMA-dense loops: build both shapes at the same output tile per wave and keep the faster by wall).
+    static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 1; }();
+    if (m16) return a.taps == 1 ? launch_big_one<1, true>(a, s) : launch_big_one<3, true>(a, s);
+    return a.taps == 1 ? launch_big_one<1, false>(a, s) : launch_big_one<3, false>(a, s);
 }
 
 }  // namespace vrd
