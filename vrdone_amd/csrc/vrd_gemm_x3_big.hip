@@ -337,10 +337,11 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
 
 // same eligibility as the 128 x 256 DMA kernel (pair-row A, staged epilogue); the caller picks by tile count
 int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s) {
-    // MFMA shape: 16x16x32 (default) or 32x32x16 (VRD_BIG_M16=0).  Same fragments, LDS traffic and MFMA cycles per K
-    // step; interleaved A/B runs in one process put 16x16x32 0.5-1 % ahead on the whole step (the guide's advice for
-    // MFMA-dense loops: build both shapes at the same output tile per wave and keep the faster by wall).
-    static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 1; }();
+    // MFMA shape: 32x32x16 (default) or 16x16x32 (VRD_BIG_M16=1).  Same fragments, LDS traffic and MFMA cycles per K
+    // step; interleaved A/B runs in one process put 16x16x32 0.5-1 % ahead on the whole step, but it sums the K
+    // dimension in a different order than the 32x32x16 kernels that serve small batches, and the path keeps its
+    // results independent of the batch composition to the last bit (tests/test_gpu_model.py), so it stays opt-in.
+    static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
     if (m16) return a.taps == 1 ? launch_big_one<1, true>(a, s) : launch_big_one<3, true>(a, s);
     return a.taps == 1 ? launch_big_one<1, false>(a, s) : launch_big_one<3, false>(a, s);
 }
