@@ -179,26 +179,28 @@ class _ConvAttention(nn.Module):
         # the branch output feeds only its 1x1 projection GEMM
         return dict(weight=conv.conv.weight, gamma=norm.weight, beta=norm.bias, pair=_ops().pair_mode())
 
-    def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1, pre_ln=None):
-        """dwconv * mask -> LN for the three branches, sharing kernel launches when inputs coincide.
-        pre_ln (gamma, beta): the inputs are LayerNorm'ed on the fly (only when all three coincide)."""
+    def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1, pre_ln=None, pre_ln_on="qkv"):
+        """dwconv * mask -> LN for the three branches; branches that read the same rows (same input tensor, mask,
+        kernel size and input-LayerNorm choice) share one kernel launch.
+        pre_ln (gamma, beta): inputs named in pre_ln_on ('q', 'k', 'v') are LayerNorm'ed as they are read."""
         ops = _ops()
-        same_ks = self.query_conv.conv.kernel_size == self.key_conv.conv.kernel_size
-        if q_in is k_in and k_in is v_in and same_ks and q_mask is kv_mask:
-            return ops.dwconv_ln(q_in, [self._branch_set(n) for n in ("query", "key", "value")], mask_out=q_mask,
-                                 stride=stride, pre_ln=pre_ln)
-        assert pre_ln is None
-        if q_in is k_in and same_ks and q_mask is kv_mask:
-            q, k = ops.dwconv_ln(q_in, [self._branch_set("query"), self._branch_set("key")], mask_out=q_mask, stride=stride)
-            v, = ops.dwconv_ln(v_in, [self._branch_set("value")], mask_out=kv_mask, stride=stride)
-            return q, k, v
-        q, = ops.dwconv_ln(q_in, [self._branch_set("query")], mask_out=q_mask, stride=stride)
-        if k_in is v_in:
-            k, v = ops.dwconv_ln(k_in, [self._branch_set("key"), self._branch_set("value")], mask_out=kv_mask, stride=stride)
-        else:
-            k, = ops.dwconv_ln(k_in, [self._branch_set("key")], mask_out=kv_mask, stride=stride)
-            v, = ops.dwconv_ln(v_in, [self._branch_set("value")], mask_out=kv_mask, stride=stride)
-        return q, k, v
+        specs = [("query", q_in, q_mask, "q"), ("key", k_in, kv_mask, "k"), ("value", v_in, kv_mask, "v")]
+        groups = []          # [(x, mask, use_ln, ks, [names])]
+        for name, x, m, tag in specs:
+            ks = getattr(self, f"{name}_conv").conv.kernel_size
+            use_ln = pre_ln is not None and tag in pre_ln_on
+            for g in groups:
+                if g[0] is x and g[1] is m and g[2] == use_ln and g[3] == ks:
+                    g[4].append(name)
+                    break
+            else:
+                groups.append((x, m, use_ln, ks, [name]))
+        outs = {}
+        for x, m, use_ln, _, names in groups:
+            res = ops.dwconv_ln(x, [self._branch_set(n) for n in names], mask_out=m, stride=stride,
+                                pre_ln=pre_ln if use_ln else None)
+            outs.update(zip(names, res))
+        return outs["query"], outs["key"], outs["value"]
 
     def _project(self, q, k, v, out_pair=False):
         ops = _ops()

@@ -38,9 +38,11 @@ class MaskedMHCA_QKV(_ConvAttention):
         self.n_qx_stride, self.n_kv_stride = n_qx_stride, n_kv_stride
         self._build(n_embd, n_head, _qkv_kernel(n_qx_stride), _qkv_kernel(n_kv_stride), 1)
 
-    def cl_qkv(self, q_in, k_in, v_in, q_mask, kv_mask, **epilogue):
+    def cl_qkv(self, q_in, k_in, v_in, q_mask, kv_mask, pre_ln=None, pre_ln_on="", **epilogue):
+        """pre_ln = (gamma, beta) with pre_ln_on naming the inputs ('q', 'k', 'v') that are passed un-normalised and
+        get that LayerNorm inside the depthwise-conv kernel (the decoder layer's ln1 / ln2)."""
         ops = _ops()
-        q, k, v = self._prep(q_in, k_in, v_in, q_mask, kv_mask)
+        q, k, v = self._prep(q_in, k_in, v_in, q_mask, kv_mask, pre_ln=pre_ln, pre_ln_on=pre_ln_on)
         # global attention on the split-precision flash kernel consumes q/k/v as pair rows
         qkv_pair = self._half_win is None and ops.flash_pair_ok(self.n_head, self.n_embd, q.shape[1])
         q, k, v = self._project(q, k, v, out_pair=qkv_pair)
@@ -127,14 +129,26 @@ class MaskedConvTransformerDecoderLayer(nn.Module):
         rows added to the normalised target.  stream_add: extra tensor added to the cross-attention
         output (the SOS update s + s_mutual of reference backbones.py:220-221), fused into the GEMM."""
         ops = _ops()
-        t2 = self.ln1.cl(tgt, post_add=query_pos)
-        tgt, _ = self.self_attn.cl_qkv(t2, t2, tgt, tgt_mask, tgt_mask, scale=self._scale(self.drop_path_attn1),
-                                       res=tgt, res_masked=True)
-        t2 = self.ln2.cl(tgt, post_add=query_pos)
+        # without query_pos (the SOS layers) ln1 / ln2 feed only the depthwise-conv branches of the attention modules
+        # and are applied inside that kernel; with query_pos (predictor) they stay separate kernels
+        fuse1 = query_pos is None and isinstance(self.self_attn, MaskedMHCA_QKV)
+        fuse2 = query_pos is None and isinstance(self.multihead_attn, MaskedMHCA_QKV)
         last = not self.with_ffn
-        tgt, _ = self.multihead_attn.cl_qkv(t2, memory, memory, tgt_mask, memory_mask,
-                                            scale=self._scale(self.drop_path_attn2), res=tgt, res_masked=True,
-                                            res2=stream_add if last else None, out=out if last else None)
+        if fuse1:
+            tgt, _ = self.self_attn.cl_qkv(tgt, tgt, tgt, tgt_mask, tgt_mask, pre_ln=(self.ln1.weight, self.ln1.bias),
+                                           pre_ln_on="qk", scale=self._scale(self.drop_path_attn1), res=tgt, res_masked=True)
+        else:
+            t2 = self.ln1.cl(tgt, post_add=query_pos)
+            tgt, _ = self.self_attn.cl_qkv(t2, t2, tgt, tgt_mask, tgt_mask, scale=self._scale(self.drop_path_attn1),
+                                           res=tgt, res_masked=True)
+        kw = dict(scale=self._scale(self.drop_path_attn2), res=tgt, res_masked=True,
+                  res2=stream_add if last else None, out=out if last else None)
+        if fuse2:
+            tgt, _ = self.multihead_attn.cl_qkv(tgt, memory, memory, tgt_mask, memory_mask,
+                                                pre_ln=(self.ln2.weight, self.ln2.bias), pre_ln_on="q", **kw)
+        else:
+            t2 = self.ln2.cl(tgt, post_add=query_pos)
+            tgt, _ = self.multihead_attn.cl_qkv(t2, memory, memory, tgt_mask, memory_mask, **kw)
         if self.with_ffn:
             assert stream_add is None
             t2 = self.ln3.cl(tgt)
