@@ -40,3 +40,27 @@ def synth_proposal(n_tracklets, c_in, min_len, max_len, seed=4321, feat_stride=1
         "cat_scores": torch.rand(n_tracklets, generator=g),
         "traj_durations": torch.tensor(durs), "so_offset": torch.tensor(offs),
     }
+
+
+def synth_relations(lengths, t_pad, n_classes, max_rel=3, seed=777):
+    """Ground truth the way the training dataloader hands it over (dataloaders/vidvrd.py:402-455): per pair
+    preds (N_i,) int64 in [1, n_classes], segs (N_i, 2) int64 [start, end) inside the pair's length, and
+    masks (N_i, t_pad) float32 with ones on [start, end)."""
+    g = torch.Generator().manual_seed(seed)
+    preds, masks, segs = [], [], []
+    for L in lengths:
+        n = int(torch.randint(1, max_rel + 1, (1,), generator=g))
+        p = torch.randint(1, n_classes + 1, (n,), generator=g)
+        sg = []
+        for _ in range(n):
+            a = int(torch.randint(0, max(L - 1, 1), (1,), generator=g))
+            b = int(torch.randint(a + 1, L + 1, (1,), generator=g))
+            sg.append([a, b])
+        sg = torch.tensor(sg, dtype=torch.int64)
+        m = torch.zeros(n, t_pad)
+        for r, (a, b) in enumerate(sg.tolist()):
+            m[r, a:b] = 1
+        preds.append(p)
+        masks.append(m)
+        segs.append(sg)
+    return preds, masks, segs

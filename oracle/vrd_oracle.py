@@ -413,6 +413,129 @@ def forward_test(sd, cfg, infer_cfg, data):
 
 
 # ----------------------------------------------------------------------------
+# training criterion as forward values (models/maskvrd.py:417-588, models/losses.py)
+# float64, one (pair, query, relation) at a time: meant for small cases only
+# ----------------------------------------------------------------------------
+def _np64(t):
+    import numpy as np
+    return np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64)
+
+
+def _sigmoid(x):
+    import numpy as np
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _softplus(x):
+    import numpy as np
+    return np.logaddexp(0.0, x)
+
+
+def relation_target(mask_row, seg, valid, with_fuzzy, scale_range):
+    """Hard 0/1 relation mask, or the fuzzy one of models/losses.py:214-227: 1 within scale_range of the
+    half-length around the centre, sqrt(cos) ramp out to 1/scale_range of it on valid frames, else 0."""
+    import numpy as np
+    if not with_fuzzy:
+        return mask_row.copy()
+    lo, hi = float(seg[0]), float(seg[1])
+    d = np.arange(len(mask_row), dtype=np.float64) - (hi - 1 + lo) / 2          # multiples of 0.5: exact
+    # the two range tests are evaluated in fp32 like the reference (a frame can sit exactly on a threshold)
+    f32 = np.float32
+    half = f32(hi - lo) / f32(2)
+    core = np.abs(d).astype(f32) < half * f32(scale_range)
+    wide = (np.abs(d).astype(f32) < half / f32(scale_range)) & valid
+    ramp = (wide ^ core) & valid
+    w = np.cos(np.pi / ((hi - lo) / scale_range) * d)
+    w = np.sqrt(np.where(w > 0, w, 0.0))
+    return w * ramp + mask_row * core
+
+
+def match_cost(logit_row, mask_logits, valid, cls, target, cost_factor, alpha=0.25, gamma=2.0):
+    """Cost of giving one relation to one query (models/maskvrd.py:447-482): CE of its predicate, focal loss
+    summed over the pair's valid frames / number of valid frames, and dice cost."""
+    import numpy as np
+    v = valid.astype(np.float64)
+    ce = np.logaddexp.reduce(logit_row) - logit_row[cls]
+    p = _sigmoid(mask_logits)
+    pos = alpha * (1 - p) ** gamma * _softplus(-mask_logits) * v
+    neg = (1 - alpha) * p ** gamma * _softplus(mask_logits) * v
+    focal = (np.sum(pos * target * v) + np.sum(neg * (1 - target) * v)) / v.sum()
+    pv, tv = p * v, target * v
+    dice = 1 - (2 * np.sum(pv * tv) + 1) / (pv.sum() + tv.sum() + 1)
+    return cost_factor["cost_class"] * ce + cost_factor["cost_mask"] * focal + cost_factor["cost_dice"] * dice
+
+
+def bipartite_match(cfg, pred_logits, pred_masks, output_mask, gt_preds, gt_masks, gt_segs):
+    """Per pair: (Q, N_i) cost matrix -> scipy Hungarian (models/maskvrd.py:484-496).  Returns the index pairs
+    and the cost matrices."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    fz, sr = cfg.get("with_fuzzy", False), cfg.get("scale_range")
+    L, M, V = _np64(pred_logits), _np64(pred_masks), _np64(output_mask)[:, 0] > 0.5
+    out, costs = [], []
+    for i in range(L.shape[0]):
+        n = len(gt_preds[i])
+        C = np.zeros((L.shape[1], n))
+        for j in range(n):
+            tgt = relation_target(_np64(gt_masks[i][j]), None if gt_segs is None else _np64(gt_segs[i][j]), V[i], fz, sr)
+            for q in range(L.shape[1]):
+                C[q, j] = match_cost(L[i, q], M[i, q], V[i], int(gt_preds[i][j]), tgt, cfg["cost_coeff_dict"])
+        out.append(linear_sum_assignment(C))
+        costs.append(C)
+    return out, costs
+
+
+def criterion_terms(cfg, pred_logits, pred_masks, output_mask, gt_preds, gt_masks, gt_segs, indices):
+    """loss_class / loss_mask / loss_dice for given matches (models/maskvrd.py:498-551, losses.py:98-172, 271-354)."""
+    import numpy as np
+    fz, sr = cfg.get("with_fuzzy", False), cfg.get("scale_range")
+    lf = cfg["loss_coeff_dict"]
+    L, M, V = _np64(pred_logits), _np64(pred_masks), _np64(output_mask)[:, 0] > 0.5
+    B, Q, K1 = L.shape
+    num = max(sum(len(g) for g in gt_preds), 1)
+    tgt_cls = np.zeros((B, Q), dtype=np.int64)
+    for i, (qs, js) in enumerate(indices):
+        for q, j in zip(qs, js):
+            tgt_cls[i, q] = int(gt_preds[i][j])
+    w = np.ones(K1)
+    w[0] = lf["eos_coef"]
+    nll = np.logaddexp.reduce(L, axis=-1) - np.take_along_axis(L, tgt_cls[..., None], axis=-1)[..., 0]
+    loss_class = np.sum(w[tgt_cls] * nll) / np.sum(w[tgt_cls])
+    focal = dice = 0.0
+    alpha, gamma = 0.25, 2.0
+    for i, (qs, js) in enumerate(indices):
+        v = V[i].astype(np.float64)
+        for q, j in zip(qs, js):
+            t = relation_target(_np64(gt_masks[i][j]), None if gt_segs is None else _np64(gt_segs[i][j]), V[i], fz, sr)
+            x = M[i, q]
+            p = _sigmoid(x)
+            t_ce = t * v if fz else t                          # losses.py:303 vs :117
+            ce = _softplus(x) - x * t_ce
+            p_t = p * t + (1 - p) * (1 - t)
+            fl = (alpha * t + (1 - alpha) * (1 - t)) * ce * (1 - p_t) ** gamma
+            focal += np.mean(v * fl)
+            pv, tv = p * v, t * v
+            dice += 1 - (2 * np.sum(pv * tv) + 1) / (pv.sum() + tv.sum() + 1)
+    return {"loss_class": lf["loss_class"] * loss_class, "loss_mask": lf["loss_mask"] * focal / num,
+            "loss_dice": lf["loss_dice"] * dice / num}
+
+
+def criterion(cfg, predictions, gt_preds, gt_masks, gt_segs=None):
+    """models/maskvrd.py:169-199, 570-588: match + losses for the final layer and each auxiliary layer; also
+    returns the final layer's matches."""
+    om = predictions["output_mask"]
+    layers = [("", predictions)] + [(f"_{i}", a) for i, a in enumerate(predictions.get("aux_outputs", []))]
+    losses, first = {}, None
+    for suffix, p in layers:
+        idx, _ = bipartite_match(cfg, p["pred_logits"], p["pred_masks"], om, gt_preds, gt_masks, gt_segs)
+        first = first or idx
+        terms = criterion_terms(cfg, p["pred_logits"], p["pred_masks"], om, gt_preds, gt_masks, gt_segs, idx)
+        losses.update({k + suffix: v for k, v in terms.items()})
+    losses["total_loss"] = sum(losses.values())
+    return losses, first
+
+
+# ----------------------------------------------------------------------------
 # deterministic synthetic weights / inputs (shared by tests, smoke and bench)
 # ----------------------------------------------------------------------------
 def synth_tensor(name, shape, ln_bias_std=0.1):

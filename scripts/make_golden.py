@@ -25,7 +25,7 @@ from models.maskvrd import MaskVRD                      # noqa: E402  (reference
 from models import blocks as ref_blocks                 # noqa: E402
 from models import local_transformer as ref_lt          # noqa: E402
 from oracle import vrd_oracle as O                      # noqa: E402
-from oracle.synth import synth_proposal                 # noqa: E402
+from oracle.synth import synth_proposal, synth_relations  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -86,6 +86,7 @@ def main():
         with open(os.path.join(OUT, f"param_checksums_{name}.json"), "w") as f:
             json.dump(chk, f)
         arrs = {}
+        crit = {}
         for (B, T, lens) in shapes:
             x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=1234 + T)
             feats, masks = model.backbone(x, m)
@@ -98,12 +99,26 @@ def main():
             for i, a in enumerate(out["aux_outputs"]):
                 arrs[f"{tag}_aux{i}_pred_logits"] = a["pred_logits"].numpy()
                 arrs[f"{tag}_aux{i}_pred_masks"] = a["pred_masks"].numpy()
+            # training criterion (forward values) on these predictions: reference matcher + losses
+            gp, gm, gs = synth_relations(lens, T, mc["num_classes"], seed=777 + T)
+            segs = gs if mc.get("with_fuzzy", False) else None
+            idx, lmask = model.bipartite_match(out["pred_logits"], gp, out["pred_masks"], gm, segs, _mask=masks[0])
+            ld = model.loss(idx, out["pred_logits"], out["pred_masks"], gp, gm, segs, _mask=masks[0],
+                            loss_mask=lmask, aux_outputs=out["aux_outputs"])
+            ld["total_loss"] = torch.stack(list(ld.values())).sum()
+            crit[tag] = {"seed": 777 + T, "indices": [[i.tolist(), j.tolist()] for i, j in idx],
+                         "losses": {k: float(v) for k, v in ld.items()}}
+            print(name, tag, "total_loss", crit[tag]["losses"]["total_loss"])
             if T <= 144 or name != "vidvrd":
                 for l, ft in enumerate(feats):
                     arrs[f"{tag}_feat{l}"] = sub(ft)
                 arrs[f"{tag}_fpn"] = sub(fpn, 8)
             print(name, tag, "logits std", float(out["pred_logits"].std()),
                   "masks std", float(out["pred_masks"].std()))
+        with open(os.path.join(OUT, f"criterion_{name}.json"), "w") as f:
+            json.dump(crit, f)
+        if "--criterion-only" in sys.argv:
+            continue
         np.savez_compressed(os.path.join(OUT, f"mask_vrd_{name}.npz"), **arrs)
 
         if name == "vidvrd":
@@ -120,6 +135,8 @@ def main():
                 json.dump(res, f)
             print("forward_test: pairs", res["n_pairs"], "triplets", len(res["triplets"]))
 
+    if "--criterion-only" in sys.argv:
+        return
     # ---- per-operator fixtures (real channel widths, small B/T), weights name-seeded ----
     ops = {}
     g = torch.Generator().manual_seed(99)

@@ -217,3 +217,43 @@ def test_pack_pairs_equals_padded_batch(precision):
     want = model._mask_vrd(x, m, with_aux=False)
     assert torch.equal(m2, m[:, 0])
     assert torch.equal(got["pred_logits"], want["pred_logits"]) and torch.equal(got["pred_masks"], want["pred_masks"])
+
+
+@pytest.mark.parametrize("name,T", [("vidvrd", 96), ("vidor_x", 512), ("vidor_local", 512)])
+def test_forward_training_loss_values_match_reference_golden(name, T, precision):
+    """Training-mode forward under no_grad = batching + HIP network + matcher + losses: the loss dict of the
+    reference (its matcher / losses run on its own predictions, scripts/make_golden.py) within 1e-3 relative,
+    with the same Hungarian matches; with autograd on it must refuse (no backward kernels)."""
+    from oracle.synth import synth_relations
+    model, mc, _, _ = get_model(name)
+    g = np.load(os.path.join(GOLDEN, f"mask_vrd_{name}.npz"))
+    with open(os.path.join(GOLDEN, f"criterion_{name}.json")) as f:
+        want = json.load(f)[f"T{T}"]
+    lens = g[f"T{T}_lengths"].tolist()
+    x, m = O.synth_pairs(len(lens), c_in(mc), T, lens, seed=1234 + T)
+    gp, gm, gs = synth_relations(lens, T, mc["num_classes"], seed=want["seed"])
+    data = {"so_features_list": [x[i, :, :n].contiguous() for i, n in enumerate(lens)],
+            "preds_list": gp, "masks_list": gm}
+    if mc.get("with_fuzzy", False):
+        data["segs_list"] = gs
+    model.train()
+    try:
+        got = model(data)
+        xb, mb = model.preprocessing(data["so_features_list"])
+        assert xb.shape == (len(lens), c_in(mc), mc["max_seq_len"]) and torch.equal(mb.cpu(), m)
+        with torch.enable_grad(), pytest.raises(NotImplementedError):
+            model(data)
+    finally:
+        model.eval()
+    assert list(got) == list(want["losses"])
+    for k, v in want["losses"].items():
+        assert got[k].is_cuda and abs(float(got[k]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(got[k]), v)
+    out = model._mask_vrd(x.to(DEV), m.to(DEV))
+    idx, _ = model.bipartite_match(out["pred_logits"], [t.to(DEV) for t in gp], out["pred_masks"],
+                                   [t.to(DEV) for t in gm], [t.to(DEV) for t in gs] if "segs_list" in data else None,
+                                   _mask=out["output_mask"])
+    # a 2-frame pair prices its queries almost identically (near-ties decided by 1e-5 differences): the matches are
+    # compared on pairs with enough frames to separate the queries, the loss values above on all of them
+    for n, (i, j), w in zip(lens, idx, want["indices"]):
+        if n >= 8:
+            assert [i.tolist(), j.tolist()] == w

@@ -3,13 +3,16 @@ checkpoint layout (models/maskvrd.py:16-167), with the relation-encoding hot pat
 hand-written HIP kernels and the eval post-processing (models/maskvrd.py:247-328) vectorised on
 the device instead of a per-candidate Python loop.
 
-Round-1 scope: inference (`model.eval()`); `forward_training` needs backward kernels and raises.
+Round-1 scope: inference (`model.eval()`) and the training criterion as forward values (`forward_training` under
+torch.no_grad(), `criterion`); a training step needs backward kernels and raises.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .backbones import MaskConvTransformerBackbone, MaskConvTransformerBackboneWithCLIP
 from .blocks import _no_autograd, _ops
+from . import losses
 from .fpns import FPN1D_Fuse
 from .predictor import MaskedTransformerPredictor
 
@@ -120,18 +123,131 @@ class MaskVRD(nn.Module):
         return merged
 
     def forward_training(self, input_data):
-        raise NotImplementedError(
-            "vrdone_amd.MaskVRD: the training step needs backward kernels for the HIP path, which this "
-            "round does not ship; use the model in eval mode")
+        """Loss dict of reference maskvrd.py:169-199 as forward VALUES: batching, network, Hungarian matching and
+        the class / focal / dice losses (+ one set per auxiliary decoder layer), ending in 'total_loss'.
+        The HIP path has no backward kernels yet, so this runs only under torch.no_grad() and the network runs its
+        deterministic kernels (drop-path / dropout are not sampled): it is the loss a validation pass reports, not
+        a training step.  With autograd enabled it raises rather than return losses that cannot be differentiated."""
+        if torch.is_grad_enabled():
+            raise NotImplementedError(
+                "vrdone_amd.MaskVRD: the training step needs backward kernels for the HIP path, which this round does "
+                "not ship; call under torch.no_grad() for the loss values, or use the model in eval mode")
+        return self.forward_loss(input_data)
+
+    @torch.no_grad()
+    def forward_loss(self, input_data):
+        x, m = self._train_batch(input_data['so_features_list'])
+        predictions = self._mask_vrd(x, m, with_aux=self.deep_supervision)
+        return self.criterion(predictions, input_data)
+
+    @torch.no_grad()
+    def criterion(self, predictions, input_data):
+        """predictions of _mask_vrd (with aux_outputs when deep_supervision) + the dataloader's ground truth
+        (preds_list (N_i,) int64, masks_list (N_i, T) 0/1 float, segs_list (N_i, 2) int64) -> loss dict."""
+        dev = predictions['pred_logits'].device
+        gt_preds = [t.to(dev) for t in input_data['preds_list']]
+        gt_masks = [t.to(dev) for t in input_data['masks_list']]
+        gt_segs = input_data.get('segs_list', None)
+        if self.with_fuzzy:
+            assert gt_segs is not None
+        if gt_segs is not None:
+            gt_segs = [t.to(dev) for t in gt_segs]
+        pred_logits, pred_masks, out_mask = predictions['pred_logits'], predictions['pred_masks'], predictions['output_mask']
+        indices, loss_mask = self.bipartite_match(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask=out_mask)
+        loss_dict = self.loss(indices, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, _mask=out_mask,
+                              loss_mask=loss_mask,
+                              aux_outputs=predictions['aux_outputs'] if self.deep_supervision else None)
+        loss_dict['total_loss'] = torch.stack(list(loss_dict.values())).sum()
+        return loss_dict
+
+    # ---- matching and losses (reference maskvrd.py:417-588) ----
+    def _fuzzy(self, gt_segs):
+        return (torch.cat(gt_segs, dim=0), self.scale_range) if self.with_fuzzy else (None, None)
+
+    @torch.no_grad()
+    def bipartite_match(self, pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask):
+        """Hungarian assignment of each pair's relations to its queries on
+        cost_class * CE + cost_mask * focal + cost_dice * dice (reference maskvrd.py:417-496).
+        Returns [(query_idx, relation_idx)] per pair (int64, CPU) and loss_mask (sum N_i, T) bool.
+        Only each pair's own (Q, N_i) block is priced (losses.pair_costs); the block goes to the host once."""
+        from scipy.optimize import linear_sum_assignment
+        dev = pred_logits.device
+        sizes = [len(p) for p in gt_preds]
+        owner = torch.repeat_interleave(torch.arange(len(sizes), device=dev), torch.tensor(sizes, device=dev))
+        valid = _mask[:, 0]
+        tgt_masks = torch.cat(gt_masks, dim=0)
+        assert tgt_masks.shape == (sum(sizes), valid.shape[-1])
+        segs, scale_range = self._fuzzy(gt_segs)
+        c_class, c_mask, c_dice = losses.pair_costs(pred_logits, pred_masks, valid, torch.cat(gt_preds, dim=0),
+                                                    tgt_masks, owner, segs, scale_range)
+        cost = (self.cost_factor['cost_class'] * c_class + self.cost_factor['cost_mask'] * c_mask +
+                self.cost_factor['cost_dice'] * c_dice).cpu()                       # (sum N_i, Q)
+        indices = []
+        for block in cost.split(sizes, dim=0):
+            rows, cols = linear_sum_assignment(block.T.numpy())
+            indices.append((torch.as_tensor(rows, dtype=torch.int64), torch.as_tensor(cols, dtype=torch.int64)))
+        return indices, valid[owner]
+
+    def _get_src_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        return batch_idx, torch.cat([src for src, _ in indices])
+
+    def _get_tgt_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(tgt, i) for i, (_, tgt) in enumerate(indices)])
+        return batch_idx, torch.cat([tgt for _, tgt in indices])
+
+    def loss_labels(self, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, indices, num_masks, loss_mask):
+        """eos-weighted cross-entropy over all (pair, query): matched queries carry their relation's predicate,
+        the rest class 0 (reference maskvrd.py:498-513)."""
+        dev = pred_logits.device
+        b, q = (t.to(dev) for t in self._get_src_permutation_idx(indices))
+        target = torch.zeros(pred_logits.shape[:2], dtype=torch.int64, device=dev)
+        target[b, q] = torch.cat([t[j.to(dev)] for t, (_, j) in zip(gt_preds, indices)])
+        ce = F.cross_entropy(pred_logits.transpose(1, 2), target, self.empty_weight.to(dev))
+        return {"loss_class": self.loss_factor['loss_class'] * ce}
+
+    def loss_masks(self, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, indices, num_masks, loss_mask):
+        """focal + dice loss between each matched query's mask and its relation's (fuzzy) mask over the pair's
+        valid frames (reference maskvrd.py:515-551)."""
+        dev = pred_masks.device
+        b, q = (t.to(dev) for t in self._get_src_permutation_idx(indices))
+        target = torch.cat([m[j.to(dev)] for m, (_, j) in zip(gt_masks, indices)])
+        picked = pred_masks[b, q]
+        assert picked.shape == target.shape
+        segs = torch.cat([s[j.to(dev)] for s, (_, j) in zip(gt_segs, indices)], dim=0) if self.with_fuzzy else None
+        focal, dice = losses.matched_losses(picked, target, num_masks, loss_mask, segs,
+                                            self.scale_range if self.with_fuzzy else None)
+        return {"loss_mask": self.loss_factor['loss_mask'] * focal, "loss_dice": self.loss_factor['loss_dice'] * dice}
+
+    def get_loss(self, loss, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, indices, num_masks, loss_mask):
+        loss_map = {"labels": self.loss_labels, "masks": self.loss_masks}
+        assert loss in loss_map, f"do you really want to compute {loss} loss?"
+        return loss_map[loss](pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, indices, num_masks, loss_mask)
+
+    def loss(self, indices, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, _mask, loss_mask, aux_outputs=None):
+        """All loss terms for the final predictions, and `<name>_<i>` for auxiliary layer i with its own matching
+        (reference maskvrd.py:570-588).  num_masks = total number of relations, at least 1."""
+        num_masks = float(max(sum(len(gt) for gt in gt_preds), 1))
+        out = {}
+        for name in self.loss_types:
+            out.update(self.get_loss(name, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, indices, num_masks,
+                                     loss_mask))
+        for i, aux in enumerate(aux_outputs or []):
+            a_logits, a_masks = aux['pred_logits'], aux['pred_masks']
+            a_idx, a_lm = self.bipartite_match(a_logits, gt_preds, a_masks, gt_masks, gt_segs, _mask=_mask)
+            for name in self.loss_types:
+                terms = self.get_loss(name, a_logits, a_masks, gt_preds, gt_masks, gt_segs, a_idx, num_masks, a_lm)
+                out.update({f"{k}_{i}": v for k, v in terms.items()})
+        return out
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def preprocessing(self, feats_list, padding_val=0.0):
         """Eval batching of reference maskvrd.py:363-414: pairs no longer than max_seq_len are
         zero-padded to max_seq_len, longer ones to the longest rounded up to max_div_factor."""
-        if self.training:
-            raise NotImplementedError("training-mode batching is part of the training step (not built yet)")
         assert padding_val == 0.0
+        if self.training:
+            return self._train_batch(feats_list)
         dev = self.device
         lens = [int(f.shape[1]) for f in feats_list]
         ids = ([i for i, n in enumerate(lens) if n <= self.max_seq_len],
@@ -144,6 +260,12 @@ class MaskVRD(nn.Module):
             inputs.append(x)
             masks.append(m)
         return tuple(inputs), tuple(masks), ids
+
+    def _train_batch(self, feats_list):
+        """Training batching (reference maskvrd.py:338-360): every pair zero-padded to max_seq_len."""
+        assert max(int(f.shape[1]) for f in feats_list) <= self.max_seq_len, \
+            "Input length must be smaller than max_seq_len during training"
+        return self._batch(feats_list, range(len(feats_list)), self.max_seq_len)
 
     def _batch(self, feats_list, ids, T):
         """Zero-padded (len(ids), C_in, T) batch and its (len(ids), 1, T) validity mask on the device."""
