@@ -115,6 +115,21 @@ def main():
                 arrs[f"{tag}_fpn"] = sub(fpn, 8)
             print(name, tag, "logits std", float(out["pred_logits"].std()),
                   "masks std", float(out["pred_masks"].std()))
+        if name == "vidvrd":
+            # BASELINE config 3 shape: a 24-pair training batch (6 videos x 4 pairs) at T_pad 96, ragged lengths;
+            # network in eval mode (no drop-path sampling) -> matcher -> losses, i.e. forward_training's values
+            B, T = 24, 96
+            lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(2024)).tolist()
+            x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=3)
+            out = model._mask_vrd(x, m)
+            gp, gm, gs = synth_relations(lens, T, mc["num_classes"], max_rel=4, seed=2025)
+            idx, lmask = model.bipartite_match(out["pred_logits"], gp, out["pred_masks"], gm, gs, _mask=out["output_mask"])
+            ld = model.loss(idx, out["pred_logits"], out["pred_masks"], gp, gm, gs, _mask=out["output_mask"],
+                            loss_mask=lmask, aux_outputs=out["aux_outputs"])
+            ld["total_loss"] = torch.stack(list(ld.values())).sum()
+            crit["train24"] = {"seed": 2025, "lengths": lens, "indices": [[i.tolist(), j.tolist()] for i, j in idx],
+                               "losses": {k: float(v) for k, v in ld.items()}}
+            print(name, "train24 total_loss", crit["train24"]["losses"]["total_loss"])
         with open(os.path.join(OUT, f"criterion_{name}.json"), "w") as f:
             json.dump(crit, f)
         if "--criterion-only" in sys.argv:

@@ -503,3 +503,71 @@ def test_flash_attention_pair_rows(H, hd, Tq, Tk, precision):
     close(ops.attention(qp, kp, vp, None, H),
           O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
                            torch.ones(B, 1, Tk, dtype=torch.bool), H).transpose(1, 2), 2e-4)
+
+
+def test_row_blocks_padding_map():
+    """vrd_row_blocks: the 32-row blocks dealt into equal segments; inside a segment the blocks holding a valid row
+    first (ascending), the fully padded ones after (ascending); every block exactly once."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for B, T in ((8, 288), (2048, 288), (64, 32), (1000, 96), (16, 288)):
+        lens = torch.randint(0, T + 1, (B,), generator=gen)
+        mask = (torch.arange(T)[None, :] < lens[:, None]).to(DEV)
+        order, count = ops.row_blocks(mask)
+        S = count.numel()
+        assert S == (8 if (B * T) % 2048 == 0 else 1)
+        flags = mask.reshape(-1, 32).any(1).cpu()
+        act, pad = torch.nonzero(flags).flatten(), torch.nonzero(~flags).flatten()
+        n, seg_len = len(act), len(flags) // S
+        first = [(s * n + S - 1) // S for s in range(S + 1)]
+        assert count.cpu().tolist() == [first[s + 1] - first[s] for s in range(S)]
+        want, p0 = [], 0
+        for s in range(S):
+            n_pad = seg_len - (first[s + 1] - first[s])
+            want += [act[first[s]:first[s + 1]], pad[p0:p0 + n_pad]]
+            p0 += n_pad
+        assert torch.equal(order.cpu().long(), torch.cat(want))
+        assert ops.row_blocks(mask) is ops.row_blocks(mask)            # cached on the mask object
+    assert ops.row_blocks(torch.ones(3, 40, dtype=torch.bool, device=DEV)) is None       # 120 rows: no whole tiles
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_gemm_padding_skip_is_exact(k, precision):
+    """The 256 x 256 kernel with a padding map: blocks without a valid row skip the contraction.  With row_mask the
+    result is bit-identical to the full computation (masked rows are res*mask + res2 either way); without it the
+    rows that hold valid frames are bit-identical and the skipped ones finite."""
+    if precision != "bf16x3":
+        pytest.skip("the LDS-DMA kernels are split-precision kernels")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(21 + k)
+    B, T, Cin, N = 320, 288, 512, 512
+    lens = torch.randint(1, T + 1, (B,), generator=gen)
+    lens[:3] = torch.tensor([288, 256, 1])
+    mask = (torch.arange(T)[None, :] < lens[:, None]).to(DEV)
+    assert int(ops.row_blocks(mask)[1].sum()) < B * T // 32 * 0.7          # plenty of fully padded blocks
+    x = torch.randn(B, T, Cin, generator=gen).to(DEV)             # padded rows hold data too (e.g. LayerNorm's beta)
+    w = (torch.randn(N, Cin, k, generator=gen) / (Cin * k) ** 0.5).to(DEV)
+    bias, scale = torch.randn(N, generator=gen).to(DEV), (torch.rand(N, generator=gen) + 0.5).to(DEV)
+    res, res2 = torch.randn(B, T, N, generator=gen).to(DEV), torch.randn(B, T, N, generator=gen).to(DEV)
+    xp = _to_pair(x)
+    cases = [dict(row_mask=mask), dict(row_mask=mask, scale=scale, res=res, res_masked=True, res2=res2),
+             dict(row_mask=mask, res=res), dict(row_mask=mask, out_pair=True)]
+    if k == 1:
+        cases += [dict(skip_rows=mask), dict(skip_rows=mask, act=ops.ACT_GELU, out_pair=True)]
+    for kw in cases:
+        old = ops._skip_padding
+        try:
+            ops._skip_padding = True
+            got = ops.conv_gemm(xp, w, bias, **kw)
+            ops._skip_padding = False
+            want = ops.conv_gemm(xp, w, bias, **kw)
+        finally:
+            ops._skip_padding = old
+        # decoded values: a masked row is (acc + bias) * 0, whose zero carries the sign of acc + bias resp. bias
+        g, wnt = (got.float(), want.float()) if isinstance(got, ops.Pair) else (got, want)
+        if "row_mask" in kw:
+            assert torch.equal(g, wnt), kw.keys()
+        else:
+            valid = mask.reshape(-1, 32).any(1).repeat_interleave(32).reshape(B, T)
+            assert torch.equal(g[valid], wnt[valid]) and bool(torch.isfinite(g).all())
+            assert not torch.equal(g, wnt)                       # the skip really happened

@@ -234,3 +234,26 @@ def test_reference_named_loss_functions_agree_with_the_oracle():
             np.testing.assert_allclose(fm[b * Q:(b + 1) * Q, g0:g0 + n].numpy(), cm[b], rtol=2e-5, atol=1e-6)
             np.testing.assert_allclose(dm[b * Q:(b + 1) * Q, g0:g0 + n].numpy(), cd[b], rtol=2e-5, atol=1e-6)
             g0 += n
+
+
+def test_training_batch_loss_values_match_reference(weights):
+    """BASELINE config 3 shape (24 pairs, T_pad 96, ragged): oracle network -> oracle matcher + losses against the
+    reference's forward_training values (network in eval mode, PYTORCH_JIT=0)."""
+    from oracle.synth import synth_relations
+    mc, _, sd = weights("vidvrd")
+    with open(os.path.join(GOLDEN, "criterion_vidvrd.json")) as f:
+        want = json.load(f)["train24"]
+    lens = want["lengths"]
+    x, m = O.synth_pairs(len(lens), c_in(mc), 96, lens, seed=3)
+    pred = O.mask_vrd(sd, mc, x, m, with_aux=True)
+    gp, gm, gs = synth_relations(lens, 96, mc["num_classes"], max_rel=4, seed=want["seed"])
+    losses, idx = O.criterion(mc, pred, gp, gm, gs)
+    _, costs = O.bipartite_match(mc, pred["pred_logits"], pred["pred_masks"], pred["output_mask"], gp, gm, gs)
+    for n, (r, c), w, C in zip(lens, idx, want["indices"], costs):
+        # pairs of < 16 frames have one valid frame at the predictor's T/8 level: their queries cost the same to
+        # ~1e-5 and the optimum is a near-tie; the reference's assignment must then be as cheap as ours
+        assert C[w[0], w[1]].sum() - C[r, c].sum() <= 1e-4
+        if n >= 16:
+            assert [list(map(int, r)), list(map(int, c))] == w
+    for k, v in want["losses"].items():
+        assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, losses[k], v)

@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("act", C.c_int32), ("row_mask", c_u8p), ("scale", c_f32p),
                 ("res", c_f32p), ("ldres", C.c_int64), ("res_masked", C.c_int32),
                 ("res2", c_f32p), ("ldres2", C.c_int64), ("W_split", C.c_void_p),
-                ("a_pair_width", C.c_int32), ("c_pair", C.c_int32)]
+                ("a_pair_width", C.c_int32), ("c_pair", C.c_int32),
+                ("row_blocks", C.c_void_p), ("row_blocks_active", C.c_void_p), ("row_block_segments", C.c_int32)]
 
 
 class DwconvLnArgs(C.Structure):
@@ -60,6 +61,7 @@ _SIGNATURES = {
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "vrd_row_blocks": (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vrd_layernorm": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int,
                                 c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_dwconv_ln": (C.c_int, [C.POINTER(DwconvLnArgs), C.c_void_p]),
@@ -77,7 +79,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):

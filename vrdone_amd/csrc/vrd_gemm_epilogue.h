@@ -48,7 +48,10 @@ __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw,
 // 16-row pass).   ROWIN: any of row_mask / scale / res / res2 may be set;  ACT: VRD_ACT_NONE or VRD_ACT_GELU.
 template <bool ROWIN, int ACT, typename Transposer>
 __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Transposer&& transpose_into, float* smem, int64_t mw,
-                                                      int nw, int wave, int lane, const EpiCols& cols) {
+                                                      int64_t mw1, int nw, int wave, int lane, const EpiCols& cols) {
+    // rows: passes 0-1 are mw .. mw+31, passes 2-3 are mw1 .. mw1+31 (mw1 = mw + 32 unless the tile's 32-row blocks
+    // come from a block list); hop = wave-uniform distance the second block is away from its contiguous place
+    const int64_t hop = mw1 - (mw + 32);
     float* stg = smem + wave * (64 * STG_PITCH);
     const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
     const int n = nw + c4;
@@ -60,6 +63,7 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
     const float* const r2_lane = (ROWIN && p.res2) ? p.res2 + m_lane * p.ldres2 + n : nullptr;
     const unsigned char* const mk_lane = (ROWIN && p.row_mask) ? p.row_mask + m_lane : nullptr;
     const int64_t c_step = p.ldc * 16, r1_step = p.ldres * 4, r2_step = p.ldres2 * 4;     // bytes / floats per 4 rows
+    const int64_t c_hop = hop * p.ldc * 4;
     struct RowIn {
         unsigned char mb[4];
         float4 r1[4], r2[4];
@@ -69,15 +73,17 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
         if (ROWIN) {
             if (p.row_mask) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) in.mb[j] = mk_lane[pass * 16 + 4 * j];
+                for (int j = 0; j < 4; ++j) in.mb[j] = mk_lane[pass * 16 + 4 * j + (pass >= 2 ? hop : 0)];
             }
             if (p.res) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) in.r1[j] = *reinterpret_cast<const float4*>(r1_lane + (pass * 4 + j) * r1_step);
+                for (int j = 0; j < 4; ++j)
+                    in.r1[j] = *reinterpret_cast<const float4*>(r1_lane + (pass * 4 + j) * r1_step + (pass >= 2 ? hop * p.ldres : 0));
             }
             if (p.res2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) in.r2[j] = *reinterpret_cast<const float4*>(r2_lane + (pass * 4 + j) * r2_step);
+                for (int j = 0; j < 4; ++j)
+                    in.r2[j] = *reinterpret_cast<const float4*>(r2_lane + (pass * 4 + j) * r2_step + (pass >= 2 ? hop * p.ldres2 : 0));
             }
         }
         return in;
@@ -139,7 +145,7 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
         if (pair) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                char* const rowp = c_lane + (pass * 4 + j) * c_step;
+                char* const rowp = c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0);
                 bf16x4_t h, l;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -152,7 +158,8 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(c_lane + (pass * 4 + j) * c_step) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                *reinterpret_cast<float4*>(c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0)) =
+                    make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
         }
     }
 }
@@ -160,7 +167,7 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
 // 32 x 32 accumulators (v_mfma_f32_32x32x16): element e of lane (li, lh) is C[(e & 3) + 8 * (e >> 2) + 4 * lh][li]
 template <bool ROWIN, int ACT>
 __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
-                                                   int nw, int wave, int lane, const EpiCols& cols) {
+                                                   int64_t mw1, int nw, int wave, int lane, const EpiCols& cols) {
     const int li = lane & 31, lh = lane >> 5;
     gemm_epilogue_lean_tr<ROWIN, ACT>(
         p,
@@ -173,14 +180,14 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
                     for (int e = 0; e < 16; ++e)
                         stg[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
         },
-        smem, mw, nw, wave, lane, cols);
+        smem, mw, mw1, nw, wave, lane, cols);
 }
 
 // 16 x 16 accumulators (v_mfma_f32_16x16x32): element j of lane l is C[4 * (l >> 4) + j][l & 15]
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <bool ROWIN, int ACT>
 __device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, const f32x4_t (&acc)[4][4], float* smem, int64_t mw,
-                                                     int nw, int wave, int lane, const EpiCols& cols) {
+                                                     int64_t mw1, int nw, int wave, int lane, const EpiCols& cols) {
     const int lc = lane & 15, lq = lane >> 4;
     gemm_epilogue_lean_tr<ROWIN, ACT>(
         p,
@@ -192,7 +199,7 @@ __device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, con
 #pragma unroll
                     for (int j = 0; j < 4; ++j) stg[(ti * 16 + 4 * lq + j) * STG_PITCH + tj * 16 + lc] = acc[ti][tj][j];
         },
-        smem, mw, nw, wave, lane, cols);
+        smem, mw, mw1, nw, wave, lane, cols);
 }
 
 // true when vrd_gemm arguments fit the lean epilogue (checked on the host before the 256 x 256 kernel is chosen)

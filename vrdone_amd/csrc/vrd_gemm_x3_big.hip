@@ -82,8 +82,22 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     const int xcd = vb & 7, q = nwg >> 3, rem = nwg & 7;
     const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (vb >> 3);
     const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int64_t m0 = (int64_t)tm * TM;
     const int n0 = tn * TN;
+    // ---- the tile's rows: eight 32-row blocks, slots tm*8 .. tm*8+7 of the block list (identity without one).
+    // With a padding map (vrd_row_blocks) the list is cut into segments -- one per XCD's contiguous share of the
+    // tiles when there are eight -- and inside a segment the blocks holding valid frames come first, so a tile is
+    // either a contraction tile or, behind those, a tile of fully padded blocks that only runs the epilogue on a
+    // zero accumulator (the reference's value wherever row_mask zeroes the row).
+    const int nblk = (int)(p.M >> 5);
+    const int32_t* const rb = p.row_blocks;
+    bool contract = true;
+    if (rb) {
+        const int seg_len = nblk / p.row_block_segments;                 // a multiple of 8 (host-checked)
+        const int seg = (tm * 8) / seg_len;
+        contract = seg < p.row_block_segments && tm * 8 - seg * seg_len < p.row_blocks_active[seg];
+    }
+    auto blk_of = [&](int slot) { return slot < nblk ? (rb ? rb[slot] : slot) : -1; };
+    const int my_blk = blk_of(tm * 8 + wave);          // the block whose A rows this wave stages
 
     // ---- DMA sources: this wave moves row blocks wave*4 .. wave*4+3 (8 rows each) of both operands.  Only piece 0's
     // per-lane pointers are kept: piece i is a wave-uniform stride further, its source-side swizzle differs from
@@ -94,11 +108,12 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     const int row0 = wave * PER * 8 + rin;                              // row inside the tile, for both operands
     const int chunk0 = (pch ^ swz(row0)) * 16;
     const char* const zero_src = reinterpret_cast<const char*>(g_big_zero);
-    const char* const a0 = reinterpret_cast<const char*>(p.A + (m0 + row0) * p.lda) + chunk0;
+    const int64_t a_row = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 + rin;
+    const char* const a0 = reinterpret_cast<const char*>(p.A + a_row * p.lda) + chunk0;
     const char* const w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(n0 + row0) * K * 4 + chunk0;
-    const int tseq0 = (TAPS == 3) ? (int)((m0 + row0) % p.T) : 0;
+    const int tseq0 = (TAPS == 3) ? (int)(a_row % p.T) : 0;
     const int64_t a_pstride = p.lda * 32, w_pstride = (int64_t)K * 32;  // bytes between pieces (8 rows)
-    const int a_in = (int)((p.M - m0 - wave * PER * 8 + 7) / 8), w_in = (p.N - n0 - wave * PER * 8 + 7) / 8;   // pieces inside
+    const int a_in = my_blk < 0 ? 0 : PER, w_in = (p.N - n0 - wave * PER * 8 + 7) / 8;   // pieces inside (M % 32 == 0)
     // piece i of W(kt) / A(kt): one DMA instruction each
     auto issue_w1 = [&](int kt, int i) {
         char* const dst = lds + W_RING + (kt % NW_STG) * W_STAGE + wave * PER * 1024;
@@ -190,6 +205,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         }
         return f;
     };
+    if (contract) {
     issue_a(0);
     issue_w(0);
     if (nkt > 1) {
@@ -274,10 +290,11 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
             }
         }
     }
+    LAB_PHASE_FLUSH(wave >> 2);
+    }       // contract
 #ifdef VRD_LAB_STAMP
     asm volatile("" ::"v"(acc[0][0][0]), "v"(acc16[0][0][0]));
 #endif
-    LAB_PHASE_FLUSH(wave >> 2);
     // every wave must be done with the rings before they are reused as epilogue staging
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -285,9 +302,11 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {          // the epilogue works on 64 x 64 halves of the wave's 128 x 64
         // (M % 64 == 0 and N % 64 == 0, checked on the host: the sub-tile is inside C or entirely outside)
-        const int64_t mw = m0 + wm * 128 + hm * 64;
+        const int slot = tm * 8 + wm * 4 + hm * 2;
+        const int blk_a = blk_of(slot), blk_b = blk_of(slot + 1);
         const int nw = n0 + wn * 64;
-        if (mw >= p.M || nw >= p.N) continue;
+        if (blk_a < 0 || nw >= p.N) continue;
+        const int64_t mw = (int64_t)blk_a * 32, mw1 = (int64_t)blk_b * 32;      // rows of passes 0-1 / 2-3
         const bool rowin = p.row_mask || p.scale || p.res || p.res2;
         if (M16) {
             vrd::f32x4_t part[4][4];
@@ -295,18 +314,18 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[i][j] = acc16[M16 ? 4 * hm + i : 0][M16 ? j : 0];
-            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU>(p, part, smem, mw, nw, wave, lane, cols);
-            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU>(p, part, smem, mw, mw1, nw, wave, lane, cols);
+            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
         } else {
             f32x16 part[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) part[i][j] = acc[M16 ? 0 : 2 * hm + i][M16 ? 0 : j];
-            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU>(p, part, smem, mw, nw, wave, lane, cols);
-            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE>(p, part, smem, mw, nw, wave, lane, cols);
+            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU>(p, part, smem, mw, mw1, nw, wave, lane, cols);
+            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
         }
     }
     LAB_STAMP(3);

@@ -393,6 +393,56 @@ __global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict_
 
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
 
+// ---- padding map: 32-row blocks dealt into S equal segments, inside a segment the blocks with a valid row first
+// (one workgroup; rows/32 is a few ten thousand at most).  Thread t owns a contiguous run of blocks, so every part
+// comes out ascending.  Active block of rank a goes to the segment s with first(s) <= a < first(s+1),
+// first(s) = ceil(s * total / S); a padded block fills what the actives leave of each segment, in order.
+constexpr int RB_THREADS = 1024;
+__global__ __launch_bounds__(RB_THREADS) void row_blocks_kernel(const uint8_t* __restrict__ mask, int nblocks, int S, int32_t* __restrict__ order,
+                                                                int32_t* __restrict__ n_active) {
+    __shared__ int counts[RB_THREADS];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + RB_THREADS - 1) / RB_THREADS;
+    const int b0 = min(tid * per, nblocks), b1 = min(b0 + per, nblocks);
+    auto active = [&](int b) {
+        const uint4* q = reinterpret_cast<const uint4*>(mask + (int64_t)b * 32);
+        const uint4 lo = q[0], hi = q[1];
+        return ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0u) ? 1 : 0;
+    };
+    int mine = 0;
+    for (int b = b0; b < b1; ++b) mine += active(b);
+    counts[tid] = mine;
+    __syncthreads();
+    // inclusive scan (Hillis-Steele over 1024 entries)
+    for (int d = 1; d < RB_THREADS; d <<= 1) {
+        const int v = tid >= d ? counts[tid - d] : 0;
+        __syncthreads();
+        counts[tid] += v;
+        __syncthreads();
+    }
+    const int total = counts[RB_THREADS - 1];
+    const int seg_len = nblocks / S;
+    auto first = [&](int s) { return (int)(((int64_t)s * total + S - 1) / S); };      // actives before segment s
+    auto pads_before = [&](int s) { return s * seg_len - first(s); };
+    int a = counts[tid] - mine;                       // rank of this run's first active / padded block
+    int i = b0 - a;
+    int sa = 0, sp = 0;
+    while (sa + 1 < S && first(sa + 1) <= a) ++sa;
+    while (sp + 1 < S && pads_before(sp + 1) <= i) ++sp;
+    for (int b = b0; b < b1; ++b) {
+        if (active(b)) {
+            while (sa + 1 < S && first(sa + 1) <= a) ++sa;
+            order[sa * seg_len + (a - first(sa))] = b;
+            ++a;
+        } else {
+            while (sp + 1 < S && pads_before(sp + 1) <= i) ++sp;
+            order[sp * seg_len + (first(sp + 1) - first(sp)) + (i - pads_before(sp))] = b;
+            ++i;
+        }
+    }
+    if (tid < S) n_active[tid] = first(tid + 1) - first(tid);
+}
+
 }  // namespace
 
 extern "C" {
@@ -424,6 +474,19 @@ int vrd_pack_pairs(const vrd_pack_args* a, void* stream) {
     const int64_t rows = (int64_t)a->P * a->T;
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * a->C_in);
     hipLaunchKernelGGL(pack_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_row_blocks(const uint8_t* mask, int64_t rows, int segments, int32_t* order, int32_t* n_active, void* stream) {
+    VRD_CHECK_ARG(mask && order && n_active, "vrd_row_blocks: null pointer");
+    VRD_CHECK_ARG(rows > 0 && rows % 32 == 0 && rows / 32 < (1 << 30), "vrd_row_blocks: rows %lld must be a positive multiple of 32", (long long)rows);
+    VRD_CHECK_ARG(segments >= 1 && segments <= 64 && (rows / 32) % segments == 0,
+                  "vrd_row_blocks: %d segments do not divide %lld blocks", segments, (long long)(rows / 32));
+    VRD_CHECK_ARG(aligned16(mask), "vrd_row_blocks: mask must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, (double)rows + 4.0 * (rows / 32));
+    hipLaunchKernelGGL(row_blocks_kernel, dim3(1), dim3(RB_THREADS), 0, s, mask, (int)(rows / 32), segments, order, n_active);
     VRD_LAUNCH_CHECK();
     return 0;
 }

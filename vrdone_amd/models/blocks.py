@@ -119,7 +119,7 @@ class ConvMLP(nn.Module):
         last = self.num_layers - 1
         for i, layer in enumerate(self.layers):
             if i < last:
-                x = ops.conv_gemm(x, layer.weight, layer.bias, act=ops.ACT_GELU, out_pair=ops.pair_mode())
+                x = ops.conv_gemm(x, layer.weight, layer.bias, act=ops.ACT_GELU, out_pair=ops.pair_mode(), skip_rows=row_mask)
             else:
                 x = ops.conv_gemm(x, layer.weight, layer.bias, row_mask=row_mask, out=out, out_pair=out_pair)
         return x
@@ -202,11 +202,13 @@ class _ConvAttention(nn.Module):
             outs.update(zip(names, res))
         return outs["query"], outs["key"], outs["value"]
 
-    def _project(self, q, k, v, out_pair=False):
+    def _project(self, q, k, v, out_pair=False, q_mask=None, kv_mask=None):
+        """1x1 projections.  q_mask / kv_mask: validity of the rows; fully padded row blocks are not contracted (their
+        keys / values are masked inside the attention kernels, their query rows by the output projection's row mask)."""
         ops = _ops()
-        return (ops.conv_gemm(q, self.query.weight, self.query.bias, out_pair=out_pair),
-                ops.conv_gemm(k, self.key.weight, self.key.bias, out_pair=out_pair),
-                ops.conv_gemm(v, self.value.weight, self.value.bias, out_pair=out_pair))
+        return (ops.conv_gemm(q, self.query.weight, self.query.bias, out_pair=out_pair, skip_rows=q_mask),
+                ops.conv_gemm(k, self.key.weight, self.key.bias, out_pair=out_pair, skip_rows=kv_mask),
+                ops.conv_gemm(v, self.value.weight, self.value.bias, out_pair=out_pair, skip_rows=kv_mask))
 
 
 class LocalMaskedMHCA(_ConvAttention):
@@ -233,7 +235,7 @@ class LocalMaskedMHCA(_ConvAttention):
             mask_out = mask if s == 1 else mask[:, ::s].contiguous()
         assert (x.shape[1] // s) % (2 * self.window_overlap) == 0      # reference blocks.py:828
         q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s, pre_ln=pre_ln)
-        q, k, v = self._project(q, k, v)
+        q, k, v = self._project(q, k, v, q_mask=mask_out, kv_mask=mask_out)
         att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap, pair=ops.pair_mode())
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
 
@@ -317,7 +319,7 @@ class TransformerBlock(nn.Module):
         y, _ = self.attn.cl(x, mask, m_out, pre_ln=(self.ln1.weight, self.ln1.bias),
                             scale=self._scale(self.drop_path_attn), res=skip, res_masked=True)
         h = self.ln2.cl(y, pair=ops.pair_mode())
-        h = ops.conv_gemm(h, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU, out_pair=ops.pair_mode())
+        h = ops.conv_gemm(h, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU, out_pair=ops.pair_mode(), skip_rows=m_out)
         y = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=m_out,
                           scale=self._scale(self.drop_path_mlp), res=y, out=out)
         return y, m_out

@@ -45,7 +45,7 @@ class MaskedMHCA_QKV(_ConvAttention):
         q, k, v = self._prep(q_in, k_in, v_in, q_mask, kv_mask, pre_ln=pre_ln, pre_ln_on=pre_ln_on)
         # global attention on the split-precision flash kernel consumes q/k/v as pair rows
         qkv_pair = self._half_win is None and ops.flash_pair_ok(self.n_head, self.n_embd, q.shape[1])
-        q, k, v = self._project(q, k, v, out_pair=qkv_pair)
+        q, k, v = self._project(q, k, v, out_pair=qkv_pair, q_mask=q_mask, kv_mask=kv_mask)
         if self._half_win is None:
             att = ops.attention(q, k, v, kv_mask, self.n_head, pair=ops.pair_mode())
         else:

@@ -210,11 +210,40 @@ def to_channels_last(x):
     return bct_to_btc(x.contiguous(), 0, Cc, out)
 
 
+_skip_padding = os.environ.get("VRDONE_SKIP_PADDING", "1") != "0"
+SKIP_MIN_ROWS = 65536        # below this the 256 x 256 GEMM kernel (the one that takes the block list) is not used
+
+
+def row_blocks(mask):
+    """Padding map of a (B, T) validity mask for vrd_gemm: (order, n_active per segment) device int32 tensors
+    (vrd_row_blocks), or None when the rows do not split into whole 256-row tiles.  Cached on the mask tensor object (the models never
+    write into a mask), so it dies with it."""
+    hit = getattr(mask, "_vrd_row_blocks", None)
+    key = (mask.data_ptr(), mask._version)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    rows = mask.numel()
+    val = None
+    if rows % 256 == 0 and mask.is_contiguous() and mask.data_ptr() % 16 == 0 and mask.dtype in (torch.bool, torch.uint8):
+        # eight segments (one per XCD of the GEMM's tile order) when they come out as whole 256-row tiles, else one
+        segments = 8 if rows % 2048 == 0 else 1
+        order = torch.empty(rows // 32, device=mask.device, dtype=torch.int32)
+        count = torch.empty(segments, device=mask.device, dtype=torch.int32)
+        _hip.check(lib.vrd_row_blocks(mask.data_ptr(), rows, segments, order.data_ptr(), count.data_ptr(), _stream()),
+                   "vrd_row_blocks")
+        val = (order, count)
+    mask._vrd_row_blocks = (key, val)
+    return val
+
+
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
-              res2=None, out=None, out_pair=False):
+              res2=None, out=None, out_pair=False, skip_rows=None):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
     vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
-    out_pair: write the result as pair rows of width N (returns a Pair)."""
+    out_pair: write the result as pair rows of width N (returns a Pair).
+    skip_rows: validity mask of the rows; aligned 32-row blocks without a valid row skip the contraction (exact with
+    row_mask, which is then the default; without row_mask those rows hold bias-only filler, so pass it only where
+    no valid row ever reads a padded one: projections feeding masked attention, an MLP's hidden layer)."""
     N, Cin, k = weight.shape
     x, a_width = _unwrap(x)
     pa, rows, cols, lda = _rows(x)
@@ -238,6 +267,13 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
         a.W_split = split_conv_weight(weight).data_ptr()
     a.a_pair_width = a_width
     a.c_pair = 1 if out_pair else 0
+    if skip_rows is None:
+        skip_rows = row_mask
+    if _skip_padding and skip_rows is not None and a_width and rows >= SKIP_MIN_ROWS and skip_rows.numel() == rows:
+        blocks = row_blocks(skip_rows)
+        if blocks is not None:
+            a.row_blocks, a.row_blocks_active = blocks[0].data_ptr(), blocks[1].data_ptr()
+            a.row_block_segments = blocks[1].numel()
     if res is not None:
         pr, rr, rc, ldr = _rows(res)
         assert rr == rows and rc == N
