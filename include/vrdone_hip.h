@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 6
+#define VRD_ABI_VERSION 7
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -173,6 +173,10 @@ typedef struct {
     int32_t out_pair[3];
     const float* pre_gamma;     /* optional LayerNorm on the input rows (needs group_in == 1, no x_up) */
     const float* pre_beta;
+    const float* packed[3];     /* optional per set: the set's parameters as the kernel keeps them on chip,
+                                   (group_in*ksize + 3) * C floats = taps [group_in][ksize][C] | bias [C] (zeros if
+                                   none) | gamma [C] (ones) | beta [C] (zeros); replaces w / bias and the values of
+                                   gamma / beta (whose pointers still say whether the set has a LayerNorm) */
 } vrd_dwconv_ln_args;
 int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
 

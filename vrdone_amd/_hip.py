@@ -40,7 +40,7 @@ class DwconvLnArgs(C.Structure):
                 ("mask_out", c_u8p), ("n_out", C.c_int32),
                 ("w", c_f32p * 3), ("bias", c_f32p * 3), ("gamma", c_f32p * 3), ("beta", c_f32p * 3),
                 ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3), ("out_pair", C.c_int32 * 3),
-                ("pre_gamma", c_f32p), ("pre_beta", c_f32p)]
+                ("pre_gamma", c_f32p), ("pre_beta", c_f32p), ("packed", c_f32p * 3)]
 
 
 class PackArgs(C.Structure):
@@ -79,7 +79,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class HipLibraryError(RuntimeError):

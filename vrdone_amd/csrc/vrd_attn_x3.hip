@@ -97,8 +97,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
 
     // DMA of tile kt: instruction j covers plane j / (32/RPI) rows (j % (32/RPI))*RPI ...; planes k_hi, k_lo, v_hi, v_lo
     const int rin = lane / G::CPR, pch = lane % G::CPR;
-    auto issue = [&](int kt) {
-        const int buf = kt & 1;
+    auto issue = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int j = wave + NW * i;
@@ -134,16 +133,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     const int nkt = (Tk + 31) / 32;
     // key bias of the whole row of tiles, once: an ordinary global load inside the loop would make the compiler
     // drain the LDS-DMA queue (vmcnt(0)) at its first use, every tile
+    // ... and, per tile of 32 keys, whether any key is valid: a tile of masked keys only adds exp(-inf) = 0 to every
+    // sum and leaves the running maxima alone, so it is not loaded or multiplied at all (padding behind the pair's
+    // frames: 32 of 288 keys at the benchmark shape, most of a max_seq_len batch of short pairs)
+    int* const tile_on = reinterpret_cast<int*>(kbias + nkt * 32);
     for (int key = tid; key < nkt * 32; key += NW * 64) {
         const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
         kbias[key] = ok ? 0.f : -INFINITY;
+        const unsigned long long bal = __ballot(ok);
+        if ((lane & 31) == 0) tile_on[key >> 5] = ((bal >> (lane & 32)) & 0xffffffffull) != 0ull;
     }
-    issue(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of tile kt (and its key-bias writes) have landed
-        __builtin_amdgcn_s_barrier();                           // ... and everybody else's; tile kt-1 is fully consumed
-        if (kt + 1 < nkt) issue(kt + 1);
-        const char* st = lds + (kt & 1) * G::STAGE;
+    __syncthreads();
+    unsigned long long act = ~0ull;                      // rows of more than 64 tiles: every tile is visited
+    if (nkt <= 64) act = __ballot(lane < nkt && tile_on[lane < nkt ? lane : 0] != 0);
+    auto next_on = [&](int from) {                       // first tile >= from that has a valid key, or nkt
+        if (from >= nkt) return nkt;
+        if (nkt > 64) return from;
+        const unsigned long long m = act & (~0ull << from);
+        return m ? (int)__builtin_ctzll(m) : nkt;
+    };
+    int kt = next_on(0);
+    if (kt < nkt) issue(kt, 0);
+    for (int it = 0; kt < nkt; ++it) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
+        __builtin_amdgcn_s_barrier();                           // ... and everybody else's; the previous tile is fully consumed
+        const int kt_next = next_on(kt + 1);
+        if (kt_next < nkt) issue(kt_next, (it + 1) & 1);
+        const char* st = lds + (it & 1) * G::STAGE;
         const float* kbs = kbias + kt * 32;
 
         // ---- S^T = K . Q^T (three products per k16 step)
@@ -240,6 +256,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[d], 0, 0, 0);
             }
         }
+        kt = kt_next;
     }
 
     const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
@@ -264,8 +281,8 @@ template <int HD, int NW>
 int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, int B, int Tq,
            int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
     auto kern = attn_flash_x3_kernel<HD, NW>;
-    constexpr size_t lds_max = 2 * AG<HD>::STAGE + 4096 * sizeof(float);       // key bias for Tk <= 4096
-    const size_t lds = 2 * AG<HD>::STAGE + (size_t)((Tk + 31) / 32) * 32 * sizeof(float);
+    constexpr size_t lds_max = 2 * AG<HD>::STAGE + (4096 + 128) * sizeof(float);       // key bias + tile flags for Tk <= 4096
+    const size_t lds = 2 * AG<HD>::STAGE + (size_t)((Tk + 31) / 32) * 33 * sizeof(float);
     if (lds > lds_max) {
         vrd::set_error("vrd_attention_pair: Tk = %d exceeds the 4096 keys the key-bias row is sized for", Tk);
         return -1;

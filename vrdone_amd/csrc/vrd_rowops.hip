@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 constexpr int DW_RW = 16;                      // output rows per wave
 
 template <int NV, int KS, int GIN>
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq) {
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq, int strips_per_wave) {
     constexpr int C = 256 * NV, NT = GIN * KS, SETF = (NT + 3) * C;
     constexpr bool WIDE = NV == 2 && GIN == 1;
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
@@ -197,6 +197,10 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     // ---- parameters -> LDS (taps transposed to tap-major so a lane's four channels are one float4)
     for (int o = 0; o < p.n_out; ++o) {
         float* const ls = dw_lds + o * SETF;
+        if (p.packed[o]) {               // the caller's image of this block: a straight copy
+            for (int idx = threadIdx.x * 4; idx < SETF; idx += 1024) st4(ls + idx, ld4(p.packed[o] + idx));
+            continue;
+        }
         for (int idx = threadIdx.x; idx < C * NT; idx += 256) ls[(idx % NT) * C + idx / NT] = p.w[o][idx];
         for (int c = threadIdx.x; c < C; c += 256) {
             ls[NT * C + c] = p.bias[o] ? p.bias[o][c] : 0.f;
@@ -211,7 +215,9 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             dw_lds[p.n_out * SETF + C + c] = p.pre_beta[c];
         }
     __syncthreads();
-    const int64_t ws = (int64_t)blockIdx.x * 4 + wave;
+    // the parameter blocks are filled once per workgroup; each wave then walks strips_per_wave consecutive strips
+    for (int si = 0; si < strips_per_wave; ++si) {
+    const int64_t ws = ((int64_t)blockIdx.x * 4 + wave) * strips_per_wave + si;
     const int b = (int)(ws / strips_per_seq);
     if (b >= p.B) return;
     const int to0 = (int)(ws - (int64_t)b * strips_per_seq) * DW_RW;
@@ -245,6 +251,42 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
         }
         return r;
     };
+    // ---- a strip of padded frames only (every mask_out byte 0): conv * 0 = 0, so each row is LayerNorm(0) = beta
+    // (0 without LayerNorm), ReLU applied -- written without reading the input.  Same bits as the path below.
+    if (p.mask_out) {
+        const int64_t r0 = (int64_t)b * Tout + to0;
+        const bool mine = lane < to1 - to0 && p.mask_out[r0 + lane] != 0;
+        if (!__any(mine)) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                if (o >= p.n_out) break;
+                const float* const lb = dw_lds + o * SETF + (NT + 2) * C;          // beta (zeros without LayerNorm)
+                float4 val[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    val[i] = *reinterpret_cast<const float4*>(lb + lane_chan<NV, WIDE>(i, lane));
+                    if (p.relu[o]) {
+                        val[i].x = fmaxf(val[i].x, 0.f); val[i].y = fmaxf(val[i].y, 0.f);
+                        val[i].z = fmaxf(val[i].z, 0.f); val[i].w = fmaxf(val[i].w, 0.f);
+                    }
+                }
+                for (int to = to0; to < to1; ++to) {
+                    const int64_t row = (int64_t)b * Tout + to;
+                    if (WIDE && p.out_pair[o]) {
+                        vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, val[0], val[NV - 1]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) {
+                            const int c = lane_chan<NV, WIDE>(i, lane);
+                            if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, val[i]);
+                            else st4(p.y[o] + row * p.ldy[o] + c, val[i]);
+                        }
+                    }
+                }
+            }
+            continue;
+        }
+    }
     // window win[k] = input row stride*to + k - KS/2; between consecutive output rows it moves by `stride`
     Row win[KS];
 #pragma unroll
@@ -328,6 +370,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             }
         }
     }
+    }       // strips of this wave
 }
 
 // ------------------------------------------------------------------------------------------
@@ -537,7 +580,8 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     VRD_CHECK_ARG(a->ldx >= (int64_t)a->C * a->group_in && a->ldx % 4 == 0 && aligned16(a->x), "vrd_dwconv_ln: bad x layout");
     VRD_CHECK_ARG(!a->x_up || (a->Tin % 2 == 0 && a->ldx_up % 4 == 0 && aligned16(a->x_up)), "vrd_dwconv_ln: bad x_up layout");
     for (int o = 0; o < a->n_out; ++o) {
-        VRD_CHECK_ARG(a->w[o] && a->y[o] && aligned16(a->w[o]) && aligned16(a->y[o]) && a->ldy[o] % 4 == 0 && a->ldy[o] >= a->C,
+        VRD_CHECK_ARG((a->w[o] || a->packed[o]) && a->y[o] && aligned16(a->w[o]) && aligned16(a->packed[o]) && aligned16(a->y[o]) &&
+                          a->ldy[o] % 4 == 0 && a->ldy[o] >= a->C,
                       "vrd_dwconv_ln: bad output set %d", o);
         VRD_CHECK_ARG((a->gamma[o] == nullptr) == (a->beta[o] == nullptr), "vrd_dwconv_ln: gamma/beta mismatch");
     }
@@ -547,9 +591,16 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     vrd::ProfScope prof(VRD_K_DWCONV_LN, s, 0.0,
                         4.0 * ((double)a->B * a->Tin * a->C * a->group_in * (a->x_up ? 1.5 : 1.0) + (double)rows * a->C * a->n_out));
     const int strips = (Tout + DW_RW - 1) / DW_RW;
-    dim3 grid((unsigned)(((int64_t)a->B * strips + 3) / 4)), block(256);
+    // strips per wave (VRD_DW_SPW): the parameter fill (12 KiB per set, a straight copy of the caller's image) is per
+    // workgroup, but measured at the benchmark shape 2 or 3 strips per wave are 5 % SLOWER than 1 (16.9 / 17.1 vs
+    // 16.1 ms per step): the kernel runs at ~4.8 TB/s, three quarters of it writes, and more, shorter workgroups
+    // keep more of them in flight
+    static const int spw_env = [] { const char* e = getenv("VRD_DW_SPW"); return e ? atoi(e) : 0; }();
+    const int64_t total_strips = (int64_t)a->B * strips;
+    const int spw = spw_env > 0 ? spw_env : 1;
+    dim3 grid((unsigned)((total_strips + 4 * spw - 1) / (4 * spw))), block(256);
     const size_t lds = ((size_t)a->n_out * (a->group_in * a->ksize + 3) + (a->pre_gamma ? 2 : 0)) * a->C * sizeof(float);
-#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips)
+#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips, spw)
     if (a->group_in == 2) VRD_DW(1, 3, 2);
     else if (a->C == 256 && a->ksize == 3) VRD_DW(1, 3, 1);
     else if (a->C == 256) VRD_DW(1, 1, 1);

@@ -303,6 +303,21 @@ def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False
     return Pair(out, cols) if pair else out
 
 
+def _dwconv_block(w, bias, gamma, beta):
+    """The on-chip parameter image of one dwconv_ln set (vrd_dwconv_ln_args.packed): taps tap-major | bias | gamma |
+    beta.  Cached on the weight, keyed on the (address, version) of all four tensors."""
+    parts = (w, bias, gamma, beta)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in parts)
+    hit = getattr(w, "_vrd_dw_block", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    Cout, g, k = w.shape
+    one = lambda t, fill: torch.full((Cout,), fill, device=w.device, dtype=torch.float32) if t is None else t.detach().float().reshape(-1)  # noqa: E731
+    val = torch.cat([w.detach().float().permute(1, 2, 0).reshape(-1), one(bias, 0.0), one(gamma, 1.0), one(beta, 0.0)]).contiguous()
+    w._vrd_dw_block = (key, val)
+    return val
+
+
 def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
     """Fused depthwise conv * mask -> LayerNorm for up to three weight sets sharing x.
     sets: list of dicts(weight=(C, g, k) Conv1d weight, bias=None, gamma=None, beta=None, relu=False, out=None).
@@ -335,6 +350,7 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
         po, ro, co, ldo = _rows(o)
         assert ro == B * Tout and co == Cout
         a.w[i], a.bias[i] = s["weight"].data_ptr(), _ptr(s.get("bias"))
+        a.packed[i] = _dwconv_block(s["weight"], s.get("bias"), s.get("gamma"), s.get("beta")).data_ptr()
         a.gamma[i], a.beta[i] = _ptr(s.get("gamma")), _ptr(s.get("beta"))
         a.relu[i] = 1 if s.get("relu") else 0
         a.y[i], a.ldy[i] = po, ldo
