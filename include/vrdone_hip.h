@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 7
+#define VRD_ABI_VERSION 8
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -53,6 +53,9 @@ int vrd_prof_reset(void);
 /* synchronises the recorded events; ms = summed kernel time, flops = summed algorithmic
  * FLOPs (GEMM / attention families; 0 elsewhere), bytes = summed algorithmic HBM bytes. */
 int vrd_prof_read(int kernel_id, double* ms, int64_t* launches, double* flops, double* bytes);
+/* Of the FLOPs vrd_prof_read reports for the family (what the launches were sized for), the part that padding maps
+ * (vrd_gemm_args.row_blocks) made the kernels skip: executed = flops - flops_skipped. */
+int vrd_prof_read_skipped(int kernel_id, double* flops_skipped);
 
 /* ---- layout change at the boundary ------------------------------------------------------
  * (B, C_total, T) -> rows (b*T+t) of `dst`, channels [c0, c0+count) of the source.

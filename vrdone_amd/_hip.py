@@ -57,6 +57,7 @@ _SIGNATURES = {
     "vrd_prof_reset": (C.c_int, []),
     "vrd_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
+    "vrd_prof_read_skipped": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
@@ -79,7 +80,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipLibraryError(RuntimeError):
@@ -119,10 +120,12 @@ def prof_reset():
 
 
 def prof_read():
-    """{family: dict(ms=, launches=, flops=, bytes=)} of everything recorded since the last reset."""
+    """{family: dict(ms=, launches=, flops=, bytes=, flops_skipped=)} of everything recorded since the last reset.
+    flops = what the launches were sized for (2*M*N*K); flops_skipped = the part padding maps made the kernel skip."""
     out = {}
     for kid, name in enumerate(KERNEL_NAMES):
-        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        ms, n, fl, by, sk = C.c_double(), C.c_int64(), C.c_double(), C.c_double(), C.c_double()
         check(lib.vrd_prof_read(kid, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "vrd_prof_read")
-        out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        check(lib.vrd_prof_read_skipped(kid, C.byref(sk)), "vrd_prof_read_skipped")
+        out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value, "flops_skipped": sk.value}
     return out

@@ -34,6 +34,9 @@ constexpr size_t BIG_LDS = (size_t)NA_STG * A_STAGE + (size_t)NW_STG * W_STAGE; 
 constexpr int PER = 4;                         // DMA instructions per wave, operand and K step (8 rows x 128 B each)
 
 __device__ __attribute__((aligned(128))) uint4 g_big_zero[8];      // 128 zero bytes: source of padded taps and outside pieces
+// sum over the tiles that skipped their contraction (padding map) of K * tile columns: 2 * 256 * this = FLOPs that
+// were launched but not executed (vrd_prof_read_skipped; the profile keeps executed and launched work apart)
+__device__ unsigned long long g_big_skipped_kn;
 
 #ifndef VRD_LAB_STAMP      // the lab harness (scripts/lab/gemm_lab.hip) defines these before including this file
 #define LAB_STAMP(slot)
@@ -98,6 +101,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     }
     auto blk_of = [&](int slot) { return slot < nblk ? (rb ? rb[slot] : slot) : -1; };
     const int my_blk = blk_of(tm * 8 + wave);          // the block whose A rows this wave stages
+    if (!contract && tid == 0 && tm * 8 < nblk)
+        atomicAdd(&g_big_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
 
     // ---- DMA sources: this wave moves row blocks wave*4 .. wave*4+3 (8 rows each) of both operands.  Only piece 0's
     // per-lane pointers are kept: piece i is a wave-uniform stride further, its source-side swizzle differs from
@@ -352,6 +357,14 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n);
     return 0;
+}
+
+// FLOPs of contractions skipped through padding maps since the last call (reads and clears the device counter)
+double take_big_skipped_flops() {
+    unsigned long long v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_big_skipped_kn), sizeof(v)) != hipSuccess) return 0.0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_big_skipped_kn), &zero, sizeof(zero));
+    return 2.0 * TM * (double)v;
 }
 
 // same eligibility as the 128 x 256 DMA kernel (pair-row A, staged epilogue); the caller picks by tile count

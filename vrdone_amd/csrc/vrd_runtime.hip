@@ -19,6 +19,8 @@ static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_free_events;
 static double g_ms[VRD_K_COUNT], g_flops[VRD_K_COUNT], g_bytes[VRD_K_COUNT];
 static int64_t g_launches[VRD_K_COUNT];
+static double g_skipped[VRD_K_COUNT];        // launched-but-skipped FLOPs (padding maps), folded in by drain()
+double take_big_skipped_flops();             // vrd_gemm_x3_big.hip
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -75,6 +77,7 @@ static void drain() {
         g_free_events.push_back(r.e1);
     }
     g_recs.clear();
+    g_skipped[VRD_K_GEMM_X3_BIG] += take_big_skipped_flops();     // synchronous copy: every launch above has finished
 }
 
 }  // namespace vrd
@@ -97,6 +100,15 @@ int vrd_prof_reset(void) {
     memset(vrd::g_flops, 0, sizeof(vrd::g_flops));
     memset(vrd::g_bytes, 0, sizeof(vrd::g_bytes));
     memset(vrd::g_launches, 0, sizeof(vrd::g_launches));
+    memset(vrd::g_skipped, 0, sizeof(vrd::g_skipped));
+    return 0;
+}
+
+int vrd_prof_read_skipped(int kernel_id, double* flops_skipped) {
+    VRD_CHECK_ARG(kernel_id >= 0 && kernel_id < VRD_K_COUNT && flops_skipped, "vrd_prof_read_skipped: bad arguments");
+    std::lock_guard<std::mutex> lk(vrd::g_mu);
+    vrd::drain();
+    *flops_skipped = vrd::g_skipped[kernel_id];
     return 0;
 }
 
