@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--precision", default=None, choices=["bf16x3", "f32"], help="GEMM product mode (default: the library default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second run in the other precision mode")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the extra run on ragged pair lengths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=64)
     return ap.parse_args()
@@ -155,8 +156,10 @@ def main():
     # every rank generates only its own shard, already in HBM
     x, m = synth.synth_pairs(hi - lo, c_in, t_pad, [args.frames] * (hi - lo), seed=1234 + rank, device=dev)
 
+    batch = {"x": x, "m": m}
+
     def step():
-        out = model._mask_vrd(x, m, with_aux=False)
+        out = model._mask_vrd(batch["x"], batch["m"], with_aux=False)
         if world > 1:
             return gather_predictions(out["pred_logits"], out["pred_masks"], args.pairs, world)
         return out["pred_logits"], out["pred_masks"]
@@ -227,6 +230,18 @@ def main():
     alt = None
     if not args.no_alt:
         alt = run(alt_mode, 1, args.steps)
+    ragged = None
+    if not args.no_ragged:
+        # SURVEY 8d's second input set, reported separately: same pairs, lengths ~ U[2, frames] (seed 1235), padded to
+        # the same T_pad like the reference's eval batching pads a slice to its longest pair
+        gen = torch.Generator().manual_seed(1235 + rank)
+        lens = torch.randint(2, args.frames + 1, (hi - lo,), generator=gen)
+        lens[0] = args.frames
+        del x, m
+        batch["x"], batch["m"] = synth.synth_pairs(hi - lo, c_in, t_pad, lens.tolist(), seed=1234 + rank, device=dev)
+        r_elapsed, _ = run(main_mode, 1, args.steps)
+        ragged = {"lengths": f"U[2, {args.frames}] (seed 1235), mean {float(lens.float().mean()):.1f}, T_pad {t_pad}",
+                  "value": args.pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps}
 
     if rank == 0:
         fpp = FLOPS_PER_PAIR.get((args.config, t_pad))
@@ -262,6 +277,8 @@ def main():
                                      "ms_per_step": 1e3 * a_elapsed / args.steps}
             if a_prof:
                 line["alt_precision"]["roofline"] = roofline(alt_mode, a_prof)
+        if ragged is not None:
+            line["ragged_variant"] = ragged
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, c_in, args.frames, t_pad, args.cpu_pairs)
