@@ -279,3 +279,27 @@ def test_forward_training_24_pair_batch(precision):
     assert list(got) == list(want["losses"])
     for k, v in want["losses"].items():
         assert abs(float(got[k]) - v) <= 1e-3 * max(1.0, abs(v)), (k, float(got[k]), v)
+
+
+@pytest.mark.parametrize("name,B,T", [("vidvrd", 256, 288), ("vidor_x", 160, 512), ("vidor_local", 160, 512)])
+def test_padding_skip_changes_nothing(name, B, T):
+    """Batches large enough for the padding maps (GEMM block lists, flash key tiles, depthwise-conv strips) on ragged
+    lengths: predictions identical to the last bit with the maps switched off (padded rows then hold the reference's
+    constants instead of filler, and no valid row ever reads them)."""
+    from vrdone_amd import ops
+    model, mc, _, _ = get_model(name)
+    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(77))
+    lens[:3] = torch.tensor([T, T - 33, 2])
+    m = (torch.arange(T)[None] < lens[:, None])[:, None].to(DEV)
+    x = torch.randn(B, c_in(mc), T, device=DEV, generator=torch.Generator(device=DEV).manual_seed(78)) * m
+    old = ops._skip_padding
+    try:
+        ops._skip_padding = True
+        got = model._mask_vrd(x, m)
+        ops._skip_padding = False
+        want = model._mask_vrd(x, m)
+    finally:
+        ops._skip_padding = old
+    assert torch.equal(got["pred_logits"], want["pred_logits"]) and torch.equal(got["pred_masks"], want["pred_masks"])
+    for a, b in zip(got["aux_outputs"], want["aux_outputs"]):
+        assert torch.equal(a["pred_logits"], b["pred_logits"]) and torch.equal(a["pred_masks"], b["pred_masks"])
