@@ -186,10 +186,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // row data, and the kernel ran at the L1's rate (2.7 TB/s of HBM) instead of HBM's.
 // LDS per set o (floats): taps [GIN*KS][C] | bias [C] | gamma [C] | beta [C]; behind the sets the optional input
 // LayerNorm's gamma [C] | beta [C].
-constexpr int DW_RW = 16;                      // output rows per wave
+constexpr int DW_RW = 16;                      // output rows per wave (default; the launcher may pick 8..32, see vrd_dwconv_ln)
 
 template <int NV, int KS, int GIN>
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq, int strips_per_wave) {
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq, int strips_per_wave, int rw) {
     constexpr int C = 256 * NV, NT = GIN * KS, SETF = (NT + 3) * C;
     constexpr bool WIDE = NV == 2 && GIN == 1;
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
@@ -220,8 +220,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     const int64_t ws = ((int64_t)blockIdx.x * 4 + wave) * strips_per_wave + si;
     const int b = (int)(ws / strips_per_seq);
     if (b >= p.B) return;
-    const int to0 = (int)(ws - (int64_t)b * strips_per_seq) * DW_RW;
-    const int to1 = min(to0 + DW_RW, Tout);
+    const int to0 = (int)(ws - (int64_t)b * strips_per_seq) * rw;
+    const int to1 = min(to0 + rw, Tout);
 
     struct Row {
         float4 v[NV][GIN];
@@ -590,7 +590,27 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_DWCONV_LN, s, 0.0,
                         4.0 * ((double)a->B * a->Tin * a->C * a->group_in * (a->x_up ? 1.5 : 1.0) + (double)rows * a->C * a->n_out));
-    const int strips = (Tout + DW_RW - 1) / DW_RW;
+    const size_t lds = ((size_t)a->n_out * (a->group_in * a->ksize + 3) + (a->pre_gamma ? 2 : 0)) * a->C * sizeof(float);
+    // rows per strip: 16 when the launch is many rounds of resident waves; for a small launch (e.g. one GPU's
+    // 256-pair shard: 4608 strips of 16 against 4096 resident waves = two rounds for 1.1 rounds of work) the strip
+    // length 8..32 that minimises rounds x (rows per strip + ~3 rows' worth of per-strip setup)
+    static const int rw_env = [] { const char* e = getenv("VRD_DW_RW"); return e ? atoi(e) : 0; }();
+    int rw = DW_RW;
+    {
+        const int64_t wgs_per_cu = lds ? (int64_t)(160 * 1024 / lds) : 8;
+        // (the 512-channel variants use ~110 VGPRs: four waves per SIMD, i.e. four workgroups per CU at most)
+        const int64_t resident = 256 * (wgs_per_cu < 1 ? 1 : wgs_per_cu > 4 ? 4 : wgs_per_cu) * 4;      // waves
+        if ((int64_t)a->B * ((Tout + DW_RW - 1) / DW_RW) < 6 * resident) {
+            double best = 1e30;
+            for (int r = 8; r <= 32; ++r) {
+                const int64_t n = (int64_t)a->B * ((Tout + r - 1) / r);
+                const double cost = (double)((n + resident - 1) / resident) * (r + 3);
+                if (cost < best - 1e-9) best = cost, rw = r;
+            }
+        }
+        if (rw_env >= 1 && rw_env <= 64) rw = rw_env;
+    }
+    const int strips = (Tout + rw - 1) / rw;
     // strips per wave (VRD_DW_SPW): the parameter fill (12 KiB per set, a straight copy of the caller's image) is per
     // workgroup, but measured at the benchmark shape 2 or 3 strips per wave are 5 % SLOWER than 1 (16.9 / 17.1 vs
     // 16.1 ms per step): the kernel runs at ~4.8 TB/s, three quarters of it writes, and more, shorter workgroups
@@ -599,8 +619,7 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     const int64_t total_strips = (int64_t)a->B * strips;
     const int spw = spw_env > 0 ? spw_env : 1;
     dim3 grid((unsigned)((total_strips + 4 * spw - 1) / (4 * spw))), block(256);
-    const size_t lds = ((size_t)a->n_out * (a->group_in * a->ksize + 3) + (a->pre_gamma ? 2 : 0)) * a->C * sizeof(float);
-#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips, spw)
+#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips, spw, rw)
     if (a->group_in == 2) VRD_DW(1, 3, 2);
     else if (a->C == 256 && a->ksize == 3) VRD_DW(1, 3, 1);
     else if (a->C == 256) VRD_DW(1, 1, 1);
