@@ -224,6 +224,10 @@ def main():
                      "algorithmic_bytes_per_launch": g["bytes"] / n,
                      "share_of_kernel_time": g["ms"] / tot if tot else 0.0}, **extra)
 
+    if world > 1:
+        # a rank's shard is a short step of ~520 launches: recording two events around each costs ~8 % of it, so the
+        # multi-GPU runs record the GEMM families only (what `roofline` needs); N = 1 records every family
+        _hip.prof_select(["gemm_f32_mfma", "gemm_bf16x3_mfma", "gemm_bf16x3_dma", "gemm_bf16x3_big"])
     main_mode = args.precision or ops.get_precision()
     alt_mode = "f32" if main_mode == "bf16x3" else "bf16x3"
     elapsed, prof = run(main_mode, args.warmup, args.steps)
@@ -265,6 +269,8 @@ def main():
             line["algorithmic_tflops"] = fpp * args.pairs * args.steps / elapsed / 1e12
         if prof:
             line["roofline"] = roofline(main_mode, prof)
+            if world > 1:
+                line["roofline"]["profiled_families"] = "GEMM families only (shares below are among those)"
             tot = sum(v["ms"] for v in prof.values())
             line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
             line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}

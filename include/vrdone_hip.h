@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 8
+#define VRD_ABI_VERSION 9
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -56,6 +56,10 @@ int vrd_prof_read(int kernel_id, double* ms, int64_t* launches, double* flops, d
 /* Of the FLOPs vrd_prof_read reports for the family (what the launches were sized for), the part that padding maps
  * (vrd_gemm_args.row_blocks) made the kernels skip: executed = flops - flops_skipped. */
 int vrd_prof_read_skipped(int kernel_id, double* flops_skipped);
+/* Restrict event recording to the kernel families whose bit (1 << vrd_kernel_id) is set (default: all).  Every
+ * recorded launch costs two event records, which also keep consecutive kernels from overlapping: ~3 us per launch,
+ * 8 % of a 256-pair step with all ~520 launches recorded, 1 % of a 2048-pair step. */
+int vrd_prof_select(unsigned long long family_mask);
 
 /* ---- layout change at the boundary ------------------------------------------------------
  * (B, C_total, T) -> rows (b*T+t) of `dst`, channels [c0, c0+count) of the source.

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "vrd_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double)]),
     "vrd_prof_read_skipped": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "vrd_prof_select": (C.c_int, [C.c_uint64]),
     "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
@@ -80,7 +81,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipLibraryError(RuntimeError):
@@ -113,6 +114,12 @@ def check(rc, what):
 
 def prof_enable(on=True):
     check(lib.vrd_prof_enable(1 if on else 0), "vrd_prof_enable")
+
+
+def prof_select(families=None):
+    """Record events only for the named kernel families (None = all)."""
+    mask = (1 << 64) - 1 if families is None else sum(1 << KERNEL_NAMES.index(f) for f in families)
+    check(lib.vrd_prof_select(mask), "vrd_prof_select")
 
 
 def prof_reset():

@@ -9,6 +9,7 @@ namespace vrd {
 static thread_local char g_err[512] = "";
 static std::mutex g_mu;
 static bool g_prof_on = false;
+static unsigned long long g_prof_mask = ~0ull;      // kernel families that record events (vrd_prof_select)
 
 struct ProfRec {
     int id;
@@ -42,7 +43,7 @@ static hipEvent_t get_event() {
 
 ProfScope::ProfScope(int kernel_id, hipStream_t s, double flops, double bytes)
     : id(kernel_id), stream(s), slot(nullptr) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || !((g_prof_mask >> kernel_id) & 1ull)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     ProfRec r;
     r.id = kernel_id;
@@ -90,6 +91,12 @@ const char* vrd_last_error(void) { return vrd::g_err; }
 int vrd_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(vrd::g_mu);
     vrd::g_prof_on = on != 0;
+    return 0;
+}
+
+int vrd_prof_select(unsigned long long family_mask) {
+    std::lock_guard<std::mutex> lk(vrd::g_mu);
+    vrd::g_prof_mask = family_mask;
     return 0;
 }
 
