@@ -29,7 +29,13 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
                                                          float* __restrict__ out, int64_t ldo, int pair) {
     constexpr int HW = W / 2;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
+    // XCD-aware renumbering (as in the GEMM / flash kernels): consecutive workgroups are dealt round-robin to the
+    // eight XCDs, and a row's K / V neighbours are re-read by the workgroups next to it -- a contiguous range of rows
+    // per XCD keeps those re-reads in one L2 instead of fetching them from HBM once per XCD
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    const int64_t row = (int64_t)lid * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
     if (row >= (int64_t)B * T) return;
     const int b = (int)(row / T), t = (int)(row - (int64_t)b * T);
     float* o = out + row * ldo + lane * 8;

@@ -215,9 +215,14 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             dw_lds[p.n_out * SETF + C + c] = p.pre_beta[c];
         }
     __syncthreads();
+    // XCD-aware renumbering: a contiguous range of strips per XCD, so the halo rows two neighbouring strips share are
+    // fetched into one L2 only
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
     // the parameter blocks are filled once per workgroup; each wave then walks strips_per_wave consecutive strips
     for (int si = 0; si < strips_per_wave; ++si) {
-    const int64_t ws = ((int64_t)blockIdx.x * 4 + wave) * strips_per_wave + si;
+    const int64_t ws = ((int64_t)lid * 4 + wave) * strips_per_wave + si;
     const int b = (int)(ws / strips_per_seq);
     if (b >= p.B) return;
     const int to0 = (int)(ws - (int64_t)b * strips_per_seq) * rw;
