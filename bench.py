@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--precision", default=None, choices=["bf16x3", "f32"], help="GEMM product mode (default: the library default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second run in the other precision mode")
     ap.add_argument("--no-ragged", action="store_true", help="skip the extra run on ragged pair lengths")
+    ap.add_argument("--no-forward-test", action="store_true", help="skip the secondary metric (whole eval call on one synthetic video)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=64)
     return ap.parse_args()
@@ -285,6 +286,26 @@ def main():
                 line["alt_precision"]["roofline"] = roofline(alt_mode, a_prof)
         if ragged is not None:
             line["ragged_variant"] = ragged
+        if world == 1 and not args.no_forward_test and args.config == "vidvrd":
+            # secondary metric: the whole eval call MaskVRD.forward_test -- batching of the dataloader's
+            # per-pair matrices, the path, device post-processing, result lists -- on one synthetic video of 46 tracklets
+            batch.clear()
+            torch.cuda.empty_cache()
+            ops.set_precision(main_mode)
+            model._config_eval(configs.inference_config(args.config))
+            video = synth.synth_video(46, c_in, 200, args.frames, seed=7, device=dev)
+            times = []
+            with torch.no_grad():
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    res = model(video)
+                    torch.cuda.synchronize()
+                    times.append(time.perf_counter() - t0)
+            wall = sorted(times[1:])[1]
+            line["forward_test"] = {"pairs": len(video["sids"]), "triplets": len(res["triplets"]), "ms": 1e3 * wall,
+                                    "value": len(video["sids"]) / wall, "unit": "pairs/s",
+                                    "note": "wall time of one eval call incl. the Python result lists; median of 3 after a warm-up"}
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, c_in, args.frames, t_pad, args.cpu_pairs)

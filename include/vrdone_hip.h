@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 9
+#define VRD_ABI_VERSION 10
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -126,26 +126,27 @@ typedef struct {
     int32_t a_pair_width;   /* > 0: A rows are pair rows (needs W_split, Cin % 32 == 0, lda % 32 == 0) */
     int32_t c_pair;         /* 1: write C as pair rows of width N (N % 32 == 0, ldc % 32 == 0) */
     /* Optional padding skip (M % 32 == 0): row_blocks = a permutation of the M/32 indices of 32-row blocks in
-     * row_block_segments equal segments (vrd_row_blocks), each holding its blocks with a valid frame first;
-     * row_blocks_active[segment] = how many those are (device memory).  A 256-row tile takes eight consecutive
-     * list entries; tiles behind a segment's active blocks skip the contraction and get the epilogue of a zero
-     * accumulator: exactly the reference value where row_mask zeroes the row (res / res2 still added), bias-only
-     * filler otherwise -- only for GEMMs whose masked rows no valid row reads (q/k/v projections feeding masked
-     * attention, the MLP hidden).  Kernels without the indirection ignore it and compute every row. */
+     * segments of row_block_seg_len entries (a multiple of 8; the last segment may be shorter), each holding its
+     * blocks with a valid frame first (vrd_row_blocks); row_blocks_active[segment] = how many those are (device
+     * memory).  A 256-row tile takes eight consecutive list entries; tiles behind a segment's active blocks skip the
+     * contraction and get the epilogue of a zero accumulator: exactly the reference value where row_mask zeroes the
+     * row (res / res2 still added), bias-only filler otherwise -- only for GEMMs whose masked rows no valid row
+     * reads (q/k/v projections feeding masked attention, the MLP hidden).  Kernels without the indirection ignore
+     * it and compute every row. */
     const int32_t* row_blocks;
     const int32_t* row_blocks_active;
-    int32_t row_block_segments;
+    int32_t row_block_seg_len;
 } vrd_gemm_args;
 int vrd_gemm(const vrd_gemm_args* a, void* stream);
 
 /* Padding map of a channels-last activation matrix: rows = B*T flat rows with validity mask[rows] (models/maskvrd.py
- * :386-392 builds it as t < len_b), rows % 32 == 0.  The rows/32 block indices are dealt into `segments` equal
- * segments of order[] (segments must divide rows/32; vrd_gemm wants segment lengths that are multiples of 8):
- * segment s = its share of the blocks with at least one valid row (ascending), then its share of the fully padded
- * ones (ascending); n_active[s] = number of the former.  The GEMM hands one segment to each XCD, so every XCD gets
- * the same amount of padding to skip.  The reference computes every padded frame (T_pad = 288 for 256 valid frames;
- * max_seq_len for short pairs). */
-int vrd_row_blocks(const uint8_t* mask, int64_t rows, int segments, int32_t* order, int32_t* n_active, void* stream);
+ * :386-392 builds it as t < len_b), rows % 32 == 0.  The rows/32 block indices are dealt into segments of seg_len
+ * entries of order[] (the last may be shorter; at most 64 segments): segment s = its proportional share of the blocks
+ * with at least one valid row (ascending), then its share of the fully padded ones (ascending); n_active[s] = number
+ * of the former.  For vrd_gemm choose seg_len = 8 * ceil(ceil(rows/32 / 8) / 8): about one segment per XCD of its
+ * tile order, so every XCD gets the same amount of padding to skip.  The reference computes every padded frame
+ * (T_pad = 288 for 256 valid frames; max_seq_len for short pairs). */
+int vrd_row_blocks(const uint8_t* mask, int64_t rows, int seg_len, int32_t* order, int32_t* n_active, void* stream);
 
 /* ---- channel LayerNorm (models/blocks.py:143-158), C in {256, 512} ----------------------
  * y[r,:] = LN(x[r,:]) * gamma + beta; optional ReLU (backbones.py:174); optional

@@ -9,7 +9,6 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.synth import synth_proposal  # noqa: E402  (input generator only)
 from vrdone_amd import configs, synth  # noqa: E402
 from vrdone_amd.models.maskvrd import MaskVRD  # noqa: E402
 
@@ -23,9 +22,8 @@ torch.set_grad_enabled(False)
 cfg = configs.model_config("vidvrd")
 model = synth.load_synthetic_weights(MaskVRD(cfg, device="cuda")).cuda().eval()
 model._config_eval(configs.inference_config("vidvrd"))
-data = synth_proposal(args.tracklets, configs.input_channels(cfg), args.min_len, args.max_len, seed=7, video_len=args.max_len + 8)
-dev = {k: ([t.cuda() for t in v] if isinstance(v, list) else v.cuda()) for k, v in data.items()}
-P = len(data["sids"])
+dev = synth.synth_video(args.tracklets, configs.input_channels(cfg), args.min_len, args.max_len, seed=7, device="cuda")
+P = len(dev["sids"])
 for it in range(args.iters + 1):
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -506,29 +506,34 @@ def test_flash_attention_pair_rows(H, hd, Tq, Tk, precision):
 
 
 def test_row_blocks_padding_map():
-    """vrd_row_blocks: the 32-row blocks dealt into equal segments; inside a segment the blocks holding a valid row
-    first (ascending), the fully padded ones after (ascending); every block exactly once."""
+    """vrd_row_blocks: the 32-row blocks dealt into segments (about eight, whole 256-row tiles, the last one shorter);
+    inside a segment the blocks holding a valid row first (ascending), the fully padded ones after (ascending); every
+    block exactly once; each segment gets its proportional share of the valid blocks."""
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(3)
-    for B, T in ((8, 288), (2048, 288), (64, 32), (1000, 96), (16, 288)):
+    for B, T in ((8, 288), (2048, 288), (2070, 288), (64, 32), (1000, 96), (17, 288), (1, 32)):
         lens = torch.randint(0, T + 1, (B,), generator=gen)
         mask = (torch.arange(T)[None, :] < lens[:, None]).to(DEV)
-        order, count = ops.row_blocks(mask)
-        S = count.numel()
-        assert S == (8 if (B * T) % 2048 == 0 else 1)
+        order, count, seg_len = ops.row_blocks(mask)
         flags = mask.reshape(-1, 32).any(1).cpu()
+        nblk = len(flags)
+        assert seg_len % 8 == 0 and seg_len == 8 * (((nblk + 7) // 8 + 7) // 8)
+        S = (nblk + seg_len - 1) // seg_len
+        assert count.numel() == S <= 8
         act, pad = torch.nonzero(flags).flatten(), torch.nonzero(~flags).flatten()
-        n, seg_len = len(act), len(flags) // S
-        first = [(s * n + S - 1) // S for s in range(S + 1)]
+        n = len(act)
+        start = [min(s * seg_len, nblk) for s in range(S + 1)]
+        first = [n * start[s] // nblk for s in range(S + 1)]
         assert count.cpu().tolist() == [first[s + 1] - first[s] for s in range(S)]
         want, p0 = [], 0
         for s in range(S):
-            n_pad = seg_len - (first[s + 1] - first[s])
+            n_pad = (start[s + 1] - start[s]) - (first[s + 1] - first[s])
+            assert n_pad >= 0
             want += [act[first[s]:first[s + 1]], pad[p0:p0 + n_pad]]
             p0 += n_pad
         assert torch.equal(order.cpu().long(), torch.cat(want))
         assert ops.row_blocks(mask) is ops.row_blocks(mask)            # cached on the mask object
-    assert ops.row_blocks(torch.ones(3, 40, dtype=torch.bool, device=DEV)) is None       # 120 rows: no whole tiles
+    assert ops.row_blocks(torch.ones(3, 40, dtype=torch.bool, device=DEV)) is None       # 120 rows: not whole blocks
 
 
 @pytest.mark.parametrize("k", [1, 3])
@@ -540,7 +545,7 @@ def test_gemm_padding_skip_is_exact(k, precision):
         pytest.skip("the LDS-DMA kernels are split-precision kernels")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(21 + k)
-    B, T, Cin, N = 320, 288, 512, 512
+    B, T, Cin, N = 310, 288, 512, 512         # 2790 blocks: segments of 352, the last one 326; a partial last tile
     lens = torch.randint(1, T + 1, (B,), generator=gen)
     lens[:3] = torch.tensor([288, 256, 1])
     mask = (torch.arange(T)[None, :] < lens[:, None]).to(DEV)

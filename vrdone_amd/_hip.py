@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("res", c_f32p), ("ldres", C.c_int64), ("res_masked", C.c_int32),
                 ("res2", c_f32p), ("ldres2", C.c_int64), ("W_split", C.c_void_p),
                 ("a_pair_width", C.c_int32), ("c_pair", C.c_int32),
-                ("row_blocks", C.c_void_p), ("row_blocks_active", C.c_void_p), ("row_block_segments", C.c_int32)]
+                ("row_blocks", C.c_void_p), ("row_blocks_active", C.c_void_p), ("row_block_seg_len", C.c_int32)]
 
 
 class DwconvLnArgs(C.Structure):
@@ -81,7 +81,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class HipLibraryError(RuntimeError):

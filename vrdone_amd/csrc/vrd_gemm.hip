@@ -228,10 +228,10 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     VRD_CHECK_ARG(a->a_pair_width == 0 || (a->W_split && a->Cin % 32 == 0 && a->lda % 32 == 0 &&
                                            aligned16(a->A) && aligned16(a->W_split)),
                   "vrd_gemm: pair-row A needs W_split, Cin %% 32 == 0 and rows that start on a 128-byte block");
-    VRD_CHECK_ARG(!a->row_blocks || (a->row_blocks_active && a->M % 32 == 0 && a->row_block_segments >= 1 &&
-                                     (a->M / 32) % (8 * a->row_block_segments) == 0),
-                  "vrd_gemm: a row-block list needs its active counts, M %% 32 == 0 and segments of a multiple of 8 blocks (M = %lld, %d segments)",
-                  (long long)a->M, a->row_block_segments);
+    VRD_CHECK_ARG(!a->row_blocks || (a->row_blocks_active && a->M % 32 == 0 && a->row_block_seg_len >= 8 &&
+                                     a->row_block_seg_len % 8 == 0),
+                  "vrd_gemm: a row-block list needs its active counts, M %% 32 == 0 and a segment length that is a multiple of 8 (M = %lld, seg_len %d)",
+                  (long long)a->M, a->row_block_seg_len);
     if (a->M == 0) return 0;
     const int64_t tiles_m64 = (a->M + BM - 1) / BM;
     const int tiles_n = (a->N + BN - 1) / BN;

@@ -95,9 +95,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     const int32_t* const rb = p.row_blocks;
     bool contract = true;
     if (rb) {
-        const int seg_len = nblk / p.row_block_segments;                 // a multiple of 8 (host-checked)
+        const int seg_len = p.row_block_seg_len;                          // a multiple of 8 (host-checked)
         const int seg = (tm * 8) / seg_len;
-        contract = seg < p.row_block_segments && tm * 8 - seg * seg_len < p.row_blocks_active[seg];
+        contract = tm * 8 < nblk && tm * 8 - seg * seg_len < p.row_blocks_active[seg];
     }
     auto blk_of = [&](int slot) { return slot < nblk ? (rb ? rb[slot] : slot) : -1; };
     const int my_blk = blk_of(tm * 8 + wave);          // the block whose A rows this wave stages

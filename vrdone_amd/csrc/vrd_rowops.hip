@@ -441,13 +441,14 @@ __global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict_
 
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
 
-// ---- padding map: 32-row blocks dealt into S equal segments, inside a segment the blocks with a valid row first
-// (one workgroup; rows/32 is a few ten thousand at most).  Thread t owns a contiguous run of blocks, so every part
-// comes out ascending.  Active block of rank a goes to the segment s with first(s) <= a < first(s+1),
-// first(s) = ceil(s * total / S); a padded block fills what the actives leave of each segment, in order.
+// ---- padding map: 32-row blocks dealt into segments of seg_len list entries (the last one may be shorter), inside a
+// segment the blocks with a valid row first (one workgroup; rows/32 is a few ten thousand at most).  Thread t owns a
+// contiguous run of blocks, so every part comes out ascending.  Segment s starts at entry start(s) = min(s * seg_len,
+// nblocks) and gets the actives of rank first(s) .. first(s+1)-1, first(s) = floor(total * start(s) / nblocks) -- its
+// proportional share, never more than it has entries; the padded blocks fill the rest of each segment, in order.
 constexpr int RB_THREADS = 1024;
-__global__ __launch_bounds__(RB_THREADS) void row_blocks_kernel(const uint8_t* __restrict__ mask, int nblocks, int S, int32_t* __restrict__ order,
-                                                                int32_t* __restrict__ n_active) {
+__global__ __launch_bounds__(RB_THREADS) void row_blocks_kernel(const uint8_t* __restrict__ mask, int nblocks, int seg_len, int S,
+                                                                int32_t* __restrict__ order, int32_t* __restrict__ n_active) {
     __shared__ int counts[RB_THREADS];
     const int tid = threadIdx.x;
     const int per = (nblocks + RB_THREADS - 1) / RB_THREADS;
@@ -469,22 +470,20 @@ __global__ __launch_bounds__(RB_THREADS) void row_blocks_kernel(const uint8_t* _
         __syncthreads();
     }
     const int total = counts[RB_THREADS - 1];
-    const int seg_len = nblocks / S;
-    auto first = [&](int s) { return (int)(((int64_t)s * total + S - 1) / S); };      // actives before segment s
-    auto pads_before = [&](int s) { return s * seg_len - first(s); };
+    auto start = [&](int s) { return min(s * seg_len, nblocks); };
+    auto first = [&](int s) { return (int)(((int64_t)total * start(s)) / nblocks); };     // actives before segment s
+    auto pads_before = [&](int s) { return start(s) - first(s); };
     int a = counts[tid] - mine;                       // rank of this run's first active / padded block
     int i = b0 - a;
     int sa = 0, sp = 0;
-    while (sa + 1 < S && first(sa + 1) <= a) ++sa;
-    while (sp + 1 < S && pads_before(sp + 1) <= i) ++sp;
     for (int b = b0; b < b1; ++b) {
         if (active(b)) {
             while (sa + 1 < S && first(sa + 1) <= a) ++sa;
-            order[sa * seg_len + (a - first(sa))] = b;
+            order[start(sa) + (a - first(sa))] = b;
             ++a;
         } else {
             while (sp + 1 < S && pads_before(sp + 1) <= i) ++sp;
-            order[sp * seg_len + (first(sp + 1) - first(sp)) + (i - pads_before(sp))] = b;
+            order[start(sp) + (first(sp + 1) - first(sp)) + (i - pads_before(sp))] = b;
             ++i;
         }
     }
@@ -526,15 +525,15 @@ int vrd_pack_pairs(const vrd_pack_args* a, void* stream) {
     return 0;
 }
 
-int vrd_row_blocks(const uint8_t* mask, int64_t rows, int segments, int32_t* order, int32_t* n_active, void* stream) {
+int vrd_row_blocks(const uint8_t* mask, int64_t rows, int seg_len, int32_t* order, int32_t* n_active, void* stream) {
     VRD_CHECK_ARG(mask && order && n_active, "vrd_row_blocks: null pointer");
     VRD_CHECK_ARG(rows > 0 && rows % 32 == 0 && rows / 32 < (1 << 30), "vrd_row_blocks: rows %lld must be a positive multiple of 32", (long long)rows);
-    VRD_CHECK_ARG(segments >= 1 && segments <= 64 && (rows / 32) % segments == 0,
-                  "vrd_row_blocks: %d segments do not divide %lld blocks", segments, (long long)(rows / 32));
+    const int nblocks = (int)(rows / 32);
+    VRD_CHECK_ARG(seg_len >= 1 && (nblocks + seg_len - 1) / seg_len <= 64, "vrd_row_blocks: segment length %d gives more than 64 segments", seg_len);
     VRD_CHECK_ARG(aligned16(mask), "vrd_row_blocks: mask must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, (double)rows + 4.0 * (rows / 32));
-    hipLaunchKernelGGL(row_blocks_kernel, dim3(1), dim3(RB_THREADS), 0, s, mask, (int)(rows / 32), segments, order, n_active);
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, (double)rows + 4.0 * nblocks);
+    hipLaunchKernelGGL(row_blocks_kernel, dim3(1), dim3(RB_THREADS), 0, s, mask, nblocks, seg_len, (nblocks + seg_len - 1) / seg_len, order, n_active);
     VRD_LAUNCH_CHECK();
     return 0;
 }

@@ -6,6 +6,8 @@ the device instead of a per-candidate Python loop.
 Round-1 scope: inference (`model.eval()`) and the training criterion as forward values (`forward_training` under
 torch.no_grad(), `criterion`); a training step needs backward kernels and raises.
 """
+import gc
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -101,11 +103,20 @@ class MaskVRD(nn.Module):
         B = batched_inputs.shape[0]
         masks2d = batched_masks.reshape(B, batched_masks.shape[-1]).contiguous()
         outs = []
-        for b0 in range(0, B, self.pair_chunk):
-            x = batched_inputs[b0:b0 + self.pair_chunk]
-            m = masks2d[b0:b0 + self.pair_chunk]
+        step = self._chunk_size(B)
+        for b0 in range(0, B, step):
+            x = batched_inputs[b0:b0 + step]
+            m = masks2d[b0:b0 + step]
             outs.append(self._heads(*self.backbone.cl(x, m), with_aux))
         return self._merge(outs)
+
+    def _chunk_size(self, n):
+        """Pairs per launch wave: one wave up to 1.25 x pair_chunk, otherwise equal waves (a 2070-pair video is one wave,
+        not 2048 + 22: a 22-pair wave runs the small-shape kernels at a fraction of the large ones' rate)."""
+        if n <= self.pair_chunk + self.pair_chunk // 4:
+            return max(n, 1)
+        waves = -(-n // self.pair_chunk)
+        return -(-n // waves)
 
     def _heads(self, feats, masks, with_aux):
         fpn_feat, _ = self.neck.cl(feats, masks)
@@ -316,8 +327,9 @@ class MaskVRD(nn.Module):
             if tables is not None:
                 # the dataloader's (L, C_in) matrices go straight into the backbone's operand buffers
                 outs = []
-                for c0 in range(0, len(ids), self.pair_chunk):
-                    sel = rows[c0:c0 + self.pair_chunk]
+                step = self._chunk_size(len(ids))
+                for c0 in range(0, len(ids), step):
+                    sel = rows[c0:c0 + step]
                     *parts, m2 = ops.pack_pairs(tables[0][sel], tables[1][sel], T, bb.n_visual, bb.n_clip,
                                                 bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
                     outs.append(self._heads(*bb.cl_parts(*parts, m2), False))
@@ -368,12 +380,20 @@ class MaskVRD(nn.Module):
         for t in used:
             rows_of[t] = flat[at:at + len(boxes[t])]
             at += len(boxes[t])
-        so_trajs = []
-        for r in host:
-            s_rows = rows_of[r[0]][r[7]:r[7] + r[9]].tolist()
-            o_rows = rows_of[r[1]][r[8]:r[8] + r[9]].tolist()
-            assert len(s_rows) == len(o_rows)
-            so_trajs.append([s_rows, o_rows])
+        # ~100 k small lists are created here; the cyclic collector would walk the whole process (every module and
+        # parameter of the model) several times on the way, for objects that cannot form cycles
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            so_trajs = []
+            for r in host:
+                s_rows = rows_of[r[0]][r[7]:r[7] + r[9]].tolist()
+                o_rows = rows_of[r[1]][r[8]:r[8] + r[9]].tolist()
+                assert len(s_rows) == len(o_rows)
+                so_trajs.append([s_rows, o_rows])
+        finally:
+            if gc_was_on:
+                gc.enable()
         return {
             "triplets": [r[2:5] for r in host],
             "triple_scores": tri[order].cpu().tolist(),

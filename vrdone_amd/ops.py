@@ -215,8 +215,8 @@ SKIP_MIN_ROWS = 65536        # below this the 256 x 256 GEMM kernel (the one tha
 
 
 def row_blocks(mask):
-    """Padding map of a (B, T) validity mask for vrd_gemm: (order, n_active per segment) device int32 tensors
-    (vrd_row_blocks), or None when the rows do not split into whole 256-row tiles.  Cached on the mask tensor object (the models never
+    """Padding map of a (B, T) validity mask for vrd_gemm: (order, n_active per segment, segment length) -- two device
+    int32 tensors made by vrd_row_blocks -- or None when the rows do not split into aligned 32-row blocks.  Cached on the mask tensor object (the models never
     write into a mask), so it dies with it."""
     hit = getattr(mask, "_vrd_row_blocks", None)
     key = (mask.data_ptr(), mask._version)
@@ -224,14 +224,15 @@ def row_blocks(mask):
         return hit[1]
     rows = mask.numel()
     val = None
-    if rows % 256 == 0 and mask.is_contiguous() and mask.data_ptr() % 16 == 0 and mask.dtype in (torch.bool, torch.uint8):
-        # eight segments (one per XCD of the GEMM's tile order) when they come out as whole 256-row tiles, else one
-        segments = 8 if rows % 2048 == 0 else 1
-        order = torch.empty(rows // 32, device=mask.device, dtype=torch.int32)
-        count = torch.empty(segments, device=mask.device, dtype=torch.int32)
-        _hip.check(lib.vrd_row_blocks(mask.data_ptr(), rows, segments, order.data_ptr(), count.data_ptr(), _stream()),
+    if rows % 32 == 0 and mask.is_contiguous() and mask.data_ptr() % 16 == 0 and mask.dtype in (torch.bool, torch.uint8):
+        # about eight segments (one per XCD of the GEMM's tile order), each a whole number of 256-row tiles
+        nblk = rows // 32
+        seg_len = 8 * (((nblk + 7) // 8 + 7) // 8)
+        order = torch.empty(nblk, device=mask.device, dtype=torch.int32)
+        count = torch.empty((nblk + seg_len - 1) // seg_len, device=mask.device, dtype=torch.int32)
+        _hip.check(lib.vrd_row_blocks(mask.data_ptr(), rows, seg_len, order.data_ptr(), count.data_ptr(), _stream()),
                    "vrd_row_blocks")
-        val = (order, count)
+        val = (order, count, seg_len)
     mask._vrd_row_blocks = (key, val)
     return val
 
@@ -273,7 +274,7 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
         blocks = row_blocks(skip_rows)
         if blocks is not None:
             a.row_blocks, a.row_blocks_active = blocks[0].data_ptr(), blocks[1].data_ptr()
-            a.row_block_segments = blocks[1].numel()
+            a.row_block_seg_len = blocks[2]
     if res is not None:
         pr, rr, rc, ldr = _rows(res)
         assert rr == rows and rc == N

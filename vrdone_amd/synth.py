@@ -46,3 +46,31 @@ def synth_pairs(n_pairs, c_in, t_pad, lengths=None, seed=1234, device="cpu"):
     lengths = torch.as_tensor(lengths).to(device)
     mask = (torch.arange(t_pad, device=device)[None, :] < lengths[:, None])[:, None, :]
     return x * mask.to(x.dtype), mask
+
+
+def synth_video(n_tracklets, c_in, min_len, max_len, seed=7, device="cpu"):
+    """One synthetic video for MaskVRD.forward_test: n tracklets with random durations inside a (max_len + 8)-frame
+    video and every ordered pair whose overlap is >= 2 frames (46 tracklets -> up to 2070 pairs), in the dataloader's
+    eval format (dataloaders/vidvrd.py:706-715): per-pair features as an (L, C_in) matrix viewed (C_in, L)."""
+    g = torch.Generator().manual_seed(seed)
+    video_len = max_len + 8
+    span, boxes = [], []
+    for _ in range(n_tracklets):
+        n = int(torch.randint(min_len, max_len + 1, (1,), generator=g))
+        t0 = int(torch.randint(0, video_len - n + 1, (1,), generator=g))
+        span.append((t0, t0 + n))
+        corner = torch.rand(n, 2, generator=g) * 100.0
+        boxes.append(torch.cat([corner, corner + torch.rand(n, 2, generator=g) * 50.0 + 1.0], dim=1).to(device))
+    sids, oids, feats = [], [], []
+    for s in range(n_tracklets):
+        for o in range(n_tracklets):
+            overlap = min(span[s][1], span[o][1]) - max(span[s][0], span[o][0])
+            if s != o and overlap >= 2:
+                sids.append(s)
+                oids.append(o)
+                feats.append(torch.randn(overlap, c_in, generator=g).to(device).permute(1, 0))
+    return {"sids": torch.tensor(sids, device=device), "oids": torch.tensor(oids, device=device),
+            "so_features_list": feats, "bboxes_list": boxes,
+            "cat_ids": torch.randint(1, 36, (n_tracklets,), generator=g).to(device),
+            "cat_scores": torch.rand(n_tracklets, generator=g).to(device),
+            "traj_durations": torch.tensor(span, device=device), "so_offset": torch.zeros(len(sids), dtype=torch.long, device=device)}
