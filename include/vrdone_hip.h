@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 10
+#define VRD_ABI_VERSION 11
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -205,9 +205,11 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
                   float* out, int64_t ldo, int algo, int out_pair, void* stream);
 
 /* Same attention for pair-row q, k, v (bf16x3 mode; rows of width n_head*head_dim written by the projection
- * GEMMs with c_pair): both contractions as split-bf16 MFMA products, f32 softmax.  head_dim in {64, 128}. */
+ * GEMMs with c_pair): both contractions as split-bf16 MFMA products, f32 softmax.  head_dim in {64, 128}.
+ * q_mask (optional, B*Tq bytes): query rows the caller zeroes afterwards anyway (the output projection's row mask,
+ * local_transformer.py:183); tiles of 32 queries without a valid one are not computed and read 0. */
 int vrd_attention_pair(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
-                       const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim,
+                       const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq, int Tk, int n_head, int head_dim,
                        float* out, int64_t ldo, int out_pair, void* stream);
 
 /* ---- MaxPool1d(3,2,1) skip * mask (models/blocks.py:1040-1046,1074) and mask[::2] ------- */

@@ -71,7 +71,7 @@ _SIGNATURES = {
                                  c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_attention": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
-    "vrd_attention_pair": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
+    "vrd_attention_pair": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_maxpool_mask": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p, C.c_int64, c_u8p,
                                    C.c_void_p]),
@@ -81,7 +81,7 @@ _SIGNATURES = {
                                   c_i32p, c_i32p, C.c_void_p]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class HipLibraryError(RuntimeError):

@@ -53,7 +53,8 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
 template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* __restrict__ q, int64_t ldq,
                                                                 const float* __restrict__ k, const float* __restrict__ v,
-                                                                int64_t ldkv, const uint8_t* __restrict__ kv_mask, int Tq,
+                                                                int64_t ldkv, const uint8_t* __restrict__ kv_mask,
+                                                                const uint8_t* __restrict__ q_mask, int Tq,
                                                                 int Tk, int width, float scale, float* __restrict__ out,
                                                                 int64_t ldo, int pair_out, int q_blocks, int n_head_) {
     using G = AG<HD>;
@@ -82,6 +83,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     const char* vb = reinterpret_cast<const char*>(v + (int64_t)b * Tk * ldkv) + h * HD * 4;
     const char* zero_src = reinterpret_cast<const char*>(g_attn_zero);
 
+    // a wave whose 32 queries are all padding (q_mask) takes part in the staging and the barriers only; its rows are
+    // written as zeros (the caller masks them)
+    const bool q_live = !q_mask || __any(q0 + li < Tq && q_mask[(int64_t)b * Tq + (q0 + li < Tq ? q0 + li : Tq - 1)] != 0);
     // Q^T fragments: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo
     bf16x8 qh[KS], ql[KS];
     {
@@ -161,6 +165,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
         if (kt_next < nkt) issue(kt_next, (it + 1) & 1);
         const char* st = lds + (it & 1) * G::STAGE;
         const float* kbs = kbias + kt * 32;
+        if (!q_live) {
+            kt = kt_next;
+            continue;
+        }
 
         // ---- S^T = K . Q^T (three products per k16 step)
         f32x16 sacc;
@@ -260,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     }
 
     const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
-    const float inv = 1.0f / l_tot;
+    const float inv = q_live ? 1.0f / l_tot : 0.f;
     const int tq = q0 + li;
     if (tq < Tq) {
         float* orow = out + ((int64_t)b * Tq + tq) * ldo;
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
 }
 
 template <int HD, int NW>
-int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, int B, int Tq,
+int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq,
            int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
     auto kern = attn_flash_x3_kernel<HD, NW>;
     constexpr size_t lds_max = 2 * AG<HD>::STAGE + (4096 + 128) * sizeof(float);       // key bias + tile flags for Tk <= 4096
@@ -297,7 +305,7 @@ int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t 
     }
     const int tiles = (Tq + 31) / 32;
     const int q_blocks = (tiles + NW - 1) / NW;
-    hipLaunchKernelGGL(kern, dim3((unsigned)q_blocks * n_head * B), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk,
+    hipLaunchKernelGGL(kern, dim3((unsigned)q_blocks * n_head * B), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, kv_mask, q_mask, Tq, Tk,
                        n_head * HD, scale, out, ldo, pair_out, q_blocks, n_head);
     return 0;
 }
@@ -307,8 +315,8 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 }  // namespace
 
 extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
-                                  const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim, float* out,
-                                  int64_t ldo, int out_pair, void* stream) {
+                                  const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq, int Tk, int n_head, int head_dim,
+                                  float* out, int64_t ldo, int out_pair, void* stream) {
     VRD_CHECK_ARG(q && k && v && out, "vrd_attention_pair: null pointer");
     VRD_CHECK_ARG(head_dim == 64 || head_dim == 128, "vrd_attention_pair: head_dim must be 64 or 128 (got %d)", head_dim);
     VRD_CHECK_ARG(B > 0 && B <= 65535 && Tq > 0 && Tk > 0 && n_head > 0 && n_head <= 65535, "vrd_attention_pair: bad sizes");
@@ -325,10 +333,10 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     static const int nw_env = [] { const char* e = getenv("VRD_FLASH_NW"); return e ? atoi(e) : 0; }();
     const int nw = nw_env == 3 || nw_env == 4 ? nw_env : ((waste3 < waste4) ? 3 : 4);
     int rc;
-    if (head_dim == 128) rc = nw == 3 ? launch<128, 3>(q, ldq, k, v, ldkv, kv_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
-                                      : launch<128, 4>(q, ldq, k, v, ldkv, kv_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
-    else rc = nw == 3 ? launch<64, 3>(q, ldq, k, v, ldkv, kv_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
-                      : launch<64, 4>(q, ldq, k, v, ldkv, kv_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
+    if (head_dim == 128) rc = nw == 3 ? launch<128, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
+                                      : launch<128, 4>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
+    else rc = nw == 3 ? launch<64, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
+                      : launch<64, 4>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
     if (rc) return rc;
     VRD_LAUNCH_CHECK();
     return 0;

@@ -47,7 +47,7 @@ class MaskedMHCA_QKV(_ConvAttention):
         qkv_pair = self._half_win is None and ops.flash_pair_ok(self.n_head, self.n_embd, q.shape[1])
         q, k, v = self._project(q, k, v, out_pair=qkv_pair, q_mask=q_mask, kv_mask=kv_mask)
         if self._half_win is None:
-            att = ops.attention(q, k, v, kv_mask, self.n_head, pair=ops.pair_mode())
+            att = ops.attention(q, k, v, kv_mask, self.n_head, pair=ops.pair_mode(), q_mask=q_mask)
         else:
             assert q.shape[1] == k.shape[1]
             att = ops.local_attention(q, k, v, kv_mask, self.n_head, self._half_win, pair=ops.pair_mode())

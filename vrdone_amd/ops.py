@@ -373,9 +373,11 @@ def local_attention(q, k, v, mask, n_head, half_win, pair=False):
     return Pair(out, Cc) if pair else out
 
 
-def attention(q, k, v, kv_mask, n_head, algo=0, pair=False):
+def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
     """Global masked attention; q: (B, Tq, C), k/v: (B, Tk, C); kv_mask (B, Tk) or None.
-    pair: pair-row output when the flash kernel runs (otherwise a plain tensor is returned)."""
+    pair: pair-row output when the flash kernel runs (otherwise a plain tensor is returned).
+    q_mask (B, Tq): rows the caller masks afterwards; the split-precision kernel leaves out query tiles without a valid
+    row (they read 0)."""
     if isinstance(q, Pair):
         assert isinstance(k, Pair) and isinstance(v, Pair) and q.width == k.width == v.width == q.shape[-1]
         q, k, v = q.t, k.t, v.t
@@ -386,7 +388,7 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False):
         pv, _, _, ldv = _rows(v)
         assert ldk == ldv
         out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
-        _hip.check(lib.vrd_attention_pair(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), B, Tq, Tk, n_head,
+        _hip.check(lib.vrd_attention_pair(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), _mask_ptr(q_mask, B * Tq), B, Tq, Tk, n_head,
                                           Cc // n_head, out.data_ptr(), Cc, 1 if pair else 0, _stream()),
                    "vrd_attention_pair")
         return Pair(out, Cc) if pair else out
