@@ -46,13 +46,14 @@ __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw,
 // straight-line code without per-row predicates or per-element selects: the epilogue is instruction-bound (two
 // waves per SIMD, ~8 cycles per instruction and wave; the general version below runs ~240 instructions per
 // 16-row pass).   ROWIN: any of row_mask / scale / res / res2 may be set;  ACT: VRD_ACT_NONE or VRD_ACT_GELU.
-template <bool ROWIN, int ACT, typename Transposer>
-__device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Transposer&& transpose_into, float* smem, int64_t mw,
-                                                      int64_t mw1, int nw, int wave, int lane, const EpiCols& cols) {
+// SLAB: rows of the wave's private staging slab `stg`: 64 (both 32-row halves transposed up front) or 32 (the second
+// half is transposed after the first one's passes, into the same slab: DS operations of a wave execute in order).
+template <bool ROWIN, int ACT, int SLAB, typename Transposer>
+__device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Transposer&& transpose_into, float* stg, int64_t mw,
+                                                      int64_t mw1, int nw, int lane, const EpiCols& cols) {
     // rows: passes 0-1 are mw .. mw+31, passes 2-3 are mw1 .. mw1+31 (mw1 = mw + 32 unless the tile's 32-row blocks
     // come from a block list); hop = wave-uniform distance the second block is away from its contiguous place
     const int64_t hop = mw1 - (mw + 32);
-    float* stg = smem + wave * (64 * STG_PITCH);
     const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
     const int n = nw + c4;
     // lane base pointers (row mw + rb0, column n); the rows of the passes are wave-uniform offsets from them
@@ -91,16 +92,18 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
     // row inputs run two passes ahead (HBM latency under load is several thousand cycles, a pass ~1.5k); the first
     // two requests go out before the transposition
     RowIn q0 = fetch(0), q1 = fetch(1);
-    transpose_into(stg);            // the wave's 64 x 64 sub-tile, accumulator layout -> slab rows
+    transpose_into(stg, SLAB == 64 ? -1 : 0);            // the wave's 64 x 64 sub-tile (or its upper half), accumulator layout -> slab rows
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
+        if (SLAB == 32 && pass == 2) transpose_into(stg, 1);
         const RowIn cur = q0;
         q0 = q1;
         if (pass + 2 < 4) q1 = fetch(pass + 2);
         float v[4][4];
+        const int srow = (SLAB == 64 ? pass : (pass & 1)) * 16 + rb0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 t = *reinterpret_cast<const float4*>(stg + (pass * 16 + rb0 + 4 * j) * STG_PITCH + c4);
+            const float4 t = *reinterpret_cast<const float4*>(stg + (srow + 4 * j) * STG_PITCH + c4);
             v[j][0] = t.x + cols.bias[0], v[j][1] = t.y + cols.bias[1], v[j][2] = t.z + cols.bias[2], v[j][3] = t.w + cols.bias[3];
         }
         if (ACT == VRD_ACT_GELU) {
@@ -165,41 +168,47 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
 }
 
 // 32 x 32 accumulators (v_mfma_f32_32x32x16): element e of lane (li, lh) is C[(e & 3) + 8 * (e >> 2) + 4 * lh][li]
-template <bool ROWIN, int ACT>
-__device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
-                                                   int64_t mw1, int nw, int wave, int lane, const EpiCols& cols) {
+template <bool ROWIN, int ACT, int SLAB = 64>
+__device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* stg, int64_t mw,
+                                                   int64_t mw1, int nw, int lane, const EpiCols& cols) {
     const int li = lane & 31, lh = lane >> 5;
-    gemm_epilogue_lean_tr<ROWIN, ACT>(
+    gemm_epilogue_lean_tr<ROWIN, ACT, SLAB>(
         p,
-        [&](float* stg) {
+        [&](float* slab, int half) {           // half: -1 = both 32-row halves (64-row slab), else that half into rows 0..31
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt) {
+                if (half >= 0 && mt != half) continue;
+                const int r0 = half < 0 ? mt * 32 : 0;
 #pragma unroll
                 for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        stg[(mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
+                        slab[(r0 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
+            }
         },
-        smem, mw, mw1, nw, wave, lane, cols);
+        stg, mw, mw1, nw, lane, cols);
 }
 
 // 16 x 16 accumulators (v_mfma_f32_16x16x32): element j of lane l is C[4 * (l >> 4) + j][l & 15]
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-template <bool ROWIN, int ACT>
-__device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, const f32x4_t (&acc)[4][4], float* smem, int64_t mw,
-                                                     int64_t mw1, int nw, int wave, int lane, const EpiCols& cols) {
+template <bool ROWIN, int ACT, int SLAB = 64>
+__device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, const f32x4_t (&acc)[4][4], float* stg, int64_t mw,
+                                                     int64_t mw1, int nw, int lane, const EpiCols& cols) {
     const int lc = lane & 15, lq = lane >> 4;
-    gemm_epilogue_lean_tr<ROWIN, ACT>(
+    gemm_epilogue_lean_tr<ROWIN, ACT, SLAB>(
         p,
-        [&](float* stg) {
+        [&](float* slab, int half) {
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti)
+            for (int ti = 0; ti < 4; ++ti) {
+                if (half >= 0 && (ti >> 1) != half) continue;
+                const int r0 = half < 0 ? ti * 16 : (ti & 1) * 16;
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) stg[(ti * 16 + 4 * lq + j) * STG_PITCH + tj * 16 + lc] = acc[ti][tj][j];
+                    for (int j = 0; j < 4; ++j) slab[(r0 + 4 * lq + j) * STG_PITCH + tj * 16 + lc] = acc[ti][tj][j];
+            }
         },
-        smem, mw, mw1, nw, wave, lane, cols);
+        stg, mw, mw1, nw, lane, cols);
 }
 
 // true when vrd_gemm arguments fit the lean epilogue (checked on the host before the 256 x 256 kernel is chosen)

@@ -65,7 +65,7 @@ __device__ unsigned long long g_big_skipped_kn;
 
 __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
 
-template <int TAPS, bool M16>
+template <int TAPS, bool M16, bool PERSIST>
 __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -77,56 +77,66 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     const int K = p.Cin * TAPS;
     const int nkt = K / 32;
     const int nwg = tiles_m * tiles_n;
-    // (persistent workgroups -- one per CU walking its tiles -- were measured: same cycles per tile, no gain)
-    const int vb = blockIdx.x;
-    {
-    LAB_STAMP(0);
-    LAB_REAL(4);
-    const int xcd = vb & 7, q = nwg >> 3, rem = nwg & 7;
-    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (vb >> 3);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int n0 = tn * TN;
-    // ---- the tile's rows: eight 32-row blocks, slots tm*8 .. tm*8+7 of the block list (identity without one).
-    // With a padding map (vrd_row_blocks) the list is cut into segments -- one per XCD's contiguous share of the
-    // tiles when there are eight -- and inside a segment the blocks holding valid frames come first, so a tile is
-    // either a contraction tile or, behind those, a tile of fully padded blocks that only runs the epilogue on a
-    // zero accumulator (the reference's value wherever row_mask zeroes the row).
+    // ---- tiles.  Virtual block id -> tile through the XCD-aware renumbering; the tile's rows are eight 32-row blocks,
+    // slots tm*8 .. tm*8+7 of the block list (identity without one).  With a padding map (vrd_row_blocks) the list is
+    // cut into segments -- one per XCD's contiguous share of the tiles when there are eight -- and inside a segment
+    // the blocks holding valid frames come first, so a tile is either a contraction tile or, behind those, a tile of
+    // fully padded blocks that only runs the epilogue on a zero accumulator (the reference's value wherever row_mask
+    // zeroes the row).
     const int nblk = (int)(p.M >> 5);
     const int32_t* const rb = p.row_blocks;
-    bool contract = true;
-    if (rb) {
-        const int seg_len = p.row_block_seg_len;                          // a multiple of 8 (host-checked)
-        const int seg = (tm * 8) / seg_len;
-        contract = tm * 8 < nblk && tm * 8 - seg * seg_len < p.row_blocks_active[seg];
-    }
     auto blk_of = [&](int slot) { return slot < nblk ? (rb ? rb[slot] : slot) : -1; };
-    const int my_blk = blk_of(tm * 8 + wave);          // the block whose A rows this wave stages
-    if (!contract && tid == 0 && tm * 8 < nblk)
-        atomicAdd(&g_big_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
-
-    // ---- DMA sources: this wave moves row blocks wave*4 .. wave*4+3 (8 rows each) of both operands.  Only piece 0's
-    // per-lane pointers are kept: piece i is a wave-uniform stride further, its source-side swizzle differs from
-    // piece 0's by bit 6 for odd i, and (M, N multiples of 64) a piece lies entirely inside or outside the matrix,
+    struct Tile {
+        int tm, n0;
+        bool contract;
+    };
+    auto tile_of = [&](int vb_) {
+        const int xcd = vb_ & 7, q = nwg >> 3, rem = nwg & 7;
+        const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (vb_ >> 3);
+        Tile t;
+        t.tm = lid / tiles_n;
+        t.n0 = (lid - t.tm * tiles_n) * TN;
+        t.contract = true;
+        if (rb) {
+            const int seg_len = p.row_block_seg_len;                          // a multiple of 8 (host-checked)
+            const int seg = (t.tm * 8) / seg_len;
+            t.contract = t.tm * 8 < nblk && t.tm * 8 - seg * seg_len < p.row_blocks_active[seg];
+        }
+        return t;
+    };
+    // ---- DMA sources of a tile: this wave moves row blocks wave*4 .. wave*4+3 (8 rows each) of both operands.  Only
+    // piece 0's per-lane pointers are kept: piece i is a wave-uniform stride further, its source-side swizzle differs
+    // from piece 0's by bit 6 for odd i, and (M, N multiples of 64) a piece lies entirely inside or outside the matrix,
     // which is a scalar test; pieces outside read the zero block.  (The bit-6 flip is applied to the pointer, which is
     // why the host sends only 128-byte aligned A and W_split here: address bits 4..6 are then the chunk index.)
     const int rin = lane >> 3, pch = lane & 7;
     const int row0 = wave * PER * 8 + rin;                              // row inside the tile, for both operands
     const int chunk0 = (pch ^ swz(row0)) * 16;
     const char* const zero_src = reinterpret_cast<const char*>(g_big_zero);
-    const int64_t a_row = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 + rin;
-    const char* const a0 = reinterpret_cast<const char*>(p.A + a_row * p.lda) + chunk0;
-    const char* const w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(n0 + row0) * K * 4 + chunk0;
-    const int tseq0 = (TAPS == 3) ? (int)(a_row % p.T) : 0;
     const int64_t a_pstride = p.lda * 32, w_pstride = (int64_t)K * 32;  // bytes between pieces (8 rows)
-    const int a_in = my_blk < 0 ? 0 : PER, w_in = (p.N - n0 - wave * PER * 8 + 7) / 8;   // pieces inside (M % 32 == 0)
+    struct Src {
+        const char *a0, *w0;
+        int tseq0, a_in, w_in;
+    };
+    auto src_of = [&](const Tile& t) {
+        const int my_blk = blk_of(t.tm * 8 + wave);          // the block whose A rows this wave stages
+        const int64_t a_row = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 + rin;
+        Src r;
+        r.a0 = reinterpret_cast<const char*>(p.A + a_row * p.lda) + chunk0;
+        r.w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + row0) * K * 4 + chunk0;
+        r.tseq0 = (TAPS == 3) ? (int)(a_row % p.T) : 0;
+        r.a_in = my_blk < 0 ? 0 : PER;                                   // pieces inside (M % 32 == 0)
+        r.w_in = (p.N - t.n0 - wave * PER * 8 + 7) / 8;
+        return r;
+    };
     // piece i of W(kt) / A(kt): one DMA instruction each
-    auto issue_w1 = [&](int kt, int i) {
+    auto issue_w1 = [&](const Src& c, int kt, int i) {
         char* const dst = lds + W_RING + (kt % NW_STG) * W_STAGE + wave * PER * 1024;
-        const char* src = i < w_in ? (w0 + i * w_pstride + (int64_t)kt * 128) : zero_src + chunk0;
+        const char* src = i < c.w_in ? (c.w0 + i * w_pstride + (int64_t)kt * 128) : zero_src + chunk0;
         if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
         __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
     };
-    auto issue_a1 = [&](int kt, int i) {
+    auto issue_a1 = [&](const Src& c, int kt, int i) {
         char* const dst = lds + (kt % NA_STG) * A_STAGE + wave * PER * 1024;
         const int k0 = kt * 32;
         int tap = 0, ci0 = k0;
@@ -135,9 +145,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
             ci0 = k0 - tap * p.Cin;
         }
         const int64_t off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 + (int64_t)ci0 * 4;
-        const char* src = i < a_in ? a0 + i * a_pstride + off : zero_src + chunk0;
+        const char* src = i < c.a_in ? c.a0 + i * a_pstride + off : zero_src + chunk0;
         if (TAPS == 3) {
-            int tt = tseq0 + 8 * i;                   // position of this piece's row in its sequence (T >= 32)
+            int tt = c.tseq0 + 8 * i;                   // position of this piece's row in its sequence (T >= 32)
             if (tt >= p.T) tt -= p.T;
             tt += tap - 1;
             if (tt < 0 || tt >= p.T) src = zero_src + chunk0;
@@ -145,14 +155,34 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
         __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
     };
-    auto issue_w = [&](int kt) {
+    auto issue_w = [&](const Src& c, int kt) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) issue_w1(kt, i);
+        for (int i = 0; i < PER; ++i) issue_w1(c, kt, i);
     };
-    auto issue_a = [&](int kt) {
+    auto issue_a = [&](const Src& c, int kt) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) issue_a1(kt, i);
+        for (int i = 0; i < PER; ++i) issue_a1(c, kt, i);
     };
+
+    // PERSIST (VRD_BIG_PERSIST=1, off by default): one workgroup per CU walks tiles vb, vb + gridDim.x, ...; behind a
+    // tile's main loop, before its epilogue, stage 0 of the NEXT tile's operands is requested, so that tile does not
+    // start with an HBM round trip (the epilogue then stages through 32-row slabs inside activation stages 1-2, which
+    // stage 0 of either ring leaves free).  Measured: correct, but 3 % SLOWER on the whole step (98.8 vs 96.1 ms of
+    // this kernel): with the tile loop around the body everything derived from the arguments stays live across it --
+    // 100 SGPRs spilled to VGPR lanes and 39 VGPRs to scratch, inside the K loop -- and re-reading the arguments per
+    // tile through a laundered kernarg pointer moved them into VGPRs instead (99 spills).  The ~4 k cycles of tile
+    // setup it would hide are 5 % of a tile; not worth a second, argument-light kernel this round.
+    bool staged0 = false;
+    int vb = blockIdx.x;
+    do {
+    LAB_STAMP(0);
+    LAB_REAL(4);
+    const Tile tile = tile_of(vb);
+    const int tm = tile.tm, n0 = tile.n0;
+    const bool contract = tile.contract;
+    const Src cur = src_of(tile);
+    if (!contract && tid == 0 && tm * 8 < nblk)
+        atomicAdd(&g_big_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
 
     // ---- fragment read offsets (bytes inside a stage).  A tile row is 128 bytes: hi chunks 0..3, lo chunks 4..7,
     // chunk index XOR-swizzled with (row >> 1) & 7 = (li >> 1) & 7 for every 32-row block.  Hence all fragment
@@ -211,11 +241,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
         return f;
     };
     if (contract) {
-    issue_a(0);
-    issue_w(0);
+    if (!(PERSIST && staged0)) {
+        issue_a(cur, 0);
+        issue_w(cur, 0);
+    }
     if (nkt > 1) {
-        issue_a(1);
-        issue_w(1);
+        issue_a(cur, 1);
+        issue_w(cur, 1);
     }
     LAB_STAMP(1);
     // stage 0: what was issued after A(0), W(0) may stay in flight (A(2) follows inside step 0, see below)
@@ -228,9 +260,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     // DMA slot d (0..7) of the batch opened by the barrier inside step kt: W(kt+2) pieces 0..3, A(kt+3) pieces 0..3
     auto dma_slot = [&](int kt_open, int d) {
         if (d < PER) {
-            if (kt_open + 2 < nkt) issue_w1(kt_open + 2, d);
+            if (kt_open + 2 < nkt) issue_w1(cur, kt_open + 2, d);
         } else {
-            if (kt_open + 3 < nkt) issue_a1(kt_open + 3, d - PER);
+            if (kt_open + 3 < nkt) issue_a1(cur, kt_open + 3, d - PER);
         }
     };
     for (int kt = 0; kt < nkt; ++kt) {
@@ -271,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
                     // groups 0..6 carry slots 1..7 of the batch opened in step kt-1, group 7 slot 0 of this step's
                     if (g < 7) {
                         if (kt > 0) dma_slot(kt - 1, g + 1);
-                        else if (g < PER && nkt > 2) issue_a1(2, g);          // step 0 has no batch of its own yet
+                        else if (g < PER && nkt > 2) issue_a1(cur, 2, g);          // step 0 has no batch of its own yet
                     } else if (!last) {
                         dma_slot(kt, 0);
                     }
@@ -304,6 +336,23 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     LAB_STAMP(2);
+    if (PERSIST) {
+        // stage 0 of the next tile (activation stage 0, weight stage 0): in flight during this tile's epilogue
+        const int vn = vb + (int)gridDim.x;
+        staged0 = false;
+        if (vn < nwg) {
+            const Tile nt = tile_of(vn);
+            if (nt.contract) {
+                const Src nx = src_of(nt);
+                issue_a(nx, 0);
+                issue_w(nx, 0);
+                staged0 = true;
+            }
+        }
+    }
+    // staging slab of this wave: 64 rows at the front of LDS, or (PERSIST) 32 rows inside activation stages 1-2
+    float* const stg = PERSIST ? smem + (A_STAGE + wave * (32 * vrd::STG_PITCH * 4)) / 4 : smem + wave * (64 * vrd::STG_PITCH);
+    constexpr int SLAB = PERSIST ? 32 : 64;
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {          // the epilogue works on 64 x 64 halves of the wave's 128 x 64
         // (M % 64 == 0 and N % 64 == 0, checked on the host: the sub-tile is inside C or entirely outside)
@@ -319,32 +368,38 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[i][j] = acc16[M16 ? 4 * hm + i : 0][M16 ? j : 0];
-            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU>(p, part, smem, mw, mw1, nw, wave, lane, cols);
-            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
+            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
+            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
         } else {
             f32x16 part[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) part[i][j] = acc[M16 ? 0 : 2 * hm + i][M16 ? 0 : j];
-            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU>(p, part, smem, mw, mw1, nw, wave, lane, cols);
-            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE>(p, part, smem, mw, mw1, nw, wave, lane, cols);
+            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
+            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
         }
     }
     LAB_STAMP(3);
     LAB_REAL(5);
+    if (PERSIST) {
+        // the slabs lie where the next tile's stage-1 / stage-2 DMAs land: everybody is done reading theirs first
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
+    vb += (int)gridDim.x;
+    } while (PERSIST && vb < nwg);       // tiles of this workgroup
 }
 
 }  // namespace
 
 namespace vrd {
 
-template <int TAPS, bool M16>
+template <int TAPS, bool M16, bool PERSIST>
 static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
-    auto kern = gemm_bf16x3_big_kernel<TAPS, M16>;
+    auto kern = gemm_bf16x3_big_kernel<TAPS, M16, PERSIST>;
     static bool reserved = false;
     if (!reserved) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIG_LDS);
@@ -355,7 +410,8 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
         reserved = true;
     }
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n);
+    const int nwg = tiles_m * tiles_n;
+    hipLaunchKernelGGL(kern, dim3(PERSIST ? (nwg < 256 ? nwg : 256) : nwg), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n);
     return 0;
 }
 
@@ -374,8 +430,11 @@ int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s) {
     // dimension in a different order than the 32x32x16 kernels that serve small batches, and the path keeps its
     // results independent of the batch composition to the last bit (tests/test_gpu_model.py), so it stays opt-in.
     static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
-    if (m16) return a.taps == 1 ? launch_big_one<1, true>(a, s) : launch_big_one<3, true>(a, s);
-    return a.taps == 1 ? launch_big_one<1, false>(a, s) : launch_big_one<3, false>(a, s);
+    // VRD_BIG_PERSIST=1: one workgroup per CU walking its tiles, the next tile's first stage requested under the epilogue
+    static const int persist = [] { const char* e = getenv("VRD_BIG_PERSIST"); return e ? atoi(e) : 0; }();
+    if (m16) return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
+    if (persist) return a.taps == 1 ? launch_big_one<1, false, true>(a, s) : launch_big_one<3, false, true>(a, s);
+    return a.taps == 1 ? launch_big_one<1, false, false>(a, s) : launch_big_one<3, false, false>(a, s);
 }
 
 }  // namespace vrd
