@@ -264,6 +264,9 @@ def main():
             "config": {"workload": f"{args.config}.yaml MaskVRD._mask_vrd, {args.pairs} pairs x {args.frames} frames "
                                    f"(T_pad {t_pad}) x C_in {c_in}, embd 512, eval, last-layer heads",
                        "pairs_per_gpu": hi - lo, "pair_chunk": model.pair_chunk, "gemm_precision": main_mode,
+                       "padding": f"{t_pad - args.frames} of {t_pad} rows per pair are padding; GEMM tiles, attention key tiles and "
+                                  "depthwise-conv strips made of padding only are not computed (outputs identical to computing "
+                                  "them, tests/test_gpu_model.py; VRDONE_SKIP_PADDING=0 switches the GEMM part off)",
                        "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of predictions" if world > 1 else "")},
         }
         if fpp:
