@@ -257,3 +257,24 @@ def test_training_batch_loss_values_match_reference(weights):
             assert [list(map(int, r)), list(map(int, c))] == w
     for k, v in want["losses"].items():
         assert abs(losses[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, losses[k], v)
+
+
+def test_criterion_with_a_pair_without_relations():
+    """A pair whose relations were all dropped (empty preds / masks / segs) takes part in the class loss only; the host
+    code and the oracle agree (the reference's dataloader never emits one, its matcher handles it the same way)."""
+    from oracle.synth import synth_relations
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, _, _ = load_case("vidvrd")
+    model = MaskVRD(mc, device="cpu")
+    model.deep_supervision = False
+    g = torch.Generator().manual_seed(0)
+    lens = [96, 50, 20, 7]
+    pred = {"pred_logits": torch.randn(4, 9, 133, generator=g), "pred_masks": torch.randn(4, 9, 96, generator=g) * 3,
+            "output_mask": (torch.arange(96)[None] < torch.tensor(lens)[:, None])[:, None]}
+    gp, gm, gs = synth_relations(lens, 96, 132, seed=1)
+    gp[2], gm[2], gs[2] = gp[2][:0], gm[2][:0], gs[2][:0]
+    got = model.criterion(pred, {"preds_list": gp, "masks_list": gm, "segs_list": gs})
+    want, idx = O.criterion(mc, pred, gp, gm, gs)
+    assert len(idx[2][0]) == 0
+    for k, v in want.items():
+        assert abs(float(got[k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), k
