@@ -85,7 +85,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
 
     // a wave whose 32 queries are all padding (q_mask) takes part in the staging and the barriers only; its rows are
     // written as zeros (the caller masks them)
-    const bool q_live = !q_mask || __any(q0 + li < Tq && q_mask[(int64_t)b * Tq + (q0 + li < Tq ? q0 + li : Tq - 1)] != 0);
+    const bool q_live = __any(q0 + li < Tq && (!q_mask || q_mask[(int64_t)b * Tq + (q0 + li < Tq ? q0 + li : Tq - 1)] != 0));
+    // a workgroup without a single live query (the padded tail of the sequence, or tiles past Tq) does not stream K / V
+    if (!__syncthreads_or(q_live)) {
+        const int tq = q0 + li;
+        if (tq < Tq) {
+            float* orow = out + ((int64_t)b * Tq + tq) * ldo + h * HD;
+            for (int c = lh * 4; c < HD; c += 8) *reinterpret_cast<float4*>(orow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     // Q^T fragments: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo
     bf16x8 qh[KS], ql[KS];
     {
@@ -328,10 +337,12 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     const float scale = 1.0f / sqrtf((float)head_dim);
     vrd::ProfScope prof(VRD_K_ATTN_FLASH, s, 4.0 * B * (double)n_head * Tq * Tk * head_dim,
                         4.0 * B * (double)width * (2.0 * Tq + 2.0 * Tk));
-    const int tiles = (Tq + 31) / 32;
-    const int waste3 = ((tiles + 2) / 3) * 3 - tiles, waste4 = ((tiles + 3) / 4) * 4 - tiles;
+    // waves (32-query tiles) per workgroup: every workgroup streams the whole K / V row of its (b, h), and the kernel is
+    // bound by that stream (LDS-DMA issue), so fewer, fuller workgroups win even when the last one is mostly empty:
+    // 288 queries = 9 tiles run as 4 + 4 + 1 (the lone tile is the padded tail at the benchmark shape and exits at
+    // once) 17 % faster than as 3 + 3 + 3.  Two workgroups of 4 waves fill a CU's registers (247 VGPRs per wave).
     static const int nw_env = [] { const char* e = getenv("VRD_FLASH_NW"); return e ? atoi(e) : 0; }();
-    const int nw = nw_env == 3 || nw_env == 4 ? nw_env : ((waste3 < waste4) ? 3 : 4);
+    const int nw = nw_env == 3 || nw_env == 4 ? nw_env : 4;
     int rc;
     if (head_dim == 128) rc = nw == 3 ? launch<128, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
                                       : launch<128, 4>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
