@@ -340,7 +340,9 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     // waves (32-query tiles) per workgroup: every workgroup streams the whole K / V row of its (b, h), and the kernel is
     // bound by that stream (LDS-DMA issue), so fewer, fuller workgroups win even when the last one is mostly empty:
     // 288 queries = 9 tiles run as 4 + 4 + 1 (the lone tile is the padded tail at the benchmark shape and exits at
-    // once) 17 % faster than as 3 + 3 + 3.  Two workgroups of 4 waves fill a CU's registers (247 VGPRs per wave).
+    // once) 17 % faster than as 3 + 3 + 3.  Two workgroups of 4 waves fill a CU's registers (247 VGPRs per wave); ONE
+    // workgroup of 8 waves (a single stream per (b, h)) was measured 70 % slower: nothing runs while it waits at its
+    // barrier for a tile.
     static const int nw_env = [] { const char* e = getenv("VRD_FLASH_NW"); return e ? atoi(e) : 0; }();
     const int nw = nw_env == 3 || nw_env == 4 ? nw_env : 4;
     int rc;
