@@ -1,15 +1,17 @@
 // Attention kernels of the relation-encoding path.
 //
-//  * local_attn_kernel   banded window attention of the stem / branch blocks.  O(T*w) work and
-//                        HBM-bound: one wavefront per query row covering all heads, window
-//                        scores in registers, head-wise dot products reduced over the 8 or 16
-//                        lanes that own one head.
+//  * local_attn_strip_kernel / local_attn_kernel
+//                        banded window attention of the stem / branch blocks.  O(T*w) work and
+//                        HBM-bound: one wavefront per strip of 16 query rows (K / V window rows in a
+//                        register ring) or per query row, covering all heads; window scores in
+//                        registers, head-wise dot products reduced over the 8 or 16 lanes of a head.
 //  * attn_small_kernel   generic masked attention on the VALU (any Tq/Tk/head_dim <= 128);
 //                        used for the predictor's 9-query decoder.
 //  * attn_flash_kernel   global masked attention (the SOS self/cross attention) on the f32
 //                        MFMA, flash style: never materialises the Tq x Tk scores.
 #include "vrd_common.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -81,6 +83,111 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
     } else {
         st4(o, a0);
         st4(o + 4, a1);
+    }
+}
+
+// Strip variant of the banded attention: one wave walks RW consecutive query rows of one sequence and keeps the K and V
+// rows of the moving window in registers (a ring of W + 1 slots, the row entering the window next already requested),
+// so every K / V row is read W + 1 -> (RW + W - 1) / RW times from the L1 instead of W times.  The ring is indexed with
+// compile-time slots: the row loop runs in rounds of R = W + 1 unrolled phases.
+template <int W, int GROUP, int RW>
+__global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, int64_t ld,
+                                                               const uint8_t* __restrict__ mask, int B, int T, int strips_per_seq,
+                                                               float scale, float* __restrict__ out, int64_t ldo, int pair) {
+    constexpr int HW = W / 2, R = W + 1;
+    const int lane = threadIdx.x & 63;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    const int64_t ws = (int64_t)lid * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = (int)(ws / strips_per_seq);
+    if (b >= B) return;
+    const int t0 = (int)(ws - (int64_t)b * strips_per_seq) * RW;
+    const int t1 = min(t0 + RW, T);
+    const int64_t row_b = (int64_t)b * T;
+    // validity of rows t0 - HW .. t0 + RW + HW - 1 as one bit each (bit i = row t0 - HW + i; outside [0, T) = 0)
+    const int tm = t0 - HW + lane;
+    const unsigned long long live = __ballot(lane < RW + 2 * HW && tm >= 0 && tm < T && mask[row_b + (tm >= 0 && tm < T ? tm : 0)] != 0);
+    if (((live >> HW) & ((1ull << (t1 - t0)) - 1ull)) == 0ull) {      // every query row of the strip is padding
+        for (int t = t0; t < t1; ++t) {
+            float* o = out + (row_b + t) * ldo + lane * 8;
+            st4(o, make_float4(0.f, 0.f, 0.f, 0.f));
+            st4(o + 4, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        return;
+    }
+    struct Row {
+        float4 a, b;
+    };
+    auto load_row = [&](const float* base, int t) {
+        Row r;
+        r.a = r.b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) {
+            const float* p = base + (row_b + t) * ld + lane * 8;
+            r.a = ld4(p), r.b = ld4(p + 4);
+        }
+        return r;
+    };
+    Row kr[R], vr[R];
+#pragma unroll
+    for (int i = 0; i < W; ++i) {          // window of the first query row: rows t0 - HW .. t0 + HW in slots 0 .. W-1
+        kr[i] = load_row(k, t0 - HW + i);
+        vr[i] = load_row(v, t0 - HW + i);
+    }
+    for (int base = 0; base < RW; base += R) {
+#pragma unroll
+        for (int ph = 0; ph < R; ++ph) {
+            const int t = t0 + base + ph;
+            if (t >= t1) break;
+            // the row that enters the window with the next query row goes into the slot the window does not cover
+            kr[(ph + W) % R] = load_row(k, t + HW + 1);
+            vr[(ph + W) % R] = load_row(v, t + HW + 1);
+            float* o = out + (row_b + t) * ldo + lane * 8;
+            const int bit0 = base + ph;                       // bit of window row j is bit0 + j (row t - HW + j)
+            if (!((live >> (bit0 + HW)) & 1ull)) {            // masked query rows are zeroed after the softmax
+                st4(o, make_float4(0.f, 0.f, 0.f, 0.f));
+                st4(o + 4, make_float4(0.f, 0.f, 0.f, 0.f));
+                continue;
+            }
+            float4 q0 = ld4(q + (row_b + t) * ld + lane * 8), q1 = ld4(q + (row_b + t) * ld + lane * 8 + 4);
+            q0.x *= scale; q0.y *= scale; q0.z *= scale; q0.w *= scale;
+            q1.x *= scale; q1.y *= scale; q1.z *= scale; q1.w *= scale;
+            float sc[W];
+            float m = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const int tj = t + j - HW;
+                if (tj < 0 || tj >= T) { sc[j] = -INFINITY; continue; }
+                const Row& kk = kr[(ph + j) % R];
+                float d = dot4(q0, kk.a) + dot4(q1, kk.b);
+#pragma unroll
+                for (int off = GROUP / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+                sc[j] = d + (((live >> (bit0 + j)) & 1ull) ? 0.f : -1e4f);
+                m = fmaxf(m, sc[j]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int j = 0; j < W; ++j) { sc[j] = __expf(sc[j] - m); den += sc[j]; }
+            const float inv = 1.0f / den;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const int tj = t + j - HW;
+                if (tj < 0 || tj >= T) continue;
+                const Row& vv = vr[(ph + j) % R];
+                const float pj = sc[j] * inv;
+                a0.x += pj * vv.a.x; a0.y += pj * vv.a.y; a0.z += pj * vv.a.z; a0.w += pj * vv.a.w;
+                a1.x += pj * vv.b.x; a1.y += pj * vv.b.y; a1.z += pj * vv.b.z; a1.w += pj * vv.b.w;
+            }
+            if (pair) {
+                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8, 512, a0);
+                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8 + 4, 512, a1);
+            } else {
+                st4(o, a0);
+                st4(o + 4, a1);
+            }
+        }
     }
 }
 
@@ -326,6 +433,22 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
     const int W = 2 * half_win + 1;
     vrd::ProfScope prof(VRD_K_LOCAL_ATTN, s, 4.0 * (double)rows * W * C, 16.0 * (double)rows * C);
     const float scale = 1.0f / sqrtf((float)(C / n_head));
+    // strips of 16 query rows per wave (default; 32 measured the same) or, VRD_LOCAL_STRIP=0, one wave per query row
+    // (6.1 vs 5.6 ms per step at the benchmark shape)
+    static const int strip_env = [] { const char* e = getenv("VRD_LOCAL_STRIP"); return e ? atoi(e) : 1; }();
+    if (strip_env) {
+        constexpr int RW = 16;
+        const int strips = (T + RW - 1) / RW;
+        dim3 grid((unsigned)(((int64_t)B * strips + 3) / 4)), block(256);
+#define VRD_LS(Wn, G) hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW>), grid, block, 0, s, q, k, v, ld, mask, B, T, strips, scale, out, ldo, out_pair)
+        if (half_win == 3 && n_head == 4) VRD_LS(7, 16);
+        else if (half_win == 3) VRD_LS(7, 8);
+        else if (n_head == 4) VRD_LS(9, 16);
+        else VRD_LS(9, 8);
+#undef VRD_LS
+        VRD_LAUNCH_CHECK();
+        return 0;
+    }
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define VRD_LA(Wn, G) hipLaunchKernelGGL((local_attn_kernel<Wn, G>), grid, block, 0, s, q, k, v, ld, mask, B, T, scale, out, ldo, out_pair)
     if (half_win == 3 && n_head == 4) VRD_LA(7, 16);
