@@ -216,8 +216,8 @@ SKIP_MIN_ROWS = 65536        # below this the 256 x 256 GEMM kernel (the one tha
 
 def row_blocks(mask):
     """Padding map of a (B, T) validity mask for vrd_gemm: (order, n_active per segment, segment length) -- two device
-    int32 tensors made by vrd_row_blocks -- or None when the rows do not split into aligned 32-row blocks.  Cached on the mask tensor object (the models never
-    write into a mask), so it dies with it."""
+    int32 tensors made by vrd_row_blocks -- or None when the rows do not split into aligned 32-row blocks.  Cached on
+    the mask tensor object (keyed on its address and version counter), so it dies with it."""
     hit = getattr(mask, "_vrd_row_blocks", None)
     key = (mask.data_ptr(), mask._version)
     if hit is not None and hit[0] == key:
