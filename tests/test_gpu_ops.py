@@ -250,6 +250,18 @@ def test_local_attention_kernel(H, w):
     want = O.banded_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H, w)
     got = ops.local_attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, w)
     close(got, want.transpose(1, 2), 2e-5)
+    # strips that end inside the sequence, validity with holes (not a prefix), whole strips of padding, pair output
+    B, T = 5, 50
+    q, k, v = (torch.randn(B, T, C, generator=gen) for _ in range(3))
+    mask = torch.rand(B, T, generator=gen) > 0.3
+    mask[1, 16:32] = False
+    mask[2] = False
+    mask[2, 49] = True
+    want = O.banded_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H, w).transpose(1, 2)
+    got = ops.local_attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, w)
+    close(got, want, 2e-5)
+    got_pair = ops.local_attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, w, pair=True)
+    assert float((got_pair.float() - got).abs().max()) <= 2 ** -15 * float(got.abs().max())
 
 
 @pytest.mark.parametrize("algo", [1, 2])
