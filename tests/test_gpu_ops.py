@@ -515,6 +515,14 @@ def test_flash_attention_pair_rows(H, hd, Tq, Tk, precision):
     close(ops.attention(qp, kp, vp, None, H),
           O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
                            torch.ones(B, 1, Tk, dtype=torch.bool), H).transpose(1, 2), 2e-4)
+    # q_mask: rows of a 32-query tile that holds a valid query are bit-identical to the call without it; tiles (and
+    # whole workgroups) of padding read 0
+    qlens = torch.tensor([Tq, min(Tq, 33), 1])
+    qm = (torch.arange(Tq)[None] < qlens[:, None])
+    masked = ops.attention(qp, kp, vp, mask.to(DEV), H, q_mask=qm.to(DEV))
+    tile_live = torch.nn.functional.pad(qm, (0, (-Tq) % 32)).reshape(B, -1, 32).any(-1).repeat_interleave(32, dim=1)[:, :Tq]
+    assert torch.equal(masked[tile_live.to(DEV)], got[tile_live.to(DEV)])
+    assert bool((masked[~tile_live.to(DEV)] == 0).all())
 
 
 def test_row_blocks_padding_map():
