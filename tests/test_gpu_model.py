@@ -303,3 +303,29 @@ def test_padding_skip_changes_nothing(name, B, T):
     assert torch.equal(got["pred_logits"], want["pred_logits"]) and torch.equal(got["pred_masks"], want["pred_masks"])
     for a, b in zip(got["aux_outputs"], want["aux_outputs"]):
         assert torch.equal(a["pred_logits"], b["pred_logits"]) and torch.equal(a["pred_masks"], b["pred_masks"])
+
+
+@pytest.mark.parametrize("B,T,mode", [(1082, 96, "ragged"), (315, 240, "ragged"), (450, 288, "short"), (429, 288, "tail")])
+def test_padding_skip_on_odd_shapes(B, T, mode):
+    """Row counts that are not whole tiles / segments, T_pad not a multiple of 32, mostly-padding batches: identical
+    bits with the padding maps off, and the first rows identical to a 3-pair batch (small-shape kernels, no maps)."""
+    from vrdone_amd import ops
+    model, mc, _, _ = get_model("vidvrd")
+    g = torch.Generator().manual_seed(B + T)
+    lens = {"ragged": torch.randint(1, T + 1, (B,), generator=g), "short": torch.randint(1, T // 4, (B,), generator=g),
+            "tail": torch.full((B,), T - 32)}[mode]
+    lens[0] = T
+    m = (torch.arange(T)[None] < lens[:, None])[:, None].to(DEV)
+    x = torch.randn(B, c_in(mc), T, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * m
+    old = ops._skip_padding
+    try:
+        ops._skip_padding = True
+        got = model._mask_vrd(x, m, with_aux=False)
+        ops._skip_padding = False
+        want = model._mask_vrd(x, m, with_aux=False)
+    finally:
+        ops._skip_padding = old
+    assert torch.equal(got["pred_logits"], want["pred_logits"]) and torch.equal(got["pred_masks"], want["pred_masks"])
+    small = model._mask_vrd(x[:3].contiguous(), m[:3].contiguous(), with_aux=False)
+    close(small["pred_logits"], got["pred_logits"][:3], 1e-5)
+    close(small["pred_masks"], got["pred_masks"][:3], 1e-4)
