@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 11
+#define VRD_ABI_VERSION 12
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -138,6 +138,11 @@ typedef struct {
     int32_t row_block_seg_len;
 } vrd_gemm_args;
 int vrd_gemm(const vrd_gemm_args* a, void* stream);
+/* `count` (1..4) GEMMs of an array of argument structs.  Problems that differ only in A, W / W_split, bias and C and
+ * that the 256 x 256 split-precision kernel takes -- the q / k / v projections of one attention block
+ * (models/blocks.py:935-947, models/local_transformer.py:157-161) -- run as ONE grid (one ragged last round of tiles
+ * instead of three); anything else is the same as calling vrd_gemm on each. */
+int vrd_gemm_batch(const vrd_gemm_args* a, int count, void* stream);
 
 /* Padding map of a channels-last activation matrix: rows = B*T flat rows with validity mask[rows] (models/maskvrd.py
  * :386-392 builds it as t < len_b), rows % 32 == 0.  The rows/32 block indices are dealt into segments of seg_len

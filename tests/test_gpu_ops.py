@@ -596,3 +596,29 @@ def test_gemm_padding_skip_is_exact(k, precision):
             valid = mask.reshape(-1, 32).any(1).repeat_interleave(32).reshape(B, T)
             assert torch.equal(g[valid], wnt[valid]) and bool(torch.isfinite(g).all())
             assert not torch.equal(g, wnt)                       # the skip really happened
+
+
+def test_gemm_batch_equals_single_calls(precision):
+    """vrd_gemm_batch: three GEMMs that differ only in input / weight / bias / output as one launch of the 256 x 256
+    kernel (with a padding map), and a mixed list that has to fall back to one launch per problem: same bits as
+    calling conv_gemm on each."""
+    if precision != "bf16x3":
+        pytest.skip("the 256 x 256 kernel is a split-precision kernel")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    B, T, Cin, N = 300, 288, 512, 512
+    lens = torch.randint(1, T + 1, (B,), generator=gen)
+    mask = (torch.arange(T)[None, :] < lens[:, None]).to(DEV)
+    xs = [_to_pair(torch.randn(B, T, Cin, generator=gen).to(DEV)) for _ in range(3)]
+    ws = [(torch.randn(N, Cin, 1, generator=gen) / Cin ** 0.5).to(DEV) for _ in range(3)]
+    bs = [torch.randn(N, generator=gen).to(DEV) for _ in range(3)]
+    for kw in (dict(out_pair=True, skip_rows=mask), dict(row_mask=mask), dict(act=ops.ACT_GELU, out_pair=True)):
+        got = ops.conv_gemm_batch([((x, w, b), dict(kw)) for x, w, b in zip(xs, ws, bs)])
+        for g, x, w, b in zip(got, xs, ws, bs):
+            want = ops.conv_gemm(x, w, b, **kw)
+            assert torch.equal(g.t if isinstance(g, ops.Pair) else g, want.t if isinstance(want, ops.Pair) else want)
+    # different epilogues / shapes in one list: one launch each
+    w_small = (torch.randn(256, Cin, 1, generator=gen) / Cin ** 0.5).to(DEV)
+    got = ops.conv_gemm_batch([((xs[0], ws[0], bs[0]), dict(out_pair=True)), ((xs[1], w_small, None), dict(row_mask=mask))])
+    assert torch.equal(got[0].t, ops.conv_gemm(xs[0], ws[0], bs[0], out_pair=True).t)
+    assert torch.equal(got[1], ops.conv_gemm(xs[1], w_small, None, row_mask=mask))

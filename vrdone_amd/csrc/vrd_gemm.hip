@@ -209,7 +209,32 @@ int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s);
 bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged);
 int launch_gemm_bf16x3_dma(const vrd_gemm_args& a, hipStream_t s);
 int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s);
+int launch_gemm_bf16x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s);
 }  // namespace vrd
+
+namespace {
+// which split-precision kernel serves these arguments (shape, layout and alignment rules; see the kernels' files)
+struct X3Choice {
+    bool x3, dma, big;
+};
+X3Choice choose_x3(const vrd_gemm_args* a, bool vec, bool staged) {
+    const int K = a->Cin * a->taps;
+    const bool x3 = a->a_pair_width > 0 || (a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split));
+    static const int dma_env = [] { const char* e = getenv("VRD_X3_DMA"); return e ? atoi(e) : 1; }();
+    // the 128 x 256 DMA kernel runs one workgroup per CU: below ~2 rounds of tiles the 128 x 128 kernel (two
+    // workgroups per CU, four times the tiles) fills the chip better
+    static const int64_t dma_min_tiles = [] { const char* e = getenv("VRD_X3_DMA_MIN_TILES"); return e ? atoll(e) : 512; }();
+    const bool dma = x3 && dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged) &&
+                     ((a->M + 127) / 128) * ((a->N + 255) / 256) >= dma_min_tiles;
+    // the 256 x 256 kernel (DMA-issue cost per MFMA a third lower) once there are about two rounds of its tiles
+    static const int64_t big_min_tiles = [] { const char* e = getenv("VRD_X3_BIG_MIN_TILES"); return e ? atoll(e) : 512; }();
+    const bool big = dma && a->N >= 256 && vrd::gemm_epilogue_lean_ok(*a) &&
+                     (a->taps == 1 || a->T >= 32) &&      // k = 3: the kernel steps its sequence position by 8 rows per piece
+                     (reinterpret_cast<uintptr_t>(a->A) & 127u) == 0 && (reinterpret_cast<uintptr_t>(a->W_split) & 127u) == 0 &&
+                     ((a->M + 255) / 256) * ((a->N + 255) / 256) >= big_min_tiles;
+    return X3Choice{x3, dma, big};
+}
+}  // namespace
 
 extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     VRD_CHECK_ARG(a != nullptr, "vrd_gemm: null args");
@@ -248,19 +273,8 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     const double flops = 2.0 * (double)a->M * a->N * K;
     const double bytes = 4.0 * ((double)a->M * a->Cin + (double)a->N * K + (double)a->M * a->N *
                                 (1.0 + (a->res ? 1.0 : 0.0) + (a->res2 ? 1.0 : 0.0)));
-    const bool x3 = a->a_pair_width > 0 || (a->W_split && vec && (K % 32 == 0) && aligned16(a->W_split));
-    static const int dma_env = [] { const char* e = getenv("VRD_X3_DMA"); return e ? atoi(e) : 1; }();
-    // the 128 x 256 DMA kernel runs one workgroup per CU: below ~2 rounds of tiles the 128 x 128 kernel (two
-    // workgroups per CU, four times the tiles) fills the chip better
-    static const int64_t dma_min_tiles = [] { const char* e = getenv("VRD_X3_DMA_MIN_TILES"); return e ? atoll(e) : 512; }();
-    const bool dma = x3 && dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged) &&
-                     ((a->M + 127) / 128) * ((a->N + 255) / 256) >= dma_min_tiles;
-    // the 256 x 256 kernel (DMA-issue cost per MFMA a third lower) once there are about two rounds of its tiles
-    static const int64_t big_min_tiles = [] { const char* e = getenv("VRD_X3_BIG_MIN_TILES"); return e ? atoll(e) : 512; }();
-    const bool big = dma && a->N >= 256 && vrd::gemm_epilogue_lean_ok(*a) &&
-                     (a->taps == 1 || a->T >= 32) &&      // k = 3: the kernel steps its sequence position by 8 rows per piece
-                     (reinterpret_cast<uintptr_t>(a->A) & 127u) == 0 && (reinterpret_cast<uintptr_t>(a->W_split) & 127u) == 0 &&
-                     ((a->M + 255) / 256) * ((a->N + 255) / 256) >= big_min_tiles;
+    const X3Choice pick = choose_x3(a, vec, staged);
+    const bool x3 = pick.x3, dma = pick.dma, big = pick.big;
     vrd::ProfScope prof(big ? VRD_K_GEMM_X3_BIG : dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
     if (x3) {
         int rc3 = big ? vrd::launch_gemm_bf16x3_big(*a, s)
@@ -274,5 +288,51 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     else          rc = staged ? launch_bk<16, true>(*a, vec, tiles_m, tiles_n, s) : launch_bk<16, false>(*a, vec, tiles_m, tiles_n, s);
     if (rc) return rc;
     VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// Several GEMMs as one launch where possible: problems that differ only in A, W / W_split, bias and C and that the
+// 256 x 256 kernel takes (the q / k / v projections of an attention block) run as one grid; anything else runs one by one.
+extern "C" int vrd_gemm_batch(const vrd_gemm_args* a, int count, void* stream) {
+    VRD_CHECK_ARG(a != nullptr && count >= 1 && count <= 4, "vrd_gemm_batch: 1..4 problems (got %d)", count);
+    bool same = count > 1 && a[0].M > 0;
+    for (int i = 1; i < count && same; ++i) {
+        const vrd_gemm_args &x = a[i], &y = a[0];
+        same = x.lda == y.lda && x.ldc == y.ldc && x.M == y.M && x.N == y.N && x.Cin == y.Cin && x.taps == y.taps && x.T == y.T &&
+               x.act == y.act && x.row_mask == y.row_mask && x.scale == y.scale && x.res == y.res && x.ldres == y.ldres &&
+               x.res_masked == y.res_masked && x.res2 == y.res2 && x.ldres2 == y.ldres2 && x.a_pair_width == y.a_pair_width &&
+               x.c_pair == y.c_pair && x.row_blocks == y.row_blocks && x.row_blocks_active == y.row_blocks_active &&
+               x.row_block_seg_len == y.row_block_seg_len && (x.bias != nullptr) == (y.bias != nullptr) &&
+               (x.W_split != nullptr) == (y.W_split != nullptr);
+    }
+    static const int batch_env = [] { const char* e = getenv("VRD_GEMM_BATCH"); return e ? atoi(e) : 1; }();
+    if (same && batch_env) {
+        bool all_big = true;
+        for (int i = 0; i < count && all_big; ++i) {
+            const vrd_gemm_args* p = &a[i];
+            if (!(p->A && p->W && p->C && p->lda >= p->Cin && p->ldc >= p->N)) { all_big = false; break; }
+            const bool vec = (p->Cin % 4 == 0) && (p->lda % 4 == 0) && aligned16(p->A) && aligned16(p->W);
+            const bool staged = (p->ldc % 4 == 0) && aligned16(p->C) && (!p->res || (p->ldres % 4 == 0 && aligned16(p->res))) &&
+                                (!p->res2 || (p->ldres2 % 4 == 0 && aligned16(p->res2)));
+            all_big = choose_x3(p, vec, staged).big && (!p->c_pair || (p->N % 32 == 0 && p->ldc % 32 == 0)) &&
+                      (!p->row_blocks || (p->row_blocks_active && p->row_block_seg_len >= 8 && p->row_block_seg_len % 8 == 0));
+        }
+        if (all_big) {
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            const int K = a[0].Cin * a[0].taps;
+            const double flops = 2.0 * (double)a[0].M * a[0].N * K * count;
+            const double bytes = 4.0 * count * ((double)a[0].M * a[0].Cin + (double)a[0].N * K + (double)a[0].M * a[0].N *
+                                                (1.0 + (a[0].res ? 1.0 : 0.0) + (a[0].res2 ? 1.0 : 0.0)));
+            vrd::ProfScope prof(VRD_K_GEMM_X3_BIG, s, flops, bytes);
+            int rc = vrd::launch_gemm_bf16x3_big_batch(a, count, s);
+            if (rc) return rc;
+            VRD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    for (int i = 0; i < count; ++i) {
+        int rc = vrd_gemm(&a[i], stream);
+        if (rc) return rc;
+    }
     return 0;
 }

@@ -65,8 +65,25 @@ __device__ unsigned long long g_big_skipped_kn;
 
 __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
 
+// operands of problems 1 .. 3 of a batched launch (blockIdx.y; problem 0 is the argument struct itself): GEMMs that
+// differ only in A, the weights, the bias and C -- the q / k / v projections of one attention block -- run as one
+// grid, so a block's three projections have one ragged last round of tiles instead of three
+struct BigBatch {
+    const float* A[3];
+    const uint16_t* W_split[3];
+    const float* bias[3];
+    float* C[3];
+};
+
 template <int TAPS, bool M16, bool PERSIST>
-__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, BigBatch bb) {
+    if (blockIdx.y) {                                    // uniform selects, no indexed access to the arguments
+        const int z = blockIdx.y;
+        p.A = z == 1 ? bb.A[0] : z == 2 ? bb.A[1] : bb.A[2];
+        p.W_split = z == 1 ? bb.W_split[0] : z == 2 ? bb.W_split[1] : bb.W_split[2];
+        p.bias = z == 1 ? bb.bias[0] : z == 2 ? bb.bias[1] : bb.bias[2];
+        p.C = z == 1 ? bb.C[0] : z == 2 ? bb.C[1] : bb.C[2];
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
@@ -398,7 +415,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
 namespace vrd {
 
 template <int TAPS, bool M16, bool PERSIST>
-static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
+static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch& bb = BigBatch{}, int count = 1) {
     auto kern = gemm_bf16x3_big_kernel<TAPS, M16, PERSIST>;
     static bool reserved = false;
     if (!reserved) {
@@ -411,8 +428,20 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s) {
     }
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
     const int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL(kern, dim3(PERSIST ? (nwg < 256 ? nwg : 256) : nwg), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(PERSIST ? (nwg < 256 ? nwg : 256) : nwg, count), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n, bb);
     return 0;
+}
+
+// `count` (2 .. 4) problems that differ only in A, W_split, bias and C, as one launch of the default kernel
+int launch_gemm_bf16x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
+    BigBatch bb{};
+    for (int i = 1; i < count; ++i) {
+        bb.A[i - 1] = a[i].A;
+        bb.W_split[i - 1] = a[i].W_split;
+        bb.bias[i - 1] = a[i].bias;
+        bb.C[i - 1] = a[i].C;
+    }
+    return a[0].taps == 1 ? launch_big_one<1, false, false>(a[0], s, bb, count) : launch_big_one<3, false, false>(a[0], s, bb, count);
 }
 
 // FLOPs of contractions skipped through padding maps since the last call (reads and clears the device counter)

@@ -206,9 +206,10 @@ class _ConvAttention(nn.Module):
         """1x1 projections.  q_mask / kv_mask: validity of the rows; fully padded row blocks are not contracted (their
         keys / values are masked inside the attention kernels, their query rows by the output projection's row mask)."""
         ops = _ops()
-        return (ops.conv_gemm(q, self.query.weight, self.query.bias, out_pair=out_pair, skip_rows=q_mask),
-                ops.conv_gemm(k, self.key.weight, self.key.bias, out_pair=out_pair, skip_rows=kv_mask),
-                ops.conv_gemm(v, self.value.weight, self.value.bias, out_pair=out_pair, skip_rows=kv_mask))
+        return tuple(ops.conv_gemm_batch([
+            ((q, self.query.weight, self.query.bias), dict(out_pair=out_pair, skip_rows=q_mask)),
+            ((k, self.key.weight, self.key.bias), dict(out_pair=out_pair, skip_rows=kv_mask)),
+            ((v, self.value.weight, self.value.bias), dict(out_pair=out_pair, skip_rows=kv_mask))]))
 
 
 class LocalMaskedMHCA(_ConvAttention):

@@ -238,7 +238,7 @@ def row_blocks(mask):
 
 
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
-              res2=None, out=None, out_pair=False, skip_rows=None):
+              res2=None, out=None, out_pair=False, skip_rows=None, _launch=None):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
     vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
     out_pair: write the result as pair rows of width N (returns a Pair).
@@ -283,8 +283,24 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
         pr, rr, rc, ldr = _rows(res2)
         assert rr == rows and rc == N
         a.res2, a.ldres2 = pr, ldr
-    _hip.check(lib.vrd_gemm(C.byref(a), _stream()), "vrd_gemm")
+    if _launch is not None:            # conv_gemm_batch collects the argument structs instead of launching
+        _launch.append(a)
+    else:
+        _hip.check(lib.vrd_gemm(C.byref(a), _stream()), "vrd_gemm")
     return Pair(out, N) if out_pair else out
+
+
+def conv_gemm_batch(calls):
+    """Several conv_gemm calls -- [(args, kwargs), ...], at most 4 -- handed to the library together (vrd_gemm_batch):
+    GEMMs that differ only in input, weight, bias and output, like the q / k / v projections of an attention block, run
+    as one launch.  Returns the list of results."""
+    assert 1 <= len(calls) <= 4
+    collected, results = [], []
+    for args, kwargs in calls:
+        results.append(conv_gemm(*args, _launch=collected, **kwargs))
+    arr = (_hip.GemmArgs * len(collected))(*collected)
+    _hip.check(lib.vrd_gemm_batch(arr, len(collected), _stream()), "vrd_gemm_batch")
+    return results
 
 
 def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False):
