@@ -86,19 +86,44 @@ def usable_cores():
     return max(1, n)
 
 
-def hbm_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_hbm_traffic.json, made by
-    scripts/collect_profiles.sh + scripts/summarize_traffic.py: counters cannot be read inside this process)."""
+def kernel_source_sha():
+    """Content hash of everything the kernels are built from (csrc/*.hip, csrc/*.h, the C-ABI header) plus the host code
+    that decides which kernels run on which shapes.  scripts/summarize_traffic.py stamps it into the PMC summary; a
+    summary whose stamp differs from the tree that is running describes other kernels and is not reported."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_hbm_traffic.json")))
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(REPO, "vrdone_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(REPO, "vrdone_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(REPO, "vrdone_amd", "*.py")) +
+                   glob.glob(os.path.join(REPO, "vrdone_amd", "models", "*.py")) +
+                   [os.path.join(REPO, "include", "vrdone_hip.h")])
+    for f in files:
+        h.update(os.path.relpath(f, REPO).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def hbm_traffic(kernel, mode):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary for this precision mode
+    (profiles/*_hbm_traffic[_f32].json, made by scripts/collect_profiles.sh + scripts/summarize_traffic.py: counters
+    cannot be read inside this process).  (None, reason) when there is none or when it was collected on other
+    kernel sources than the ones running (its kernel_src_sha stamp differs)."""
+    import glob
+    suffix = "_hbm_traffic.json" if mode == "bf16x3" else f"_hbm_traffic_{mode}.json"
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*" + suffix)))
     if not files:
-        return None, None
+        return None, "no PMC summary committed for this mode"
     with open(files[-1]) as f:
         d = json.load(f)
+    name = os.path.basename(files[-1])
+    if d.get("kernel_src_sha") != kernel_source_sha():
+        return None, f"{name} is stale: collected on kernel sources {d.get('kernel_src_sha')}, running {kernel_source_sha()}"
     k = d.get("kernels", {}).get(kernel)
     if not k:
-        return None, None
-    return k["hbm_bytes_per_launch"], f"{os.path.basename(files[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)"
+        return None, f"{name} has no entry for {kernel}"
+    return k["hbm_bytes_per_launch"], f"{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload, git {d.get('git_sha', '?')})"
 
 
 def cpu_baseline(model_cfg, sd_cpu, c_in, frames, t_pad, n_pairs):
@@ -216,7 +241,7 @@ def main():
         else:
             peak, extra, kern = PEAK_F32_MFMA_TFLOPS, {}, "gemm_f32_mfma_kernel"
         tot = sum(v["ms"] for v in prof.values())
-        traffic, src = hbm_traffic(kern)
+        traffic, src = hbm_traffic(kern, mode)
         if src:
             extra = dict(extra, traffic_source=src)
         return dict({"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -259,7 +284,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16x3 split products, f32 accumulate (f32-equivalent)" if main_mode == "bf16x3" else "f32",
+            "dtype": "bf16x3 split (~17-bit products), f32 accumulate" if main_mode == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}.yaml MaskVRD._mask_vrd, {args.pairs} pairs x {args.frames} frames "
                                    f"(T_pad {t_pad}) x C_in {c_in}, embd 512, eval, last-layer heads",
@@ -267,7 +292,9 @@ def main():
                        "padding": f"{t_pad - args.frames} of {t_pad} rows per pair are padding; GEMM tiles, attention key tiles and "
                                   "depthwise-conv strips made of padding only are not computed (outputs identical to computing "
                                   "them, tests/test_gpu_model.py; VRDONE_SKIP_PADDING=0 switches the GEMM part off)",
-                       "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of predictions" if world > 1 else "")},
+                       "parallelism": f"pair-sharded x{world}" + (" + all-gather of predictions" if world > 1 else ""),
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": dist.get_backend() if world > 1 else None},
         }
         if fpp:
             line["algorithmic_tflops"] = fpp * args.pairs * args.steps / elapsed / 1e12

@@ -1,21 +1,42 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun) from the repo root:  bash scripts/collect_profiles.sh r01
-# Produces, under gpurun_out/profiles_<tag>/ (copy the summaries you want judged into profiles/):
-#   bench.json                 the bench line (events on, CPU baseline on)
-#   kernel_stats.csv           rocprofv3 --kernel-trace --stats of the same command
-#   pmc_fetch.csv / pmc_write.csv   FETCH_SIZE and WRITE_SIZE per dispatch, separate passes (TCC slots)
+# Run on the GPU box (through gpurun) from the repo root:  bash scripts/collect_profiles.sh r02 [bf16x3|f32|both] [sq]
+# Produces, under gpurun_out/profiles_<tag>/ (copy the summaries you want judged into profiles/ with
+# scripts/summarize_traffic.py / scripts/summarize_sq.py):
+#   bench.json                       the bench line (events on, CPU baseline on), default mode, alt mode included
+#   kernel_stats[_f32].csv           rocprofv3 --kernel-trace --stats of the same command in one precision mode
+#   pmc_FETCH_SIZE[_f32].csv / pmc_WRITE_SIZE[_f32].csv   per dispatch, separate passes (TCC slots)
+#   pmc_SQ.csv                       (with `sq`) one SQ pass: MFMA busy / wave cycles / waits / MFMA ops, every dispatch
+#   kernel_src_sha.txt               hash of the kernel sources these were collected on (bench.kernel_source_sha)
+# rocprofv3 is always followed directly by `python3 bench.py ...` (no wrapper after `--`), counters in their own passes.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
+MODES=${2:-both}
+SQ=${3:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 python3 $R/bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-ragged --no-forward-test > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err || exit 1
-cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --no-ragged --no-forward-test --no-prof > /dev/null 2> $OUT/pmc_$c.err || exit 1
-  cp $OUT/pmc_$c/*/*counter_collection.csv $OUT/pmc_$c.csv
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha())" > $OUT/kernel_src_sha.txt || exit 1
+echo "[collect] bench line" && timeout -k 10 500 python3 $R/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+LEAN="--no-cpu-baseline --no-alt --no-ragged --no-forward-test"
+for MODE in bf16x3 f32; do
+  if [ "$MODES" != both ] && [ "$MODES" != $MODE ]; then continue; fi
+  SUF=""; [ $MODE = f32 ] && SUF="_f32"
+  echo "[collect] $MODE kernel trace"
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace$SUF -- python3 $R/bench.py --steps 3 --warmup 1 --precision $MODE $LEAN > $OUT/bench_under_rocprof$SUF.json 2> $OUT/rocprof$SUF.err || exit 1
+  cp $OUT/trace$SUF/*/*kernel_stats.csv $OUT/kernel_stats$SUF.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "[collect] $MODE $c"
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c$SUF -- python3 $R/bench.py --steps 1 --warmup 1 --precision $MODE $LEAN --no-prof > /dev/null 2> $OUT/pmc_$c$SUF.err || exit 1
+    cp $OUT/pmc_$c$SUF/*/*counter_collection.csv $OUT/pmc_$c$SUF.csv
+  done
+  rm -rf $OUT/trace$SUF $OUT/pmc_FETCH_SIZE$SUF $OUT/pmc_WRITE_SIZE$SUF
 done
-rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+if [ "$SQ" = sq ]; then
+  echo "[collect] SQ pass"
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py --steps 1 --warmup 1 --precision bf16x3 $LEAN --no-prof > /dev/null 2> $OUT/pmc_SQ.err || exit 1
+  cp $OUT/pmc_SQ/*/*counter_collection.csv $OUT/pmc_SQ.csv
+  rm -rf $OUT/pmc_SQ
+fi
 ls -la $OUT

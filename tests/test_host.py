@@ -134,3 +134,64 @@ def test_synthetic_weights_match_the_oracle_recipe():
     x1, m1 = synth.synth_pairs(3, 7, 12, [12, 5, 1], seed=9)
     x2, m2 = O.synth_pairs(3, 7, 12, [12, 5, 1], seed=9)
     assert torch.equal(x1, x2) and torch.equal(m1, m2)
+
+
+def test_dropin_launcher_takes_precedence_over_the_checkouts_models(tmp_path):
+    """a mock reference tree whose own models/ package must NOT be the one imported when its
+    eval.py runs through dropin/run.py (plain `python eval.py` with PYTHONPATH would import the checkout's package:
+    the script directory precedes PYTHONPATH)."""
+    import subprocess
+    import sys
+    ref = tmp_path / "vrdone"
+    (ref / "models").mkdir(parents=True)
+    (ref / "utils").mkdir()
+    (ref / "models" / "__init__.py").write_text("")
+    (ref / "models" / "maskvrd.py").write_text("class MaskVRD:\n    pass\n")
+    (ref / "models" / "blocks.py").write_text("class MaskedConv1D: pass\nclass Scale: pass\nclass AffineDropPath: pass\nclass LayerNorm: pass\n")
+    (ref / "utils" / "__init__.py").write_text("")
+    (ref / "utils" / "train_utils.py").write_text("from models.blocks import MaskedConv1D, Scale, AffineDropPath, LayerNorm\nKIND = LayerNorm.__module__\n")
+    (ref / "eval.py").write_text(
+        "import sys\nfrom models.maskvrd import MaskVRD\nfrom utils import train_utils\n"
+        "print('MODEL', MaskVRD.__module__)\nprint('BLOCKS', train_utils.KIND)\nprint('ARGS', sys.argv[1:])\n")
+    run = os.path.join(REPO, "dropin", "run.py")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    out = subprocess.run([sys.executable, run, "eval.py", "--cfg_path", "x.yaml"], cwd=ref, env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert "MODEL vrdone_amd.models.maskvrd" in out.stdout
+    assert "BLOCKS vrdone_amd.models.blocks" in out.stdout
+    assert "ARGS ['--cfg_path', 'x.yaml']" in out.stdout
+    # the failure mode the launcher exists for
+    env["PYTHONPATH"] = os.path.join(REPO, "dropin") + os.pathsep + REPO
+    plain = subprocess.run([sys.executable, "eval.py"], cwd=ref, env=env, capture_output=True, text=True, timeout=300)
+    assert "MODEL models.maskvrd" in plain.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/utils"), reason="needs the reference checkout (build container only)")
+def test_reference_optimizer_and_ema_accept_the_dropin():
+    """utils/train_utils.py of the REFERENCE (build_optimizer's weight-decay grouping, ModelEma's state_dict zip) run
+    against the drop-in model, in a child process with dropin/ ahead of the checkout (nothing of the reference is
+    imported into this test process)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os\n"
+        f"sys.path[:0] = [{os.path.join(REPO, 'dropin')!r}, {REPO!r}, '/root/reference']\n"
+        "import yaml, torch\n"
+        "from models.maskvrd import MaskVRD\n"
+        "assert MaskVRD.__module__.startswith('vrdone_amd.')\n"
+        "from utils.train_utils import build_optimizer, ModelEma\n"
+        "cfg = yaml.safe_load(open('/root/reference/configs/vidvrd.yaml'))\n"
+        "model = MaskVRD(cfg['model_config'], device='cpu')\n"
+        "opt = build_optimizer(model, cfg['training_config'])\n"
+        "n = [len(g['params']) for g in opt.param_groups]\n"
+        "ema = ModelEma(model)\n"
+        "with torch.no_grad():\n"
+        "    for p in model.parameters(): p.add_(1.0)\n"
+        "ema.update(model)\n"
+        "k = 'backbone.stem.0.ln1.bias'\n"
+        "d = float((ema.module.state_dict()[k] - model.state_dict()[k]).abs().max())\n"
+        "print('GROUPS', n, 'EMA_LAG', round(d, 4))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "GROUPS [176, 345]" in out.stdout and "EMA_LAG 0.999" in out.stdout, out.stdout

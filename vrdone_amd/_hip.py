@@ -12,10 +12,11 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvrdone_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
- K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_COUNT) = range(13)
+ K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_GEMM_X3_BIG, K_COUNT) = range(14)      # enum vrd_kernel_id
 KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
                 "maxpool_mask", "mask_head", "transpose", "postprocess", "gemm_bf16x3_mfma", "gemm_bf16x3_dma",
                 "gemm_bf16x3_big"]
+assert len(KERNEL_NAMES) == K_COUNT
 
 c_f32p = C.c_void_p      # device pointers travel as plain integers
 c_u8p = C.c_void_p

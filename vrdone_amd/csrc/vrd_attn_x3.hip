@@ -304,14 +304,7 @@ int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t 
         vrd::set_error("vrd_attention_pair: Tk = %d exceeds the 4096 keys the key-bias row is sized for", Tk);
         return -1;
     }
-    static bool reserved = false;
-    if (!reserved) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max) != hipSuccess) {
-            vrd::set_error("vrd_attention_pair: cannot reserve %zu B of LDS", lds_max);
-            return -2;
-        }
-        reserved = true;
-    }
+    if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds_max, "vrd_attention_pair")) return rc;
     const int tiles = (Tq + 31) / 32;
     const int q_blocks = (tiles + NW - 1) / NW;
     hipLaunchKernelGGL(kern, dim3((unsigned)q_blocks * n_head * B), dim3(NW * 64), lds, s, q, ldq, k, v, ldkv, kv_mask, q_mask, Tq, Tk,

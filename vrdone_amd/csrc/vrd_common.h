@@ -10,6 +10,10 @@ namespace vrd {
 
 void set_error(const char* fmt, ...);
 
+// Opt `kernel` in to `bytes` of dynamic LDS on the CURRENT device (the attribute belongs to the function on a device).
+// Remembered per (function, device) under the library mutex; 0 on success, -2 (error string set) otherwise.
+int reserve_lds(const void* kernel, size_t bytes, const char* what);
+
 // RAII profiling scope: when profiling is on, records a HIP event pair on `stream`
 // around the launch(es) issued inside the scope.
 struct ProfScope {

@@ -179,17 +179,8 @@ template <bool VEC, int TAPS, int BK, bool STAGED>
 int launch_variant(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t s) {
     auto kern = gemm_f32_mfma_kernel<VEC, TAPS, BK, STAGED>;
     constexpr size_t lds = lds_bytes(BK);
-    if (lds > 48 * 1024) {      // opt in to a large dynamic LDS carve once per variant
-        static bool done = false;
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) {
-                vrd::set_error("vrd_gemm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-                return -2;
-            }
-            done = true;
-        }
-    }
+    if (lds > 48 * 1024)        // opt in to a large dynamic LDS carve (per variant and device)
+        if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm")) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);
     return 0;
 }
@@ -236,8 +227,9 @@ X3Choice choose_x3(const vrd_gemm_args* a, bool vec, bool staged) {
 }
 }  // namespace
 
-extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
-    VRD_CHECK_ARG(a != nullptr, "vrd_gemm: null args");
+// Host-side validation shared by vrd_gemm and vrd_gemm_batch: nothing is launched for a problem that fails it.
+namespace {
+int validate_gemm_args(const vrd_gemm_args* a) {
     VRD_CHECK_ARG(a->A && a->W && a->C, "vrd_gemm: null operand");
     VRD_CHECK_ARG(a->M >= 0 && a->N > 0 && a->Cin > 0, "vrd_gemm: bad sizes M=%lld N=%d Cin=%d",
                   (long long)a->M, a->N, a->Cin);
@@ -257,6 +249,13 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
                                      a->row_block_seg_len % 8 == 0),
                   "vrd_gemm: a row-block list needs its active counts, M %% 32 == 0 and a segment length that is a multiple of 8 (M = %lld, seg_len %d)",
                   (long long)a->M, a->row_block_seg_len);
+    return 0;
+}
+}  // namespace
+
+extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
+    VRD_CHECK_ARG(a != nullptr, "vrd_gemm: null args");
+    if (int rc = validate_gemm_args(a)) return rc;
     if (a->M == 0) return 0;
     const int64_t tiles_m64 = (a->M + BM - 1) / BM;
     const int tiles_n = (a->N + BN - 1) / BN;
@@ -295,6 +294,8 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
 // 256 x 256 kernel takes (the q / k / v projections of an attention block) run as one grid; anything else runs one by one.
 extern "C" int vrd_gemm_batch(const vrd_gemm_args* a, int count, void* stream) {
     VRD_CHECK_ARG(a != nullptr && count >= 1 && count <= 4, "vrd_gemm_batch: 1..4 problems (got %d)", count);
+    for (int i = 0; i < count; ++i)
+        if (int rc = validate_gemm_args(&a[i])) return rc;
     bool same = count > 1 && a[0].M > 0;
     for (int i = 1; i < count && same; ++i) {
         const vrd_gemm_args &x = a[i], &y = a[0];

@@ -219,15 +219,7 @@ namespace vrd {
 template <int TAPS, bool STAGED, bool APAIR>
 static int launch_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t s) {
     auto kern = gemm_bf16x3_kernel<TAPS, STAGED, APAIR>;
-    static bool reserved = false;
-    if (!reserved) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS);
-        if (e != hipSuccess) {
-            set_error("vrd_gemm(bf16x3): cannot reserve %zu B of LDS: %s", X3_LDS, hipGetErrorString(e));
-            return -2;
-        }
-        reserved = true;
-    }
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), X3_LDS, "vrd_gemm(bf16x3)")) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), X3_LDS, s, a, tiles_m, tiles_n);
     return 0;
 }

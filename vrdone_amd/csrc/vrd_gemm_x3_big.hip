@@ -417,15 +417,7 @@ namespace vrd {
 template <int TAPS, bool M16, bool PERSIST>
 static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch& bb = BigBatch{}, int count = 1) {
     auto kern = gemm_bf16x3_big_kernel<TAPS, M16, PERSIST>;
-    static bool reserved = false;
-    if (!reserved) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BIG_LDS);
-        if (e != hipSuccess) {
-            set_error("vrd_gemm(bf16x3 256x256): cannot reserve %zu B of LDS: %s", BIG_LDS, hipGetErrorString(e));
-            return -2;
-        }
-        reserved = true;
-    }
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), BIG_LDS, "vrd_gemm(bf16x3 256x256)")) return rc;
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
     const int nwg = tiles_m * tiles_n;
     hipLaunchKernelGGL(kern, dim3(PERSIST ? (nwg < 256 ? nwg : 256) : nwg, count), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n, bb);

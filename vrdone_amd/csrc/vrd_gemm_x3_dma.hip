@@ -636,15 +636,7 @@ static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
     auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK, DBM, NSTG, PP, BLK>;
     constexpr size_t lds = Geo<DBK, DBM, NSTG, BLK>::LDS;
     static_assert(lds >= 8 * 16384 && lds <= 160 * 1024, "ring must hold the epilogue slabs and fit the CU");
-    static bool reserved = false;
-    if (!reserved) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("vrd_gemm(bf16x3 dma): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-            return -2;
-        }
-        reserved = true;
-    }
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3 dma)")) return rc;
     const int tiles_m = (int)((a.M + DBM - 1) / DBM), tiles_n = (a.N + DBN - 1) / DBN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
     return 0;
@@ -654,15 +646,7 @@ template <int TAPS, bool BLK, int NPROD, int NCONS = 8>
 static int launch_ws_one(const vrd_gemm_args& a, hipStream_t s) {
     auto kern = gemm_bf16x3_ws_kernel<TAPS, BLK, NPROD, NCONS>;
     constexpr size_t lds = Geo<32, 128, 3, BLK>::LDS;
-    static bool reserved = false;
-    if (!reserved) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_error("vrd_gemm(bf16x3 ws): cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-            return -2;
-        }
-        reserved = true;
-    }
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3 dma)")) return rc;
     const int tiles_m = (int)((a.M + 127) / 128), tiles_n = (a.N + DBN - 1) / DBN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * (NCONS + NPROD)), lds, s, a, tiles_m, tiles_n);
     return 0;

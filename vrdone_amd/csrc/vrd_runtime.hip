@@ -2,6 +2,7 @@
 #include "vrd_common.h"
 #include <mutex>
 #include <vector>
+#include <utility>
 #include <cstring>
 
 namespace vrd {
@@ -28,6 +29,22 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int reserve_lds(const void* kernel, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    static std::vector<std::pair<const void*, int>> done;
+    for (const auto& d : done)
+        if (d.first == kernel && d.second == dev) return 0;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        set_error("%s: cannot reserve %zu B of LDS on device %d: %s", what, bytes, dev, hipGetErrorString(e));
+        return -2;
+    }
+    done.emplace_back(kernel, dev);
+    return 0;
 }
 
 static hipEvent_t get_event() {

@@ -44,6 +44,21 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _param_ptr(t, like, what="parameter"):
+    """Device pointer of a parameter tensor handed to a kernel as a flat f32 array (None stays None): it must be a
+    contiguous float32 tensor on the activations' device -- a model left on the CPU, or after .half() / .double(),
+    raises here instead of faulting on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.device != like.device:
+        raise RuntimeError(f"{what} lives on {t.device}, the activations on {like.device}: move the model with .to(device)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+    return t.data_ptr()
+
+
 class Pair:
     """A channels-last tensor stored in the GEMM-operand "pair" format of the bf16x3 mode: the 4*C bytes of a
     C-channel row (C % 32 == 0) hold, per block of 32 channels, [32 x bf16 hi | 32 x bf16 lo] (hi = bf16(x),
@@ -114,7 +129,7 @@ def packed_conv_weight(w):
 #   "bf16x3" (default): every f32 product a*w is formed as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16
 #            MFMA with f32 accumulation (x = x_hi + x_lo split in bf16): ~17 significand bits per product.
 #            Measured end to end: logits within 7e-5 of the reference (stated tolerance 1e-3).
-#   "f32":   exact f32 MFMA products (bit-level fmaf chains); logits within 7e-6; ~1.55x slower end to end.
+#   "f32":   exact f32 MFMA products (bit-level fmaf chains); logits within 9e-6; ~2.8x slower end to end (bench.py).
 # Select with set_precision() or the VRDONE_PRECISION environment variable.  Everything outside the
 # conv GEMMs (LayerNorm, depthwise convs, softmax, attention) is f32 in both modes.
 _PRECISIONS = ("f32", "bf16x3")
@@ -256,12 +271,12 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     assert rows_c == rows and cols_c == N
     w = packed_conv_weight(weight)
     a = _hip.GemmArgs()
-    a.A, a.lda, a.W, a.bias = pa, lda, w.data_ptr(), _ptr(bias)
+    a.A, a.lda, a.W, a.bias = pa, lda, _param_ptr(w, x, "conv weight"), _param_ptr(bias, x, "conv bias")
     a.C, a.ldc = pc, ldc
     a.M, a.N, a.Cin, a.taps, a.T = rows, N, Cin, k, T
     a.act = act
     a.row_mask = _mask_ptr(row_mask, rows)
-    a.scale = _ptr(scale)
+    a.scale = _param_ptr(scale, x, "drop-path scale")
     if a_width:
         assert _precision == "bf16x3" and Cin % 32 == 0, "pair input needs bf16x3 precision and Cin % 32 == 0"
     if _precision == "bf16x3" and (Cin * k) % 32 == 0:
@@ -315,7 +330,9 @@ def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False
     if post_add is not None:
         pa, period, ca, lda = _rows(post_add)
         assert ca == cols
-    _hip.check(lib.vrd_layernorm(px, ldx, py, ldy, rows, cols, gamma.data_ptr(), beta.data_ptr(), 1 if relu else 0,
+    assert gamma.numel() == cols and beta.numel() == cols
+    _hip.check(lib.vrd_layernorm(px, ldx, py, ldy, rows, cols, _param_ptr(gamma, x, "LayerNorm weight"),
+                                 _param_ptr(beta, x, "LayerNorm bias"), 1 if relu else 0,
                                  pa, lda, period, 1 if pair else 0, _stream()), "vrd_layernorm")
     return Pair(out, cols) if pair else out
 
@@ -355,7 +372,7 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
     a.B, a.Tin, a.C, a.ksize, a.stride, a.group_in = B, Tin, Cout, k, stride, g
     if pre_ln is not None:
         assert g == 1 and x_up is None
-        a.pre_gamma, a.pre_beta = pre_ln[0].data_ptr(), pre_ln[1].data_ptr()
+        a.pre_gamma, a.pre_beta = _param_ptr(pre_ln[0], x, "LayerNorm weight"), _param_ptr(pre_ln[1], x, "LayerNorm bias")
     a.mask_out = _mask_ptr(mask_out, B * Tout)
     a.n_out = len(sets)
     outs = []
@@ -366,9 +383,10 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
             o = torch.empty(B, Tout, Cout, device=x.device, dtype=torch.float32)
         po, ro, co, ldo = _rows(o)
         assert ro == B * Tout and co == Cout
-        a.w[i], a.bias[i] = s["weight"].data_ptr(), _ptr(s.get("bias"))
+        a.w[i], a.bias[i] = _param_ptr(s["weight"], x, "depthwise weight"), _param_ptr(s.get("bias"), x, "depthwise bias")
+        a.gamma[i], a.beta[i] = (_param_ptr(s.get("gamma"), x, "LayerNorm weight"),
+                                 _param_ptr(s.get("beta"), x, "LayerNorm bias"))
         a.packed[i] = _dwconv_block(s["weight"], s.get("bias"), s.get("gamma"), s.get("beta")).data_ptr()
-        a.gamma[i], a.beta[i] = _ptr(s.get("gamma")), _ptr(s.get("beta"))
         a.relu[i] = 1 if s.get("relu") else 0
         a.y[i], a.ldy[i] = po, ldo
         a.out_pair[i] = 1 if s.get("pair") else 0
