@@ -5,10 +5,15 @@ cat_ids, cat_scores, traj_durations, so_offset)."""
 import torch
 
 
-def synth_proposal(n_tracklets, c_in, min_len, max_len, seed=4321, feat_stride=1, video_len=None):
+def synth_proposal(n_tracklets, c_in, min_len, max_len, seed=4321, feat_stride=1, video_len=None, random_offset=False,
+                   sort_by_length=False):
     """All ordered pairs of n tracklets whose durations overlap by >= 2 feature steps.
     Feature tensors are handed over the way the reference dataloader does: an (L, C)
-    row-major tensor viewed as (C, L) (dataloaders/vidvrd.py:693)."""
+    row-major tensor viewed as (C, L) (dataloaders/vidvrd.py:693).
+    random_offset: each pair starts its temporal sub-sampling at a random frame offset in [0, feat_stride), as the
+    dataloader does with `random_stride` (dataloaders/vidor.py:660, :678-692: feat[offset::feat_stride]) -- so_offset != 0.
+    sort_by_length: tracklets in ascending length, so the pairs of early subjects are short and the slices of the
+    reference's max_so_pair loop (models/maskvrd.py:208) pad their long pairs to different lengths."""
     g = torch.Generator().manual_seed(seed)
     video_len = video_len or (max_len * feat_stride + 16)
     durs, boxes = [], []
@@ -20,18 +25,22 @@ def synth_proposal(n_tracklets, c_in, min_len, max_len, seed=4321, feat_stride=1
         xy = torch.rand(L, 2, generator=g) * 100.0
         wh = torch.rand(L, 2, generator=g) * 50.0 + 1.0
         boxes.append(torch.cat([xy, xy + wh], dim=1))
+    if sort_by_length:
+        order = sorted(range(n_tracklets), key=lambda i: durs[i][1] - durs[i][0])
+        durs, boxes = [durs[i] for i in order], [boxes[i] for i in order]
     sids, oids, feats, offs = [], [], [], []
     for s in range(n_tracklets):
         for o in range(n_tracklets):
             if s == o:
                 continue
             a, b = max(durs[s][0], durs[o][0]), min(durs[s][1], durs[o][1])
-            n_steps = (b - a + feat_stride - 1) // feat_stride if b > a else 0
+            off = int(torch.randint(0, feat_stride, (1,), generator=g)) if random_offset else 0
+            n_steps = (b - a - off + feat_stride - 1) // feat_stride if b - off > a else 0
             if n_steps < 2:
                 continue
             sids.append(s)
             oids.append(o)
-            offs.append(0)
+            offs.append(off)
             feats.append(torch.randn(n_steps, c_in, generator=g).permute(1, 0))
     return {
         "sids": torch.tensor(sids), "oids": torch.tensor(oids),

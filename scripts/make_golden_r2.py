@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Round-2 additions to tests/golden/ from the REAL reference (build container only, like scripts/make_golden.py,
+whose helpers this reuses; nothing already committed is regenerated):
+
+  forward_test_vidvrd_slices.json   forward_test on > 2 * max_so_pair pairs (3 slices of the reference's slice loop
+                                    models/maskvrd.py:208-227, each padding its long pairs to its OWN longest)
+  forward_test_vidor_x.json         forward_test under vidor_x.yaml (Q = 10, topk 6, feat_stride 4) with so_offset != 0
+  mask_vrd_vidvrd_b256.npz          _mask_vrd on 256 pairs x T_pad 288 (the batch size that selects the 256 x 256 GEMM
+                                    kernel and the padding maps); logits / masks of every 16th pair
+
+    python scripts/make_golden_r2.py [--only-vidor-x]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_golden import OUT, build, c_in, load_cfg          # noqa: E402  (puts the reference on sys.path)
+from oracle import vrd_oracle as O                          # noqa: E402
+from oracle.synth import synth_proposal                     # noqa: E402
+
+torch.set_grad_enabled(False)
+
+# shared with the tests (tests/golden_cases.py imports nothing from here: the numbers are repeated there)
+SLICES = dict(n_tracklets=23, min_len=30, max_len=250, seed=2718, sort_by_length=True)
+VIDOR_X = dict(n_tracklets=5, min_len=150, max_len=800, seed=1618, feat_stride=4, random_offset=True)
+B256 = dict(B=256, T=288, seed=31415, every=16)
+
+
+def digest(res, data):
+    res["so_trajs_digest"] = [[len(t[0]), float(np.sum(np.asarray(t, dtype=np.float64)))] for t in res.pop("so_trajs")]
+    res["n_pairs"] = len(data["sids"])
+    res["pair_lengths"] = [int(f.shape[1]) for f in data["so_features_list"]]
+    res["so_offset"] = data["so_offset"].tolist()
+    return res
+
+
+def b256_lengths():
+    g = torch.Generator().manual_seed(B256["seed"])
+    lens = torch.randint(2, B256["T"] + 1, (B256["B"],), generator=g)
+    lens[::16] = torch.tensor([288, 287, 256, 255, 200, 129, 97, 96, 64, 33, 32, 31, 17, 3, 2, 288])
+    return lens.tolist()
+
+
+def main():
+    if "--only-vidor-x" not in sys.argv:
+        vidvrd_cases()
+    vidor_x_case()
+
+
+def vidvrd_cases():
+    cfg, mc = load_cfg("vidvrd.yaml")
+    model, _, _ = build(mc)
+    model._config_eval(cfg["inference_config"])
+
+    t0 = time.time()
+    data = synth_proposal(c_in=c_in(mc), **SLICES)
+    lens = [int(f.shape[1]) for f in data["so_features_list"]]
+    P, S = len(lens), mc["max_so_pair"]
+    d = model.max_div_factor
+    t_long = [(max(lens[s:s + S] + [mc["max_seq_len"]]) + d - 1) // d * d for s in range(0, P, S)]
+    print("slices case: pairs", P, "slice T_long", t_long, "long pairs", sum(n > mc["max_seq_len"] for n in lens))
+    assert P > 2 * S and len(set(t_long)) >= 2, "need >= 3 slices with different padded lengths"
+    res = digest(model(data), data)
+    res["slice_t_long"] = t_long
+    with open(os.path.join(OUT, "forward_test_vidvrd_slices.json"), "w") as f:
+        json.dump(res, f)
+    print("  triplets", len(res["triplets"]), f"{time.time() - t0:.0f} s")
+
+    t0 = time.time()
+    x, m = O.synth_pairs(B256["B"], c_in(mc), B256["T"], b256_lengths(), seed=B256["seed"])
+    out = model._mask_vrd(x, m)
+    e = B256["every"]
+    np.savez_compressed(os.path.join(OUT, "mask_vrd_vidvrd_b256.npz"),
+                        lengths=np.asarray(b256_lengths()), pred_logits=out["pred_logits"][::e].numpy(),
+                        pred_masks=out["pred_masks"][::e].numpy())
+    print("b256 case:", tuple(out["pred_logits"].shape), f"{time.time() - t0:.0f} s")
+
+
+def vidor_x_case():
+    t0 = time.time()
+    cfg, mc = load_cfg("vidor_x.yaml")
+    model, _, _ = build(mc)
+    model._config_eval(cfg["inference_config"])
+    data = synth_proposal(c_in=c_in(mc), **VIDOR_X)
+    print("vidor_x case: pairs", len(data["sids"]), "lengths", sorted(int(f.shape[1]) for f in data["so_features_list"]),
+          "offsets", sorted(set(data["so_offset"].tolist())))
+    assert len(set(data["so_offset"].tolist())) >= 3
+    res = digest(model(data), data)
+    with open(os.path.join(OUT, "forward_test_vidor_x.json"), "w") as f:
+        json.dump(res, f)
+    print("  triplets", len(res["triplets"]), f"{time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

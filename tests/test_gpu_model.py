@@ -148,6 +148,60 @@ def test_forward_test_matches_reference_golden(precision):
     assert len(dig & wdig) >= len(wdig) - 4
 
 
+def _on_device(data):
+    return {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in data.items()}
+
+
+def test_forward_test_many_slices_matches_reference_golden(precision):
+    """494 pairs = three slices of the reference's max_so_pair loop (models/maskvrd.py:208-227) whose long pairs are
+    padded to 192 / 240 / 240 frames: the length-bucketed batching of MaskVRD.forward_test against the REFERENCE."""
+    from golden_cases import SLICES, compare_forward_test
+    model, mc, ic, _ = get_model("vidvrd")
+    with open(os.path.join(GOLDEN, "forward_test_vidvrd_slices.json")) as f:
+        ref = json.load(f)
+    data = synth_proposal(c_in=c_in(mc), **SLICES)
+    assert len(data["sids"]) == ref["n_pairs"] > 2 * mc["max_so_pair"]
+    res = model(_on_device(data))
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-5, slack=4)
+
+
+def test_forward_test_vidor_x_matches_reference_golden(precision):
+    """vidor_x.yaml end to end (CLIP slabs, Q = 10, topk 6, feat_stride 4, so_offset in 0..3; 14 pairs at T 512 and 6
+    at T_long 640) against the REFERENCE's forward_test."""
+    from golden_cases import VIDOR_X, compare_forward_test
+    model, mc, ic, _ = get_model("vidor_x")
+    with open(os.path.join(GOLDEN, "forward_test_vidor_x.json")) as f:
+        ref = json.load(f)
+    data = synth_proposal(c_in=c_in(mc), **VIDOR_X)
+    assert data["so_offset"].tolist() == ref["so_offset"]
+    res = model(_on_device(data))
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-5, slack=4)
+
+
+def test_mask_vrd_b256_matches_reference_golden(precision):
+    """256 pairs x T_pad 288 with ragged lengths: the batch size at which the model selects the 256 x 256 LDS-DMA GEMM
+    kernel, the padding maps and vrd_gemm_batch (ops.SKIP_MIN_ROWS rows), compared with the REFERENCE's outputs for
+    every 16th pair."""
+    from golden_cases import B256, b256_lengths
+    from vrdone_amd import _hip, ops
+    model, mc, _, _ = get_model("vidvrd")
+    g = np.load(os.path.join(GOLDEN, "mask_vrd_vidvrd_b256.npz"))
+    lens = b256_lengths()
+    x, m = O.synth_pairs(B256["B"], c_in(mc), B256["T"], lens, seed=B256["seed"])
+    assert 2 * B256["B"] * B256["T"] >= ops.SKIP_MIN_ROWS
+    _hip.prof_enable(True)
+    _hip.prof_reset()
+    out = model._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
+    torch.cuda.synchronize()
+    prof = _hip.prof_read()
+    _hip.prof_enable(False)
+    e = B256["every"]
+    close(out["pred_logits"][::e], g["pred_logits"], LOGIT_TOL)
+    close(out["pred_masks"][::e], g["pred_masks"], MASK_TOL)
+    if precision == "bf16x3":       # the kernel this case exists for did run, and skipped padded tiles
+        assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
+
+
 def test_forward_test_matches_oracle_small():
     model, mc, ic, sd = get_model("vidvrd")
     data = synth_proposal(4, c_in(mc), 10, 110, seed=99)

@@ -136,6 +136,49 @@ def test_forward_test_matches_reference(weights):
     np.testing.assert_allclose(dig, ref["so_trajs_digest"], rtol=1e-9)
 
 
+def test_forward_test_many_slices_matches_reference(weights):
+    """> 2 * max_so_pair pairs: three slices of the reference's slice loop (models/maskvrd.py:208-227), whose long pairs
+    are padded to 192 / 240 / 240 frames; pins the per-slice padding rule the HIP path's bucketing must reproduce."""
+    from golden_cases import SLICES, compare_forward_test
+    mc, ic, sd = weights("vidvrd")
+    with open(os.path.join(GOLDEN, "forward_test_vidvrd_slices.json")) as f:
+        ref = json.load(f)
+    data = synth_proposal(c_in=c_in(mc), **SLICES)
+    assert [int(f.shape[1]) for f in data["so_features_list"]] == ref["pair_lengths"]
+    assert len(data["sids"]) > 2 * mc["max_so_pair"] and len(set(ref["slice_t_long"])) >= 2
+    res = O.forward_test(sd, mc, ic, data)
+    np.testing.assert_allclose(res["triple_scores"], ref["triple_scores"], atol=1e-5, rtol=0)
+    compare_forward_test(res, ref, ic["n_max_pair"], 1e-5, slack=0)
+
+
+def test_forward_test_vidor_x_with_offsets_matches_reference(weights):
+    """vidor_x.yaml (Q = 10, topk 6, feat_stride 4, pred_min_frames 5) with so_offset in {0..3}
+    (models/maskvrd.py:283-299: start = first * feat_stride + offset)."""
+    from golden_cases import VIDOR_X, compare_forward_test
+    mc, ic, sd = weights("vidor_x")
+    with open(os.path.join(GOLDEN, "forward_test_vidor_x.json")) as f:
+        ref = json.load(f)
+    data = synth_proposal(c_in=c_in(mc), **VIDOR_X)
+    assert [int(f.shape[1]) for f in data["so_features_list"]] == ref["pair_lengths"]
+    assert data["so_offset"].tolist() == ref["so_offset"] and len(set(ref["so_offset"])) >= 3
+    res = O.forward_test(sd, mc, ic, data)
+    compare_forward_test(res, ref, ic["n_max_pair"], 1e-5, slack=0)
+
+
+def test_mask_vrd_b256_matches_reference(weights):
+    """The reference ran the 256-pair batch; pairs are independent, so the oracle recomputes only the 16 stored ones."""
+    from golden_cases import B256, b256_lengths
+    mc, _, sd = weights("vidvrd")
+    g = np.load(os.path.join(GOLDEN, "mask_vrd_vidvrd_b256.npz"))
+    lens = b256_lengths()
+    assert g["lengths"].tolist() == lens
+    x, m = O.synth_pairs(B256["B"], c_in(mc), B256["T"], lens, seed=B256["seed"])
+    e = B256["every"]
+    out = O.mask_vrd(sd, mc, x[::e].contiguous(), m[::e].contiguous(), with_aux=False)
+    np.testing.assert_allclose(out["pred_logits"].numpy(), g["pred_logits"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["pred_masks"].numpy(), g["pred_masks"], atol=2e-4, rtol=0)
+
+
 def test_preprocess_eval_shapes():
     mc, _, _ = load_case("vidvrd")
     assert O.max_div_factor(mc) == 48
