@@ -202,6 +202,42 @@ def test_mask_vrd_b256_matches_reference_golden(precision):
         assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_forward_test_equals_single_process(world, monkeypatch):
+    """MaskVRD.shard_pairs(): every rank runs its round-robin share of the length-sorted pairs and the ranks exchange
+    compact candidates.  Here the ranks run one after another in this process (the collective is replaced by computing
+    the other ranks' shares; the collective itself is covered by tests/test_parallel_cpu.py on gloo and by
+    scripts/sharded_eval_check.py with real processes): every rank's result must equal the unsharded one exactly."""
+    from golden_cases import SLICES
+    from vrdone_amd import parallel
+    model, mc, ic, _ = get_model("vidvrd")
+    data = _on_device(synth_proposal(c_in=c_in(mc), **SLICES))
+    want = model(data)
+    feats = data["so_features_list"]
+    lens = [int(f.shape[1]) for f in feats]
+    order, t_pad = model.eval_plan(lens)
+    P = len(lens)
+    per = (P + world - 1) // world
+    try:
+        model.shard_pairs()
+        for rank in range(world):
+            def fake_all_gather(t, w, group=None):
+                parts = []
+                for r in range(w):
+                    c = t if r == rank else model.pair_candidates(feats, lens, order[r::w], t_pad, model.topk)
+                    if c.shape[0] < per:
+                        c = torch.cat([c, c.new_zeros(per - c.shape[0], *c.shape[1:])], dim=0)
+                    parts.append(c)
+                return torch.stack(parts)
+            monkeypatch.setattr(parallel, "rank_world", lambda group=None: (rank, world))
+            monkeypatch.setattr(parallel, "_all_gather", fake_all_gather)
+            got = model(data)
+            for key in ("triplets", "pred_durations", "so_tids", "triple_scores", "triple_scores_avg", "so_trajs"):
+                assert got[key] == want[key], (rank, key)
+    finally:
+        model.shard_pairs(enable=False)
+
+
 def test_forward_test_matches_oracle_small():
     model, mc, ic, sd = get_model("vidvrd")
     data = synth_proposal(4, c_in(mc), 10, 110, seed=99)

@@ -287,59 +287,101 @@ class MaskVRD(nn.Module):
         n = torch.tensor([feats_list[i].shape[1] for i in ids], device=dev)
         return x, (torch.arange(T, device=dev)[None, :] < n[:, None])[:, None, :]
 
+    def shard_pairs(self, group=None, enable=True):
+        """Pair-sharded evaluation: with torch.distributed initialised, every rank of `group` calls
+        forward_test with the SAME video, runs the network on its share of the pairs, and the ranks exchange compact
+        per-pair candidates (vrdone_amd.parallel.gather_candidates) in front of the global top-n_max_pair selection;
+        every rank returns the same result.  Off by default (each process evaluates its own videos, like eval.py)."""
+        self._shard = (group,) if enable else None
+        return self
+
+    def eval_plan(self, lens):
+        """Batching plan of one video's pairs.  The reference walks the pairs in slices of max_so_pair and pads the long
+        pairs of a slice to that slice's longest (maskvrd.py:208-227, :373-379).  A pair's result depends only on its
+        own padded length, so each pair gets the padded length its slice gives it, and pairs are ordered by (padded
+        length, valid length, index): every padded length then is ONE batch (short pairs of all slices share
+        max_seq_len), and dealing that order round-robin gives every rank of a sharded run the same mix of lengths.
+        Returns (order: list of pair ids, t_pad: padded length per pair id)."""
+        P, d = len(lens), self.max_div_factor
+        t_pad = [0] * P
+        for s0 in range(0, P, self.max_so_pair):
+            sl = range(s0, min(s0 + self.max_so_pair, P))
+            t_long = (max([lens[i] for i in sl] + [self.max_seq_len]) + d - 1) // d * d
+            for i in sl:
+                t_pad[i] = self.max_seq_len if lens[i] <= self.max_seq_len else t_long
+        return sorted(range(P), key=lambda i: (t_pad[i], lens[i], i)), t_pad
+
+    def pair_candidates(self, feats, lens, ids, t_pad, k):
+        """Network + per-(pair, query) post-processing kernel for the pairs `ids` (already grouped by padded length).
+        Returns ONE float32 tensor (len(ids), Q, 2k + 2) = [top-k scores | top-k class ids | first | last frame], the
+        three integer fields bit-cast: the compact candidate record that sharded runs exchange (SURVEY 8e option i)."""
+        ops = _ops()
+        dev = self.device
+        Q = self.predictor.num_queries
+        cand = torch.empty(len(ids), Q, 2 * k + 2, device=dev, dtype=torch.float32)
+        if not ids:
+            return cand
+        ints = cand.view(torch.int32)
+        # every host->device table goes up before the first kernel is queued (such a copy waits for the queue)
+        lens_dev = torch.tensor([lens[i] for i in ids], dtype=torch.int32, device=dev)
+        local = [feats[i] for i in ids]
+        tables = ops.pair_table(local)          # None unless the features are the dataloader's frame-major matrices
+        bb = self.backbone
+        at = 0
+        while at < len(ids):
+            T = t_pad[ids[at]]
+            n = 1
+            while at + n < len(ids) and t_pad[ids[at + n]] == T:
+                n += 1
+            if tables is not None:
+                # the dataloader's (L, C_in) matrices go straight into the backbone's operand buffers
+                outs = []
+                step = self._chunk_size(n)
+                for c0 in range(at, at + n, step):
+                    c1 = min(c0 + step, at + n)
+                    *parts, m2 = ops.pack_pairs(tables[0][c0:c1], tables[1][c0:c1], T, bb.n_visual, bb.n_clip,
+                                                bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+                    outs.append(self._heads(*bb.cl_parts(*parts, m2), False))
+                out = self._merge(outs)
+            else:
+                x, m = self._batch(local, range(at, at + n), T)
+                out = self._mask_vrd(x, m, with_aux=False)
+            ts, tc, sf, sl_ = ops.postprocess(out["pred_logits"].contiguous(), out["pred_masks"].contiguous(),
+                                              lens_dev[at:at + n], k)
+            cand[at:at + n, :, :k] = ts
+            ints[at:at + n, :, k:2 * k] = tc
+            ints[at:at + n, :, 2 * k] = sf
+            ints[at:at + n, :, 2 * k + 1] = sl_
+            at += n
+        return cand
+
     @torch.no_grad()
     def forward_test(self, input_data):
         """Same inputs / outputs as reference maskvrd.py:201-337.  Per (pair, query) the softmax,
         class top-k and mask -> [start, end] run in one HIP kernel; the candidate filter and the
         global top-n_max_pair selection are batched tensor ops; only the <= n_max_pair winners
-        are brought to the host."""
-        ops = _ops()
+        are brought to the host.  After shard_pairs() the pairs are split over the ranks of the process group."""
+        from .. import parallel
         dev = self.device
         feats = input_data['so_features_list']
         P = len(input_data['sids'])
         Q, k = self.predictor.num_queries, self.topk
-        top_score = torch.empty(P, Q, k, device=dev)
-        top_cat = torch.empty(P, Q, k, device=dev, dtype=torch.int32)
-        first = torch.empty(P, Q, device=dev, dtype=torch.int32)
-        last = torch.empty(P, Q, device=dev, dtype=torch.int32)
-        # The reference walks the pairs in slices of max_so_pair and pads the long pairs of a slice to that
-        # slice's longest (maskvrd.py:208-227, :373-379).  A pair's result depends only on its own padded
-        # length, so pairs are bucketed by the padded length their slice gives them and every bucket runs as
-        # ONE batch (short pairs of all slices share max_seq_len).
         lens = [int(f.shape[1]) for f in feats]
-        d = self.max_div_factor
-        buckets = {}
-        for s0 in range(0, P, self.max_so_pair):
-            sl = range(s0, min(s0 + self.max_so_pair, P))
-            t_long = (max([lens[i] for i in sl] + [self.max_seq_len]) + d - 1) // d * d
-            for i in sl:
-                buckets.setdefault(self.max_seq_len if lens[i] <= self.max_seq_len else t_long, []).append(i)
-        buckets = sorted(buckets.items())
-        # every host->device table goes up before the first kernel is queued (such a copy waits for the queue)
-        order = torch.tensor([i for _, ids in buckets for i in ids], device=dev)
-        lens_dev = torch.tensor(lens, dtype=torch.int32, device=dev)
-        tables = ops.pair_table(feats)          # None unless the features are the dataloader's frame-major matrices
-        bb = self.backbone
-        at = 0
-        for T, ids in buckets:
-            rows = order[at:at + len(ids)]
-            at += len(ids)
-            if tables is not None:
-                # the dataloader's (L, C_in) matrices go straight into the backbone's operand buffers
-                outs = []
-                step = self._chunk_size(len(ids))
-                for c0 in range(0, len(ids), step):
-                    sel = rows[c0:c0 + step]
-                    *parts, m2 = ops.pack_pairs(tables[0][sel], tables[1][sel], T, bb.n_visual, bb.n_clip,
-                                                bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
-                    outs.append(self._heads(*bb.cl_parts(*parts, m2), False))
-                out = self._merge(outs)
-            else:
-                x, m = self._batch(feats, ids, T)
-                out = self._mask_vrd(x, m, with_aux=False)
-            ts, tc, sf, sl_ = ops.postprocess(out["pred_logits"].contiguous(), out["pred_masks"].contiguous(),
-                                              lens_dev[rows], k)
-            top_score[rows], top_cat[rows], first[rows], last[rows] = ts, tc, sf, sl_
+        order, t_pad = self.eval_plan(lens)
+        shard = getattr(self, "_shard", None)
+        rank, world = parallel.rank_world(shard[0]) if shard else (0, 1)
+        mine = order[rank::world]                      # round-robin over the length-sorted order
+        unsort = torch.empty(P, dtype=torch.int64)
+        unsort[torch.tensor(order, dtype=torch.int64)] = torch.arange(P)
+        unsort = unsort.to(dev)                         # uploaded before the first kernel is queued
+        cand = self.pair_candidates(feats, lens, mine, t_pad, k)
+        if world > 1:
+            cand = parallel.gather_candidates(cand, P, shard[0])       # (P, Q, 2k + 2) in `order`
+        cand = cand[unsort]                             # back to the dataloader's pair order
+        ints = cand.view(torch.int32)
+        top_score = cand[:, :, :k].contiguous()
+        top_cat = ints[:, :, k:2 * k].contiguous()
+        first, last = ints[:, :, 2 * k].contiguous(), ints[:, :, 2 * k + 1].contiguous()
 
         to = lambda t: torch.as_tensor(t).to(dev)     # noqa: E731
         sids, oids = to(input_data['sids']).long(), to(input_data['oids']).long()
@@ -361,7 +403,7 @@ class MaskVRD(nn.Module):
         tri = torch.stack([cat_scores[sids[pair_of]], p_score, cat_scores[oids[pair_of]]], dim=1)
         avg = tri.mean(dim=-1)
         cand = torch.nonzero(keep).flatten()             # reference candidate order: pair, query, class rank
-        order = cand[torch.argsort(avg[cand], descending=True)[:self.n_max_pair]]
+        order = cand[torch.argsort(avg[cand], descending=True, stable=True)[:self.n_max_pair]]
 
         pp, qq = pair_of[order], query_of[order]
         sel_s, sel_o = sids[pp], oids[pp]
