@@ -273,6 +273,32 @@ def main():
         ragged = {"lengths": f"U[2, {args.frames}] (seed 1235), mean {float(lens.float().mean()):.1f}, T_pad {t_pad}",
                   "value": args.pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps}
 
+    ft = None
+    if not args.no_forward_test and args.config == "vidvrd":
+        # secondary metric: the whole eval call MaskVRD.forward_test -- batching of the dataloader's
+        # per-pair matrices, the path, device post-processing, result lists -- on one synthetic video of 46 tracklets;
+        # with N > 1 the product's pair-sharded form (MaskVRD.shard_pairs: compact-candidate all-gather), every rank
+        # holding the same video
+        batch.clear()
+        torch.cuda.empty_cache()
+        ops.set_precision(main_mode)
+        model._config_eval(configs.inference_config(args.config))
+        if world > 1:
+            model.shard_pairs()
+        video = synth.synth_video(46, c_in, 200, args.frames, seed=7, device=dev)
+        times = []
+        with torch.no_grad():
+            for _ in range(4):
+                fence()
+                t0 = time.perf_counter()
+                res = model(video)
+                fence()
+                times.append(time.perf_counter() - t0)
+        wall = sorted(times[1:])[1]
+        ft = {"pairs": len(video["sids"]), "triplets": len(res["triplets"]), "ms": 1e3 * wall,
+              "value": len(video["sids"]) / wall, "unit": "pairs/s", "sharded_over_ranks": world,
+              "note": "wall time of one eval call incl. the Python result lists; median of 3 after a warm-up"}
+
     if rank == 0:
         fpp = FLOPS_PER_PAIR.get((args.config, t_pad))
         line = {
@@ -316,26 +342,8 @@ def main():
                 line["alt_precision"]["roofline"] = roofline(alt_mode, a_prof)
         if ragged is not None:
             line["ragged_variant"] = ragged
-        if world == 1 and not args.no_forward_test and args.config == "vidvrd":
-            # secondary metric: the whole eval call MaskVRD.forward_test -- batching of the dataloader's
-            # per-pair matrices, the path, device post-processing, result lists -- on one synthetic video of 46 tracklets
-            batch.clear()
-            torch.cuda.empty_cache()
-            ops.set_precision(main_mode)
-            model._config_eval(configs.inference_config(args.config))
-            video = synth.synth_video(46, c_in, 200, args.frames, seed=7, device=dev)
-            times = []
-            with torch.no_grad():
-                for _ in range(4):
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    res = model(video)
-                    torch.cuda.synchronize()
-                    times.append(time.perf_counter() - t0)
-            wall = sorted(times[1:])[1]
-            line["forward_test"] = {"pairs": len(video["sids"]), "triplets": len(res["triplets"]), "ms": 1e3 * wall,
-                                    "value": len(video["sids"]) / wall, "unit": "pairs/s",
-                                    "note": "wall time of one eval call incl. the Python result lists; median of 3 after a warm-up"}
+        if ft is not None:
+            line["forward_test"] = ft
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, c_in, args.frames, t_pad, args.cpu_pairs)

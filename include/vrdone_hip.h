@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 12
+#define VRD_ABI_VERSION 13
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -41,7 +41,8 @@ enum vrd_kernel_id {
     VRD_K_GEMM = 0, VRD_K_LAYERNORM = 1, VRD_K_DWCONV_LN = 2, VRD_K_LOCAL_ATTN = 3,
     VRD_K_ATTN_SMALL = 4, VRD_K_ATTN_FLASH = 5, VRD_K_POOL = 6, VRD_K_MASK_HEAD = 7,
     VRD_K_TRANSPOSE = 8, VRD_K_POSTPROC = 9, VRD_K_GEMM_X3 = 10, VRD_K_GEMM_X3_DMA = 11, VRD_K_GEMM_X3_BIG = 12,
-    VRD_K_COUNT = 13
+    VRD_K_BACKWARD = 13,
+    VRD_K_COUNT = 14
 };
 
 int vrd_abi_version(void);
@@ -238,6 +239,90 @@ int vrd_postprocess(const float* logits, const float* masks, const int32_t* vali
                     int P, int Q, int K1, int T, int topk,
                     float* top_score, int32_t* top_cat, int32_t* seg_first, int32_t* seg_last,
                     void* stream);
+
+/* ====================================================================================================================
+ * Backward kernels (training step: the reference differentiates its ATen graph with autograd, train.py:186;
+ * models/maskvrd.py:168-198).  All f32 rows (no pair rows).  Parameter gradients are ACCUMULATED (+=) into buffers the
+ * caller zeroes; where several workgroups add to one element the order (last bits) varies between runs.
+ * The forward of a training step runs the same forward kernels, less fused, so that every op has saved inputs:
+ *   y = vrd_gemm(x, W, b, row_mask)                       dense conv, mask only
+ *   u = vrd_activation(y)                                        GELU / ReLU
+ *   out = vrd_rowcol_scale(u, scale, row_scale, res...)     AffineDropPath scale * per-sample keep factor + residuals
+ * ==================================================================================================================== */
+
+/* Weight gradient of vrd_gemm's convolution (models/blocks.py:99 under autograd):
+ *   dW[n, tap*Cin + ci] += sum_r G[r, n] * row_mask[r] * X[r + tap - taps/2, ci]      (rows outside r's length-T sequence: 0)
+ * dW is (N, taps*Cin) tap-major like vrd_gemm's W.  f32 MFMA, exact f32 products. */
+int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
+                   int taps, int T, float* dW, void* stream);
+
+/* out[c] += sum_r a[r, c] * (b ? b[brow(r), c * b_cstride + b_coffset] : 1) * (row_mask ? row_mask[r] : 1) * (row_scale ?
+ * row_scale[r] : 1), brow(r = s*T + t) = s * (b_rstride*T) + b_rstride*t + shift when that stays inside the sequence
+ * (else the row contributes 0).  Bias gradients (b = NULL), AffineDropPath scale gradients (b = the branch value),
+ * depthwise-conv weight gradients (b = conv input, shift = k - ksize/2, b_rstride = stride, b_cstride = inputs per group). */
+int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_cstride, int b_coffset, int b_rstride, int shift,
+               int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, void* stream);
+
+/* out[r,c] = v[r,c] * col_scale[c] * row_scale[r] * row_mask[r] + res[r,c] * (res_masked ? row_mask[r] : 1) + res2[r,c]
+ * (every factor / term optional).  Training form of the affine drop-path residual: models/blocks.py:1074-1076 with
+ * AffineDropPath (:1148) = scale[c] * keep[b] / keep_prob (drop_path, :1107-1120), local_transformer.py:815,829,833;
+ * also its gradient w.r.t. v (res = NULL) and the row masking of an upstream gradient. */
+int vrd_rowcol_scale(const float* v, int64_t ldv, int64_t rows, int C, const float* col_scale, const float* row_scale,
+                     const uint8_t* row_mask, const float* res, int64_t ldres, int res_masked, const float* res2, int64_t ldres2,
+                     float* out, int64_t ldo, void* stream);
+
+/* dy == NULL: out = act(x) (VRD_ACT_RELU / VRD_ACT_GELU, erf form: models/blocks.py:59,1056);  else out = dy * act'(x). */
+int vrd_activation(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int C, int act, float* out, int64_t ldo,
+            void* stream);
+
+/* Channel LayerNorm backward (models/blocks.py:143-158 under autograd), C in {256, 512}; with relu != 0 the forward was
+ * ReLU(LN(x)).  dx written; dgamma / dbeta (C floats each) accumulated. */
+int vrd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int C, const float* gamma,
+                      const float* beta, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream);
+
+/* Input gradient of the depthwise convolution of vrd_dwconv_ln (without its LayerNorms: in a training step those run as
+ * separate vrd_layernorm calls): dD[o] = gradient w.r.t. the masked conv output of set o, (B*Tin/stride, C) rows;
+ * w[o] = the (C, group_in, ksize) Conv1d weight.  dx (B*Tin, C*group_in) written; with dx_up also the gradient of the
+ * nearest-x2-upsampled addend x_up (B*Tin/2 rows): dx_up[b, t] = dx[b, 2t] + dx[b, 2t+1] (models/fpns.py:252). */
+typedef struct {
+    const float* dD[3];  int64_t lddd[3];
+    const float* w[3];
+    int32_t n_out, B, Tin, C, ksize, stride, group_in;
+    const uint8_t* mask_out;
+    float* dx;  int64_t lddx;
+    float* dx_up;  int64_t lddx_up;
+} vrd_dwconv_bwd_args;
+int vrd_dwconv_bwd(const vrd_dwconv_bwd_args* a, void* stream);
+
+/* Banded attention backward (vrd_local_attn; models/blocks.py:950-986): dq, dk, dv (leading dimension ldd) from the
+ * forward inputs and dO.  scratch: 2 * B*T * n_head * (2*half_win+1) floats. */
+int vrd_local_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dO, int64_t lddo,
+                       const uint8_t* mask, int B, int T, int C, int n_head, int half_win, float* dq, float* dk, float* dv,
+                       int64_t ldd, float* scratch, void* stream);
+
+/* Global attention backward, first half (vrd_attention; models/local_transformer.py:44-63,163-183): the probabilities
+ * P (B, n_head, Tq, Tk) and the gradient dS w.r.t. the scaled scores.  Then dq = head_dim^-0.5 * dS K, dk = head_dim^-0.5
+ * * dS^T Q, dv = P^T dO are three vrd_bmm calls.  Tk <= 1024, head_dim <= 128. */
+int vrd_attn_bwd_probs(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dO, int64_t lddo,
+                       const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim, float* P, float* dS, void* stream);
+
+/* Strided batched matmul, f32: C[z][i][n] (= or +=) alpha * sum_k A[z][i][k] * B[z][k][n], z = (z0 < Z0, z1 < Z1); every
+ * operand is addressed by (stride of z0, stride of z1, stride of its row index, stride of its column index) in floats.
+ * Fastest when B and C are contiguous along n. */
+typedef struct {
+    const float* A;  int64_t a_z0, a_z1, a_row, a_col;
+    const float* B;  int64_t b_z0, b_z1, b_row, b_col;
+    float* C;  int64_t c_z0, c_z1, c_row, c_col;
+    int32_t Z0, Z1, M, N, K;
+    float alpha;
+    int32_t accumulate;
+} vrd_bmm_args;
+int vrd_bmm(const vrd_bmm_args* a, void* stream);
+
+/* MaxPool1d(3,2,1)(x) * mask[::2] backward (vrd_maxpool_mask; models/blocks.py:1040-1046,1074): the gradient goes to
+ * the first maximum of each window (ATen's rule). */
+int vrd_maxpool_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int B, int Tin, int C, const uint8_t* mask_in, float* dx,
+                    int64_t lddx, void* stream);
 
 #ifdef __cplusplus
 }

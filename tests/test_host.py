@@ -62,7 +62,7 @@ def test_no_cpu_fallback_and_no_oracle_import():
     with pytest.raises(RuntimeError, match="HIP device only"):
         model._mask_vrd(x, m)
     model.train()
-    with torch.enable_grad(), pytest.raises(NotImplementedError):      # a training step needs backward kernels
+    with torch.enable_grad(), pytest.raises(RuntimeError, match="HIP device only"):      # a training step: same device rule
         model({"so_features_list": [x[0]]})
     with torch.no_grad(), pytest.raises(RuntimeError, match="HIP device only"):   # loss values: same network path
         model({"so_features_list": [x[0]]})

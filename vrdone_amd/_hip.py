@@ -12,10 +12,10 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvrdone_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
- K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_GEMM_X3_BIG, K_COUNT) = range(14)      # enum vrd_kernel_id
+ K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_GEMM_X3_BIG, K_BACKWARD, K_COUNT) = range(15)   # enum vrd_kernel_id
 KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
                 "maxpool_mask", "mask_head", "transpose", "postprocess", "gemm_bf16x3_mfma", "gemm_bf16x3_dma",
-                "gemm_bf16x3_big"]
+                "gemm_bf16x3_big", "backward"]
 assert len(KERNEL_NAMES) == K_COUNT
 
 c_f32p = C.c_void_p      # device pointers travel as plain integers
@@ -51,6 +51,21 @@ class PackArgs(C.Structure):
                 ("vis", c_f32p), ("clip", c_f32p), ("so_box", c_f32p), ("ent", c_f32p), ("pair_wide", C.c_int32)]
 
 
+class DwconvBwdArgs(C.Structure):
+    _fields_ = [("dD", c_f32p * 3), ("lddd", C.c_int64 * 3), ("w", c_f32p * 3),
+                ("n_out", C.c_int32), ("B", C.c_int32), ("Tin", C.c_int32), ("C", C.c_int32), ("ksize", C.c_int32),
+                ("stride", C.c_int32), ("group_in", C.c_int32),
+                ("mask_out", c_u8p), ("dx", c_f32p), ("lddx", C.c_int64), ("dx_up", c_f32p), ("lddx_up", C.c_int64)]
+
+
+class BmmArgs(C.Structure):
+    _fields_ = [("A", c_f32p), ("a_z0", C.c_int64), ("a_z1", C.c_int64), ("a_row", C.c_int64), ("a_col", C.c_int64),
+                ("B", c_f32p), ("b_z0", C.c_int64), ("b_z1", C.c_int64), ("b_row", C.c_int64), ("b_col", C.c_int64),
+                ("C", c_f32p), ("c_z0", C.c_int64), ("c_z1", C.c_int64), ("c_row", C.c_int64), ("c_col", C.c_int64),
+                ("Z0", C.c_int32), ("Z1", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("alpha", C.c_float), ("accumulate", C.c_int32)]
+
+
 _SIGNATURES = {
     "vrd_abi_version": (C.c_int, []),
     "vrd_last_error": (C.c_char_p, []),
@@ -81,9 +96,27 @@ _SIGNATURES = {
                                 C.c_float, c_f32p, C.c_void_p]),
     "vrd_postprocess": (C.c_int, [c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_i32p,
                                   c_i32p, c_i32p, C.c_void_p]),
+    # ---- backward kernels (training step)
+    "vrd_gemm_wgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 c_f32p, C.c_void_p]),
+    "vrd_colsum": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p,
+                             C.c_int64, C.c_int, c_f32p, C.c_void_p]),
+    "vrd_rowcol_scale": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, c_u8p, c_f32p, C.c_int64, C.c_int,
+                                   c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p]),
+    "vrd_activation": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
+    "vrd_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p,
+                                    C.c_int64, c_f32p, c_f32p, C.c_void_p]),
+    "vrd_dwconv_bwd": (C.c_int, [C.POINTER(DwconvBwdArgs), C.c_void_p]),
+    "vrd_local_attn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "vrd_attn_bwd_probs": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p]),
+    "vrd_bmm": (C.c_int, [C.POINTER(BmmArgs), C.c_void_p]),
+    "vrd_maxpool_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p, C.c_int64,
+                                  C.c_void_p]),
 }
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class HipLibraryError(RuntimeError):

@@ -1,0 +1,399 @@
+"""Differentiable forms of the ops in vrdone_amd.ops: one torch.autograd.Function per kernel family, forward AND
+backward on hand-written HIP kernels (csrc/vrd_backward.hip for the gradients).  The reference gets its gradients from
+autograd over ATen ops (train.py:186, models/maskvrd.py:168-198); this is what makes `loss.backward()` work on the HIP
+path.
+
+ops.* dispatch here when autograd is recording (torch.is_grad_enabled()) and an input requires a gradient.  In that
+mode every activation is a plain f32 channels-last tensor (no pair rows, no writes into concatenation slabs, no padding
+skip), and a fused eval op is run as its differentiable parts, each of which saves what its backward needs:
+
+    conv_gemm(x, W, b, act, row_mask, scale, row_scale, res, res2)
+        = ScaleResidual( Activation( Linear(x, W, b, row_mask) ), scale, row_scale, row_mask, res, res2 )
+    dwconv_ln(x, sets, mask_out, stride, x_up, pre_ln)
+        = [ LayerNorm_o( DepthwiseConv_o( LayerNorm_pre(x) (+ up2(x_up)) ) ) ]
+
+PyTorch is used for memory, views / concatenations of results and autograd's own bookkeeping (summing the gradients
+of a tensor used twice); the arithmetic of every forward and backward op is a kernel of libvrdone_hip.so.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _hip, ops
+from ._hip import lib
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU, _mask_ptr, _param_ptr, _ptr, _rows, _stream
+
+check = _hip.check
+
+
+def _new_like_rows(t, cols=None):
+    return torch.empty(*t.shape[:-1], t.shape[-1] if cols is None else cols, device=t.device, dtype=torch.float32)
+
+
+def _dense(t):
+    """Gradients arrive with arbitrary strides (expanded, sliced): kernels want uniformly strided rows."""
+    return t if (t.stride(-1) == 1 and t.is_contiguous()) else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------- raw launchers
+def colsum(a, out, *, b=None, b_cstride=1, b_coffset=0, b_rstride=1, shift=0, T=1, row_mask=None, row_scale=None):
+    """out[c] += sum_r a[r,c] * b[...] * mask[r] * row_scale[r]  (vrd_colsum)."""
+    pa, rows, cols, lda = _rows(a)
+    pb, ldb = (None, 0)
+    if b is not None:
+        pb, _, _, ldb = _rows(b)
+    assert out.numel() == cols and out.is_contiguous() and out.dtype == torch.float32
+    check(lib.vrd_colsum(pa, lda, pb, ldb, b_cstride, b_coffset, b_rstride, shift, T, _mask_ptr(row_mask, rows),
+                         _ptr(row_scale), rows, cols, out.data_ptr(), _stream()), "vrd_colsum")
+    return out
+
+
+def rowcol_scale(v, *, col_scale=None, row_scale=None, row_mask=None, res=None, res_masked=False, res2=None):
+    pv, rows, cols, ldv = _rows(v)
+    out = _new_like_rows(v)
+    po, _, _, ldo = _rows(out)
+    pr, ldr = (None, 0) if res is None else (_rows(res)[0], _rows(res)[3])
+    pr2, ldr2 = (None, 0) if res2 is None else (_rows(res2)[0], _rows(res2)[3])
+    if row_scale is not None:
+        assert row_scale.numel() == rows and row_scale.is_contiguous() and row_scale.dtype == torch.float32
+    check(lib.vrd_rowcol_scale(pv, ldv, rows, cols, _ptr(col_scale), _ptr(row_scale), _mask_ptr(row_mask, rows), pr, ldr,
+                               1 if res_masked else 0, pr2, ldr2, po, ldo, _stream()), "vrd_rowcol_scale")
+    return out
+
+
+def activation(x, act, dy=None):
+    px, rows, cols, ldx = _rows(x)
+    out = _new_like_rows(x)
+    po, _, _, ldo = _rows(out)
+    pd, ldd = (None, 0) if dy is None else (_rows(dy)[0], _rows(dy)[3])
+    check(lib.vrd_activation(px, ldx, pd, ldd, rows, cols, act, po, ldo, _stream()), "vrd_activation")
+    return out
+
+
+def bmm(A, a_strides, B, b_strides, Cmat, c_strides, Z0, Z1, M, N, K, alpha=1.0, accumulate=False):
+    """Strided batched matmul (vrd_bmm); *_strides = (z0, z1, row, col) in floats."""
+    a = _hip.BmmArgs()
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), Cmat.data_ptr()
+    a.a_z0, a.a_z1, a.a_row, a.a_col = a_strides
+    a.b_z0, a.b_z1, a.b_row, a.b_col = b_strides
+    a.c_z0, a.c_z1, a.c_row, a.c_col = c_strides
+    a.Z0, a.Z1, a.M, a.N, a.K, a.alpha, a.accumulate = Z0, Z1, M, N, K, alpha, 1 if accumulate else 0
+    check(lib.vrd_bmm(C.byref(a), _stream()), "vrd_bmm")
+    return Cmat
+
+
+# ------------------------------------------------------------------------------------------------------ Functions
+class Linear(Function):
+    """y = Conv1d(x; W (N, Cin, k), b) * row_mask, k in {1, 3}, on channels-last rows (vrd_gemm without epilogue terms)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, row_mask):
+        y = ops.conv_gemm(x, weight, bias, row_mask=row_mask)
+        ctx.save_for_backward(x, weight)
+        ctx.row_mask, ctx.has_bias = row_mask, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        mask = ctx.row_mask
+        dy = _dense(dy)
+        N, Cin, k = weight.shape
+        pg, rows, _, ldg = _rows(dy)
+        T = x.shape[-2]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if k == 1:       # masking the rows of dy = masking the rows of dx
+                dx = ops.conv_gemm(dy, weight.detach().permute(1, 0, 2).contiguous(), None, row_mask=mask)
+            else:            # dx[r] = sum_tap (dy * mask)[r - (tap - 1)] W[:, :, tap]: a k=3 conv with flipped, transposed taps
+                g = rowcol_scale(dy, row_mask=mask) if mask is not None else dy
+                dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None)
+        if ctx.needs_input_grad[1]:
+            packed = torch.zeros(N, k * Cin, device=dy.device, dtype=torch.float32)
+            px, _, _, ldx = _rows(x)
+            check(lib.vrd_gemm_wgrad(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(), _stream()),
+                  "vrd_gemm_wgrad")
+            dw = packed.view(N, k, Cin).permute(0, 2, 1)           # tap-major -> the Conv1d layout (N, Cin, k)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, torch.zeros(N, device=dy.device, dtype=torch.float32), row_mask=mask)
+        return dx, dw, db, None
+
+
+class Activation(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return activation(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return activation(x, ctx.act, dy=_dense(dy)), None
+
+
+class ScaleResidual(Function):
+    """out = v * scale[c] * row_scale[r] * mask[r] + res * (mask if res_masked) + res2."""
+
+    @staticmethod
+    def forward(ctx, v, scale, row_scale, row_mask, res, res_masked, res2):
+        ctx.save_for_backward(v, scale if scale is not None else v.new_empty(0))
+        ctx.has_scale = scale is not None
+        ctx.row_scale, ctx.row_mask, ctx.res_masked = row_scale, row_mask, res_masked
+        return rowcol_scale(v, col_scale=scale, row_scale=row_scale, row_mask=row_mask, res=res, res_masked=res_masked, res2=res2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, scale = ctx.saved_tensors
+        scale = scale if ctx.has_scale else None
+        dy = _dense(dy)
+        dv = ds = dres = dres2 = None
+        if ctx.needs_input_grad[0]:
+            dv = rowcol_scale(dy, col_scale=scale, row_scale=ctx.row_scale, row_mask=ctx.row_mask)
+        if scale is not None and ctx.needs_input_grad[1]:
+            ds = colsum(dy, torch.zeros(v.shape[-1], device=dy.device, dtype=torch.float32), b=v, T=1,
+                        row_mask=ctx.row_mask, row_scale=ctx.row_scale).view_as(scale)
+        if ctx.needs_input_grad[4]:
+            dres = rowcol_scale(dy, row_mask=ctx.row_mask) if (ctx.res_masked and ctx.row_mask is not None) else dy
+        if ctx.needs_input_grad[6]:
+            dres2 = dy
+        return dv, ds, None, None, dres, None, dres2
+
+
+class LayerNormFn(Function):
+    """Channel LayerNorm (+ReLU) (+post_add rows, period = post_add.shape[0])."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, relu, post_add):
+        y = ops.layernorm(x, gamma, beta, relu=relu, post_add=post_add)
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.relu, ctx.period = relu, None if post_add is None else post_add.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        dy = _dense(dy)
+        px, rows, cols, ldx = _rows(x)
+        pd, _, _, ldd = _rows(dy)
+        dx = _new_like_rows(x)
+        pdx, _, _, lddx = _rows(dx)
+        dg = torch.zeros(cols, device=x.device, dtype=torch.float32)
+        db = torch.zeros(cols, device=x.device, dtype=torch.float32)
+        check(lib.vrd_layernorm_bwd(px, ldx, pd, ldd, rows, cols, gamma.data_ptr(), beta.data_ptr(), 1 if ctx.relu else 0,
+                                    pdx, lddx, dg.data_ptr(), db.data_ptr(), _stream()), "vrd_layernorm_bwd")
+        dpost = None
+        if ctx.period is not None and ctx.needs_input_grad[4]:
+            # y[r] += post_add[r % period]: sum dy over the rows of each residue = column sums of the (rows/period, period*C) view
+            dpost = colsum(dy.reshape(rows // ctx.period, ctx.period * cols),
+                           torch.zeros(ctx.period * cols, device=x.device, dtype=torch.float32)).view(ctx.period, cols)
+        return dx, dg.view_as(gamma), db.view_as(beta), None, dpost
+
+
+class DepthwiseConv(Function):
+    """D_o = mask_out * (bias_o + depthwise_conv(x (+ up2(x_up)); w_o)) for 1..3 weight sets (vrd_dwconv_ln without
+    LayerNorm).  args after the fixed ones: w_0, b_0, w_1, b_1, ... (b_i may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, x_up, mask_out, stride, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        outs = ops.dwconv_ln(x, [dict(weight=w, bias=b) for w, b in zip(ws, bs)], mask_out=mask_out, stride=stride, x_up=x_up)
+        ctx.save_for_backward(x, *( [x_up] if x_up is not None else [] ), *ws)
+        ctx.has_up, ctx.mask_out, ctx.stride, ctx.has_bias = x_up is not None, mask_out, stride, [b is not None for b in bs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dDs):
+        saved = ctx.saved_tensors
+        x = saved[0]
+        x_up = saved[1] if ctx.has_up else None
+        ws = saved[2 if ctx.has_up else 1:]
+        n = len(ws)
+        B, Tin, Cx = x.shape
+        Cout, gin, k = ws[0].shape
+        s = ctx.stride
+        Tout = Tin // s
+        dev = x.device
+        dDs = [_dense(d) if d is not None else torch.zeros(B, Tout, Cout, device=dev) for d in dDs]
+        a = _hip.DwconvBwdArgs()
+        for i in range(n):
+            p, _, _, ld = _rows(dDs[i])
+            a.dD[i], a.lddd[i], a.w[i] = p, ld, ws[i].data_ptr()
+        a.n_out, a.B, a.Tin, a.C, a.ksize, a.stride, a.group_in = n, B, Tin, Cout, k, s, gin
+        a.mask_out = _mask_ptr(ctx.mask_out, B * Tout)
+        dx = torch.empty(B, Tin, Cx, device=dev, dtype=torch.float32)
+        a.dx, a.lddx = dx.data_ptr(), Cx
+        dx_up = None
+        if ctx.has_up:
+            dx_up = torch.empty(B, Tin // 2, Cx, device=dev, dtype=torch.float32)
+            a.dx_up, a.lddx_up = dx_up.data_ptr(), Cx
+        check(lib.vrd_dwconv_bwd(C.byref(a), _stream()), "vrd_dwconv_bwd")
+        xin = x if x_up is None else x + x_up.repeat_interleave(2, dim=1)       # the conv's input, for the weight gradients
+        grads = []
+        for i in range(n):
+            gw = torch.zeros(gin, k, Cout, device=dev, dtype=torch.float32)
+            for g in range(gin):
+                for kk in range(k):
+                    colsum(dDs[i], gw[g, kk], b=xin, b_cstride=gin, b_coffset=g, b_rstride=s, shift=kk - k // 2, T=Tout,
+                           row_mask=ctx.mask_out)
+            grads.append(gw.permute(2, 0, 1))                                     # (C, gin, k)
+            grads.append(colsum(dDs[i], torch.zeros(Cout, device=dev, dtype=torch.float32), row_mask=ctx.mask_out)
+                         if ctx.has_bias[i] else None)
+        return (dx, dx_up, None, None, *grads)
+
+
+class LocalAttention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, n_head, half_win):
+        out = ops.local_attention(q, k, v, mask, n_head, half_win)
+        ctx.save_for_backward(q, k, v)
+        ctx.mask, ctx.n_head, ctx.half_win = mask, n_head, half_win
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v = ctx.saved_tensors
+        dO = _dense(dO)
+        B, T, Cc = q.shape
+        q, k, v = (t if t.stride(-2) == Cc and t.is_contiguous() else t.contiguous() for t in (q, k, v))
+        W = 2 * ctx.half_win + 1
+        dq, dk, dv = (torch.empty(B, T, Cc, device=q.device, dtype=torch.float32) for _ in range(3))
+        scratch = torch.empty(2 * B * T * ctx.n_head * W, device=q.device, dtype=torch.float32)
+        check(lib.vrd_local_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), Cc, dO.data_ptr(), Cc, _mask_ptr(ctx.mask, B * T),
+                                     B, T, Cc, ctx.n_head, ctx.half_win, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), Cc,
+                                     scratch.data_ptr(), _stream()), "vrd_local_attn_bwd")
+        return dq, dk, dv, None, None, None
+
+
+class Attention(Function):
+    """Global masked attention (f32 kernels of vrd_attention)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kv_mask, n_head):
+        out = ops.attention(q, k, v, kv_mask, n_head)
+        ctx.save_for_backward(q, k, v)
+        ctx.kv_mask, ctx.n_head = kv_mask, n_head
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v = (t.contiguous() for t in ctx.saved_tensors)
+        dO = dO.contiguous()
+        B, Tq, Cc = q.shape
+        Tk, H = k.shape[1], ctx.n_head
+        hd = Cc // H
+        dev = q.device
+        P = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)
+        dS = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)
+        check(lib.vrd_attn_bwd_probs(q.data_ptr(), Cc, k.data_ptr(), v.data_ptr(), Cc, dO.data_ptr(), Cc,
+                                     _mask_ptr(ctx.kv_mask, B * Tk), B, Tq, Tk, H, hd, P.data_ptr(), dS.data_ptr(), _stream()),
+              "vrd_attn_bwd_probs")
+        scale = hd ** -0.5
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        sc = (H * Tq * Tk, Tq * Tk)                   # z strides of P / dS
+        row_q, row_k = (Tq * Cc, hd), (Tk * Cc, hd)   # z strides of (B, T, H*hd) operands
+        # dq[b, i, h, :] = scale * sum_j dS[b,h,i,j] k[b,j,h,:]
+        bmm(dS, (*sc, Tk, 1), k, (*row_k, Cc, 1), dq, (*row_q, Cc, 1), B, H, Tq, hd, Tk, alpha=scale)
+        # dk[b, j, h, :] = scale * sum_i dS[b,h,i,j] q[b,i,h,:]
+        bmm(dS, (*sc, 1, Tk), q, (*row_q, Cc, 1), dk, (*row_k, Cc, 1), B, H, Tk, hd, Tq, alpha=scale)
+        # dv[b, j, h, :] = sum_i P[b,h,i,j] dO[b,i,h,:]
+        bmm(P, (*sc, 1, Tk), dO, (*row_q, Cc, 1), dv, (*row_k, Cc, 1), B, H, Tk, hd, Tq)
+        return dq, dk, dv, None, None
+
+
+class MaxPoolMask(Function):
+    @staticmethod
+    def forward(ctx, x, mask_in):
+        y, m_out = ops.maxpool_mask(x, mask_in)
+        ctx.save_for_backward(x)
+        ctx.mask_in = mask_in
+        ctx.mark_non_differentiable(m_out)
+        return y, m_out
+
+    @staticmethod
+    def backward(ctx, dy, _dm):
+        (x,) = ctx.saved_tensors
+        dy = _dense(dy)
+        B, T, Cc = x.shape
+        px, _, _, ldx = _rows(x)
+        pd, _, _, ldd = _rows(dy)
+        dx = torch.empty(B, T, Cc, device=x.device, dtype=torch.float32)
+        check(lib.vrd_maxpool_bwd(px, ldx, pd, ldd, B, T, Cc, _mask_ptr(ctx.mask_in, B * T), dx.data_ptr(), Cc, _stream()),
+              "vrd_maxpool_bwd")
+        return dx, None
+
+
+class MaskHead(Function):
+    @staticmethod
+    def forward(ctx, emb, feat, out_mask, fill):
+        seg = ops.mask_head(emb, feat, out_mask, fill)
+        ctx.save_for_backward(emb, feat)
+        ctx.out_mask = out_mask
+        return seg
+
+    @staticmethod
+    def backward(ctx, dseg):
+        emb, feat = (t.contiguous() for t in ctx.saved_tensors)
+        B, Q, Dp = emb.shape
+        T = feat.shape[1]
+        g = (dseg * ctx.out_mask[:, None, :]).contiguous()             # filled frames carry no gradient
+        demb, dfeat = torch.empty_like(emb), torch.empty_like(feat)
+        # demb[b, q, :] = sum_t g[b,q,t] feat[b,t,:];  dfeat[b, t, :] = sum_q g[b,q,t] emb[b,q,:]
+        bmm(g, (Q * T, 0, T, 1), feat, (T * Dp, 0, Dp, 1), demb, (Q * Dp, 0, Dp, 1), B, 1, Q, Dp, T)
+        bmm(g, (Q * T, 0, 1, T), emb, (Q * Dp, 0, Dp, 1), dfeat, (T * Dp, 0, Dp, 1), B, 1, T, Dp, Q)
+        return demb, dfeat, None, None
+
+
+class ToChannelsLast(Function):
+    """(B, C, T) -> (B, T, C); its backward is the opposite layout change."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.to_channels_last(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.btc_to_bct(_dense(dy))
+
+
+class FromChannelsLast(Function):
+    @staticmethod
+    def forward(ctx, x):
+        return ops.btc_to_bct(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.to_channels_last(dy.contiguous())
+
+
+# ---------------------------------------------------------------------------------- differentiable ops (ops.* call these)
+def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, row_scale=None, res=None, res_masked=False,
+              res2=None):
+    v = Linear.apply(x, weight, bias, row_mask)
+    if act != ACT_NONE:
+        v = Activation.apply(v, act)          # act(0) = 0 for ReLU and GELU: masking before the activation = after it
+    if scale is not None or row_scale is not None or res is not None or res2 is not None:
+        v = ScaleResidual.apply(v, scale, row_scale, row_mask, res, res_masked, res2)
+    return v
+
+
+def layernorm(x, gamma, beta, *, relu=False, post_add=None):
+    return LayerNormFn.apply(x, gamma, beta, relu, post_add)
+
+
+def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
+    if pre_ln is not None:
+        x = LayerNormFn.apply(x, pre_ln[0], pre_ln[1], False, None)
+    wb = []
+    for s in sets:
+        wb += [s["weight"], s.get("bias")]
+    outs = DepthwiseConv.apply(x, x_up, mask_out, stride, *wb)
+    res = []
+    for s, d in zip(sets, outs):
+        if s.get("gamma") is not None:
+            d = LayerNormFn.apply(d, s["gamma"], s["beta"], bool(s.get("relu")), None)
+        elif s.get("relu"):
+            d = Activation.apply(d, ACT_RELU)
+        res.append(d)
+    return res

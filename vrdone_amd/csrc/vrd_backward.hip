@@ -1,0 +1,720 @@
+// Backward kernels of the relation-encoding path (training step, BASELINE config 3).
+//
+// The reference differentiates its ATen graph with autograd (train.py:186); here every forward kernel family gets
+// the hand-written kernel(s) that compute its input / parameter gradients, bound through the same C ABI and wrapped
+// as torch.autograd.Function in vrdone_amd/autograd.py.  Training batches are small (24 pairs x 96 frames = 2,304
+// rows for vidvrd.yaml; 48 x 512 for vidor), so these kernels are written for correctness and sane memory access
+// (coalesced rows, one wave per row, f32 MFMA for the one real contraction), not tuned like the forward path.
+// Everything is f32; parameter gradients are ACCUMULATED (+=) into caller-zeroed buffers with float atomics where
+// several workgroups contribute to the same element (summation order, hence the last bits, vary from run to run).
+//
+//  vrd_gemm_wgrad      dW of a dense conv (k = 1 / 3):  dW[n, tap*Cin+ci] += sum_r G[r,n] X[r+tap-1, ci]   (f32 MFMA)
+//  vrd_colsum          out[c] += sum_r a[r,c] * b[s*r+shift, c*bc+bo] * mask[r] * rscale[r]: bias, drop-path-scale,
+//                      depthwise-conv-weight gradients
+//  vrd_rowcol_scale    out = v * colscale[c] * rowscale[r] * mask[r] + res * (mask) + res2: the affine drop-path
+//                      residual of blocks.py:1074-1076,1148 in training form, and its input gradient
+//  vrd_act / _bwd      GELU (erf) / ReLU and their derivative
+//  vrd_layernorm_bwd   dx, dgamma, dbeta of the channel LayerNorm (+ReLU)
+//  vrd_dwconv_bwd      input gradient of the depthwise conv (k 1/3, stride 1/2, 1 or 2 inputs per group, up to 3 sets,
+//                      optional nearest-x2-upsample-add input)
+//  vrd_local_attn_bwd  banded attention: dq, dk, dv
+//  vrd_attn_bwd_probs  global attention: probabilities P and score gradients dS, row by row
+//  vrd_bmm             strided batched matmul (dq = dS K, dk = dS^T Q, dv = P^T dO; mask head)
+//  vrd_maxpool_bwd     MaxPool1d(3,2,1) * mask
+#include "vrd_common.h"
+#include <cmath>
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// dW[n, j] += sum_{r in chunk} G[r, n] * X[r + tap(j) - taps/2, ci(j)],  j = tap*Cin + ci, rows outside the length-T
+// sequence of r contribute 0.  One wave per 32 x 32 tile of dW and per chunk of rows: v_mfma_f32_32x32x2_f32 takes
+// the two operands of two rows straight from global memory (a lane holds G[r0 + (lane >> 5)][n0 + (lane & 31)] and
+// X[r0 + (lane >> 5) + shift][ci]: 128-byte row segments), accumulates in f32 and adds its partial tile atomically.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WG_CHUNK = 512;      // rows per wave
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
+                                                    int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M, int N,
+                                                    int Cin, int taps, int T, int tiles_k, float* __restrict__ dW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = Cin * taps;
+    const int tile = blockIdx.x;
+    const int n0 = (tile / tiles_k) * 32, j0 = (tile % tiles_k) * 32;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = n0 + li, j = j0 + li;
+    const int tap = j < K ? j / Cin : 0;
+    const int ci = j < K ? j - tap * Cin : 0;
+    const int shift = tap - taps / 2;
+    const int64_t r_begin = ((int64_t)blockIdx.y * 4 + wave) * WG_CHUNK;
+    const int64_t r_end = r_begin + WG_CHUNK < M ? r_begin + WG_CHUNK : M;
+    if (r_begin >= M) return;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 2) {
+        const int64_t r = r0 + lh;
+        float a = 0.f, b = 0.f;
+        if (r < r_end) {
+            if (n < N && (!row_mask || row_mask[r])) a = G[r * ldg + n];
+            if (j < K) {
+                const int t = (int)(r % T) + shift;
+                if (t >= 0 && t < T) b = X[(r + shift) * ldx + ci];
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    // element e of lane (li, lh): row (e & 3) + 8 * (e >> 2) + 4 * lh (n index), column li (j index)
+    if (j < K) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int nn = n0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (nn < N) atomicAdd(dW + (int64_t)nn * K + j, acc[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// out[c] += sum_r a[r, c] * (b ? b[brow(r), c * bc + bo] : 1) * (mask ? mask[r] : 1) * (rscale ? rscale[r] : 1)
+// brow(r): r = s * T + t  ->  s * (bs * T) + bs * t + shift, contributing only if 0 <= bs * t + shift < bs * T.
+// thread = one column; block = 64 rows x 256 columns; one atomic per thread.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int CS_ROWS = 64;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                                     int64_t ldb, int bc, int bo, int bs, int shift, int T,
+                                                     const uint8_t* __restrict__ mask, const float* __restrict__ rscale,
+                                                     int64_t rows, int C, float* __restrict__ out) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
+    const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        float f = 1.f;
+        if (mask) {
+            if (!mask[r]) continue;
+        }
+        if (rscale) f = rscale[r];
+        float bv = 1.f;
+        if (b) {
+            const int64_t seq = r / T;
+            const int tb = bs * (int)(r - seq * T) + shift;
+            if (tb < 0 || tb >= bs * T) continue;
+            bv = b[(seq * (int64_t)bs * T + tb) * ldb + (int64_t)c * bc + bo];
+        }
+        s = fmaf(a[r * lda + c] * f, bv, s);
+    }
+    atomicAdd(out + c, s);
+}
+
+// out[r,c] = v[r,c] * cs[c] * rs[r] * m[r] + res[r,c] * (res_masked ? m[r] : 1) + res2[r,c]
+__global__ __launch_bounds__(256) void rowcol_scale_kernel(const float* __restrict__ v, int64_t ldv, int64_t rows, int C4,
+                                                           const float* __restrict__ cs, const float* __restrict__ rs,
+                                                           const uint8_t* __restrict__ mask, const float* __restrict__ res,
+                                                           int64_t ldres, int res_masked, const float* __restrict__ res2,
+                                                           int64_t ldres2, float* __restrict__ out, int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C4) return;
+    const int64_t r = idx / C4;
+    const int c = (int)(idx - r * C4) * 4;
+    const float m = mask ? (float)mask[r] : 1.f;
+    const float f = (rs ? rs[r] : 1.f) * m;
+    float4 x = ld4(v + r * ldv + c);
+    float4 k = cs ? ld4(cs + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    x.x *= k.x * f; x.y *= k.y * f; x.z *= k.z * f; x.w *= k.w * f;
+    if (res) {
+        const float4 q = ld4(res + r * ldres + c);
+        const float rm = res_masked ? m : 1.f;
+        x.x += q.x * rm; x.y += q.y * rm; x.z += q.z * rm; x.w += q.w * rm;
+    }
+    if (res2) {
+        const float4 q = ld4(res2 + r * ldres2 + c);
+        x.x += q.x; x.y += q.y; x.z += q.z; x.w += q.w;
+    }
+    st4(out + r * ldo + c, x);
+}
+
+// y = act(x), or dx = dy * act'(x)  (act: 1 ReLU, 2 GELU(erf)); n4 float4 groups of a dense (rows x C) matrix with
+// leading dimensions
+__device__ __forceinline__ float act_fwd(float x, int act) { return act == VRD_ACT_RELU ? fmaxf(x, 0.f) : vrd::gelu_erf(x); }
+__device__ __forceinline__ float act_grad(float x, int act) {
+    if (act == VRD_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    // d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+    const float phi = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return 0.5f * (1.f + vrd::erf_f32(x * 0.70710678118654752440f)) + x * phi;
+}
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                  int64_t lddy, int64_t rows, int C4, int act, float* __restrict__ out, int64_t ldo) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C4) return;
+    const int64_t r = idx / C4;
+    const int c = (int)(idx - r * C4) * 4;
+    const float4 a = ld4(x + r * ldx + c);
+    float4 o;
+    if (dy) {
+        const float4 g = ld4(dy + r * lddy + c);
+        o = make_float4(g.x * act_grad(a.x, act), g.y * act_grad(a.y, act), g.z * act_grad(a.z, act), g.w * act_grad(a.w, act));
+    } else {
+        o = make_float4(act_fwd(a.x, act), act_fwd(a.y, act), act_fwd(a.z, act), act_fwd(a.w, act));
+    }
+    st4(out + r * ldo + c, o);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  One wave per row, several rows per wave; y = xhat * gamma + beta (ReLU optional):
+//   g = dy * (relu ? y > 0 : 1) * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+//   dgamma += sum_r dy' * xhat,  dbeta += sum_r dy'     (per-lane partial sums, one atomic per channel and wave)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int LNB_ROWS = 8;        // rows per wave
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                            int64_t lddy, int64_t rows, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu, float* __restrict__ dx,
+                                                            int64_t lddx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr float inv_c = 1.0f / (256.0f * NV);
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t r0 = w * LNB_ROWS;
+    if (r0 >= rows) return;
+    float4 g4[NV], b4[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g4[i] = ld4(gamma + i * 256 + lane * 4);
+        b4[i] = ld4(beta + i * 256 + lane * 4);
+        dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t r = r0; r < r0 + LNB_ROWS && r < rows; ++r) {
+        float4 v[NV], d[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = ld4(x + r * ldx + i * 256 + lane * 4);
+            d[i] = ld4(dy + r * lddy + i * 256 + lane * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = vrd::wave_sum(s) * inv_c;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+        const float rstd = 1.0f / sqrtf(vrd::wave_sum(ss) * inv_c + LN_EPS);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float* xh = reinterpret_cast<float*>(&v[i]);
+            float* dd = reinterpret_cast<float*>(&d[i]);
+            const float* gg = reinterpret_cast<const float*>(&g4[i]);
+            const float* bb = reinterpret_cast<const float*>(&b4[i]);
+            float* pdg = reinterpret_cast<float*>(&dg[i]);
+            float* pdb = reinterpret_cast<float*>(&db[i]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xh[c] *= rstd;
+                if (relu && fmaf(xh[c], gg[c], bb[c]) <= 0.f) dd[c] = 0.f;
+                pdg[c] = fmaf(dd[c], xh[c], pdg[c]);
+                pdb[c] += dd[c];
+                dd[c] *= gg[c];
+                sg += dd[c];
+                sgx = fmaf(dd[c], xh[c], sgx);
+            }
+        }
+        const float mg = vrd::wave_sum(sg) * inv_c, mgx = vrd::wave_sum(sgx) * inv_c;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float4 o;
+            o.x = rstd * (d[i].x - mg - v[i].x * mgx);
+            o.y = rstd * (d[i].y - mg - v[i].y * mgx);
+            o.z = rstd * (d[i].z - mg - v[i].z * mgx);
+            o.w = rstd * (d[i].w - mg - v[i].w * mgx);
+            st4(dx + r * lddx + i * 256 + lane * 4, o);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float* pdg = reinterpret_cast<const float*>(&dg[i]);
+        const float* pdb = reinterpret_cast<const float*>(&db[i]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            atomicAdd(dgamma + i * 256 + lane * 4 + c, pdg[c]);
+            atomicAdd(dbeta + i * 256 + lane * 4 + c, pdb[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// depthwise conv, input gradient.  Forward: D_o[b, to, c] = mask[b, to] * (bias + sum_{g,k} w_o[c,g,k] *
+// xin[b, s*to + k - ks/2, gin*c + g]),  xin = x (+ x_up[b, t/2]).  Hence
+//   dxin[b, ti, gin*c+g] = sum_o sum_k [to = (ti - k + ks/2) / s integral, in range] mask[b,to] dD_o[b,to,c] w_o[c,g,k]
+// thread = one input element (b, ti, cin); with dx_up the thread owns the input pair (2 tu, 2 tu + 1) and also writes
+// their sum (gradient of the nearest x2 upsample).
+// ------------------------------------------------------------------------------------------------------------------
+struct DwBwdArgs {
+    const float* dD[3];
+    int64_t lddd[3];
+    const float* w[3];
+    int n_out, B, Tin, C, ksize, stride, gin;
+    const uint8_t* mask_out;
+    float* dx;
+    int64_t lddx;
+    float* dx_up;
+    int64_t lddx_up;
+};
+__device__ __forceinline__ float dw_bwd_elem(const DwBwdArgs& p, int b, int ti, int cin) {
+    const int c = cin / p.gin, g = cin - c * p.gin;
+    const int Tout = p.Tin / p.stride;
+    float s = 0.f;
+    for (int k = 0; k < p.ksize; ++k) {
+        const int tn = ti - k + p.ksize / 2;
+        if (tn < 0 || tn % p.stride) continue;
+        const int to = tn / p.stride;
+        if (to >= Tout) continue;
+        const int64_t row = (int64_t)b * Tout + to;
+        if (p.mask_out && !p.mask_out[row]) continue;
+        for (int o = 0; o < p.n_out; ++o) s = fmaf(p.dD[o][row * p.lddd[o] + c], p.w[o][(c * p.gin + g) * p.ksize + k], s);
+    }
+    return s;
+}
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
+    const int Cin = p.C * p.gin;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p.dx_up) {
+        const int64_t total = (int64_t)p.B * (p.Tin / 2) * Cin;
+        if (idx >= total) return;
+        const int cin = (int)(idx % Cin);
+        const int64_t ru = idx / Cin;
+        const int b = (int)(ru / (p.Tin / 2)), tu = (int)(ru - (int64_t)b * (p.Tin / 2));
+        const float g0 = dw_bwd_elem(p, b, 2 * tu, cin), g1 = dw_bwd_elem(p, b, 2 * tu + 1, cin);
+        p.dx[((int64_t)b * p.Tin + 2 * tu) * p.lddx + cin] = g0;
+        p.dx[((int64_t)b * p.Tin + 2 * tu + 1) * p.lddx + cin] = g1;
+        p.dx_up[ru * p.lddx_up + cin] = g0 + g1;
+        return;
+    }
+    const int64_t total = (int64_t)p.B * p.Tin * Cin;
+    if (idx >= total) return;
+    const int cin = (int)(idx % Cin);
+    const int64_t r = idx / Cin;
+    const int b = (int)(r / p.Tin), ti = (int)(r - (int64_t)b * p.Tin);
+    p.dx[r * p.lddx + cin] = dw_bwd_elem(p, b, ti, cin);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// banded attention backward (C = 512; lane l owns channels [8l, 8l+8); GROUP = head_dim / 8 lanes per head).
+// Pass 1, one wave per query row t: recompute the window probabilities P[t, j] (models/blocks.py:950-986: masked keys
+// -1e4, out-of-range -inf, masked query rows all zero), dP = dO . v, dS = P * (dP - sum_j P dP); dq = scale * sum_j dS k;
+// P and dS of the row go to scratch (rows x heads x W).  Pass 2, one wave per key row j: dk_j = scale * sum_t dS[t, j] q_t,
+// dv_j = sum_t P[t, j] dO_t over the (at most W) queries whose window holds j.
+// ------------------------------------------------------------------------------------------------------------------
+template <int GROUP>
+__device__ __forceinline__ float head_sum(float d) {
+#pragma unroll
+    for (int off = GROUP / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+    return d;
+}
+__device__ __forceinline__ float dot8(const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
+    return (a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w) + (a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w);
+}
+constexpr int LA_WMAX = 9;
+template <int GROUP>
+__global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                               const float* __restrict__ v, int64_t ld,
+                                                               const float* __restrict__ dO, int64_t lddo,
+                                                               const uint8_t* __restrict__ mask, int B, int T, int W, float scale,
+                                                               float* __restrict__ dq, int64_t lddq, float* __restrict__ P,
+                                                               float* __restrict__ dS) {
+    const int HW = W / 2;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * T) return;
+    const int t = (int)(row % T);
+    constexpr int H = 64 / GROUP;
+    const int head = lane / GROUP;
+    float* const Pr = P + (row * H + head) * W;
+    float* const dSr = dS + (row * H + head) * W;
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+    if (!mask[row]) {
+        if (lane % GROUP == 0)
+            for (int j = 0; j < W; ++j) Pr[j] = 0.f, dSr[j] = 0.f;
+        st4(dq + row * lddq + lane * 8, g0);
+        st4(dq + row * lddq + lane * 8 + 4, g0);
+        return;
+    }
+    const float4 q0 = ld4(q + row * ld + lane * 8), q1 = ld4(q + row * ld + lane * 8 + 4);
+    const float4 o0 = ld4(dO + row * lddo + lane * 8), o1 = ld4(dO + row * lddo + lane * 8 + 4);
+    float s[LA_WMAX], dp[LA_WMAX];
+    float m = -INFINITY;
+    for (int j = 0; j < W; ++j) {
+        const int tj = t + j - HW;
+        s[j] = -INFINITY;
+        dp[j] = 0.f;
+        if (tj < 0 || tj >= T) continue;
+        const float* kr = k + (row + j - HW) * ld + lane * 8;
+        const float* vr = v + (row + j - HW) * ld + lane * 8;
+        const float d = head_sum<GROUP>(dot8(q0, q1, ld4(kr), ld4(kr + 4))) * scale;
+        dp[j] = head_sum<GROUP>(dot8(o0, o1, ld4(vr), ld4(vr + 4)));
+        s[j] = d + (mask[row + j - HW] ? 0.f : -1e4f);
+        m = fmaxf(m, s[j]);
+    }
+    float den = 0.f;
+    for (int j = 0; j < W; ++j) { s[j] = __expf(s[j] - m); den += s[j]; }
+    const float inv = 1.0f / den;
+    float dsum = 0.f;
+    for (int j = 0; j < W; ++j) { s[j] *= inv; dsum = fmaf(s[j], dp[j], dsum); }
+    for (int j = 0; j < W; ++j) {
+        const float ds = s[j] * (dp[j] - dsum);
+        if (lane % GROUP == 0) Pr[j] = s[j], dSr[j] = ds;
+        const int tj = t + j - HW;
+        if (tj < 0 || tj >= T) continue;
+        const float* kr = k + (row + j - HW) * ld + lane * 8;
+        const float4 k0 = ld4(kr), k1 = ld4(kr + 4);
+        const float f = ds * scale;
+        g0.x = fmaf(f, k0.x, g0.x); g0.y = fmaf(f, k0.y, g0.y); g0.z = fmaf(f, k0.z, g0.z); g0.w = fmaf(f, k0.w, g0.w);
+        g1.x = fmaf(f, k1.x, g1.x); g1.y = fmaf(f, k1.y, g1.y); g1.z = fmaf(f, k1.z, g1.z); g1.w = fmaf(f, k1.w, g1.w);
+    }
+    st4(dq + row * lddq + lane * 8, g0);
+    st4(dq + row * lddq + lane * 8 + 4, g1);
+}
+template <int GROUP>
+__global__ __launch_bounds__(256) void local_attn_bwd_kv_kernel(const float* __restrict__ q, int64_t ld,
+                                                                const float* __restrict__ dO, int64_t lddo, int B, int T, int W,
+                                                                float scale, const float* __restrict__ P,
+                                                                const float* __restrict__ dS, float* __restrict__ dk,
+                                                                float* __restrict__ dv, int64_t lddkv) {
+    const int HW = W / 2;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // key row j
+    if (row >= (int64_t)B * T) return;
+    const int tj = (int)(row % T);
+    constexpr int H = 64 / GROUP;
+    const int head = lane / GROUP;
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, c0 = a0, c1 = a0;
+    for (int i = 0; i < W; ++i) {           // query t = tj + HW - i sees key tj at window position i
+        const int t = tj + HW - i;
+        if (t < 0 || t >= T) continue;
+        const int64_t qr = row + HW - i;
+        const float p = P[(qr * H + head) * W + i], ds = dS[(qr * H + head) * W + i] * scale;
+        const float4 q0 = ld4(q + qr * ld + lane * 8), q1 = ld4(q + qr * ld + lane * 8 + 4);
+        const float4 o0 = ld4(dO + qr * lddo + lane * 8), o1 = ld4(dO + qr * lddo + lane * 8 + 4);
+        a0.x = fmaf(ds, q0.x, a0.x); a0.y = fmaf(ds, q0.y, a0.y); a0.z = fmaf(ds, q0.z, a0.z); a0.w = fmaf(ds, q0.w, a0.w);
+        a1.x = fmaf(ds, q1.x, a1.x); a1.y = fmaf(ds, q1.y, a1.y); a1.z = fmaf(ds, q1.z, a1.z); a1.w = fmaf(ds, q1.w, a1.w);
+        c0.x = fmaf(p, o0.x, c0.x); c0.y = fmaf(p, o0.y, c0.y); c0.z = fmaf(p, o0.z, c0.z); c0.w = fmaf(p, o0.w, c0.w);
+        c1.x = fmaf(p, o1.x, c1.x); c1.y = fmaf(p, o1.y, c1.y); c1.z = fmaf(p, o1.z, c1.z); c1.w = fmaf(p, o1.w, c1.w);
+    }
+    st4(dk + row * lddkv + lane * 8, a0);
+    st4(dk + row * lddkv + lane * 8 + 4, a1);
+    st4(dv + row * lddkv + lane * 8, c0);
+    st4(dv + row * lddkv + lane * 8 + 4, c1);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// global attention backward, scores: one wave per (b, h, tq).  P = softmax_j(scale q.k_j | kv_mask (masked: -inf)),
+// dP_j = dO . v_j, dS = P * (dP - sum P dP).  Lane j handles keys j, j + 64, ...; q and dO rows sit in LDS.
+// (models/local_transformer.py:163-183; the predictor's 9-query attention :44-63 runs through the same kernel)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int AB_HD_MAX = 128, AB_TK_MAX = 1024;
+__global__ __launch_bounds__(256) void attn_bwd_probs_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                             const float* __restrict__ v, int64_t ldkv,
+                                                             const float* __restrict__ dO, int64_t lddo,
+                                                             const uint8_t* __restrict__ kv_mask, int B, int Tq, int Tk, int H,
+                                                             int hd, float scale, float* __restrict__ P, float* __restrict__ dS) {
+    __shared__ float qs[4][AB_HD_MAX], os[4][AB_HD_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;          // (b, h, tq)
+    const bool live = w < (int64_t)B * H * Tq;
+    const int tq = live ? (int)(w % Tq) : 0;
+    const int h = live ? (int)((w / Tq) % H) : 0;
+    const int b = live ? (int)(w / ((int64_t)Tq * H)) : 0;
+    if (live)
+        for (int d = lane; d < hd; d += 64) {
+            qs[wave][d] = q[((int64_t)b * Tq + tq) * ldq + h * hd + d] * scale;
+            os[wave][d] = dO[((int64_t)b * Tq + tq) * lddo + h * hd + d];
+        }
+    __syncthreads();
+    if (!live) return;
+    constexpr int NJ = AB_TK_MAX / 64;
+    float s[NJ], dp[NJ];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int j = lane + 64 * i;
+        s[i] = -INFINITY;
+        dp[i] = 0.f;
+        if (j >= Tk) continue;
+        if (kv_mask && !kv_mask[(int64_t)b * Tk + j]) continue;
+        const float* kr = k + ((int64_t)b * Tk + j) * ldkv + h * hd;
+        const float* vr = v + ((int64_t)b * Tk + j) * ldkv + h * hd;
+        float a = 0.f, c = 0.f;
+        for (int d = 0; d < hd; d += 4) {
+            const float4 kk = ld4(kr + d), vv = ld4(vr + d);
+            a += qs[wave][d] * kk.x + qs[wave][d + 1] * kk.y + qs[wave][d + 2] * kk.z + qs[wave][d + 3] * kk.w;
+            c += os[wave][d] * vv.x + os[wave][d + 1] * vv.y + os[wave][d + 2] * vv.z + os[wave][d + 3] * vv.w;
+        }
+        s[i] = a;
+        dp[i] = c;
+        m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        s[i] = (m == -INFINITY || s[i] == -INFINITY) ? 0.f : __expf(s[i] - m);
+        den += s[i];
+    }
+    den = vrd::wave_sum(den);
+    const float inv = den > 0.f ? 1.0f / den : 0.f;
+    float dsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) { s[i] *= inv; dsum = fmaf(s[i], dp[i], dsum); }
+    dsum = vrd::wave_sum(dsum);
+    float* const Pr = P + w * Tk;
+    float* const dSr = dS + w * Tk;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int j = lane + 64 * i;
+        if (j < Tk) { Pr[j] = s[i]; dSr[j] = s[i] * (dp[i] - dsum); }
+    }
+}
+
+// C[z][i][n] (= or +=) alpha * sum_k A[z][i][k] * B[z][k][n];  z = (z0, z1) with z1 < Z1; every operand addressed by
+// (offset of z0, offset of z1, stride of the row index, stride of the column index), in floats.  thread = (i, n), n
+// fastest: choose the operand roles so that B and C are contiguous along n.  K loop in registers, no staging.
+struct BmmArgs {
+    const float *A, *B;
+    float* C;
+    int64_t a0, a1, ai, ak;
+    int64_t b0, b1, bk, bn;
+    int64_t c0, c1, ci, cn;
+    int Z0, Z1, M, N, K;
+    float alpha;
+    int accumulate;
+};
+__global__ __launch_bounds__(256) void bmm_kernel(BmmArgs p) {
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int z = blockIdx.z;
+    if (n >= p.N || i >= p.M) return;
+    const int z0 = z / p.Z1, z1 = z - z0 * p.Z1;
+    const float* a = p.A + z0 * p.a0 + z1 * p.a1 + i * p.ai;
+    const float* b = p.B + z0 * p.b0 + z1 * p.b1 + n * p.bn;
+    float s = 0.f;
+    for (int k = 0; k < p.K; ++k) s = fmaf(a[k * p.ak], b[k * p.bk], s);
+    float* c = p.C + z0 * p.c0 + z1 * p.c1 + i * p.ci + n * p.cn;
+    *c = p.accumulate ? *c + p.alpha * s : p.alpha * s;
+}
+
+// MaxPool1d(3, 2, 1)(x) * mask[::2] backward: dx[b, ti, c] = sum over the (1 or 2) windows holding ti in which ti is the
+// FIRST maximum (ATen's tie rule) of mask[2 to] * dy[b, to, c]
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                          int64_t lddy, int B, int Tin, int C, const uint8_t* __restrict__ mask_in,
+                                                          float* __restrict__ dx, int64_t lddx) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)B * Tin * C) return;
+    const int c = (int)(idx % C);
+    const int64_t r = idx / C;
+    const int b = (int)(r / Tin), ti = (int)(r - (int64_t)b * Tin);
+    const int Tout = Tin / 2;
+    const float xv = x[r * ldx + c];
+    float g = 0.f;
+    // windows: to with 2 to - 1 <= ti <= 2 to + 1
+    for (int to = (ti + 1) / 2 - ((ti & 1) ? 1 : 0); to <= (ti + 1) / 2; ++to) {
+        if (to < 0 || to >= Tout) continue;
+        if (!mask_in[(int64_t)b * Tin + 2 * to]) continue;
+        bool first_max = true;
+        for (int tt = 2 * to - 1; tt <= 2 * to + 1; ++tt) {
+            if (tt < 0 || tt >= Tin || tt == ti) continue;
+            const float o = x[((int64_t)b * Tin + tt) * ldx + c];
+            if (o > xv || (o == xv && tt < ti)) first_max = false;
+        }
+        if (first_max) g += dy[((int64_t)b * Tout + to) * lddy + c];
+    }
+    dx[r * lddx + c] = g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
+                   int taps, int T, float* dW, void* stream) {
+    VRD_CHECK_ARG(G && X && dW, "vrd_gemm_wgrad: null pointer");
+    VRD_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && (taps == 1 || taps == 3), "vrd_gemm_wgrad: bad sizes M=%lld N=%d Cin=%d taps=%d", (long long)M, N, Cin, taps);
+    VRD_CHECK_ARG(ldg >= N && ldx >= Cin, "vrd_gemm_wgrad: leading dimension too small");
+    VRD_CHECK_ARG(T > 0 && M % T == 0, "vrd_gemm_wgrad: M (%lld) must be a multiple of T (%d)", (long long)M, T);
+    const int K = Cin * taps;
+    const int tiles_n = (N + 31) / 32, tiles_k = (K + 31) / 32;
+    const int64_t chunks = (M + 4 * WG_CHUNK - 1) / (4 * WG_CHUNK);
+    VRD_CHECK_ARG(chunks <= 65535, "vrd_gemm_wgrad: too many rows (%lld)", (long long)M);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * (double)M * N * K, 4.0 * ((double)M * (N + Cin) + (double)N * K));
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles_n * tiles_k, (unsigned)chunks), dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin, taps, T,
+                       tiles_k, dW);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_cstride, int b_coffset, int b_rstride, int shift,
+               int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, void* stream) {
+    VRD_CHECK_ARG(a && out && rows > 0 && C > 0 && lda >= C, "vrd_colsum: bad arguments");
+    VRD_CHECK_ARG(!b || (T > 0 && rows % T == 0 && b_cstride >= 1 && b_rstride >= 1 && b_coffset >= 0 && b_coffset < b_cstride),
+                  "vrd_colsum: bad second operand (T=%d rows=%lld)", T, (long long)rows);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * (b ? 2 : 1));
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (C + 255) / 256), dim3(256), 0, s, a, lda, b, ldb,
+                       b ? b_cstride : 1, b ? b_coffset : 0, b ? b_rstride : 1, shift, b ? T : 1, row_mask, row_scale, rows, C, out);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_rowcol_scale(const float* v, int64_t ldv, int64_t rows, int C, const float* col_scale, const float* row_scale,
+                     const uint8_t* row_mask, const float* res, int64_t ldres, int res_masked, const float* res2, int64_t ldres2,
+                     float* out, int64_t ldo, void* stream) {
+    VRD_CHECK_ARG(v && out && rows > 0 && C > 0 && C % 4 == 0, "vrd_rowcol_scale: bad arguments (C %% 4 == 0 required)");
+    VRD_CHECK_ARG(ldv >= C && ldo >= C && ldv % 4 == 0 && ldo % 4 == 0 && aligned16(v) && aligned16(out) && aligned16(col_scale),
+                  "vrd_rowcol_scale: rows must be 16-byte aligned");
+    VRD_CHECK_ARG(!res || (ldres >= C && ldres % 4 == 0 && aligned16(res)), "vrd_rowcol_scale: bad res layout");
+    VRD_CHECK_ARG(!res2 || (ldres2 >= C && ldres2 % 4 == 0 && aligned16(res2)), "vrd_rowcol_scale: bad res2 layout");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * (2 + (res ? 1 : 0) + (res2 ? 1 : 0)));
+    const int64_t n = rows * (C / 4);
+    hipLaunchKernelGGL(rowcol_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, ldv, rows, C / 4, col_scale, row_scale,
+                       row_mask, res, ldres, res_masked, res2, ldres2, out, ldo);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_activation(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int C, int act, float* out, int64_t ldo,
+            void* stream) {
+    VRD_CHECK_ARG(x && out && rows > 0 && C > 0 && C % 4 == 0, "vrd_activation: bad arguments (C %% 4 == 0 required)");
+    VRD_CHECK_ARG(act == VRD_ACT_RELU || act == VRD_ACT_GELU, "vrd_activation: activation must be ReLU or GELU");
+    VRD_CHECK_ARG(ldx >= C && ldo >= C && ldx % 4 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(out), "vrd_activation: bad layout");
+    VRD_CHECK_ARG(!dy || (lddy >= C && lddy % 4 == 0 && aligned16(dy)), "vrd_activation: bad dy layout");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * (dy ? 3 : 2));
+    const int64_t n = rows * (C / 4);
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, dy, lddy, rows, C / 4, act, out, ldo);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int C, const float* gamma,
+                      const float* beta, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream) {
+    VRD_CHECK_ARG(x && dy && gamma && beta && dx && dgamma && dbeta, "vrd_layernorm_bwd: null pointer");
+    VRD_CHECK_ARG(C == 256 || C == 512, "vrd_layernorm_bwd: C must be 256 or 512 (got %d)", C);
+    VRD_CHECK_ARG(ldx >= C && lddy >= C && lddx >= C && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && aligned16(x) && aligned16(dy) &&
+                      aligned16(dx) && aligned16(gamma) && aligned16(beta),
+                  "vrd_layernorm_bwd: rows must be 16-byte aligned");
+    if (rows <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 12.0 * (double)rows * C);
+    dim3 grid((unsigned)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)));
+    if (C == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_dwconv_bwd(const vrd_dwconv_bwd_args* a, void* stream) {
+    VRD_CHECK_ARG(a && a->dx, "vrd_dwconv_bwd: null args");
+    VRD_CHECK_ARG(a->n_out >= 1 && a->n_out <= 3 && a->B > 0 && a->Tin > 0 && a->C > 0, "vrd_dwconv_bwd: bad sizes");
+    VRD_CHECK_ARG((a->ksize == 1 || a->ksize == 3) && (a->stride == 1 || a->stride == 2) && (a->group_in == 1 || a->group_in == 2) &&
+                      a->Tin % a->stride == 0,
+                  "vrd_dwconv_bwd: ksize 1/3, stride 1/2, group_in 1/2, Tin %% stride == 0");
+    VRD_CHECK_ARG(!a->dx_up || (a->Tin % 2 == 0 && a->lddx_up >= (int64_t)a->C * a->group_in), "vrd_dwconv_bwd: bad dx_up");
+    VRD_CHECK_ARG(a->lddx >= (int64_t)a->C * a->group_in, "vrd_dwconv_bwd: lddx too small");
+    DwBwdArgs p{};
+    for (int o = 0; o < a->n_out; ++o) {
+        VRD_CHECK_ARG(a->dD[o] && a->w[o] && a->lddd[o] >= a->C, "vrd_dwconv_bwd: bad set %d", o);
+        p.dD[o] = a->dD[o], p.lddd[o] = a->lddd[o], p.w[o] = a->w[o];
+    }
+    p.n_out = a->n_out, p.B = a->B, p.Tin = a->Tin, p.C = a->C, p.ksize = a->ksize, p.stride = a->stride, p.gin = a->group_in;
+    p.mask_out = a->mask_out, p.dx = a->dx, p.lddx = a->lddx, p.dx_up = a->dx_up, p.lddx_up = a->lddx_up;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)a->B * (a->dx_up ? a->Tin / 2 : a->Tin) * a->C * a->group_in;
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)a->B * a->Tin * a->C * (a->group_in + a->n_out));
+    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_local_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dO, int64_t lddo,
+                       const uint8_t* mask, int B, int T, int C, int n_head, int half_win, float* dq, float* dk, float* dv,
+                       int64_t ldd, float* scratch, void* stream) {
+    VRD_CHECK_ARG(q && k && v && dO && mask && dq && dk && dv && scratch, "vrd_local_attn_bwd: null pointer");
+    VRD_CHECK_ARG(C == 512 && (n_head == 4 || n_head == 8), "vrd_local_attn_bwd: built for C = 512 with 4 or 8 heads");
+    const int W = 2 * half_win + 1;
+    VRD_CHECK_ARG(half_win >= 1 && W <= LA_WMAX, "vrd_local_attn_bwd: window %d not supported (max %d)", W, LA_WMAX);
+    VRD_CHECK_ARG(ld % 4 == 0 && lddo % 4 == 0 && ldd % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(dO) &&
+                      aligned16(dq) && aligned16(dk) && aligned16(dv),
+                  "vrd_local_attn_bwd: rows must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t rows = (int64_t)B * T;
+    const float scale = 1.0f / sqrtf((float)(C / n_head));
+    float* P = scratch;
+    float* dS = scratch + rows * n_head * W;
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * 8);
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (n_head == 4) {
+        hipLaunchKernelGGL(local_attn_bwd_q_kernel<16>, grid, dim3(256), 0, s, q, k, v, ld, dO, lddo, mask, B, T, W, scale, dq, ldd, P, dS);
+        hipLaunchKernelGGL(local_attn_bwd_kv_kernel<16>, grid, dim3(256), 0, s, q, ld, dO, lddo, B, T, W, scale, P, dS, dk, dv, ldd);
+    } else {
+        hipLaunchKernelGGL(local_attn_bwd_q_kernel<8>, grid, dim3(256), 0, s, q, k, v, ld, dO, lddo, mask, B, T, W, scale, dq, ldd, P, dS);
+        hipLaunchKernelGGL(local_attn_bwd_kv_kernel<8>, grid, dim3(256), 0, s, q, ld, dO, lddo, B, T, W, scale, P, dS, dk, dv, ldd);
+    }
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_attn_bwd_probs(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dO, int64_t lddo,
+                       const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim, float* P, float* dS, void* stream) {
+    VRD_CHECK_ARG(q && k && v && dO && P && dS, "vrd_attn_bwd_probs: null pointer");
+    VRD_CHECK_ARG(B > 0 && Tq > 0 && Tk > 0 && Tk <= AB_TK_MAX && n_head > 0 && head_dim > 0 && head_dim <= AB_HD_MAX && head_dim % 4 == 0,
+                  "vrd_attn_bwd_probs: Tk <= %d, head_dim <= %d and %% 4 == 0 (got Tk %d, head_dim %d)", AB_TK_MAX, AB_HD_MAX, Tk, head_dim);
+    VRD_CHECK_ARG(ldkv % 4 == 0 && aligned16(k) && aligned16(v), "vrd_attn_bwd_probs: k / v rows must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)B * n_head * Tq;
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 4.0 * (double)n * Tk * head_dim, 8.0 * (double)n * Tk);
+    hipLaunchKernelGGL(attn_bwd_probs_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, q, ldq, k, v, ldkv, dO, lddo, kv_mask, B, Tq, Tk,
+                       n_head, head_dim, 1.0f / sqrtf((float)head_dim), P, dS);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_bmm(const vrd_bmm_args* a, void* stream) {
+    VRD_CHECK_ARG(a && a->A && a->B && a->C, "vrd_bmm: null pointer");
+    VRD_CHECK_ARG(a->Z0 > 0 && a->Z1 > 0 && a->M > 0 && a->N > 0 && a->K > 0 && (int64_t)a->Z0 * a->Z1 <= 65535 && (a->M + 3) / 4 <= 65535,
+                  "vrd_bmm: bad sizes");
+    BmmArgs p;
+    p.A = a->A, p.B = a->B, p.C = a->C;
+    p.a0 = a->a_z0, p.a1 = a->a_z1, p.ai = a->a_row, p.ak = a->a_col;
+    p.b0 = a->b_z0, p.b1 = a->b_z1, p.bk = a->b_row, p.bn = a->b_col;
+    p.c0 = a->c_z0, p.c1 = a->c_z1, p.ci = a->c_row, p.cn = a->c_col;
+    p.Z0 = a->Z0, p.Z1 = a->Z1, p.M = a->M, p.N = a->N, p.K = a->K, p.alpha = a->alpha, p.accumulate = a->accumulate;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * a->Z0 * a->Z1 * (double)a->M * a->N * a->K, 0.0);
+    hipLaunchKernelGGL(bmm_kernel, dim3((a->N + 63) / 64, (a->M + 3) / 4, a->Z0 * a->Z1), dim3(256), 0, s, p);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_maxpool_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int B, int Tin, int C, const uint8_t* mask_in, float* dx,
+                    int64_t lddx, void* stream) {
+    VRD_CHECK_ARG(x && dy && mask_in && dx && B > 0 && Tin > 0 && Tin % 2 == 0 && C > 0, "vrd_maxpool_bwd: bad arguments");
+    VRD_CHECK_ARG(ldx >= C && lddy >= C && lddx >= C, "vrd_maxpool_bwd: leading dimension too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)B * Tin * C;
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)n * 2.5);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, dy, lddy, B, Tin, C, mask_in, dx, lddx);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -10,7 +10,7 @@ materialised -- producers write into column slabs of the consumer's input buffer
 import torch
 from torch import nn
 
-from .blocks import ConvMLP, LayerNorm, MaskedConv1D, TransformerBlock, _from_cl, _mask2d, _no_autograd, _ops
+from .blocks import ConvMLP, LayerNorm, MaskedConv1D, TransformerBlock, _from_cl, _mask2d, _ops
 from .local_transformer import MaskedConvTransformerDecoderLayer
 
 
@@ -131,33 +131,34 @@ class MaskConvTransformerBackbone(nn.Module):
         cat = (lambda t: ops.Pair(t, D)) if pair else (lambda t: t)          # noqa: E731
 
         # [visual (+clip) | entity box] -> visual_bbox_fuse
+        # (ops.join: the slab-filled buffer, or -- under autograd, where ops return fresh tensors -- the concatenation)
         fuse_in = new(2 * B, T, 2 * D)
         if Cc:
             vc = new(2 * B, T, 2 * D)
-            self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
-            self._embed(clip, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
-            self.visual_clip_fuse.cl(cat(vc), row_mask=mask2, out=fuse_in[..., :D], out_pair=pair)
+            a = self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
+            b = self._embed(clip, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
+            a = self.visual_clip_fuse.cl(cat(ops.join(vc, (a, b))), row_mask=mask2, out=fuse_in[..., :D], out_pair=pair)
         else:
-            self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
-        self._embed(ent, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
-        so = self.visual_bbox_fuse.cl(cat(fuse_in), row_mask=mask2)         # (2B, T, D): subject rows then object rows
+            a = self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
+        b = self._embed(ent, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
+        so = self.visual_bbox_fuse.cl(cat(ops.join(fuse_in, (a, b))), row_mask=mask2)   # (2B, T, D): subject rows then object rows
 
         for stem, s_attn, o_attn in zip(self.stem, self.s_attn, self.o_attn):
             so, _ = stem.cl(so, mask2)
             s, o = so[:B], so[B:]
             nxt = new(2 * B, T, D)
-            s_attn.cl(s, o, mask, mask, stream_add=s, out=nxt[:B])         # s + s_attn(s, o)
-            o_attn.cl(o, s, mask, mask, stream_add=o, out=nxt[B:])         # uses the pre-update s
-            so = nxt
+            s2, _ = s_attn.cl(s, o, mask, mask, stream_add=s, out=nxt[:B])         # s + s_attn(s, o)
+            o2, _ = o_attn.cl(o, s, mask, mask, stream_add=o, out=nxt[B:])         # uses the pre-update s
+            so = ops.join(nxt, (s2, o2), dim=0)
 
         so_in = new(B, T, 2 * D)
-        self.s_fuse_norm.cl(so[:B], out=so_in[..., :D], pair=pair)
-        self.o_fuse_norm.cl(so[B:], out=so_in[..., D:], pair=pair)
+        a = self.s_fuse_norm.cl(so[:B], out=so_in[..., :D], pair=pair)
+        b = self.o_fuse_norm.cl(so[B:], out=so_in[..., D:], pair=pair)
         pair_box = new(B, T, 2 * D)
-        self.so_fuse.cl(cat(so_in), row_mask=mask, out=pair_box[..., :D], out_pair=pair)
+        a = self.so_fuse.cl(cat(ops.join(so_in, (a, b))), row_mask=mask, out=pair_box[..., :D], out_pair=pair)
         conv = self.bbox_so_embd.conv
-        ops.conv_gemm(so_box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:], out_pair=pair)
-        e = self.so_visual_bbox_fuse.cl(cat(pair_box), row_mask=mask)
+        b = ops.conv_gemm(so_box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:], out_pair=pair)
+        e = self.so_visual_bbox_fuse.cl(cat(ops.join(pair_box, (a, b))), row_mask=mask)
 
         feats, masks = [e], [mask]
         for blk in self.branch:
@@ -167,7 +168,6 @@ class MaskConvTransformerBackbone(nn.Module):
         return feats, masks
 
     def forward(self, x, mask):
-        _no_autograd(self)
         feats, masks = self.cl(x, _mask2d(mask))
         return tuple(_from_cl(f) for f in feats), tuple(m[:, None, :] for m in masks)
 

@@ -8,8 +8,9 @@ Two call forms per module:
     masks (a layout change is done around the channels-last core; used by module-level tests),
   * ``cl(...)``       the channels-last core on ``(B, T, C)`` tensors / ``(B, T)`` masks that
     MaskVRD chains end to end without any transposes.
-Eval only for now: the kernels have no backward, so a forward under autograd in training mode
-raises instead of silently detaching.
+Under torch.no_grad() (eval, validation) the modules run the fused inference kernels; with autograd recording
+they run the differentiable composition of vrdone_amd/autograd.py (HIP forward and backward kernels, plain f32 rows),
+and in training mode AffineDropPath samples its per-sample keep factors (reference blocks.py:1107-1120).
 """
 import math
 
@@ -22,12 +23,6 @@ from .transformer import _get_activation_fn  # noqa: F401  (re-exported like the
 def _ops():
     from .. import ops      # deferred: constructing / loading a model needs no GPU
     return ops
-
-
-def _no_autograd(module):
-    if module.training and torch.is_grad_enabled():
-        raise NotImplementedError(
-            f"{type(module).__name__}: the HIP path is forward-only for now (call .eval() / no_grad)")
 
 
 def _mask2d(mask):
@@ -72,7 +67,6 @@ class MaskedConv1D(nn.Module):
         return y, m_out
 
     def forward(self, x, mask, downsample=True):
-        _no_autograd(self)
         assert downsample or self.stride == 1
         y, m = self.cl(_to_cl(x), _mask2d(mask))
         return _from_cl(y), m[:, None, :]
@@ -94,7 +88,6 @@ class LayerNorm(nn.Module):
         return _ops().layernorm(x, self.weight, self.bias, relu=relu, post_add=post_add, out=out, pair=pair)
 
     def forward(self, x):
-        _no_autograd(self)
         assert x.dim() == 3 and x.shape[1] == self.num_channels
         return _from_cl(self.cl(_to_cl(x)))
 
@@ -125,7 +118,6 @@ class ConvMLP(nn.Module):
         return x
 
     def forward(self, x):
-        _no_autograd(self)
         return _from_cl(self.cl(_to_cl(x)))
 
 
@@ -137,10 +129,28 @@ class AffineDropPath(nn.Module):
         super().__init__()
         self.scale = nn.Parameter(init_scale_value * torch.ones(1, num_dim, 1))
         self.drop_prob = drop_prob
+        self.keep = None            # tests may pin the per-sample keep decisions: a (B,) 0/1 tensor used instead of sampling
+
+    def row_factors(self, n_samples, rows_per_sample, device):
+        """Stochastic depth per sample (reference drop_path, blocks.py:1107-1120): factor_b = floor(keep_prob + U[0,1))
+        / keep_prob, one per sample, expanded to one per row of the (n_samples * rows_per_sample, C) branch; None when
+        nothing is dropped (eval, drop_prob 0, or autograd not recording)."""
+        if not self.training or self.drop_prob == 0.0 or not torch.is_grad_enabled():
+            return None
+        keep_prob = 1.0 - self.drop_prob
+        if self.keep is not None:
+            keep = self.keep.to(device=device, dtype=torch.float32)
+            assert keep.shape == (n_samples,)
+        else:
+            keep = torch.floor(keep_prob + torch.rand(n_samples, device=device))
+        return (keep / keep_prob)[:, None].expand(n_samples, rows_per_sample).contiguous().view(-1)
 
     def forward(self, x):
-        _no_autograd(self)
-        return x * self.scale
+        """(B, C, T) * scale, with the training-time drop (plain tensor arithmetic: the hot path applies scale and
+        factors inside the output-projection / MLP GEMM's epilogue instead, see TransformerBlock.cl)."""
+        y = x * self.scale
+        rf = self.row_factors(x.shape[0], 1, x.device)
+        return y if rf is None else y * rf.view(-1, 1, 1)
 
 
 class Scale(nn.Module):
@@ -241,7 +251,6 @@ class LocalMaskedMHCA(_ConvAttention):
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
 
     def forward(self, x, mask):
-        _no_autograd(self)
         y, m = self.cl(_to_cl(x), _mask2d(mask))
         return _from_cl(y), m[:, None, :]
 
@@ -270,7 +279,6 @@ class MaskedMHA(nn.Module):
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=q_mask, **epilogue), q_mask
 
     def forward(self, x, mask):
-        _no_autograd(self)
         m = _mask2d(mask)
         xc = _to_cl(x)
         y, _ = self.cl_qkv(xc, xc, xc, m, m)
@@ -310,6 +318,11 @@ class TransformerBlock(nn.Module):
     def _scale(dp):
         return dp.scale if isinstance(dp, AffineDropPath) else None
 
+    @staticmethod
+    def _drop(dp, mask):
+        """Per-row stochastic-depth factors of a branch whose rows follow `mask` (B, T'), or None."""
+        return dp.row_factors(mask.shape[0], mask.shape[1], mask.device) if isinstance(dp, AffineDropPath) else None
+
     def cl(self, x, mask, out=None):
         ops = _ops()
         if self.attn.n_kv_stride > 1:
@@ -318,15 +331,15 @@ class TransformerBlock(nn.Module):
             skip, m_out = x, mask
         # ln1 is applied to the rows inside the depthwise-conv kernel (its only consumer)
         y, _ = self.attn.cl(x, mask, m_out, pre_ln=(self.ln1.weight, self.ln1.bias),
-                            scale=self._scale(self.drop_path_attn), res=skip, res_masked=True)
+                            scale=self._scale(self.drop_path_attn), row_scale=self._drop(self.drop_path_attn, m_out),
+                            res=skip, res_masked=True)
         h = self.ln2.cl(y, pair=ops.pair_mode())
         h = ops.conv_gemm(h, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU, out_pair=ops.pair_mode(), skip_rows=m_out)
-        y = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=m_out,
-                          scale=self._scale(self.drop_path_mlp), res=y, out=out)
+        y = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=m_out, scale=self._scale(self.drop_path_mlp),
+                          row_scale=self._drop(self.drop_path_mlp, m_out), res=y, out=out)
         return y, m_out
 
     def forward(self, x, mask, pos_embd=None):
-        _no_autograd(self)
         assert pos_embd is None
         y, m = self.cl(_to_cl(x), _mask2d(mask))
         return _from_cl(y), m[:, None, :]

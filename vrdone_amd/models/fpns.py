@@ -8,7 +8,7 @@ mask-feature map.  Same constructor and parameter tree as the reference's FPN1D_
 """
 from torch import nn
 
-from .blocks import LayerNorm, MaskedConv1D, _from_cl, _mask2d, _no_autograd, _ops, _to_cl
+from .blocks import LayerNorm, MaskedConv1D, _from_cl, _mask2d, _ops, _to_cl
 
 
 class FPN1D_Fuse(nn.Module):
@@ -56,7 +56,6 @@ class FPN1D_Fuse(nn.Module):
         return out, masks[0]
 
     def forward(self, inputs, fpn_masks):
-        _no_autograd(self)
         assert len(inputs) == len(self.in_channels) == len(fpn_masks)
         out, m = self.cl([_to_cl(x) for x in inputs], [_mask2d(m) for m in fpn_masks])
         return _from_cl(out), m[:, None, :]

@@ -7,7 +7,7 @@ from typing import Optional
 import torch
 from torch import nn, Tensor
 
-from .blocks import (AffineDropPath, LayerNorm, MaskedMHA, _ConvAttention, _from_cl, _mask2d, _no_autograd, _ops,
+from .blocks import (AffineDropPath, LayerNorm, MaskedMHA, _ConvAttention, _from_cl, _mask2d, _ops,
                      _to_cl)
 from .transformer import _get_clones
 
@@ -16,7 +16,6 @@ class MaskedMHA_QKV(MaskedMHA):
     """Separate q/k/v inputs, plain 1x1 projections; reference models/local_transformer.py:13-67."""
 
     def forward(self, q, k, v, _qx_mask, _kv_mask, _attn_mask=None):
-        _no_autograd(self)
         assert _attn_mask is None
         y, _ = self.cl_qkv(_to_cl(q), _to_cl(k), _to_cl(v), _mask2d(_qx_mask), _mask2d(_kv_mask))
         return _from_cl(y), _qx_mask
@@ -54,7 +53,6 @@ class MaskedMHCA_QKV(_ConvAttention):
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=q_mask, **epilogue), q_mask
 
     def forward(self, q, k, v, _qx_mask, _kv_mask, _attn_mask=None):
-        _no_autograd(self)
         assert _attn_mask is None
         qc = _to_cl(q)
         kc = qc if k is q else _to_cl(k)
@@ -124,6 +122,11 @@ class MaskedConvTransformerDecoderLayer(nn.Module):
     def _scale(dp):
         return dp.scale if isinstance(dp, AffineDropPath) else None
 
+    @staticmethod
+    def _drop(dp, tgt):
+        """Per-row stochastic-depth factors for a branch shaped like tgt (B, Tq, C), or None."""
+        return dp.row_factors(tgt.shape[0], tgt.shape[1], tgt.device) if isinstance(dp, AffineDropPath) else None
+
     def cl(self, tgt, memory, tgt_mask, memory_mask, query_pos=None, stream_add=None, out=None):
         """tgt (B, Tq, C), memory (B, Tk, C); masks (B, T) or None (= all valid).  query_pos: (Tq, C)
         rows added to the normalised target.  stream_add: extra tensor added to the cross-attention
@@ -136,13 +139,14 @@ class MaskedConvTransformerDecoderLayer(nn.Module):
         last = not self.with_ffn
         if fuse1:
             tgt, _ = self.self_attn.cl_qkv(tgt, tgt, tgt, tgt_mask, tgt_mask, pre_ln=(self.ln1.weight, self.ln1.bias),
-                                           pre_ln_on="qk", scale=self._scale(self.drop_path_attn1), res=tgt, res_masked=True)
+                                           pre_ln_on="qk", scale=self._scale(self.drop_path_attn1),
+                                           row_scale=self._drop(self.drop_path_attn1, tgt), res=tgt, res_masked=True)
         else:
             t2 = self.ln1.cl(tgt, post_add=query_pos)
             tgt, _ = self.self_attn.cl_qkv(t2, t2, tgt, tgt_mask, tgt_mask, scale=self._scale(self.drop_path_attn1),
-                                           res=tgt, res_masked=True)
-        kw = dict(scale=self._scale(self.drop_path_attn2), res=tgt, res_masked=True,
-                  res2=stream_add if last else None, out=out if last else None)
+                                           row_scale=self._drop(self.drop_path_attn1, tgt), res=tgt, res_masked=True)
+        kw = dict(scale=self._scale(self.drop_path_attn2), row_scale=self._drop(self.drop_path_attn2, tgt), res=tgt,
+                  res_masked=True, res2=stream_add if last else None, out=out if last else None)
         if fuse2:
             tgt, _ = self.multihead_attn.cl_qkv(tgt, memory, memory, tgt_mask, memory_mask,
                                                 pre_ln=(self.ln2.weight, self.ln2.bias), pre_ln_on="q", **kw)
@@ -153,14 +157,13 @@ class MaskedConvTransformerDecoderLayer(nn.Module):
             assert stream_add is None
             t2 = self.ln3.cl(tgt)
             h = ops.conv_gemm(t2, self.mlp[0].weight, self.mlp[0].bias, act=ops.ACT_GELU)
-            tgt = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=tgt_mask,
-                                scale=self._scale(self.drop_path_mlp), res=tgt, out=out)
+            tgt = ops.conv_gemm(h, self.mlp[3].weight, self.mlp[3].bias, row_mask=tgt_mask, scale=self._scale(self.drop_path_mlp),
+                                row_scale=self._drop(self.drop_path_mlp, tgt), res=tgt, out=out)
         return tgt, tgt_mask
 
     def forward(self, tgt, memory, tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
                 pos: Optional[Tensor] = None, query_pos: Optional[Tensor] = None, cross_first: bool = False,
                 attn_mask: Optional[Tensor] = None):
-        _no_autograd(self)
         assert pos is None and not cross_first and attn_mask is None, "only the call form used on the path is built"
         qp = None
         if query_pos is not None:      # (B, C, Tq), identical over B on the path (predictor query embedding)

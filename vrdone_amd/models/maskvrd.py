@@ -3,8 +3,9 @@ checkpoint layout (models/maskvrd.py:16-167), with the relation-encoding hot pat
 hand-written HIP kernels and the eval post-processing (models/maskvrd.py:247-328) vectorised on
 the device instead of a per-candidate Python loop.
 
-Round-1 scope: inference (`model.eval()`) and the training criterion as forward values (`forward_training` under
-torch.no_grad(), `criterion`); a training step needs backward kernels and raises.
+Training: `model.train()(input_data)` returns the reference's loss dict (maskvrd.py:168-198) and
+`loss_dict['total_loss'].backward()` runs the backward kernels of vrdone_amd/autograd.py; under torch.no_grad() the same
+call is a validation pass on the fused inference kernels (no drop-path sampling).
 """
 import gc
 
@@ -13,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .backbones import MaskConvTransformerBackbone, MaskConvTransformerBackboneWithCLIP
-from .blocks import _no_autograd, _ops
+from .blocks import _ops
 from . import losses
 from .fpns import FPN1D_Fuse
 from .predictor import MaskedTransformerPredictor
@@ -97,7 +98,6 @@ class MaskVRD(nn.Module):
     def _mask_vrd(self, batched_inputs, batched_masks, with_aux=None):
         """(B, C_in, T) fp32, (B, 1, T) bool -> dict(pred_logits (B,Q,K+1), pred_masks (B,Q,T),
         [aux_outputs], output_mask (B,1,T)); backbone -> neck -> predictor like the reference."""
-        _no_autograd(self)
         if not batched_inputs.is_cuda:
             raise RuntimeError("MaskVRD._mask_vrd runs on the HIP device only; move the model and inputs to 'cuda'")
         B = batched_inputs.shape[0]
@@ -134,27 +134,24 @@ class MaskVRD(nn.Module):
         return merged
 
     def forward_training(self, input_data):
-        """Loss dict of reference maskvrd.py:169-199 as forward VALUES: batching, network, Hungarian matching and
-        the class / focal / dice losses (+ one set per auxiliary decoder layer), ending in 'total_loss'.
-        The HIP path has no backward kernels yet, so this runs only under torch.no_grad() and the network runs its
-        deterministic kernels (drop-path / dropout are not sampled): it is the loss a validation pass reports, not
-        a training step.  With autograd enabled it raises rather than return losses that cannot be differentiated."""
-        if torch.is_grad_enabled():
-            raise NotImplementedError(
-                "vrdone_amd.MaskVRD: the training step needs backward kernels for the HIP path, which this round does "
-                "not ship; call under torch.no_grad() for the loss values, or use the model in eval mode")
-        return self.forward_loss(input_data)
-
-    @torch.no_grad()
-    def forward_loss(self, input_data):
+        """Loss dict of reference maskvrd.py:169-199: batching, network, Hungarian matching and the class / focal /
+        dice losses (+ one set per auxiliary decoder layer), ending in 'total_loss'.
+        With autograd recording (a training step, train.py:182-186) the network runs the differentiable HIP ops of
+        vrdone_amd/autograd.py, AffineDropPath samples per-sample keep factors, and total_loss.backward() reaches
+        every parameter.  Under torch.no_grad() it is the validation loss on the fused inference kernels."""
         x, m = self._train_batch(input_data['so_features_list'])
         predictions = self._mask_vrd(x, m, with_aux=self.deep_supervision)
         return self.criterion(predictions, input_data)
 
     @torch.no_grad()
+    def forward_loss(self, input_data):
+        return self.forward_training(input_data)
+
     def criterion(self, predictions, input_data):
         """predictions of _mask_vrd (with aux_outputs when deep_supervision) + the dataloader's ground truth
-        (preds_list (N_i,) int64, masks_list (N_i, T) 0/1 float, segs_list (N_i, 2) int64) -> loss dict."""
+        (preds_list (N_i,) int64, masks_list (N_i, T) 0/1 float, segs_list (N_i, 2) int64) -> loss dict.  The matching
+        runs without autograd (like the reference's @torch.no_grad() matcher, maskvrd.py:417); the losses are plain
+        differentiable tensor code."""
         dev = predictions['pred_logits'].device
         gt_preds = [t.to(dev) for t in input_data['preds_list']]
         gt_masks = [t.to(dev) for t in input_data['masks_list']]

@@ -5,7 +5,7 @@ import math
 
 from torch import nn
 
-from .blocks import ConvMLP, LayerNorm, _mask2d, _no_autograd, _ops, _to_cl
+from .blocks import ConvMLP, LayerNorm, _mask2d, _ops, _to_cl
 from .local_transformer import MaskedConvTransformerDecoderOnly
 
 
@@ -57,6 +57,5 @@ class MaskedTransformerPredictor(nn.Module):
         return out
 
     def forward(self, x, mask_features, mask, output_mask, non_attn_const=(-10)):
-        _no_autograd(self)
         return self.cl(_to_cl(x), _to_cl(mask_features), _mask2d(mask), _mask2d(output_mask),
                        non_attn_const=non_attn_const)

@@ -86,12 +86,27 @@ class Pair:
 
 def flash_pair_ok(n_head, channels, Tq):
     """True when global attention of this shape runs the split-precision flash kernel on pair-row q/k/v."""
-    return _precision == "bf16x3" and channels // n_head in (64, 128) and Tq >= 32
+    return pair_mode() and channels // n_head in (64, 128) and Tq >= 32
 
 
 def pair_mode():
-    """True when producers should emit pair rows for GEMM-only consumers (bf16x3 precision)."""
-    return _precision == "bf16x3"
+    """True when producers should emit pair rows for GEMM-only consumers: bf16x3 precision and autograd not recording
+    (a differentiable forward keeps every activation as plain f32 rows, see vrdone_amd/autograd.py)."""
+    return _precision == "bf16x3" and not torch.is_grad_enabled()
+
+
+def recording(*tensors):
+    """True when autograd is recording and one of the tensors needs a gradient: the op then runs as the
+    torch.autograd.Function(s) of vrdone_amd/autograd.py (HIP kernels forward and backward)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def join(buf, parts, dim=-1):
+    """The concatenation of `parts` along `dim`: `buf`, which the producers already filled through `out=` slabs, or
+    -- under autograd, where ops return fresh tensors and ignore `out=` -- torch.cat(parts)."""
+    if torch.is_grad_enabled() and any(torch.is_tensor(q) and q.requires_grad for q in parts):
+        return torch.cat(parts, dim=dim)
+    return buf
 
 
 def _unwrap(x):
@@ -211,6 +226,9 @@ def pack_pairs(table, lens, T, V, Cc, S, E, pair_wide):
 
 def btc_to_bct(x):
     """(B, T, C) channels-last -> new (B, C, T) tensor."""
+    if recording(x):
+        from . import autograd
+        return autograd.FromChannelsLast.apply(x)
     B, T, Cc = x.shape
     p, rows, cols, ld = _rows(x)
     out = torch.empty(B, Cc, T, device=x.device, dtype=torch.float32)
@@ -220,6 +238,9 @@ def btc_to_bct(x):
 
 def to_channels_last(x):
     """(B, C, T) -> (B, T, C)."""
+    if recording(x):
+        from . import autograd
+        return autograd.ToChannelsLast.apply(x)
     B, Cc, T = x.shape
     out = torch.empty(B, T, Cc, device=x.device, dtype=torch.float32)
     return bct_to_btc(x.contiguous(), 0, Cc, out)
@@ -253,13 +274,21 @@ def row_blocks(mask):
 
 
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
-              res2=None, out=None, out_pair=False, skip_rows=None, _launch=None):
+              res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
     vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
     out_pair: write the result as pair rows of width N (returns a Pair).
     skip_rows: validity mask of the rows; aligned 32-row blocks without a valid row skip the contraction (exact with
     row_mask, which is then the default; without row_mask those rows hold bias-only filler, so pass it only where
-    no valid row ever reads a padded one: projections feeding masked attention, an MLP's hidden layer)."""
+    no valid row ever reads a padded one: projections feeding masked attention, an MLP's hidden layer).
+    row_scale (rows,): per-row factor on the branch term (stochastic depth, blocks.py:1107-1120); autograd path only.
+    Under autograd (`recording`) the op runs as autograd.conv_gemm and returns a fresh tensor (`out` is ignored)."""
+    if _launch is None and not isinstance(x, Pair) and recording(x, weight, bias, scale, res, res2):
+        from . import autograd
+        assert not out_pair
+        return autograd.conv_gemm(x, weight, bias, act=act, row_mask=row_mask, scale=scale, row_scale=row_scale, res=res,
+                                  res_masked=res_masked, res2=res2)
+    assert row_scale is None, "row_scale (drop-path sampling) exists on the autograd path only"
     N, Cin, k = weight.shape
     x, a_width = _unwrap(x)
     pa, rows, cols, lda = _rows(x)
@@ -310,6 +339,8 @@ def conv_gemm_batch(calls):
     GEMMs that differ only in input, weight, bias and output, like the q / k / v projections of an attention block, run
     as one launch.  Returns the list of results."""
     assert 1 <= len(calls) <= 4
+    if torch.is_grad_enabled():         # differentiable path: one op per projection
+        return [conv_gemm(*args, **kwargs) for args, kwargs in calls]
     collected, results = [], []
     for args, kwargs in calls:
         results.append(conv_gemm(*args, _launch=collected, **kwargs))
@@ -321,6 +352,10 @@ def conv_gemm_batch(calls):
 def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False):
     """Channel LayerNorm.  post_add: (period, C) rows added after the affine, row r gets
     post_add[r % period].  pair: write pair rows (returns a Pair)."""
+    if recording(x, gamma, beta, post_add):
+        from . import autograd
+        assert not pair
+        return autograd.layernorm(x, gamma, beta, relu=relu, post_add=post_add)
     px, rows, cols, ldx = _rows(x)
     if out is None:
         out = torch.empty(*x.shape, device=x.device, dtype=torch.float32)
@@ -357,6 +392,10 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
     sets: list of dicts(weight=(C, g, k) Conv1d weight, bias=None, gamma=None, beta=None, relu=False, out=None).
     pre_ln = (gamma, beta): the input rows are LayerNorm'ed as they are read (the block's ln1).
     Returns the list of outputs, each (B, T/stride, C)."""
+    if recording(x, x_up, *(t for st in sets for t in (st["weight"], st.get("bias"), st.get("gamma"), st.get("beta"))),
+                 *(pre_ln or ())):
+        from . import autograd
+        return autograd.dwconv_ln(x, sets, mask_out=mask_out, stride=stride, x_up=x_up, pre_ln=pre_ln)
     B, Tin, Cx = x.shape
     w0 = sets[0]["weight"]
     Cout, g, k = w0.shape
@@ -396,6 +435,9 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
 
 
 def local_attention(q, k, v, mask, n_head, half_win, pair=False):
+    if recording(q, k, v):
+        from . import autograd
+        return autograd.LocalAttention.apply(q, k, v, mask, n_head, half_win)
     B, T, Cc = q.shape
     pq, rows, cols, ld = _rows(q)
     pk, _, _, ldk = _rows(k)
@@ -412,6 +454,9 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
     pair: pair-row output when the flash kernel runs (otherwise a plain tensor is returned).
     q_mask (B, Tq): rows the caller masks afterwards; the split-precision kernel leaves out query tiles without a valid
     row (they read 0)."""
+    if not isinstance(q, Pair) and recording(q, k, v):
+        from . import autograd
+        return autograd.Attention.apply(q, k, v, kv_mask, n_head)
     if isinstance(q, Pair):
         assert isinstance(k, Pair) and isinstance(v, Pair) and q.width == k.width == v.width == q.shape[-1]
         q, k, v = q.t, k.t, v.t
@@ -443,6 +488,9 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
 
 def maxpool_mask(x, mask_in):
     """MaxPool1d(3, 2, 1)(x) * mask[::2]; returns (pooled (B, T/2, C), mask_out (B, T/2) bool)."""
+    if recording(x):
+        from . import autograd
+        return autograd.MaxPoolMask.apply(x, mask_in)
     B, T, Cc = x.shape
     px, rows, cols, ldx = _rows(x)
     y = torch.empty(B, T // 2, Cc, device=x.device, dtype=torch.float32)
@@ -454,6 +502,9 @@ def maxpool_mask(x, mask_in):
 
 def mask_head(emb, feat, out_mask, fill=-10.0):
     """emb (B, Q, Dp), feat (B, T, Dp), out_mask (B, T) -> (B, Q, T)."""
+    if recording(emb, feat):
+        from . import autograd
+        return autograd.MaskHead.apply(emb, feat, out_mask, fill)
     B, Q, Dp = emb.shape
     T = feat.shape[1]
     pe, _, _, lde = _rows(emb)
