@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""A training loop body on the HIP path: own code mirroring the reference's train.py:176-191 (forward -> zero_grad ->
+backward -> clip_grad_norm_ -> AdamW step -> EMA update) with its optimizer recipe (utils/train_utils.py:35-95: AdamW,
+no weight decay on biases, LayerNorm / scale parameters and embeddings; configs/vidvrd.yaml training_config), on the
+24-pair synthetic batch of BASELINE config 3 (6 videos x 4 pairs, T = max_seq_len = 96).
+
+    python scripts/train_step.py --steps 5          # on the GPU box
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def param_groups(model, weight_decay):
+    """decay: conv / linear weights; no decay: biases, LayerNorm affine, drop-path scales, embeddings (the split of the
+    reference's build_optimizer)."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        leaf = name.rsplit(".", 1)[-1]
+        is_ln = p.dim() == 3 and p.shape[0] == 1 and p.shape[2] == 1
+        (no_decay if (leaf in ("bias", "scale") or is_ln or "query_embed" in name) else decay).append(p)
+    return [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0.0}]
+
+
+def synthetic_batch(cfg, c_in, device, n_pairs=24, seed=0):
+    from vrdone_amd import synth
+    T = cfg["max_seq_len"]
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(8, T + 1, (n_pairs,), generator=g).tolist()
+    x, _ = synth.synth_pairs(n_pairs, c_in, T, lens, seed=seed + 1)
+    preds, masks, segs = [], [], []
+    for L in lens:
+        n = int(torch.randint(1, 4, (1,), generator=g))
+        a = torch.randint(0, max(L - 2, 1), (n,), generator=g)
+        b = torch.minimum(a + 1 + torch.randint(1, L, (n,), generator=g), torch.tensor(L))
+        m = torch.zeros(n, T)
+        for r in range(n):
+            m[r, a[r]:b[r]] = 1
+        preds.append(torch.randint(1, cfg["num_classes"] + 1, (n,), generator=g))
+        masks.append(m)
+        segs.append(torch.stack([a, b], dim=1))
+    to = lambda ts: [t.to(device) for t in ts]      # noqa: E731
+    return {"so_features_list": to([x[i, :, :n].contiguous() for i, n in enumerate(lens)]),
+            "preds_list": to(preds), "masks_list": to(masks), "segs_list": to(segs)}
+
+
+def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, ema_decay=0.999, verbose=True, drop_path=True):
+    from vrdone_amd import configs, synth
+    from vrdone_amd.models.maskvrd import MaskVRD
+    cfg = configs.model_config("vidvrd")
+    torch.manual_seed(seed)
+    model = synth.load_synthetic_weights(MaskVRD(cfg, device=device)).to(device).train()
+    if not drop_path:
+        from vrdone_amd.models.blocks import AffineDropPath
+        for mod in model.modules():
+            if isinstance(mod, AffineDropPath):
+                mod.drop_prob = 0.0
+    ema = copy.deepcopy(model).eval()
+    opt = torch.optim.AdamW(param_groups(model, weight_decay), lr=lr)
+    data = synthetic_batch(cfg, configs.input_channels(cfg), device, seed=seed)
+    start = [p.detach().clone() for p in model.parameters()]
+    log = {"total_loss": [], "step_ms": [], "params_without_grad": [], "nonfinite_grads": []}
+    for step in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss_dict = model(data)                                           # train.py:182
+        opt.zero_grad(set_to_none=True)
+        loss_dict["total_loss"].backward()                                # train.py:186
+        for name, p in model.named_parameters():
+            if p.grad is None:
+                log["params_without_grad"].append(name)
+            elif not bool(torch.isfinite(p.grad).all()):
+                log["nonfinite_grads"].append(name)
+        if clip > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip)     # train.py:187-188
+        opt.step()
+        with torch.no_grad():                                             # ModelEma.update, utils/train_utils.py:21-29
+            for e, m in zip(ema.state_dict().values(), model.state_dict().values()):
+                if e.dtype.is_floating_point:
+                    e.mul_(ema_decay).add_(m.detach(), alpha=1 - ema_decay)
+        torch.cuda.synchronize()
+        log["step_ms"].append(1e3 * (time.perf_counter() - t0))
+        log["total_loss"].append(float(loss_dict["total_loss"]))
+        if verbose:
+            print(f"step {step}: total_loss {log['total_loss'][-1]:.4f}  ({log['step_ms'][-1]:.1f} ms)", flush=True)
+    with torch.no_grad():
+        log["param_delta_norm"] = float(torch.sqrt(sum(((p - s) ** 2).sum() for p, s in zip(model.parameters(), start))))
+        log["ema_delta_norm"] = float(torch.sqrt(sum(((p - s) ** 2).sum() for p, s in zip(ema.parameters(), start))))
+    return log
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    print(json.dumps(run(steps=args.steps, seed=args.seed)))

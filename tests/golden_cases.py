@@ -30,3 +30,72 @@ def compare_forward_test(res, ref, n_max_pair, score_tol, slack):
     dig = {(len(t[0]), round(float(np.sum(np.asarray(t, dtype=np.float64))), 3)) for t in res["so_trajs"]}
     wdig = {(int(a), round(b, 3)) for a, b in ref["so_trajs_digest"]}
     assert len(dig & wdig) >= len(wdig) - slack
+
+
+# ---- training step (scripts/make_golden_train.py)
+TRAIN = dict(B=24, T=96, seed_len=2024, seed_x=3, seed_gt=2025)
+
+
+def train_batch(mc, c_in, device="cpu"):
+    """The 24-pair training batch of the train_step golden, in the dataloader's training format
+    (dataloaders/vidvrd.py:451-457): so_features_list (C_in, L_i), preds_list, masks_list (N_i, max_seq_len), segs_list."""
+    from oracle import vrd_oracle as O
+    from oracle.synth import synth_relations
+    B, T = TRAIN["B"], TRAIN["T"]
+    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(TRAIN["seed_len"])).tolist()
+    x, m = O.synth_pairs(B, c_in, T, lens, seed=TRAIN["seed_x"])
+    gp, gm, gs = synth_relations(lens, T, mc["num_classes"], max_rel=4, seed=TRAIN["seed_gt"])
+    to = lambda ts: [t.to(device) for t in ts]      # noqa: E731
+    data = {"so_features_list": to([x[i, :, :n].contiguous() for i, n in enumerate(lens)]),
+            "preds_list": to(gp), "masks_list": to(gm), "segs_list": to(gs)}
+    return lens, x, m, data
+
+
+def replay_matching(model, recorded):
+    """Make model.bipartite_match return the reference's recorded assignments (final head, then the auxiliary layers, in
+    call order) instead of its own: both sides then differentiate the same loss function even where a cost matrix
+    has a near-tie (pairs shorter than 16 frames have ONE valid frame at the predictor's T/8 level: their queries cost
+    the same to ~1e-5, tests/test_oracle_golden.py::test_criterion_train24).  Returns a list that collects, per call,
+    the pairs on which the model's own matching differs from the recorded one."""
+    real = model.bipartite_match
+    state = {"call": 0}
+    differing = []
+
+    def match(*a, **kw):
+        idx, lm = real(*a, **kw)
+        rec = recorded[state["call"]]
+        state["call"] += 1
+        differing.append([n for n, ((i, j), r) in enumerate(zip(idx, rec)) if not (i.tolist() == r[0] and j.tolist() == r[1])])
+        return [(torch.tensor(r[0], dtype=torch.int64), torch.tensor(r[1], dtype=torch.int64)) for r in rec], lm
+    model.bipartite_match = match
+    return differing
+
+
+def compare_grads(named_grads, golden_npz, meta, case, rtol, atol_frac=1e-6, median_tol=None):
+    """Every parameter's gradient against the stored reference gradient: full tensor when it has <= 2048 elements, the
+    stride-`sample_stride` sample otherwise; error measured relative to the l2 norm of the stored entries (plus
+    atol_frac of the largest gradient norm of the model, for gradients that are ~0).  rtol bounds the worst parameter,
+    median_tol the median over parameters.  Returns (worst, median) relative error."""
+    import numpy as np
+    stride = meta["sample_stride"]
+    stats = meta["cases"][case]["grad_stats"]
+    biggest = max(s[2] for s in stats.values())
+    worst, worst_name, errs = 0.0, None, []
+    for name, g in named_grads:
+        assert g is not None, f"{name} received no gradient"
+        g = g.detach().float().cpu()
+        assert bool(torch.isfinite(g).all()), name
+        want = golden_npz[f"{case}/{name}"]
+        got = (g if g.numel() <= 2048 else g.flatten()[::stride]).numpy()
+        assert got.shape == want.shape, name
+        err = float(np.linalg.norm(got.astype(np.float64) - want)) / (float(np.linalg.norm(want)) + atol_frac * biggest)
+        errs.append(err)
+        if err > worst:
+            worst, worst_name = err, name
+        # whole-tensor checksum: the l2 norm of the full gradient
+        l2 = float(g.double().norm())
+        assert abs(l2 - stats[name][2]) <= rtol * stats[name][2] + atol_frac * biggest, (name, l2, stats[name][2])
+    assert worst <= rtol, f"{worst_name}: relative gradient error {worst:.3e} > {rtol:.1e}"
+    median = float(np.median(errs))
+    assert median_tol is None or median <= median_tol, f"median relative gradient error {median:.3e} > {median_tol:.1e}"
+    return worst, median

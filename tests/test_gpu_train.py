@@ -1,0 +1,201 @@
+"""Training step on the HIP path (BASELINE config 3): module-level forward+backward against autograd
+through the oracle, and one whole optimisation step -- losses and the gradient of EVERY parameter -- against gradients
+produced by the REAL reference's forward_training + autograd (tests/golden/train_step_vidvrd.*,
+scripts/make_golden_train.py), with stochastic depth off and with pinned keep decisions.
+
+Stated tolerances: losses 1e-5 relative (same Hungarian assignments: the reference's recorded ones are replayed, so a
+near-tie between equivalent queries cannot change the loss function); gradients, per parameter, relative to the l2 norm
+of the reference gradient: MEDIAN over the 521 parameters <= 2e-5 in f32 mode (measured 8e-7) and <= 5e-4 in bf16x3
+mode (measured 4e-5); WORST parameter <= 3e-2.  Why the worst is loose: the network has two kinks -- ReLU after the
+embedding LayerNorms and the arg-max of MaxPool1d in the branch blocks -- and with activations that differ from the
+reference's by 1e-6 one element per step or so lands on the other side of one (measured: one ReLU gate of channel 206
+of visual_embd_norm.0 in the "nodrop" case, 8e-4 on that weight; one max-pool arg-max of pair 21 at level 1 in the
+"pinned" case, 1e-3 on everything below it).  Kernel-level exactness is what tests/test_gpu_backward.py and the two
+module tests below pin (float64 oracle, 2e-5 / 5e-5), and scripts/dev/block_isolate.py shows each block of this very
+step matching the float64 oracle to 1e-6 on its real activations."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_case
+from golden_cases import compare_grads, replay_matching, train_batch
+from oracle import vrd_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def c_in(mc):
+    cc = mc["clip_dim"] if mc.get("with_clip_feature", False) else 0
+    return 2 * mc["visual_dim"] + 2 * cc + mc["bbox_so_dim"] + 2 * mc["bbox_entity_dim"]
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def precision(request):
+    from vrdone_amd import ops
+    old = ops.get_precision()
+    ops.set_precision(request.param)
+    yield request.param
+    ops.set_precision(old)
+
+
+def build(name="vidvrd"):
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, ic, keys = load_case(name)
+    sd = O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"])
+    model = MaskVRD(mc, device=DEV)
+    model.load_state_dict(sd, strict=True)
+    return model.to(DEV), mc, sd
+
+
+def rel(got, want, floor=0.0):
+    """l2 error relative to the l2 norm of `want` (+ floor: some gradients are mathematically zero -- a key LayerNorm's
+    bias shifts every score of a query equally -- and hold only rounding noise on both sides)."""
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    assert got.shape == want.shape and bool(torch.isfinite(got).all())
+    return float((got - want).norm()) / (float(want.norm()) + floor + 1e-12)
+
+
+def check_param_grads(module, ref_grads, prefix, tol):
+    floor = 1e-3 * max(float(g.norm()) for g in ref_grads.values())
+    for name, p in module.named_parameters():
+        assert p.grad is not None, name
+        assert rel(p.grad, ref_grads[prefix + name], floor) < tol, name
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_transformer_block_forward_backward_vs_oracle(stride, precision):
+    """Stage-1 criterion: one TransformerBlock (LN -> depthwise conv + LN -> q/k/v GEMMs -> banded attention -> projection
+    + drop-path scale + (max-pooled) skip -> LN -> MLP) forward and backward, every parameter gradient and the input
+    gradient, against float64 autograd of the oracle's restatement of reference blocks.py:1070-1080."""
+    from vrdone_amd.models.blocks import TransformerBlock
+    torch.manual_seed(0)
+    C, H, B, T = 512, 4, 3, 48
+    blk = TransformerBlock(C, H, n_ds_strides=(stride, stride), path_pdrop=0.1, mha_win_size=7)
+    keys = [(f"blk.{k}", list(v.shape)) for k, v in blk.state_dict().items()]
+    sd = O.synth_state_dict(keys)
+    blk.load_state_dict({k[4:]: v for k, v in sd.items()})
+    blk = blk.to(DEV).eval()                      # eval: no stochastic depth (the oracle has none); autograd still records
+    lens = torch.tensor([48, 31, 6])
+    m = (torch.arange(T)[None] < lens[:, None])[:, None]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, C, T, generator=g) * m
+    dy = torch.randn(B, C, T // stride, generator=g)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    yr, _ = O.transformer_block(sd64, "blk", x64, m, H, 7, stride)
+    yr.backward(dy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    with torch.enable_grad():
+        y, _ = blk(xd, m.to(DEV))
+    y.backward(dy.to(DEV))
+    tol = 5e-5 if precision == "f32" else 5e-4
+    assert rel(y, yr) < tol
+    assert rel(xd.grad, x64.grad) < tol
+    check_param_grads(blk, {k: v.grad for k, v in sd64.items()}, "blk.", tol)
+
+
+def test_sos_decoder_layer_forward_backward_vs_oracle(precision):
+    """The subject-object mutual attention layer (self-attention + cross-attention with global masked attention, no FFN;
+    reference local_transformer.py:807-835) forward and backward."""
+    from vrdone_amd.models.local_transformer import MaskedConvTransformerDecoderLayer
+    C, H, B, T = 512, 4, 2, 48
+    layer = MaskedConvTransformerDecoderLayer(C, H, path_pdrop=0.1, n_qx_stride=1, n_kv_stride=1, with_ffn=False, use_local=False)
+    keys = [(f"sos.{k}", list(v.shape)) for k, v in layer.state_dict().items()]
+    sd = O.synth_state_dict(keys)
+    layer.load_state_dict({k[4:]: v for k, v in sd.items()})
+    layer = layer.to(DEV).eval()
+    lens = torch.tensor([48, 17])
+    m = (torch.arange(T)[None] < lens[:, None])[:, None]
+    g = torch.Generator().manual_seed(2)
+    x, y_in = torch.randn(B, C, T, generator=g) * m, torch.randn(B, C, T, generator=g) * m
+    dy = torch.randn(B, C, T, generator=g)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    x64, y64 = x.double().requires_grad_(True), y_in.double().requires_grad_(True)
+    outr = O.decoder_layer(sd64, "sos", x64, y64, m, m, H)
+    outr = outr[0] if isinstance(outr, tuple) else outr
+    outr.backward(dy.double())
+    xd, yd = x.to(DEV).requires_grad_(True), y_in.to(DEV).requires_grad_(True)
+    with torch.enable_grad():
+        out, _ = layer(xd, yd, m.to(DEV), m.to(DEV))
+    out.backward(dy.to(DEV))
+    tol = 5e-5 if precision == "f32" else 5e-4
+    assert rel(out, outr) < tol
+    assert rel(xd.grad, x64.grad) < tol and rel(yd.grad, y64.grad) < tol
+    check_param_grads(layer, {k: v.grad for k, v in sd64.items()}, "sos.", tol)
+
+
+@pytest.mark.parametrize("case", ["nodrop", "pinned"])
+def test_training_step_matches_reference_gradients(case, precision):
+    """model.train()(batch) -> total_loss.backward() on the HIP path vs the reference's own training step."""
+    from vrdone_amd.models.blocks import AffineDropPath
+    model, mc, _ = build()
+    with open(os.path.join(GOLDEN, "train_step_vidvrd.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "train_step_vidvrd.npz"))
+    lens, _, _, data = train_batch(mc, c_in(mc), device=DEV)
+    assert lens == meta["lengths"]
+    model.train()
+    n_dp = 0
+    for name, mod in model.named_modules():
+        if isinstance(mod, AffineDropPath):
+            n_dp += 1
+            if case == "nodrop":
+                mod.drop_prob = 0.0
+            else:
+                mod.keep = torch.tensor(meta["keep"][name], dtype=torch.float32)
+    assert n_dp == len(meta["keep"]) == 30
+    differing = replay_matching(model, meta["cases"][case]["indices"])
+    with torch.enable_grad():
+        loss = model(data)
+        loss["total_loss"].backward()
+    want = meta["cases"][case]["losses"]
+    assert set(loss) == set(want)
+    for k, v in want.items():
+        assert abs(float(loss[k]) - v) <= (1e-5 if precision == "f32" else 2e-4) * max(1.0, abs(v)), (k, float(loss[k]), v)
+    # own matching = the reference's except a few near-ties (pairs of < 16 frames have one valid frame at the predictor's
+    # T/8 level, and the first decoder layers' queries are still close to each other): with the reference's assignments
+    # replayed the losses agree to 1e-6, so a flipped assignment is a tie, not a different prediction
+    assert all(len(call) <= 6 for call in differing), differing
+    worst, median = compare_grads(((n, p.grad) for n, p in model.named_parameters()), g, meta, case,
+                                  rtol=3e-2, atol_frac=1e-4, median_tol=2e-5 if precision == "f32" else 5e-4)
+    print(f"[{case}/{precision}] relative gradient error: worst {worst:.2e}, median {median:.2e}")
+
+
+def test_drop_path_sampling_statistics():
+    """AffineDropPath in training mode: per-sample factors are 0 or 1/keep_prob, E[factor] = 1, one decision per sample
+    repeated over its rows; nothing is sampled in eval or under no_grad."""
+    from vrdone_amd.models.blocks import AffineDropPath
+    dp = AffineDropPath(512, drop_prob=0.1).to(DEV).train()
+    torch.manual_seed(0)
+    with torch.enable_grad():
+        f = dp.row_factors(20000, 3, DEV)
+    assert f.shape == (60000,)
+    per = f.view(20000, 3)
+    assert bool((per == per[:, :1]).all())
+    vals = sorted(per[:, 0].unique().cpu().tolist())
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / 0.9) < 1e-6
+    assert abs(float(per[:, 0].mean()) - 1.0) < 0.02
+    with torch.no_grad():
+        assert dp.row_factors(4, 3, DEV) is None
+    with torch.enable_grad():
+        assert dp.eval().row_factors(4, 3, DEV) is None
+
+
+def test_optimisation_steps_reduce_the_loss():
+    """scripts/train_step.py (own code mirroring reference train.py:176-191: forward, zero_grad, backward, grad-norm
+    clipping, AdamW with the reference's weight-decay grouping, EMA update): four steps on the 24-pair batch (stochastic
+    depth off, so that the loss is the same function at every step); every parameter gets a finite gradient each step,
+    parameters move, the EMA lags, the loss goes down."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_step", os.path.join(os.path.dirname(GOLDEN), "..", "scripts", "train_step.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    log = ts.run(steps=4, seed=0, device=DEV, verbose=False, lr=2e-5, drop_path=False)
+    assert len(log["total_loss"]) == 4 and all(np.isfinite(log["total_loss"]))
+    assert log["total_loss"][-1] < log["total_loss"][0]
+    assert log["params_without_grad"] == [] and log["nonfinite_grads"] == []
+    assert log["param_delta_norm"] > 0 and 0 < log["ema_delta_norm"] < log["param_delta_norm"]

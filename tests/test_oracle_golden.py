@@ -179,6 +179,36 @@ def test_mask_vrd_b256_matches_reference(weights):
     np.testing.assert_allclose(out["pred_masks"].numpy(), g["pred_masks"], atol=2e-4, rtol=0)
 
 
+def test_training_step_gradients_match_reference(weights):
+    """One training step's losses and parameter gradients (reference forward_training + autograd, stochastic depth off,
+    tests/golden/train_step_vidvrd.*) against autograd through the oracle's network and the product's criterion
+    (vrdone_amd.models.maskvrd.MaskVRD.criterion is plain tensor code and runs on CPU tensors): pins the golden, the
+    oracle as a gradient reference for the per-op GPU tests, and the differentiability of the loss code."""
+    from golden_cases import compare_grads, replay_matching, train_batch
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, _, sd = weights("vidvrd")
+    with open(os.path.join(GOLDEN, "train_step_vidvrd.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "train_step_vidvrd.npz"))
+    lens, x, m, data = train_batch(mc, c_in(mc))
+    assert lens == meta["lengths"]
+    model = MaskVRD(mc, device="cpu").train()
+    differing = replay_matching(model, meta["cases"]["nodrop"]["indices"])
+    names = [n for n, _ in model.named_parameters()]
+    leaves = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        pred = O.mask_vrd(leaves, mc, x, m, with_aux=True)
+        loss = model.criterion(pred, data)
+        loss["total_loss"].backward()
+    want = meta["cases"]["nodrop"]["losses"]
+    assert set(loss) == set(want)
+    for k, v in want.items():
+        assert abs(float(loss[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
+    # the product's matcher finds the reference's assignments on these predictions, except near-ties of very short pairs
+    assert len(differing) == 4 and all(lens[n] < 16 for call in differing for n in call)
+    compare_grads([(n, leaves[n].grad) for n in names], g, meta, "nodrop", rtol=1e-3, median_tol=2e-5)
+
+
 def test_preprocess_eval_shapes():
     mc, _, _ = load_case("vidvrd")
     assert O.max_div_factor(mc) == 48

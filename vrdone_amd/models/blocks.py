@@ -129,7 +129,7 @@ class AffineDropPath(nn.Module):
         super().__init__()
         self.scale = nn.Parameter(init_scale_value * torch.ones(1, num_dim, 1))
         self.drop_prob = drop_prob
-        self.keep = None            # tests may pin the per-sample keep decisions: a (B,) 0/1 tensor used instead of sampling
+        self.keep = None            # tests may pin the per-sample keep decisions: a 0/1 vector (>= B entries) used instead of sampling
 
     def row_factors(self, n_samples, rows_per_sample, device):
         """Stochastic depth per sample (reference drop_path, blocks.py:1107-1120): factor_b = floor(keep_prob + U[0,1))
@@ -139,8 +139,8 @@ class AffineDropPath(nn.Module):
             return None
         keep_prob = 1.0 - self.drop_prob
         if self.keep is not None:
-            keep = self.keep.to(device=device, dtype=torch.float32)
-            assert keep.shape == (n_samples,)
+            assert self.keep.numel() >= n_samples
+            keep = self.keep[:n_samples].to(device=device, dtype=torch.float32)
         else:
             keep = torch.floor(keep_prob + torch.rand(n_samples, device=device))
         return (keep / keep_prob)[:, None].expand(n_samples, rows_per_sample).contiguous().view(-1)
