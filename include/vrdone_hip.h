@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 13
+#define VRD_ABI_VERSION 14
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -87,6 +87,30 @@ typedef struct {
     int32_t pair_wide;
 } vrd_pack_args;
 int vrd_pack_pairs(const vrd_pack_args* a, void* stream);
+
+/* Eval batching from PER-TRACKLET features (what dataloaders/vidvrd.py:652-693 + utils/misc.py:158-217 do on the host,
+ * one (L, C_in) matrix per pair): vis (sum L, V), clip (sum L, Cc) or NULL and boxes (sum L, 4; x0 y0 x1 y1, already
+ * clamped to the frame, dataloaders/vidvrd.py:567-571) hold every tracklet's frames once; pair p covers `lens[p]` frames,
+ * frame t being row s_row[p] + t*stride of the subject's arrays and o_row[p] + t*stride of the object's (the dataloader's
+ * feat[start_offset::feat_stride] slicing, :678-692).  Writes the same operand buffers as vrd_pack_pairs (zero rows for
+ * t >= lens[p]); so_box = the 5 subject-object box features, ent = the 8 entity box features of subject then object rows
+ * (boxes normalised by the frame size w x h, first differences along the sub-sampled frames). */
+typedef struct {
+    const float* vis;
+    const float* clip;
+    const float* boxes;
+    const int64_t* s_row;
+    const int64_t* o_row;
+    const int32_t* lens;
+    int32_t P, T, V, Cc, stride;
+    float w, h;
+    float* out_vis;
+    float* out_clip;
+    float* out_so_box;
+    float* out_ent;
+    int32_t pair_wide;
+} vrd_gather_args;
+int vrd_gather_pairs(const vrd_gather_args* a, void* stream);
 
 /* rows (b*T+t) x C (leading dim ld_src) -> (B, C, T) contiguous. */
 int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float* dst, void* stream);

@@ -121,6 +121,17 @@ def local_mhca(sd, pre, x, mask, n_head, win, stride):
     return o * qm.to(o.dtype), qm
 
 
+def global_mhca(sd, pre, x, mask, n_head, stride):
+    """MaskedMHCA.forward, models/blocks.py:303-359: the conv attention of a TransformerBlock whose window is <= 1 --
+    depthwise conv (stride) * mask -> LN -> 1x1 for q, k, v, full masked attention, projection * mask."""
+    q, qm = _qkv_branch(sd, pre, "query", x, mask, stride)
+    k, km = _qkv_branch(sd, pre, "key", x, mask, stride)
+    v, _ = _qkv_branch(sd, pre, "value", x, mask, stride)
+    o = full_attention(q, k, v, km, n_head)
+    o = F.conv1d(o, sd[f"{pre}.proj.weight"], sd[f"{pre}.proj.bias"])
+    return o * qm.to(o.dtype), qm
+
+
 def mhca_qkv(sd, pre, q_in, k_in, v_in, q_mask, kv_mask, n_head, half_win=None):
     """MaskedMHCA_QKV.forward, models/local_transformer.py:144-187 (LocalMaskedMHCA_QKV
     :553-623 when half_win is given)."""
@@ -148,7 +159,10 @@ def mha_qkv(sd, pre, q_in, k_in, v_in, q_mask, kv_mask, n_head):
 def transformer_block(sd, pre, x, mask, n_head, win, stride):
     """TransformerBlock.forward, models/blocks.py:1070-1080 (eval: drop-path = channel scale)."""
     h = channel_ln(x, sd[f"{pre}.ln1.weight"], sd[f"{pre}.ln1.bias"])
-    a, m = local_mhca(sd, f"{pre}.attn", h, mask, n_head, win, stride)
+    if win > 1:
+        a, m = local_mhca(sd, f"{pre}.attn", h, mask, n_head, win, stride)
+    else:           # models/blocks.py:1029-1036
+        a, m = global_mhca(sd, f"{pre}.attn", h, mask, n_head, stride)
     mf = m.to(x.dtype)
     skip = x if stride == 1 else F.max_pool1d(x, stride + 1, stride, (stride + 1) // 2)
     y = skip * mf + sd[f"{pre}.drop_path_attn.scale"] * a

@@ -46,10 +46,68 @@ def b256_lengths():
     return lens.tolist()
 
 
+def global_block_case():
+    """TransformerBlock with GLOBAL conv attention (n_mha_win_size <= 1, models/blocks.py:1029-1036), stride 1 and 2:
+    inputs x / lens of tests/golden/ops.npz, every 4th output channel stored."""
+    from models import blocks as ref_blocks
+    ops = np.load(os.path.join(OUT, "ops.npz"))
+    x, lens = torch.from_numpy(ops["x"]), torch.from_numpy(ops["lens"])
+    m = (torch.arange(x.shape[-1])[None] < lens[:, None])[:, None]
+    arrs = {}
+    for stride in (1, 2):
+        mod = ref_blocks.TransformerBlock(512, 4, n_ds_strides=(stride, stride), path_pdrop=0.1, mha_win_size=-1)
+        keys = [(f"op.block_global_s{stride}.{k}", list(v.shape)) for k, v in mod.state_dict().items()]
+        sd = O.synth_state_dict(keys)
+        mod.load_state_dict({k[len(f"op.block_global_s{stride}."):]: v for k, v in sd.items()}, strict=True)
+        arrs[f"block_global_s{stride}"] = mod.eval()(x, m)[0][:, ::4].contiguous().numpy()
+    np.savez_compressed(os.path.join(OUT, "ops_r2.npz"), **arrs)
+    print("global-attention block case:", {k: v.shape for k, v in arrs.items()})
+
+
+PROPOSAL_CASES = {   # name -> (synth_raw_video kwargs, dataloader settings)
+    "vidvrd": (dict(n_tracklets=8, video_len=120, min_len=12, max_len=100, seed=5),
+               dict(feat_stride=1, stride_offset=0, proposal_min_frames=2)),
+    "strided": (dict(n_tracklets=6, video_len=400, min_len=30, max_len=380, seed=6),
+                dict(feat_stride=4, stride_offset=2, proposal_min_frames=5)),
+}
+
+
+def proposal_case():
+    """Eval-time pair construction: the reference dataloader's own `_test_getitem`
+    (dataloaders/vidvrd.py:552-715: box clamp, vIoU de-dup, per-pair feature slicing + box features) on a synthetic
+    `_prepare_test` output.  Stored per case: the surviving pairs, their lengths / offsets, the 21 box-feature channels of
+    every pair in full, and (sum, abs-sum) of every pair's visual slab (a pure gather: checked bit for bit)."""
+    from dataloaders.vidvrd import VidVRD
+    from oracle.proposal import synth_raw_video
+    arrs = {}
+    for name, (vid_kw, dl_kw) in PROPOSAL_CASES.items():
+        raw = synth_raw_video(**vid_kw)
+        ds = object.__new__(VidVRD)                    # the method needs only these attributes, no files
+        ds.feat_stride, ds.stride_offset, ds.proposal_min_frames, ds.random_stride = (
+            dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], False)
+        out = ds._test_getitem(raw)
+        feats = out["so_features_list"]
+        arrs[f"{name}/sids"], arrs[f"{name}/oids"] = out["sids"].numpy(), out["oids"].numpy()
+        arrs[f"{name}/so_offset"] = out["so_offset"].numpy()
+        arrs[f"{name}/lens"] = np.asarray([f.shape[1] for f in feats])
+        arrs[f"{name}/box_feats"] = torch.cat([f[-21:].T for f in feats], dim=0).numpy()            # (sum L, 21)
+        arrs[f"{name}/vis_sums"] = np.asarray([[float(f[:-21].double().sum()), float(f[:-21].double().abs().sum())] for f in feats])
+        arrs[f"{name}/boxes_clamped"] = torch.cat(out["bboxes_list"], dim=0).numpy()
+        print("proposal case", name, "pairs", len(feats), "of", len(raw["sids"]), "lens", arrs[f"{name}/lens"].tolist()[:12])
+        assert len(feats) < len(raw["sids"])             # the de-dup (and the length filters) removed something
+    np.savez_compressed(os.path.join(OUT, "proposal.npz"), **arrs)
+
+
 def main():
+    if "--only-proposal" in sys.argv:
+        return proposal_case()
+    if "--only-global-block" in sys.argv:
+        return global_block_case()
     if "--only-vidor-x" not in sys.argv:
         vidvrd_cases()
     vidor_x_case()
+    global_block_case()
+    proposal_case()
 
 
 def vidvrd_cases():

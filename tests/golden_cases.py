@@ -99,3 +99,12 @@ def compare_grads(named_grads, golden_npz, meta, case, rtol, atol_frac=1e-6, med
     median = float(np.median(errs))
     assert median_tol is None or median <= median_tol, f"median relative gradient error {median:.3e} > {median_tol:.1e}"
     return worst, median
+
+
+# ---- eval-time pair construction (scripts/make_golden_r2.py proposal_case)
+PROPOSAL_CASES = {   # name -> (oracle.proposal.synth_raw_video kwargs, dataloader settings)
+    "vidvrd": (dict(n_tracklets=8, video_len=120, min_len=12, max_len=100, seed=5),
+               dict(feat_stride=1, stride_offset=0, proposal_min_frames=2)),
+    "strided": (dict(n_tracklets=6, video_len=400, min_len=30, max_len=380, seed=6),
+                dict(feat_stride=4, stride_offset=2, proposal_min_frames=5)),
+}

@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _autograd_on():
+    """Other GPU test modules switch autograd off globally at import; these tests need it recording."""
+    with torch.enable_grad():
+        yield
+
+
 @pytest.fixture(params=["f32", "bf16x3"])
 def precision(request):
     from vrdone_amd import ops

@@ -238,6 +238,59 @@ def test_sharded_forward_test_equals_single_process(world, monkeypatch):
         model.shard_pairs(enable=False)
 
 
+@pytest.mark.parametrize("name", ["vidvrd", "strided"])
+def test_gather_pairs_matches_the_reference_dataloader(name):
+    """vrd_gather_pairs (per-tracklet rows on the device -> backbone operand buffers, box features computed on the way)
+    against the pair matrices of the reference dataloader's `_test_getitem` (oracle.proposal restates it and is pinned
+    bit for bit by tests/golden/proposal.npz): visual rows and the non-logarithmic box features bit-equal, the three
+    log features within 2e-6."""
+    from golden_cases import PROPOSAL_CASES
+    from oracle import proposal as P
+    from vrdone_amd import ops
+    from vrdone_amd.proposals import prepare_test_proposal
+    vid_kw, dl_kw = PROPOSAL_CASES[name]
+    raw = P.synth_raw_video(**vid_kw)
+    want = P.test_getitem(raw, **dl_kw)["so_features_list"]
+    prop = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], DEV)
+    src = prop["pair_source"]
+    Pn, T = len(src), max(src.lens) + 3
+    sel = torch.arange(Pn, device=DEV)
+    vis, clip, so_box, ent, mask = ops.gather_pairs(src, sel, T, 5, 8, False)
+    assert clip is None and mask.sum(1).tolist() == src.lens
+    V = src.n_visual
+    for p, f in enumerate(want):
+        L = f.shape[1]
+        ft = f.T.contiguous()
+        assert torch.equal(vis[p, :L].cpu(), ft[:, :V]) and torch.equal(vis[Pn + p, :L].cpu(), ft[:, V:2 * V])
+        box = ft[:, 2 * V:]
+        got_so, got_s, got_o = so_box[p, :L].cpu(), ent[p, :L].cpu(), ent[Pn + p, :L].cpu()
+        assert torch.equal(got_so[:, :2], box[:, :2])
+        np.testing.assert_allclose(got_so[:, 2:].numpy(), box[:, 2:5].numpy(), rtol=0, atol=2e-6)
+        assert torch.equal(got_s, box[:, 5:13]) and torch.equal(got_o, box[:, 13:21])
+        for buf in (vis[p, L:], vis[Pn + p, L:], so_box[p, L:], ent[p, L:], ent[Pn + p, L:]):
+            assert not bool(buf.any())
+    # pair rows (bf16x3 operand format) decode to the same values to 2^-16
+    visp, _, _, _, _ = ops.gather_pairs(src, sel, T, 5, 8, True)
+    assert float((visp.float() - vis).abs().max()) <= 2.0 ** -15 * float(vis.abs().max())
+
+
+def test_forward_test_from_tracklet_features_equals_pair_matrices(precision):
+    """The whole eval call fed with per-tracklet features (proposals.prepare_test_proposal -> pair_source) returns what it
+    returns when fed the reference dataloader's per-pair matrices."""
+    from golden_cases import PROPOSAL_CASES
+    from oracle import proposal as P
+    from vrdone_amd.proposals import prepare_test_proposal
+    model, mc, ic, _ = get_model("vidvrd")
+    vid_kw, dl_kw = PROPOSAL_CASES["vidvrd"]
+    raw = P.synth_raw_video(**vid_kw)
+    a = model(_on_device(P.test_getitem(raw, **dl_kw)))
+    prop = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], DEV)
+    b = model({k: (v if k == "pair_source" else ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV))) for k, v in prop.items()})
+    assert a["triplets"] == b["triplets"] and a["pred_durations"] == b["pred_durations"] and a["so_tids"] == b["so_tids"]
+    np.testing.assert_allclose(a["triple_scores_avg"], b["triple_scores_avg"], rtol=0, atol=2e-6)
+    assert a["so_trajs"] == b["so_trajs"]
+
+
 def test_forward_test_matches_oracle_small():
     model, mc, ic, sd = get_model("vidvrd")
     data = synth_proposal(4, c_in(mc), 10, 110, seed=99)
@@ -313,7 +366,8 @@ def test_pack_pairs_equals_padded_batch(precision):
 def test_forward_training_loss_values_match_reference_golden(name, T, precision):
     """Training-mode forward under no_grad = batching + HIP network + matcher + losses: the loss dict of the
     reference (its matcher / losses run on its own predictions, scripts/make_golden.py) within 1e-3 relative,
-    with the same Hungarian matches; with autograd on it must refuse (no backward kernels)."""
+    with the same Hungarian matches; with autograd recording the same call is a training step: total_loss.backward()
+    gives every parameter a finite gradient (vidvrd, vidor_x with the CLIP slabs, vidor_local with banded SOS layers)."""
     from oracle.synth import synth_relations
     model, mc, _, _ = get_model(name)
     g = np.load(os.path.join(GOLDEN, f"mask_vrd_{name}.npz"))
@@ -331,9 +385,15 @@ def test_forward_training_loss_values_match_reference_golden(name, T, precision)
         got = model(data)
         xb, mb = model.preprocessing(data["so_features_list"])
         assert xb.shape == (len(lens), c_in(mc), mc["max_seq_len"]) and torch.equal(mb.cpu(), m)
-        with torch.enable_grad(), pytest.raises(NotImplementedError):
-            model(data)
+        with torch.enable_grad():
+            model.zero_grad(set_to_none=True)
+            step = model(data)
+            assert step["total_loss"].requires_grad
+            step["total_loss"].backward()
+        missing = [n for n, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+        assert missing == [], missing
     finally:
+        model.zero_grad(set_to_none=True)
         model.eval()
     assert list(got) == list(want["losses"])
     for k, v in want["losses"].items():

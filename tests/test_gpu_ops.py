@@ -101,6 +101,20 @@ def test_transformer_block(g, stride):
     close(out, g[f"block_s{stride}"], 1e-4, gemm=True)
 
 
+@pytest.mark.parametrize("stride", [1, 2])
+def test_transformer_block_global_attention(g, stride):
+    """TransformerBlock with n_mha_win_size <= 1: MaskedMHCA (global conv attention, reference blocks.py:245-359,
+    1029-1036) vs the reference's own output (every 4th channel stored)."""
+    from vrdone_amd.models.blocks import MaskedMHCA, TransformerBlock
+    mod, _ = seeded(TransformerBlock(512, 4, n_ds_strides=(stride, stride), path_pdrop=0.1, mha_win_size=-1),
+                    f"op.block_global_s{stride}")
+    assert isinstance(mod.attn, MaskedMHCA)
+    g2 = np.load(os.path.join(GOLDEN, "ops_r2.npz"))
+    out, m = mod(g["xt"].to(DEV), g["mt"].to(DEV))
+    close(out[:, ::4], g2[f"block_global_s{stride}"], 1e-4, gemm=True)
+    assert torch.equal(m.cpu(), g["mt"][..., ::stride])
+
+
 def test_mhca_qkv_global(g):
     from vrdone_amd.models.local_transformer import MaskedMHCA_QKV
     mod, _ = seeded(MaskedMHCA_QKV(512, 4, n_qx_stride=1, n_kv_stride=1), "op.mhca_qkv")

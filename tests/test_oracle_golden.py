@@ -100,6 +100,15 @@ def test_operators_match_reference():
             (f"{p}.drop_path_attn.scale", (1, C, 1)), (f"{p}.drop_path_mlp.scale", (1, C, 1))]
         out, _ = O.transformer_block(O.synth_state_dict(keys), p, x, m, 4, 7, stride)
         np.testing.assert_allclose(out.numpy(), g[f"block_s{stride}"], atol=5e-5, rtol=0)
+    g2 = np.load(os.path.join(GOLDEN, "ops_r2.npz"))
+    for stride in (1, 2):            # global conv attention inside the block (n_mha_win_size <= 1, blocks.py:1029-1036)
+        p = f"op.block_global_s{stride}"
+        keys = ln_keys(f"{p}.ln1") + ln_keys(f"{p}.ln2") + attn_keys(f"{p}.attn") + [
+            (f"{p}.mlp.0.weight", (4 * C, C, 1)), (f"{p}.mlp.0.bias", (4 * C,)),
+            (f"{p}.mlp.3.weight", (C, 4 * C, 1)), (f"{p}.mlp.3.bias", (C,)),
+            (f"{p}.drop_path_attn.scale", (1, C, 1)), (f"{p}.drop_path_mlp.scale", (1, C, 1))]
+        out, _ = O.transformer_block(O.synth_state_dict(keys), p, x, m, 4, -1, stride)
+        np.testing.assert_allclose(out[:, ::4].numpy(), g2[f"block_global_s{stride}"], atol=5e-5, rtol=0)
     p = "op.local_mhca_w9"
     out, _ = O.local_mhca(O.synth_state_dict(attn_keys(p)), p, x, m, 8, 9, 1)
     np.testing.assert_allclose(out.numpy(), g["local_mhca_w9"], atol=2e-5, rtol=0)
@@ -351,3 +360,23 @@ def test_criterion_with_a_pair_without_relations():
     assert len(idx[2][0]) == 0
     for k, v in want.items():
         assert abs(float(got[k]) - float(v)) <= 2e-5 * max(1.0, abs(float(v))), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# eval-time pair construction: oracle/proposal.py vs the reference dataloader's _test_getitem
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["vidvrd", "strided"])
+def test_pair_construction_matches_reference_dataloader(name):
+    from golden_cases import PROPOSAL_CASES
+    from oracle import proposal as P
+    g = np.load(os.path.join(GOLDEN, "proposal.npz"))
+    vid_kw, dl_kw = PROPOSAL_CASES[name]
+    out = P.test_getitem(P.synth_raw_video(**vid_kw), **dl_kw)
+    assert out["sids"].tolist() == g[f"{name}/sids"].tolist() and out["oids"].tolist() == g[f"{name}/oids"].tolist()
+    assert out["so_offset"].tolist() == g[f"{name}/so_offset"].tolist()
+    feats = out["so_features_list"]
+    assert [f.shape[1] for f in feats] == g[f"{name}/lens"].tolist()
+    np.testing.assert_array_equal(torch.cat(out["bboxes_list"], dim=0).numpy(), g[f"{name}/boxes_clamped"])
+    np.testing.assert_array_equal(torch.cat([f[-21:].T for f in feats], dim=0).numpy(), g[f"{name}/box_feats"])   # same torch ops: bit-equal
+    sums = np.asarray([[float(f[:-21].double().sum()), float(f[:-21].double().abs().sum())] for f in feats])
+    np.testing.assert_array_equal(sums, g[f"{name}/vis_sums"])

@@ -66,6 +66,14 @@ class BmmArgs(C.Structure):
                 ("alpha", C.c_float), ("accumulate", C.c_int32)]
 
 
+class GatherArgs(C.Structure):
+    _fields_ = [("vis", c_f32p), ("clip", c_f32p), ("boxes", c_f32p), ("s_row", C.c_void_p), ("o_row", C.c_void_p),
+                ("lens", C.c_void_p), ("P", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("Cc", C.c_int32),
+                ("stride", C.c_int32), ("w", C.c_float), ("h", C.c_float),
+                ("out_vis", c_f32p), ("out_clip", c_f32p), ("out_so_box", c_f32p), ("out_ent", c_f32p),
+                ("pair_wide", C.c_int32)]
+
+
 _SIGNATURES = {
     "vrd_abi_version": (C.c_int, []),
     "vrd_last_error": (C.c_char_p, []),
@@ -78,6 +86,7 @@ _SIGNATURES = {
     "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
+    "vrd_gather_pairs": (C.c_int, [C.POINTER(GatherArgs), C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_gemm_batch": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "vrd_row_blocks": (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -116,7 +125,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class HipLibraryError(RuntimeError):

@@ -113,6 +113,99 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(vrd_pack_args a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// eval batching straight from PER-TRACKLET features: the reference's dataloader builds one (L, C_in) matrix
+// per ordered pair by slicing and concatenating tracklet features on the host (dataloaders/vidvrd.py:652-693: every
+// tracklet is copied into 2 (N - 1) pairs) and computes the pairs' box features there (utils/misc.py:158-217).  Here
+// the tracklets' rows live on the device once -- vis (sum L, V), clip, boxes (sum L, 4, already clamped) -- and one
+// wave per (pair, frame) gathers the subject and object rows and computes the 5 + 8 + 8 box features, writing the
+// backbone's channels-last operand buffers exactly like pack_pairs_kernel.  Frame t of pair p is row
+// s_row[p] + t * stride (o_row[p] + t * stride) of the concatenated arrays.
+// Box arithmetic is written operation by operation with the round-to-nearest intrinsics (no FMA contraction), in the
+// reference's order, so everything but the three logarithms is the reference's f32 value bit for bit.
+// ------------------------------------------------------------------------------------------
+struct Box4 {
+    float x0, y0, x1, y1;
+};
+__device__ __forceinline__ Box4 load_box(const float* boxes, int64_t row) {
+    const float4 b = *reinterpret_cast<const float4*>(boxes + row * 4);
+    return Box4{b.x, b.y, b.z, b.w};
+}
+// normalised (cx, cy, w, h) of utils/misc.py:184-192
+__device__ __forceinline__ void entity_geom(const Box4& b, float w, float h, float (&g)[4]) {
+    const float x0 = __fdiv_rn(b.x0, w), x1 = __fdiv_rn(b.x1, w), y0 = __fdiv_rn(b.y0, h), y1 = __fdiv_rn(b.y1, h);
+    g[0] = __fdiv_rn(__fadd_rn(x1, x0), 2.0f);
+    g[1] = __fdiv_rn(__fadd_rn(y1, y0), 2.0f);
+    g[2] = __fsub_rn(x1, x0);
+    g[3] = __fsub_rn(y1, y0);
+}
+// [cx, dcx, cy, dcy, w, dw, h, dh] of frame t of an n-frame strided box sequence starting at row0 (utils/misc.py:194-217)
+__device__ __forceinline__ void entity_feats(const float* boxes, int64_t row0, int stride, int t, int n, float w, float h,
+                                             float (&f)[8]) {
+    float g[4], a[4], b[4];
+    entity_geom(load_box(boxes, row0 + (int64_t)t * stride), w, h, g);
+    float d[4];
+    if (t > 0) {
+        entity_geom(load_box(boxes, row0 + (int64_t)(t - 1) * stride), w, h, a);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = __fsub_rn(g[i], a[i]);
+    } else {            // first frame: d0 - (d1 - d0) with d0 = v1 - v0, d1 = v2 - v1; just d0 when there are two frames
+        entity_geom(load_box(boxes, row0 + stride), w, h, a);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = __fsub_rn(a[i], g[i]);
+        if (n > 2) {
+            entity_geom(load_box(boxes, row0 + 2 * (int64_t)stride), w, h, b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] = __fsub_rn(d[i], __fsub_rn(__fsub_rn(b[i], a[i]), d[i]));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[2 * i] = g[i], f[2 * i + 1] = d[i];
+}
+
+__global__ __launch_bounds__(256) void gather_pairs_kernel(vrd_gather_args a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= (int64_t)a.P * a.T) return;
+    const int p = (int)(row / a.T), t = (int)(row - (int64_t)p * a.T);
+    const int n = a.lens[p];
+    const bool live = t < n;
+    const int64_t rs = a.s_row[p] + (int64_t)t * a.stride, ro = a.o_row[p] + (int64_t)t * a.stride;
+    const int64_t half = (int64_t)a.P * a.T;
+    pack_segment(a.vis + (live ? rs : 0) * a.V, live, lane, a.V, a.out_vis + row * a.V, a.pair_wide);
+    pack_segment(a.vis + (live ? ro : 0) * a.V, live, lane, a.V, a.out_vis + (half + row) * a.V, a.pair_wide);
+    if (a.Cc) {
+        pack_segment(a.clip + (live ? rs : 0) * a.Cc, live, lane, a.Cc, a.out_clip + row * a.Cc, a.pair_wide);
+        pack_segment(a.clip + (live ? ro : 0) * a.Cc, live, lane, a.Cc, a.out_clip + (half + row) * a.Cc, a.pair_wide);
+    }
+    // box features: lanes 0 (subject-object), 1 (subject), 2 (object) compute, everybody stores zeros for padded frames
+    float* const so = a.out_so_box + row * 5;
+    float* const es = a.out_ent + row * 8;
+    float* const eo = a.out_ent + (half + row) * 8;
+    if (!live) {
+        if (lane < 5) so[lane] = 0.f;
+        if (lane < 8) es[lane] = 0.f, eo[lane] = 0.f;
+        return;
+    }
+    if (lane == 0) {        // utils/misc.py:158-178
+        const Box4 s = load_box(a.boxes, rs), o = load_box(a.boxes, ro);
+        const float s_cx = __fdiv_rn(__fadd_rn(s.x1, s.x0), 2.0f), s_cy = __fdiv_rn(__fadd_rn(s.y1, s.y0), 2.0f);
+        const float o_cx = __fdiv_rn(__fadd_rn(o.x1, o.x0), 2.0f), o_cy = __fdiv_rn(__fadd_rn(o.y1, o.y0), 2.0f);
+        const float s_w = __fsub_rn(s.x1, s.x0), s_h = __fsub_rn(s.y1, s.y0), o_w = __fsub_rn(o.x1, o.x0), o_h = __fsub_rn(o.y1, o.y0);
+        so[0] = __fdiv_rn(__fsub_rn(s_cx, o_cx), o_cx);
+        so[1] = __fdiv_rn(__fsub_rn(s_cy, o_cy), o_cy);
+        so[2] = logf(__fdiv_rn(s_w, o_w));
+        so[3] = logf(__fdiv_rn(s_h, o_h));
+        so[4] = logf(__fdiv_rn(__fmul_rn(s_w, s_h), __fmul_rn(o_w, o_h)));
+    } else if (lane == 1 || lane == 2) {
+        float f[8];
+        entity_feats(a.boxes, lane == 1 ? a.s_row[p] : a.o_row[p], a.stride, t, n, a.w, a.h, f);
+        float* const dst = lane == 1 ? es : eo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = f[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm over channels; NV = C / 256
 // ------------------------------------------------------------------------------------------
 // lane's channels: WIDE (NV == 2): 8 consecutive channels lane*8 .. lane*8+7 (v[0], v[1]), so that pair rows are
@@ -521,6 +614,21 @@ int vrd_pack_pairs(const vrd_pack_args* a, void* stream) {
     const int64_t rows = (int64_t)a->P * a->T;
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * a->C_in);
     hipLaunchKernelGGL(pack_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_gather_pairs(const vrd_gather_args* a, void* stream) {
+    VRD_CHECK_ARG(a && a->vis && a->boxes && a->s_row && a->o_row && a->lens && a->out_vis && a->out_so_box && a->out_ent,
+                  "vrd_gather_pairs: null pointer");
+    VRD_CHECK_ARG(a->P > 0 && a->T > 0 && a->V > 0 && a->Cc >= 0 && a->stride >= 1 && a->w > 0.f && a->h > 0.f, "vrd_gather_pairs: bad sizes");
+    VRD_CHECK_ARG(a->Cc == 0 || (a->clip && a->out_clip), "vrd_gather_pairs: clip buffers missing");
+    VRD_CHECK_ARG(!a->pair_wide || (a->V % 32 == 0 && a->Cc % 32 == 0), "vrd_gather_pairs: pair rows need widths %% 32 == 0");
+    VRD_CHECK_ARG(aligned16(a->boxes), "vrd_gather_pairs: boxes must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t rows = (int64_t)a->P * a->T;
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * (2 * a->V + 2 * a->Cc + 21));
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
     VRD_LAUNCH_CHECK();
     return 0;
 }

@@ -255,6 +255,35 @@ class LocalMaskedMHCA(_ConvAttention):
         return _from_cl(y), m[:, None, :]
 
 
+class MaskedMHCA(_ConvAttention):
+    """Conv attention with FULL (global) masked attention: what TransformerBlock uses when n_mha_win_size <= 1;
+    reference models/blocks.py:245-359.  Same parameter tree as LocalMaskedMHCA; the attention core is the global
+    flash kernel of the SOS layers (keys outside the mask get -inf, :337)."""
+
+    def __init__(self, n_embd, n_head, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0):
+        super().__init__()
+        assert n_qx_stride == n_kv_stride and n_kv_stride in (1, 2), "built for equal query / key-value strides 1 or 2"
+        assert attn_pdrop == 0.0 and proj_pdrop == 0.0
+        self.n_qx_stride, self.n_kv_stride = n_qx_stride, n_kv_stride
+        ks = n_kv_stride + 1 if n_kv_stride > 1 else 3
+        self._build(n_embd, n_head, ks, ks, n_kv_stride)
+
+    def cl(self, x, mask, mask_out=None, pre_ln=None, **epilogue):
+        ops = _ops()
+        s = self.n_kv_stride
+        if mask_out is None:
+            mask_out = mask if s == 1 else mask[:, ::s].contiguous()
+        q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s, pre_ln=pre_ln)
+        qkv_pair = ops.flash_pair_ok(self.n_head, self.n_embd, q.shape[1])
+        q, k, v = self._project(q, k, v, out_pair=qkv_pair, q_mask=mask_out, kv_mask=mask_out)
+        att = ops.attention(q, k, v, mask_out, self.n_head, pair=ops.pair_mode(), q_mask=mask_out)
+        return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
+
+    def forward(self, x, mask):
+        y, m = self.cl(_to_cl(x), _mask2d(mask))
+        return _from_cl(y), m[:, None, :]
+
+
 class MaskedMHA(nn.Module):
     """Plain masked multi-head attention parameters; reference models/blocks.py:177-242."""
 
@@ -292,14 +321,15 @@ class TransformerBlock(nn.Module):
                  attn_pdrop=0.0, proj_pdrop=0.0, path_pdrop=0.0, mha_win_size=-1, use_rel_pe=False):
         super().__init__()
         assert len(n_ds_strides) == 2 and act_layer is nn.GELU
-        if mha_win_size <= 1:
-            raise NotImplementedError("global-attention TransformerBlock (n_mha_win_size <= 1) is not used by any "
-                                      "shipped config and is not built")
         self.ln1 = LayerNorm(n_embd)
         self.ln2 = LayerNorm(n_embd)
-        self.attn = LocalMaskedMHCA(n_embd, n_head, window_size=mha_win_size, n_qx_stride=n_ds_strides[0],
-                                    n_kv_stride=n_ds_strides[1], attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop,
-                                    use_rel_pe=use_rel_pe)
+        if mha_win_size > 1:
+            self.attn = LocalMaskedMHCA(n_embd, n_head, window_size=mha_win_size, n_qx_stride=n_ds_strides[0],
+                                        n_kv_stride=n_ds_strides[1], attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop,
+                                        use_rel_pe=use_rel_pe)
+        else:       # reference blocks.py:1029-1036 (no shipped config takes this branch)
+            self.attn = MaskedMHCA(n_embd, n_head, n_qx_stride=n_ds_strides[0], n_kv_stride=n_ds_strides[1],
+                                   attn_pdrop=attn_pdrop, proj_pdrop=proj_pdrop)
         s = n_ds_strides[0]
         self.pool_skip = nn.MaxPool1d(s + 1, stride=s, padding=(s + 1) // 2) if s > 1 else nn.Identity()
         n_hidden = n_hidden or 4 * n_embd

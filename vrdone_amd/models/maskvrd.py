@@ -308,8 +308,10 @@ class MaskVRD(nn.Module):
                 t_pad[i] = self.max_seq_len if lens[i] <= self.max_seq_len else t_long
         return sorted(range(P), key=lambda i: (t_pad[i], lens[i], i)), t_pad
 
-    def pair_candidates(self, feats, lens, ids, t_pad, k):
+    def pair_candidates(self, feats, lens, ids, t_pad, k, source=None):
         """Network + per-(pair, query) post-processing kernel for the pairs `ids` (already grouped by padded length).
+        source: a proposals.PairSource -- pair rows are then gathered on the device from the per-tracklet features
+        (vrd_gather_pairs) and `feats` is not used.
         Returns ONE float32 tensor (len(ids), Q, 2k + 2) = [top-k scores | top-k class ids | first | last frame], the
         three integer fields bit-cast: the compact candidate record that sharded runs exchange (SURVEY 8e option i)."""
         ops = _ops()
@@ -321,8 +323,12 @@ class MaskVRD(nn.Module):
         ints = cand.view(torch.int32)
         # every host->device table goes up before the first kernel is queued (such a copy waits for the queue)
         lens_dev = torch.tensor([lens[i] for i in ids], dtype=torch.int32, device=dev)
-        local = [feats[i] for i in ids]
-        tables = ops.pair_table(local)          # None unless the features are the dataloader's frame-major matrices
+        if source is not None:
+            ids_dev = torch.tensor(ids, dtype=torch.int64, device=dev)
+            local, tables = None, None
+        else:
+            local = [feats[i] for i in ids]
+            tables = ops.pair_table(local)      # None unless the features are the dataloader's frame-major matrices
         bb = self.backbone
         at = 0
         while at < len(ids):
@@ -330,14 +336,19 @@ class MaskVRD(nn.Module):
             n = 1
             while at + n < len(ids) and t_pad[ids[at + n]] == T:
                 n += 1
-            if tables is not None:
-                # the dataloader's (L, C_in) matrices go straight into the backbone's operand buffers
+            if source is not None or tables is not None:
+                # per-tracklet rows (gathered, box features computed on the device) or the dataloader's (L, C_in)
+                # matrices go straight into the backbone's operand buffers
                 outs = []
                 step = self._chunk_size(n)
                 for c0 in range(at, at + n, step):
                     c1 = min(c0 + step, at + n)
-                    *parts, m2 = ops.pack_pairs(tables[0][c0:c1], tables[1][c0:c1], T, bb.n_visual, bb.n_clip,
-                                                bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+                    if source is not None:
+                        assert (source.n_visual, source.n_clip) == (bb.n_visual, bb.n_clip)
+                        *parts, m2 = ops.gather_pairs(source, ids_dev[c0:c1], T, bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+                    else:
+                        *parts, m2 = ops.pack_pairs(tables[0][c0:c1], tables[1][c0:c1], T, bb.n_visual, bb.n_clip,
+                                                    bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
                     outs.append(self._heads(*bb.cl_parts(*parts, m2), False))
                 out = self._merge(outs)
             else:
@@ -360,10 +371,12 @@ class MaskVRD(nn.Module):
         are brought to the host.  After shard_pairs() the pairs are split over the ranks of the process group."""
         from .. import parallel
         dev = self.device
-        feats = input_data['so_features_list']
+        source = input_data.get('pair_source')          # proposals.prepare_test_proposal: per-tracklet features on the device
+        feats = None if source is not None else input_data['so_features_list']
         P = len(input_data['sids'])
         Q, k = self.predictor.num_queries, self.topk
-        lens = [int(f.shape[1]) for f in feats]
+        lens = list(source.lens) if source is not None else [int(f.shape[1]) for f in feats]
+        assert len(lens) == P
         order, t_pad = self.eval_plan(lens)
         shard = getattr(self, "_shard", None)
         rank, world = parallel.rank_world(shard[0]) if shard else (0, 1)
@@ -371,7 +384,7 @@ class MaskVRD(nn.Module):
         unsort = torch.empty(P, dtype=torch.int64)
         unsort[torch.tensor(order, dtype=torch.int64)] = torch.arange(P)
         unsort = unsort.to(dev)                         # uploaded before the first kernel is queued
-        cand = self.pair_candidates(feats, lens, mine, t_pad, k)
+        cand = self.pair_candidates(feats, lens, mine, t_pad, k, source=source)
         if world > 1:
             cand = parallel.gather_candidates(cand, P, shard[0])       # (P, Q, 2k + 2) in `order`
         cand = cand[unsort]                             # back to the dataloader's pair order

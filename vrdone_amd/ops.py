@@ -224,6 +224,33 @@ def pack_pairs(table, lens, T, V, Cc, S, E, pair_wide):
     return vis, clip, so_box, ent, mask
 
 
+def gather_pairs(source, sel, T, S, E, pair_wide):
+    """Batch the pairs `sel` (device int64 indices into a proposals.PairSource) straight from the per-tracklet rows into
+    the backbone's operand buffers, computing the box features on the way (vrd_gather_pairs).
+    Returns (vis, clip or None, so_box, ent, mask) like pack_pairs."""
+    assert S == 5 and E == 8, "the reference's box features are 5 (pair) + 8 (entity) channels (utils/misc.py:158-217)"
+    B = sel.shape[0]
+    dev = source.vis.device
+    V, Cc = source.n_visual, source.n_clip
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)      # noqa: E731
+    vis, so_box, ent = new(2 * B, T, V), new(B, T, S), new(2 * B, T, E)
+    clip = new(2 * B, T, Cc) if Cc else None
+    s_row, o_row, lens = source.s_row[sel].contiguous(), source.o_row[sel].contiguous(), source.lens_dev[sel].contiguous()
+    a = _hip.GatherArgs()
+    a.vis, a.clip, a.boxes = source.vis.data_ptr(), _ptr(source.clip), source.boxes.data_ptr()
+    a.s_row, a.o_row, a.lens = s_row.data_ptr(), o_row.data_ptr(), lens.data_ptr()
+    a.P, a.T, a.V, a.Cc, a.stride = B, T, V, Cc, source.stride
+    a.w, a.h = source.wh
+    a.out_vis, a.out_clip, a.out_so_box, a.out_ent = vis.data_ptr(), _ptr(clip), so_box.data_ptr(), ent.data_ptr()
+    a.pair_wide = 1 if pair_wide else 0
+    _hip.check(lib.vrd_gather_pairs(C.byref(a), _stream()), "vrd_gather_pairs")
+    mask = torch.arange(T, device=dev)[None, :] < lens[:, None]
+    if pair_wide:
+        vis = Pair(vis, V)
+        clip = Pair(clip, Cc) if Cc else None
+    return vis, clip, so_box, ent, mask
+
+
 def btc_to_bct(x):
     """(B, T, C) channels-last -> new (B, C, T) tensor."""
     if recording(x):

@@ -1,0 +1,106 @@
+"""Eval-time pair construction on the device (with the host half of 8f-2).
+
+The reference's test dataloader (dataloaders/vidvrd.py:552-715, dataloaders/vidor.py:640-735) clamps the tracklet
+boxes to the frame, drops tracklets shadowed by a same-category tracklet (vIoU > 0.9), and then builds, per ordered
+(subject, object) pair, an (L, C_in) matrix on the host by slicing / concatenating the two tracklets' per-frame features
+and computing 21 box-feature channels -- every tracklet is copied into 2 (N - 1) pair matrices, which then travel to the
+device one by one (utils/misc.py:98-112).
+
+`prepare_test_proposal` keeps the cheap, irregular part on the host (clamp, de-dup, the pair list and its offsets) and
+uploads each tracklet's rows ONCE; `MaskVRD.forward_test` then gathers pair rows and computes their box features on the
+device (`vrd_gather_pairs`), straight into the backbone's operand buffers.  The returned dict is the reference's eval
+proposal with `pair_source` in place of `so_features_list`; everything else (`sids`, `oids`, `cat_ids`, `cat_scores`,
+`traj_durations`, `bboxes_list`, `so_offset`) is what `_test_getitem` returns.
+"""
+import numpy as np
+import torch
+
+
+class PairSource:
+    """Per-tracklet rows on the device + per-pair tables: pair p = `lens[p]` frames, frame t = row s_row[p] + t*stride of
+    the subject's tracklet and o_row[p] + t*stride of the object's in the concatenated (sum L, .) arrays."""
+
+    def __init__(self, vis, clip, boxes, s_row, o_row, lens, stride, wh):
+        self.vis, self.clip, self.boxes = vis, clip, boxes
+        self.s_row, self.o_row, self.lens_dev = s_row, o_row, lens
+        self.lens = lens.tolist()
+        self.stride, self.wh = int(stride), (float(wh[0]), float(wh[1]))
+        self.n_visual = vis.shape[1]
+        self.n_clip = 0 if clip is None else clip.shape[1]
+
+    def __len__(self):
+        return len(self.lens)
+
+
+def _clamped(boxes, w, h):
+    b = boxes.clone()
+    b[:, 0:2].clamp_(min=0)
+    b[:, 2].clamp_(max=w - 1)
+    b[:, 3].clamp_(max=h - 1)
+    if not bool(((b[:, 2] > b[:, 0]) & (b[:, 3] > b[:, 1])).all()):
+        raise ValueError("a tracklet box is empty after clamping to the frame")
+    return b
+
+
+def shadowed_tracklets(boxes, spans, cat_ids, threshold=0.9):
+    """Indices of tracklets to drop (reference dataloaders/vidvrd.py:577-636): walking tracklets i < j of one category
+    whose durations overlap, j goes when i spans j's whole duration and the per-frame box intersections (+1 pixel
+    convention) sum to more than `threshold` of j's summed box area; i goes (and its scan stops) in the mirrored case."""
+    n = len(boxes)
+    gone = np.zeros(n, dtype=bool)
+    for i in range(n):
+        for j in range(i + 1, n):
+            if gone[j] or cat_ids[i] != cat_ids[j]:
+                continue
+            lo, hi = max(spans[i][0], spans[j][0]), min(spans[i][1], spans[j][1])
+            if hi <= lo:
+                continue
+            bi = boxes[i][lo - spans[i][0]:hi - spans[i][0]]
+            bj = boxes[j][lo - spans[j][0]:hi - spans[j][0]]
+            wh = (torch.minimum(bi[:, 2:], bj[:, 2:]) - torch.maximum(bi[:, :2], bj[:, :2]) + 1).clamp_(min=0)
+            inter = float((wh[:, 0] * wh[:, 1]).sum())
+            a_i = float((bi[:, 2] - bi[:, 0] + 1).mul(bi[:, 3] - bi[:, 1] + 1).sum())
+            a_j = float((bj[:, 2] - bj[:, 0] + 1).mul(bj[:, 3] - bj[:, 1] + 1).sum())
+            if inter / a_j > threshold and spans[i][0] <= spans[j][0] and spans[i][1] >= spans[j][1]:
+                gone[j] = True
+            elif inter / a_i > threshold and spans[j][0] <= spans[i][0] and spans[j][1] >= spans[i][1]:
+                gone[i] = True
+                break
+    return np.nonzero(gone)[0].tolist()
+
+
+def prepare_test_proposal(raw, feat_stride, stride_offset, proposal_min_frames, device, viou_threshold=0.9):
+    """raw: the dict `_prepare_test` hands to `_test_getitem` (sids, oids, cat_ids, cat_scores, bboxes_list,
+    traj_durations [start, end), visual_features_list, optional clip_features_list, video_wh).  Returns {} when no pair
+    survives, else the eval proposal with a device-resident `pair_source`."""
+    w, h = raw["video_wh"]
+    boxes = [_clamped(b, w, h) for b in raw["bboxes_list"]]
+    spans = [(int(a), int(e)) for a, e in raw["traj_durations"].tolist()]
+    dropped = set(shadowed_tracklets(boxes, spans, raw["cat_ids"].tolist(), viou_threshold))
+    first_row = np.concatenate([[0], np.cumsum([len(b) for b in boxes])])            # tracklet -> first row of its frames
+    sids, oids, s_row, o_row, lens = [], [], [], [], []
+    for s, o in zip(raw["sids"].tolist(), raw["oids"].tolist()):
+        if s in dropped or o in dropped:
+            continue
+        lo, hi = max(spans[s][0], spans[o][0]), min(spans[s][1], spans[o][1])
+        shared = hi - lo
+        steps = len(range(stride_offset, shared, feat_stride)) if shared > 0 else 0
+        if shared < proposal_min_frames or steps < 2:
+            continue
+        sids.append(s)
+        oids.append(o)
+        s_row.append(first_row[s] + lo - spans[s][0] + stride_offset)
+        o_row.append(first_row[o] + lo - spans[o][0] + stride_offset)
+        lens.append(steps)
+    if not sids:
+        return {}
+    clip = raw.get("clip_features_list")
+    src = PairSource(
+        torch.cat(raw["visual_features_list"], dim=0).to(device=device, dtype=torch.float32).contiguous(),
+        None if clip is None else torch.cat(clip, dim=0).to(device=device, dtype=torch.float32).contiguous(),
+        torch.cat(boxes, dim=0).to(device=device, dtype=torch.float32).contiguous(),
+        torch.tensor(s_row, dtype=torch.int64, device=device), torch.tensor(o_row, dtype=torch.int64, device=device),
+        torch.tensor(lens, dtype=torch.int32, device=device), feat_stride, (w, h))
+    return {"sids": torch.tensor(sids), "oids": torch.tensor(oids), "cat_ids": raw["cat_ids"], "cat_scores": raw["cat_scores"],
+            "traj_durations": raw["traj_durations"], "bboxes_list": boxes,
+            "so_offset": torch.full((len(sids),), stride_offset, dtype=torch.int64), "pair_source": src}
