@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 14
+#define VRD_ABI_VERSION 15
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -347,6 +347,20 @@ int vrd_bmm(const vrd_bmm_args* a, void* stream);
  * the first maximum of each window (ATen's rule). */
 int vrd_maxpool_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int B, int Tin, int C, const uint8_t* mask_in, float* dx,
                     int64_t lddx, void* stream);
+
+/* ---- training tail on the device ----------------------------------------------------------------------
+ * Hungarian assignment of the matcher (models/maskvrd.py:484-492: `.cpu()` + scipy linear_sum_assignment per pair).
+ * cost: (sum N, Q) rows = relations (leading dimension ld), row r of pair p = first[p] + r, count[p] = N_p <= Q <= 16.
+ * query_of[first[p] + r] = the query relation r of pair p is assigned to (the minimum-cost assignment; pairs with
+ * count 0 are skipped).  Double-precision potentials; the result equals scipy's whenever the optimum is unique. */
+int vrd_assign(const float* cost, int64_t ld, const int32_t* first, const int32_t* count, int P, int Q, int32_t* query_of, void* stream);
+
+/* EMA of a whole state dict in one launch (utils/train_utils.py:21-29): for every tensor t and element i,
+ * ema[t][i] = decay * ema[t][i] + one_minus_decay * model[t][i], both products and the sum rounded to f32 (the reference's
+ * tensor expression, bit for bit).  ema / model: device arrays of device pointers; numel: elements per tensor; the launch
+ * is cut into chunks of 4096 elements: chunk c works on tensor chunk_tensor[c], elements chunk_index[c]*4096 ... */
+int vrd_ema_update(float* const* ema, const float* const* model, const int64_t* numel, const int32_t* chunk_tensor,
+                   const int32_t* chunk_index, int n_chunks, float decay, float one_minus_decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,7 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
                     e.mul_(ema_decay).add_(m.detach(), alpha=1 - ema_decay)
         torch.cuda.synchronize()
         log["step_ms"].append(1e3 * (time.perf_counter() - t0))
-        log["total_loss"].append(float(loss_dict["total_loss"]))
+        log["total_loss"].append(float(loss_dict["total_loss"].detach()))
         if verbose:
             print(f"step {step}: total_loss {log['total_loss'][-1]:.4f}  ({log['step_ms'][-1]:.1f} ms)", flush=True)
     with torch.no_grad():

@@ -206,3 +206,71 @@ def test_optimisation_steps_reduce_the_loss():
     assert log["total_loss"][-1] < log["total_loss"][0]
     assert log["params_without_grad"] == [] and log["nonfinite_grads"] == []
     assert log["param_delta_norm"] > 0 and 0 < log["ema_delta_norm"] < log["param_delta_norm"]
+
+
+def test_device_assignment_equals_scipy():
+    """vrd_assign (one thread per pair, Hungarian with potentials) against scipy.optimize.linear_sum_assignment -- what the
+    reference's matcher calls per pair (models/maskvrd.py:492) -- on random cost blocks of every size N <= Q, Q = 9, 10, 16."""
+    from scipy.optimize import linear_sum_assignment
+    from vrdone_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for Q in (9, 10, 16):
+        sizes = [int(n) for n in torch.randint(0, Q + 1, (200,), generator=g)]
+        sizes[:3] = [Q, 1, 0]
+        cost = torch.randn(sum(sizes), Q, generator=g)
+        got = ops.assign(cost.to(DEV), sizes).cpu()
+        at = 0
+        for n in sizes:
+            if n:
+                rows, cols = linear_sum_assignment(cost[at:at + n].T.numpy())       # rows = queries, cols = relations
+                want = torch.empty(n, dtype=torch.int32)
+                want[torch.as_tensor(cols)] = torch.as_tensor(rows, dtype=torch.int32)
+                assert torch.equal(got[at:at + n], want), (Q, n)
+            at += n
+
+
+def test_device_matching_gives_the_host_matchings():
+    """MaskVRD.bipartite_match with the device assignment vs the scipy path on the training batch's predictions."""
+    model, mc, _ = build()
+    lens, x, m, data = train_batch(mc, c_in(mc), device=DEV)
+    with torch.no_grad():
+        out = model.eval()._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
+        args = (out["pred_logits"], data["preds_list"], out["pred_masks"], data["masks_list"], data["segs_list"])
+        model.device_matching = True
+        a, _ = model.bipartite_match(*args, _mask=out["output_mask"])
+        model.device_matching = False
+        b, _ = model.bipartite_match(*args, _mask=out["output_mask"])
+    for n, ((ai, aj), (bi, bj)) in enumerate(zip(a, b)):
+        if lens[n] >= 16:          # shorter pairs price their queries identically to ~1e-5: ties
+            assert ai.tolist() == bi.tolist() and aj.tolist() == bj.tolist(), n
+        assert sorted(aj.tolist()) == sorted(bj.tolist()) and len(set(ai.tolist())) == len(ai)
+
+
+def test_ema_update_is_one_launch_and_bit_identical():
+    """vrdone_amd.ema.ModelEma.update (vrd_ema_update over a pointer table) vs the reference's per-tensor expression
+    decay * e + (1 - decay) * m (utils/train_utils.py:21-29), three updates in a row."""
+    import copy
+    from vrdone_amd import _hip
+    from vrdone_amd.ema import ModelEma
+    model, mc, _ = build()
+    ema = ModelEma(model, decay=0.999)
+    ref = copy.deepcopy(model).eval()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for step in range(3):
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(torch.randn(p.shape, device=DEV, generator=g) * 0.01)
+            for e, mv in zip(ref.state_dict().values(), model.state_dict().values()):
+                e.copy_(0.999 * e + (1.0 - 0.999) * mv)
+        _hip.prof_enable(True)
+        _hip.prof_reset()
+        ema.update(model)
+        torch.cuda.synchronize()
+        launches = _hip.prof_read()["backward"]["launches"]
+        _hip.prof_enable(False)
+        assert launches == 1
+        for (k, a), b in zip(ema.module.state_dict().items(), ref.state_dict().values()):
+            assert torch.equal(a, b), (step, k)
+    ema.set(model)
+    for a, b in zip(ema.module.state_dict().values(), model.state_dict().values()):
+        assert torch.equal(a, b)

@@ -1,0 +1,98 @@
+// Training tail on the device: the Hungarian assignment of the matcher and the EMA weight update.
+//
+//  vrd_assign       models/maskvrd.py:484-492 hands the (B*Q, sum N) cost matrix to the host and runs scipy's
+//                   linear_sum_assignment once per pair.  Here every pair's (N_i relations x Q queries) block is solved by
+//                   one thread with the O(n^2 m) shortest-augmenting-path form of the Hungarian algorithm (potentials
+//                   u, v; N_i <= Q <= 16), in double precision; only the assignment (one int per relation) leaves the
+//                   device.  The optimum is the one scipy finds whenever it is unique.
+//  vrd_ema_update   utils/train_utils.py:21-29 walks the ~520 state-dict tensors with three elementwise launches
+//                   each; here ONE launch updates all of them through a chunk table:
+//                   ema = decay * ema + (1 - decay) * model, each product and the sum rounded to f32 like the
+//                   reference's tensor expression (no FMA contraction), so the result is bit-identical.
+#include "vrd_common.h"
+
+namespace {
+
+constexpr int AS_MAX = 16;
+
+__global__ __launch_bounds__(64) void assign_kernel(const float* __restrict__ cost, int64_t ld, const int32_t* __restrict__ first,
+                                                    const int32_t* __restrict__ count, int P, int Q, int32_t* __restrict__ query_of) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= P) return;
+    const int n = count[p], r0 = first[p];
+    if (n <= 0) return;
+    // rows = relations 1..n, columns = queries 1..Q (1-based like the textbook form); way / minv per column
+    double u[AS_MAX + 1], v[AS_MAX + 1], minv[AS_MAX + 1];
+    int match[AS_MAX + 1], way[AS_MAX + 1];
+    bool used[AS_MAX + 1];
+    for (int j = 0; j <= Q; ++j) v[j] = 0.0, match[j] = 0;
+    for (int i = 0; i <= n; ++i) u[i] = 0.0;
+    for (int i = 1; i <= n; ++i) {
+        match[0] = i;
+        int j0 = 0;
+        for (int j = 0; j <= Q; ++j) minv[j] = 1e300, used[j] = false;
+        do {
+            used[j0] = true;
+            const int i0 = match[j0];
+            double delta = 1e300;
+            int j1 = 0;
+            for (int j = 1; j <= Q; ++j) {
+                if (used[j]) continue;
+                const double cur = (double)cost[(int64_t)(r0 + i0 - 1) * ld + (j - 1)] - u[i0] - v[j];
+                if (cur < minv[j]) minv[j] = cur, way[j] = j0;
+                if (minv[j] < delta) delta = minv[j], j1 = j;
+            }
+            for (int j = 0; j <= Q; ++j) {
+                if (used[j]) u[match[j]] += delta, v[j] -= delta;
+                else minv[j] -= delta;
+            }
+            j0 = j1;
+        } while (match[j0] != 0);
+        do {
+            const int j1 = way[j0];
+            match[j0] = match[j1];
+            j0 = j1;
+        } while (j0);
+    }
+    for (int j = 1; j <= Q; ++j)
+        if (match[j]) query_of[r0 + match[j] - 1] = j - 1;
+}
+
+constexpr int EMA_CHUNK = 4096;
+__global__ __launch_bounds__(256) void ema_kernel(float* const* __restrict__ ema, const float* const* __restrict__ model,
+                                                  const int64_t* __restrict__ numel, const int32_t* __restrict__ chunk_tensor,
+                                                  const int32_t* __restrict__ chunk_index, float decay, float one_minus) {
+    const int t = chunk_tensor[blockIdx.x];
+    const int64_t base = (int64_t)chunk_index[blockIdx.x] * EMA_CHUNK;
+    const int64_t n = numel[t];
+    float* const e = ema[t];
+    const float* const m = model[t];
+    for (int64_t i = base + threadIdx.x; i < base + EMA_CHUNK && i < n; i += 256)
+        e[i] = __fadd_rn(__fmul_rn(decay, e[i]), __fmul_rn(one_minus, m[i]));
+}
+
+}  // namespace
+
+extern "C" {
+
+int vrd_assign(const float* cost, int64_t ld, const int32_t* first, const int32_t* count, int P, int Q, int32_t* query_of, void* stream) {
+    VRD_CHECK_ARG(cost && first && count && query_of, "vrd_assign: null pointer");
+    VRD_CHECK_ARG(P > 0 && Q >= 1 && Q <= AS_MAX && ld >= Q, "vrd_assign: Q must be 1..%d (got %d)", AS_MAX, Q);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 0.0);
+    hipLaunchKernelGGL(assign_kernel, dim3((P + 63) / 64), dim3(64), 0, s, cost, ld, first, count, P, Q, query_of);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_ema_update(float* const* ema, const float* const* model, const int64_t* numel, const int32_t* chunk_tensor,
+                   const int32_t* chunk_index, int n_chunks, float decay, float one_minus_decay, void* stream) {
+    VRD_CHECK_ARG(ema && model && numel && chunk_tensor && chunk_index && n_chunks > 0, "vrd_ema_update: bad arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 12.0 * (double)n_chunks * EMA_CHUNK);
+    hipLaunchKernelGGL(ema_kernel, dim3(n_chunks), dim3(256), 0, s, ema, model, numel, chunk_tensor, chunk_index, decay, one_minus_decay);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

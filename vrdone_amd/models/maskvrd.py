@@ -82,6 +82,7 @@ class MaskVRD(nn.Module):
         # 2*chunk*T*2048 floats = 9.7 GB at 2048 pairs x 288 frames, of 288 GB).  Measured: 256 -> 1024 pairs +15 %,
         # 1024 -> 2048 +2.5 % (fewer launches of the small predictor / pyramid GEMMs, longer tile runs)
         self.pair_chunk = 2048
+        self.device_matching = True       # Hungarian assignment on the device (vrd_assign); False: scipy on the host
 
     @torch.no_grad()
     def _config_eval(self, infer_config):
@@ -189,11 +190,20 @@ class MaskVRD(nn.Module):
         c_class, c_mask, c_dice = losses.pair_costs(pred_logits, pred_masks, valid, torch.cat(gt_preds, dim=0),
                                                     tgt_masks, owner, segs, scale_range)
         cost = (self.cost_factor['cost_class'] * c_class + self.cost_factor['cost_mask'] * c_mask +
-                self.cost_factor['cost_dice'] * c_dice).cpu()                       # (sum N_i, Q)
+                self.cost_factor['cost_dice'] * c_dice)                             # (sum N_i, Q)
+        Q = cost.shape[1]
         indices = []
-        for block in cost.split(sizes, dim=0):
-            rows, cols = linear_sum_assignment(block.T.numpy())
-            indices.append((torch.as_tensor(rows, dtype=torch.int64), torch.as_tensor(cols, dtype=torch.int64)))
+        if cost.is_cuda and sizes and 0 < max(sizes) <= Q <= 16 and self.device_matching:
+            # every pair's assignment on the device (vrd_assign); one small copy brings the result back in the reference's
+            # format: per pair (query indices ascending, the relation each one got)
+            q_of = _ops().assign(cost.contiguous(), sizes).cpu().long()
+            for block in q_of.split(sizes):
+                rows, order = torch.sort(block)
+                indices.append((rows, order))
+        else:
+            for block in cost.cpu().split(sizes, dim=0):
+                rows, cols = linear_sum_assignment(block.T.numpy())
+                indices.append((torch.as_tensor(rows, dtype=torch.int64), torch.as_tensor(cols, dtype=torch.int64)))
         return indices, valid[owner]
 
     def _get_src_permutation_idx(self, indices):
