@@ -114,7 +114,8 @@ class Linear(Function):
             px, _, _, ldx = _rows(x)
             check(lib.vrd_gemm_wgrad(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(), _stream()),
                   "vrd_gemm_wgrad")
-            dw = packed.view(N, k, Cin).permute(0, 2, 1)           # tap-major -> the Conv1d layout (N, Cin, k)
+            # tap-major -> the Conv1d layout (N, Cin, k), with the parameter's own strides (DDP's bucket views expect them)
+            dw = packed.view(N, Cin, 1) if k == 1 else packed.view(N, k, Cin).permute(0, 2, 1).contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, torch.zeros(N, device=dy.device, dtype=torch.float32), row_mask=mask)
         return dx, dw, db, None
@@ -237,7 +238,7 @@ class DepthwiseConv(Function):
                 for kk in range(k):
                     colsum(dDs[i], gw[g, kk], b=xin, b_cstride=gin, b_coffset=g, b_rstride=s, shift=kk - k // 2, T=Tout,
                            row_mask=ctx.mask_out)
-            grads.append(gw.permute(2, 0, 1))                                     # (C, gin, k)
+            grads.append(gw.permute(2, 0, 1).contiguous())                        # (C, gin, k)
             grads.append(colsum(dDs[i], torch.zeros(Cout, device=dev, dtype=torch.float32), row_mask=ctx.mask_out)
                          if ctx.has_bias[i] else None)
         return (dx, dx_up, None, None, *grads)
