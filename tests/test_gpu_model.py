@@ -323,6 +323,27 @@ def test_full_size_properties():
     close(small["pred_masks"], out["pred_masks"][:4], 1e-4)
 
 
+def test_full_size_properties_vidor_x():
+    """BASELINE config 5 shape class (vidor_x.yaml: C_in 3093 with the CLIP slabs, 8 heads, window 9, T = 512): 384 pairs x
+    512 frames -- enough rows (393k stacked) for the 256 x 256 GEMM kernel, the padding maps and the batched q/k/v
+    launches -- finite outputs, -10 on masked frames, and rows equal to a 3-pair run of the small-shape kernels."""
+    model, mc, _, _ = get_model("vidor_x")
+    B, T = 384, 512
+    gen = torch.Generator(device=DEV).manual_seed(15)
+    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(16))
+    lens[:3] = torch.tensor([512, 333, 65])
+    m = (torch.arange(T)[None] < lens[:, None])[:, None].to(DEV)
+    x = torch.randn(B, c_in(mc), T, device=DEV, generator=gen) * m
+    out = model._mask_vrd(x, m, with_aux=False)
+    Q = mc["predictor"]["num_queries"]
+    assert out["pred_logits"].shape == (B, Q, mc["num_classes"] + 1) and out["pred_masks"].shape == (B, Q, T)
+    assert bool(torch.isfinite(out["pred_logits"]).all()) and bool(torch.isfinite(out["pred_masks"]).all())
+    assert bool((out["pred_masks"].masked_select(~m.expand(-1, Q, -1)) == -10.0).all())
+    small = model._mask_vrd(x[:3].contiguous(), m[:3].contiguous(), with_aux=False)
+    close(small["pred_logits"], out["pred_logits"][:3], 1e-5)
+    close(small["pred_masks"], out["pred_masks"][:3], 1e-4)
+
+
 def test_extension_is_loaded_and_profiled():
     """The HIP library is the code that ran: its per-family event profile sees the launches."""
     from vrdone_amd import _hip
