@@ -159,3 +159,35 @@ def synth_raw_video(n_tracklets=8, video_len=120, min_len=12, max_len=100, n_vis
     if n_clip:
         out["clip_features_list"] = clip
     return out
+
+
+def write_synth_pickles(directory, video_name="vid0", n_tracklets=6, video_len=60, n_visual=32, seed=9):
+    """Write the two per-video files `_prepare_test` reads (dataloaders/vidvrd.py:466-467,510-511): <dir>/info/<name>.pkl
+    with the trajectory proposals (inclusive end frames) and <dir>/feat/<name>.pkl with the per-frame RoI features.
+    Returns (info path, features path)."""
+    import os
+    import pickle
+    g = torch.Generator().manual_seed(seed)
+    durs, boxes = [], []
+    for _ in range(n_tracklets):
+        L = int(torch.randint(3, video_len // 2, (1,), generator=g))
+        st = int(torch.randint(0, video_len - L + 1, (1,), generator=g))
+        durs.append([st, st + L - 1])                                        # inclusive end, as stored on disk
+        xy = torch.rand(L, 2, generator=g) * 200.0
+        boxes.append(torch.cat([xy, xy + torch.rand(L, 2, generator=g) * 80.0 + 5.0], dim=1))
+    feats = {t: torch.randn(durs[t][1] - durs[t][0] + 1, n_visual, generator=g) for t in range(n_tracklets)}
+    frames = {}
+    for fid in range(video_len):
+        tids = [t for t in range(n_tracklets) if durs[t][0] <= fid <= durs[t][1]]
+        if tids:
+            frames[fid] = {"frame_id": fid, "tids": tids, "visual_features": [feats[t][fid - durs[t][0]].numpy() for t in tids]}
+    info = {"traj_proposal": {"num_proposals": n_tracklets, "cat_ids": torch.randint(1, 36, (n_tracklets,), generator=g),
+                              "scores": torch.rand(n_tracklets, generator=g), "bboxes_list": boxes,
+                              "traj_durations": torch.tensor(durs), "video_wh": (640, 360)}}
+    os.makedirs(os.path.join(directory, "info"), exist_ok=True)
+    os.makedirs(os.path.join(directory, "feat"), exist_ok=True)
+    paths = (os.path.join(directory, "info", video_name + ".pkl"), os.path.join(directory, "feat", video_name + ".pkl"))
+    for path, obj in zip(paths, (info, frames)):
+        with open(path, "wb") as f:
+            pickle.dump(obj, f)
+    return paths

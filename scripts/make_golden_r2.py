@@ -95,6 +95,19 @@ def proposal_case():
         arrs[f"{name}/boxes_clamped"] = torch.cat(out["bboxes_list"], dim=0).numpy()
         print("proposal case", name, "pairs", len(feats), "of", len(raw["sids"]), "lens", arrs[f"{name}/lens"].tolist()[:12])
         assert len(feats) < len(raw["sids"])             # the de-dup (and the length filters) removed something
+    # the on-disk layout: the reference's `_prepare_test` on two synthetic per-video pickles
+    import tempfile
+    from oracle.proposal import write_synth_pickles
+    with tempfile.TemporaryDirectory() as tmp:
+        info, feat = write_synth_pickles(tmp)
+        ds = object.__new__(VidVRD)
+        ds.split, ds.info_dir, ds.test_boxfeatures_dir = "test", os.path.dirname(info), os.path.dirname(feat)
+        out = ds._prepare_test("vid0")
+    arrs["pickles/sids"], arrs["pickles/oids"] = out["sids"].numpy(), out["oids"].numpy()
+    arrs["pickles/traj_durations"] = out["traj_durations"].numpy()
+    arrs["pickles/visual_features"] = torch.cat(out["visual_features_list"]).numpy()
+    arrs["pickles/bboxes"] = torch.cat(out["bboxes_list"]).numpy()
+    print("pickle case: tracklets", len(out["bboxes_list"]), "pairs", len(out["sids"]))
     np.savez_compressed(os.path.join(OUT, "proposal.npz"), **arrs)
 
 

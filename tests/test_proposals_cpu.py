@@ -36,3 +36,31 @@ def test_no_pair_survives():
     raw = P.synth_raw_video(n_tracklets=3, video_len=40, min_len=4, max_len=6, seed=1)
     raw["sids"], raw["oids"] = raw["sids"][:0], raw["oids"][:0]
     assert prepare_test_proposal(raw, 1, 0, 2, "cpu") == {}
+
+
+def test_load_test_video_reads_the_reference_pickle_layout(tmp_path, golden_dir):
+    """vrdone_amd.proposals.load_test_video (restating `_prepare_test`, dataloaders/vidvrd.py:459-550) on the two per-video
+    pickles: pair order, [start, end) durations and per-tracklet feature stacks against the reference's own `_prepare_test`
+    run on the same files (tests/golden/proposal.npz, keys pickles/*), and against the reference itself when it is here."""
+    import os
+    from vrdone_amd.proposals import load_test_video
+    info, feat = P.write_synth_pickles(str(tmp_path))
+    got = load_test_video(info, feat)
+    g = np.load(f"{golden_dir}/proposal.npz")
+    assert got["sids"].tolist() == g["pickles/sids"].tolist() and got["oids"].tolist() == g["pickles/oids"].tolist()
+    np.testing.assert_array_equal(got["traj_durations"].numpy(), g["pickles/traj_durations"])
+    np.testing.assert_array_equal(torch.cat(got["visual_features_list"]).numpy(), g["pickles/visual_features"])
+    np.testing.assert_array_equal(torch.cat(got["bboxes_list"]).numpy(), g["pickles/bboxes"])
+    assert tuple(got["video_wh"]) == (640, 360)
+    if os.path.isdir("/root/reference/dataloaders"):
+        import subprocess, sys, json
+        code = (f"import sys, json; sys.path.insert(0, '/root/reference')\n"
+                f"from dataloaders.vidvrd import VidVRD\n"
+                f"ds = object.__new__(VidVRD); ds.split = 'test'; ds.info_dir = {os.path.dirname(info)!r}; ds.test_boxfeatures_dir = {os.path.dirname(feat)!r}\n"
+                f"out = ds._prepare_test('vid0')\n"
+                f"print(json.dumps([out['sids'].tolist(), out['oids'].tolist(), out['traj_durations'].tolist(), float(sum(v.double().sum() for v in out['visual_features_list']))]))\n")
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-1500:]
+        sids, oids, durs, fsum = json.loads(res.stdout.strip().splitlines()[-1])
+        assert got["sids"].tolist() == sids and got["oids"].tolist() == oids and got["traj_durations"].tolist() == durs
+        assert abs(float(sum(v.double().sum() for v in got["visual_features_list"])) - fsum) < 1e-9

@@ -69,6 +69,48 @@ def shadowed_tracklets(boxes, spans, cat_ids, threshold=0.9):
     return np.nonzero(gone)[0].tolist()
 
 
+def load_test_video(info_pkl, features_pkl):
+    """The two per-video pickles of the reference's test split -> the dict its `_test_getitem` (and
+    `prepare_test_proposal`) takes; restates `_prepare_test`, dataloaders/vidvrd.py:459-550.
+      info_pkl      {'traj_proposal': {num_proposals, cat_ids (N,), scores (N,), bboxes_list [N x (L_i, 4)],
+                     traj_durations (N, 2) with INCLUSIVE end frames, video_wh}}
+      features_pkl  {frame id: {'frame_id', 'tids' [tracklet ids present], 'visual_features' [one (V,) row per tid]}}
+    Returns {} for a video with fewer than two tracklets or without a pair of tracklets that share a frame."""
+    import pickle
+    with open(info_pkl, "rb") as f:
+        prop = pickle.load(f)["traj_proposal"]
+    if prop["num_proposals"] < 2:
+        return {}
+    spans = np.asarray(prop["traj_durations"]).astype(np.int64).copy()
+    spans[:, 1] += 1                                           # [start, end)
+    n = len(spans)
+    s_id, o_id = np.meshgrid(np.arange(n), np.arange(n))       # the reference's pair order: object-major
+    s_id, o_id = s_id.flatten(), o_id.flatten()
+    keep = s_id != o_id
+    s_id, o_id = s_id[keep], o_id[keep]
+    overlap = np.minimum(spans[s_id, 1], spans[o_id, 1]) > np.maximum(spans[s_id, 0], spans[o_id, 0])
+    if not overlap.any():
+        return {}
+    s_id, o_id = s_id[overlap], o_id[overlap]
+    with open(features_pkl, "rb") as f:
+        frames = pickle.load(f)
+    rows = [[] for _ in range(n)]
+    for fid in sorted(frames):
+        rec = frames[fid]
+        assert rec["frame_id"] == fid
+        for i, tid in enumerate(rec["tids"]):
+            assert spans[tid][0] <= fid < spans[tid][1]
+            rows[tid].append(np.asarray(rec["visual_features"][i]))
+    assert all(len(r) == spans[t][1] - spans[t][0] for t, r in enumerate(rows)), "a tracklet misses frames in the feature file"
+    return {"sids": torch.as_tensor(s_id, dtype=torch.int64), "oids": torch.as_tensor(o_id, dtype=torch.int64),
+            "cat_ids": torch.as_tensor(np.asarray(prop["cat_ids"]), dtype=torch.int64),
+            "cat_scores": torch.as_tensor(np.asarray(prop["scores"]), dtype=torch.float32),
+            "bboxes_list": [torch.as_tensor(np.asarray(b), dtype=torch.float32) for b in prop["bboxes_list"]],
+            "traj_durations": torch.as_tensor(spans, dtype=torch.int64),
+            "visual_features_list": [torch.as_tensor(np.stack(r, axis=0), dtype=torch.float32) for r in rows],
+            "video_wh": prop["video_wh"]}
+
+
 def prepare_test_proposal(raw, feat_stride, stride_offset, proposal_min_frames, device, viou_threshold=0.9):
     """raw: the dict `_prepare_test` hands to `_test_getitem` (sids, oids, cat_ids, cat_scores, bboxes_list,
     traj_durations [start, end), visual_features_list, optional clip_features_list, video_wh).  Returns {} when no pair
