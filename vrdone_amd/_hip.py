@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvrdone_hip.so")
+# VRDONE_HIP_LIB: another build of the same library (kernel experiments, A/B runs in one box session)
+LIB_PATH = os.environ.get("VRDONE_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrdone_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,

@@ -230,7 +230,8 @@ class DepthwiseConv(Function):
             dx_up = torch.empty(B, Tin // 2, Cx, device=dev, dtype=torch.float32)
             a.dx_up, a.lddx_up = dx_up.data_ptr(), Cx
         check(lib.vrd_dwconv_bwd(C.byref(a), _stream()), "vrd_dwconv_bwd")
-        xin = x if x_up is None else x + x_up.repeat_interleave(2, dim=1)       # the conv's input, for the weight gradients
+        # the conv's input, for the weight gradients: x + nearest-x2-upsampled x_up (the copy is torch's, the add a kernel)
+        xin = x if x_up is None else rowcol_scale(x, res2=x_up.repeat_interleave(2, dim=1))
         grads = []
         for i in range(n):
             gw = torch.zeros(gin, k, Cout, device=dev, dtype=torch.float32)
@@ -338,7 +339,7 @@ class MaskHead(Function):
         emb, feat = (t.contiguous() for t in ctx.saved_tensors)
         B, Q, Dp = emb.shape
         T = feat.shape[1]
-        g = (dseg * ctx.out_mask[:, None, :]).contiguous()             # filled frames carry no gradient
+        g = dseg.masked_fill(~ctx.out_mask[:, None, :].bool(), 0.0).contiguous()    # filled frames carry no gradient
         demb, dfeat = torch.empty_like(emb), torch.empty_like(feat)
         # demb[b, q, :] = sum_t g[b,q,t] feat[b,t,:];  dfeat[b, t, :] = sum_q g[b,q,t] emb[b,q,:]
         bmm(g, (Q * T, 0, T, 1), feat, (T * Dp, 0, Dp, 1), demb, (Q * Dp, 0, Dp, 1), B, 1, Q, Dp, T)
