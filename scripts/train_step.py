@@ -7,7 +7,6 @@ no weight decay on biases, LayerNorm / scale parameters and embeddings; configs/
     python scripts/train_step.py --steps 5          # on the GPU box
 """
 import argparse
-import copy
 import json
 import os
 import sys
@@ -64,7 +63,8 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
         for mod in model.modules():
             if isinstance(mod, AffineDropPath):
                 mod.drop_prob = 0.0
-    ema = copy.deepcopy(model).eval()
+    from vrdone_amd.ema import ModelEma
+    ema = ModelEma(model, decay=ema_decay)                                # one-launch EMA (vrd_ema_update), same values
     opt = torch.optim.AdamW(param_groups(model, weight_decay), lr=lr)
     data = synthetic_batch(cfg, configs.input_channels(cfg), device, seed=seed)
     start = [p.detach().clone() for p in model.parameters()]
@@ -83,10 +83,7 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
         if clip > 0:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)     # train.py:187-188
         opt.step()
-        with torch.no_grad():                                             # ModelEma.update, utils/train_utils.py:21-29
-            for e, m in zip(ema.state_dict().values(), model.state_dict().values()):
-                if e.dtype.is_floating_point:
-                    e.mul_(ema_decay).add_(m.detach(), alpha=1 - ema_decay)
+        ema.update(model)                                                 # train.py:194 (ModelEma.update, utils/train_utils.py:21-29)
         torch.cuda.synchronize()
         log["step_ms"].append(1e3 * (time.perf_counter() - t0))
         log["total_loss"].append(float(loss_dict["total_loss"].detach()))
@@ -94,7 +91,7 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
             print(f"step {step}: total_loss {log['total_loss'][-1]:.4f}  ({log['step_ms'][-1]:.1f} ms)", flush=True)
     with torch.no_grad():
         log["param_delta_norm"] = float(torch.sqrt(sum(((p - s) ** 2).sum() for p, s in zip(model.parameters(), start))))
-        log["ema_delta_norm"] = float(torch.sqrt(sum(((p - s) ** 2).sum() for p, s in zip(ema.parameters(), start))))
+        log["ema_delta_norm"] = float(torch.sqrt(sum(((p - s) ** 2).sum() for p, s in zip(ema.module.parameters(), start))))
     return log
 
 

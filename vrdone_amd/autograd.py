@@ -22,7 +22,7 @@ from torch.autograd import Function
 
 from . import _hip, ops
 from ._hip import lib
-from .ops import ACT_GELU, ACT_NONE, ACT_RELU, _mask_ptr, _param_ptr, _ptr, _rows, _stream
+from .ops import ACT_NONE, ACT_RELU, _mask_ptr, _ptr, _rows, _stream
 
 check = _hip.check
 

@@ -148,6 +148,9 @@ __device__ __forceinline__ void entity_feats(const float* boxes, int64_t row0, i
         entity_geom(load_box(boxes, row0 + (int64_t)(t - 1) * stride), w, h, a);
 #pragma unroll
         for (int i = 0; i < 4; ++i) d[i] = __fsub_rn(g[i], a[i]);
+    } else if (n < 2) {     // a one-frame pair has no difference (the dataloader never emits one; never read past the pair)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = 0.f;
     } else {            // first frame: d0 - (d1 - d0) with d0 = v1 - v0, d1 = v2 - v1; just d0 when there are two frames
         entity_geom(load_box(boxes, row0 + stride), w, h, a);
 #pragma unroll

@@ -21,6 +21,10 @@ __global__ __launch_bounds__(64) void assign_kernel(const float* __restrict__ co
     if (p >= P) return;
     const int n = count[p], r0 = first[p];
     if (n <= 0) return;
+    if (n > Q) {                  // more relations than queries: no complete assignment exists (the augmenting search would
+        for (int i = 0; i < n; ++i) query_of[r0 + i] = -1;      // never end); the host routes such pairs to scipy
+        return;
+    }
     // rows = relations 1..n, columns = queries 1..Q (1-based like the textbook form); way / minv per column
     double u[AS_MAX + 1], v[AS_MAX + 1], minv[AS_MAX + 1];
     int match[AS_MAX + 1], way[AS_MAX + 1];
