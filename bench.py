@@ -298,6 +298,34 @@ def main():
         ft = {"pairs": len(video["sids"]), "triplets": len(res["triplets"]), "ms": 1e3 * wall,
               "value": len(video["sids"]) / wall, "unit": "pairs/s", "sharded_over_ranks": world,
               "note": "wall time of one eval call incl. the Python result lists; median of 3 after a warm-up"}
+        if world == 1:
+            # the same call fed from PER-TRACKLET features on the host (what the dataloader holds before it builds pair
+            # matrices): host preparation (box clamp, vIoU de-dup, pair tables) + upload of every tracklet once
+            # (proposals.prepare_test_proposal), then forward_test gathering pair rows / box features on the device
+            from vrdone_amd.proposals import prepare_test_proposal
+            del video
+            torch.cuda.empty_cache()
+            ic = configs.inference_config(args.config)
+            raw = synth.synth_raw_video(46, cfg["visual_dim"], 200, args.frames, seed=7)
+            prep, fwd = [], []
+            with torch.no_grad():
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    prop = prepare_test_proposal(raw, ic["feat_stride"], 0, 2, dev)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    res2 = model(prop)
+                    torch.cuda.synchronize()
+                    prep.append(t1 - t0)
+                    fwd.append(time.perf_counter() - t1)
+            host_mb = sum(v.numel() for v in raw["visual_features_list"]) * 4 / 1e6
+            pair_mb = sum(prop["pair_source"].lens) * c_in * 4 / 1e6
+            ft["from_tracklets"] = {"pairs": len(prop["sids"]), "triplets": len(res2["triplets"]),
+                                    "prepare_ms": 1e3 * sorted(prep[1:])[1], "forward_test_ms": 1e3 * sorted(fwd[1:])[1],
+                                    "uploaded_MB": round(host_mb, 1), "pair_matrices_would_be_MB": round(pair_mb, 1),
+                                    "note": "host features -> result: prepare = clamp + de-dup + pair tables + upload of each "
+                                            "tracklet once; the reference uploads one (L, C_in) matrix per pair"}
 
     if rank == 0:
         fpp = FLOPS_PER_PAIR.get((args.config, t_pad))

@@ -195,3 +195,19 @@ def test_reference_optimizer_and_ema_accept_the_dropin():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GROUPS [176, 345]" in out.stdout and "EMA_LAG 0.999" in out.stdout, out.stdout
+
+
+def test_synthetic_raw_video_has_the_dataloader_layout():
+    """synth_raw_video hands out what `_prepare_test` does: per-tracklet features / boxes of the tracklet's own length,
+    half-open durations, and only pairs that share a frame."""
+    from vrdone_amd import synth
+    raw = synth.synth_raw_video(7, 16, 20, 40, seed=3, n_clip=8)
+    spans = raw["traj_durations"]
+    assert len(raw["visual_features_list"]) == len(raw["bboxes_list"]) == len(raw["clip_features_list"]) == 7
+    for i in range(7):
+        n = int(spans[i, 1] - spans[i, 0])
+        assert raw["visual_features_list"][i].shape == (n, 16) and raw["bboxes_list"][i].shape == (n, 4)
+        assert (raw["bboxes_list"][i][:, 2:] > raw["bboxes_list"][i][:, :2]).all()
+    assert len(raw["sids"]) == len(raw["oids"]) > 0
+    for s, o in zip(raw["sids"].tolist(), raw["oids"].tolist()):
+        assert s != o and min(spans[s, 1], spans[o, 1]) > max(spans[s, 0], spans[o, 0])

@@ -74,3 +74,34 @@ def synth_video(n_tracklets, c_in, min_len, max_len, seed=7, device="cpu"):
             "cat_ids": torch.randint(1, 36, (n_tracklets,), generator=g).to(device),
             "cat_scores": torch.rand(n_tracklets, generator=g).to(device),
             "traj_durations": torch.tensor(span, device=device), "so_offset": torch.zeros(len(sids), dtype=torch.long, device=device)}
+
+
+def synth_raw_video(n_tracklets, n_visual, min_len, max_len, seed=7, n_clip=0, wh=(1280, 720)):
+    """One synthetic video in the form the reference's `_prepare_test` hands to `_test_getitem`
+    (dataloaders/vidvrd.py:459-550) and vrdone_amd.proposals.prepare_test_proposal takes: per-TRACKLET visual (and CLIP)
+    features and boxes on the host, durations [start, end), distinct categories, every ordered pair of tracklets that
+    share a frame."""
+    g = torch.Generator().manual_seed(seed)
+    video_len = max_len + 8
+    spans, boxes, vis, clip = [], [], [], []
+    for _ in range(n_tracklets):
+        n = int(torch.randint(min_len, max_len + 1, (1,), generator=g))
+        t0 = int(torch.randint(0, video_len - n + 1, (1,), generator=g))
+        spans.append((t0, t0 + n))
+        corner = torch.rand(n, 2, generator=g) * torch.tensor([wh[0] * 0.6, wh[1] * 0.6])
+        boxes.append(torch.cat([corner, corner + torch.rand(n, 2, generator=g) * torch.tensor([wh[0] * 0.3, wh[1] * 0.3]) + 8.0], dim=1))
+        vis.append(torch.randn(n, n_visual, generator=g))
+        if n_clip:
+            clip.append(torch.randn(n, n_clip, generator=g))
+    sids, oids = [], []
+    for s in range(n_tracklets):
+        for o in range(n_tracklets):
+            if s != o and min(spans[s][1], spans[o][1]) > max(spans[s][0], spans[o][0]):
+                sids.append(s)
+                oids.append(o)
+    out = {"sids": torch.tensor(sids), "oids": torch.tensor(oids), "cat_ids": torch.arange(1, n_tracklets + 1),
+           "cat_scores": torch.rand(n_tracklets, generator=g), "bboxes_list": boxes,
+           "traj_durations": torch.tensor(spans, dtype=torch.int64), "visual_features_list": vis, "video_wh": wh}
+    if n_clip:
+        out["clip_features_list"] = clip
+    return out
