@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 15
+#define VRD_ABI_VERSION 16
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -94,7 +94,8 @@ int vrd_pack_pairs(const vrd_pack_args* a, void* stream);
  * frame t being row s_row[p] + t*stride of the subject's arrays and o_row[p] + t*stride of the object's (the dataloader's
  * feat[start_offset::feat_stride] slicing, :678-692).  Writes the same operand buffers as vrd_pack_pairs (zero rows for
  * t >= lens[p]); so_box = the 5 subject-object box features, ent = the 8 entity box features of subject then object rows
- * (boxes normalised by the frame size w x h, first differences along the sub-sampled frames). */
+ * (boxes normalised by the frame size w x h, first differences along the sub-sampled frames).
+ * out_vis == NULL: only the box features are written (the wide rows then come from vrd_assemble_pairs). */
 typedef struct {
     const float* vis;
     const float* clip;
@@ -111,6 +112,31 @@ typedef struct {
     int32_t pair_wide;
 } vrd_gather_args;
 int vrd_gather_pairs(const vrd_gather_args* a, void* stream);
+
+/* Entity-stage rows of a batch of P pairs put together from rows computed ONCE PER TRACKLET (second half).
+ * The reference runs the embedding convs, the visual/box fusion and the first stem block on the subject and the object
+ * of every pair (models/backbones.py:172-214), although every op there sees one tracklet only and reaches at most `reach`
+ * frames to either side: frame t of a pair with n frames equals the same frame computed on the whole tracklet when
+ * reach <= t < n - reach; only the frames within `reach` of the pair's window edges (zero padding there) differ.
+ *   streams   (., D)        rows of the per-tracklet computation; stream_row[e] = the row holding frame 0 of entity e
+ *                           (e = p for the subject, P + p for the object of pair p)
+ *   snippets  (4P, L, D)    the same stage run on short pieces at the window edges, `piece` >= 2*reach frames each, in
+ *                           buffers of L > piece frames: [subject start P | subject end P | object start P | object end P].
+ *                           A start piece holds frames [0, min(n, piece)); an end piece holds frames [n - piece, n) followed by
+ *                           padding -- like the pair's own rows when n < T: the reference's LayerNorms turn a padded frame
+ *                           into their bias, which the next conv reads (models/backbones.py:196-207, blocks.py:828-860) -- or,
+ *                           when n == T (no padded frame follows in the pair's batch either), frames [n - L, n) filling the
+ *                           buffer.  End pieces are unused when n <= piece.
+ *   out       (2P, T, D)    subject rows then object rows; zero for t >= n */
+typedef struct {
+    const float* streams;
+    const float* snippets;
+    const int64_t* stream_row;
+    const int32_t* lens;
+    int32_t P, T, D, L, piece, reach;
+    float* out;
+} vrd_assemble_args;
+int vrd_assemble_pairs(const vrd_assemble_args* a, void* stream);
 
 /* rows (b*T+t) x C (leading dim ld_src) -> (B, C, T) contiguous. */
 int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float* dst, void* stream);

@@ -291,6 +291,69 @@ def test_forward_test_from_tracklet_features_equals_pair_matrices(precision):
     assert a["so_trajs"] == b["so_trajs"]
 
 
+@pytest.mark.parametrize("cfg_name,case,full", [("vidvrd", "vidvrd", False), ("vidvrd", "strided", True), ("vidor_x", "strided", False),
+                                                ("vidor_x", "vidvrd", True)])
+def test_entity_stage_once_per_tracklet_is_bit_equal(cfg_name, case, full, precision):
+    """The backbone's entity stage (embeddings, visual/box fusion, first stem block) run once per tracklet and pieced
+    together per pair (MaskVRD._entity_streams / vrd_assemble_pairs) gives, bit for bit, the rows of running it on every
+    pair's subject and object: tracklets of different spans (pair windows that start / end inside a tracklet), pairs
+    shorter than an edge piece, feat_stride 1 and 4 with an offset, attention windows 7 and 9."""
+    from golden_cases import PROPOSAL_CASES
+    from oracle import proposal as P
+    from vrdone_amd import ops
+    from vrdone_amd.proposals import prepare_test_proposal
+    model, mc, ic, _ = get_model(cfg_name)
+    bb = model.backbone
+    vid_kw, dl_kw = PROPOSAL_CASES[case]
+    raw = P.synth_raw_video(**dict(vid_kw, n_visual=bb.n_visual, n_clip=bb.n_clip))
+    prop = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], DEV)
+    src = prop["pair_source"]
+    ids = sorted(range(len(src)), key=lambda i: src.lens[i])
+    shared = model._entity_streams(src, ids)
+    assert shared is not None and shared[3] == bb.entity_reach() == 3 + bb.mha_win_size[0] // 2
+    from vrdone_amd.proposals import PairSource
+    lens = src.lens_dev.clone()
+    piece, buf = shared[2]
+    # windows cut short (of long pairs, so that they stay inside the tracklets): edge pieces that overlap / cover the pair
+    lens[torch.tensor(ids[-8:-2])] = torch.tensor([2, 3, piece - 1, piece, piece + 1, buf], dtype=torch.int32, device=DEV)
+    if full:        # pairs that fill their T frames (no padded frame behind them): cut the long pairs' windows to T
+        T = (max(src.lens) - 1) // 24 * 24
+        lens.clamp_(max=T)
+    else:
+        T = -(-max(src.lens) // 96) * 96
+    src = PairSource(src.vis, src.clip, src.boxes, src.s_row, src.o_row, lens, src.stride, src.wh, src.first_row)
+    assert max(src.lens) >= 2 * buf and (not full or sum(n == T for n in src.lens) >= 2)
+    sel = torch.tensor(ids, device=DEV)
+    so, so_box, mask = model._shared_entity_rows(src, sel, shared, 0, T)
+    vis, clip, so_box2, ent, mask2 = ops.gather_pairs(src, sel, T, bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+    want = bb.entity_stage(vis, clip, ent, torch.cat([mask2, mask2], dim=0))
+    assert torch.equal(mask, mask2) and torch.equal(so_box, so_box2)
+    assert torch.equal(so, want), f"max abs diff {float((so - want).abs().max()):.3g}"
+    # and the frames at a window edge do differ from the tracklet's own somewhere (the case exercises the pieces)
+    rows, stream_row = shared[0].view(-1, so.shape[-1]), shared[1].reshape(-1).tolist()
+    assert any(not torch.equal(rows[r], want[e, 0]) for e, r in enumerate(stream_row))
+
+
+@pytest.mark.parametrize("cfg_name,case", [("vidvrd", "vidvrd"), ("vidor_x", "strided")])
+def test_forward_test_sharing_tracklets_changes_nothing(cfg_name, case, precision):
+    from golden_cases import PROPOSAL_CASES
+    from oracle import proposal as P
+    from vrdone_amd.proposals import prepare_test_proposal
+    model, mc, ic, _ = get_model(cfg_name)
+    vid_kw, dl_kw = PROPOSAL_CASES[case]
+    raw = P.synth_raw_video(**dict(vid_kw, n_visual=model.backbone.n_visual, n_clip=model.backbone.n_clip))
+    prop = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], DEV)
+    old_stride = model.feat_stride
+    model.feat_stride = dl_kw["feat_stride"]
+    try:
+        a = model(prop)
+        model.share_tracklets = False
+        b = model(prop)
+    finally:
+        model.share_tracklets, model.feat_stride = True, old_stride
+    assert a == b
+
+
 def test_forward_test_matches_oracle_small():
     model, mc, ic, sd = get_model("vidvrd")
     data = synth_proposal(4, c_in(mc), 10, 110, seed=99)

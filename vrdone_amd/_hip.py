@@ -75,6 +75,12 @@ class GatherArgs(C.Structure):
                 ("pair_wide", C.c_int32)]
 
 
+class AssembleArgs(C.Structure):
+    _fields_ = [("streams", c_f32p), ("snippets", c_f32p), ("stream_row", C.c_void_p), ("lens", C.c_void_p),
+                ("P", C.c_int32), ("T", C.c_int32), ("D", C.c_int32), ("L", C.c_int32), ("piece", C.c_int32), ("reach", C.c_int32),
+                ("out", c_f32p)]
+
+
 _SIGNATURES = {
     "vrd_abi_version": (C.c_int, []),
     "vrd_last_error": (C.c_char_p, []),
@@ -88,6 +94,7 @@ _SIGNATURES = {
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
     "vrd_gather_pairs": (C.c_int, [C.POINTER(GatherArgs), C.c_void_p]),
+    "vrd_assemble_pairs": (C.c_int, [C.POINTER(AssembleArgs), C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_gemm_batch": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "vrd_row_blocks": (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -128,7 +135,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class HipLibraryError(RuntimeError):

@@ -174,11 +174,13 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(vrd_gather_args a) {
     const bool live = t < n;
     const int64_t rs = a.s_row[p] + (int64_t)t * a.stride, ro = a.o_row[p] + (int64_t)t * a.stride;
     const int64_t half = (int64_t)a.P * a.T;
-    pack_segment(a.vis + (live ? rs : 0) * a.V, live, lane, a.V, a.out_vis + row * a.V, a.pair_wide);
-    pack_segment(a.vis + (live ? ro : 0) * a.V, live, lane, a.V, a.out_vis + (half + row) * a.V, a.pair_wide);
-    if (a.Cc) {
-        pack_segment(a.clip + (live ? rs : 0) * a.Cc, live, lane, a.Cc, a.out_clip + row * a.Cc, a.pair_wide);
-        pack_segment(a.clip + (live ? ro : 0) * a.Cc, live, lane, a.Cc, a.out_clip + (half + row) * a.Cc, a.pair_wide);
+    if (a.out_vis) {        // NULL: box features only (the wide rows come from the per-tracklet streams, vrd_assemble_pairs)
+        pack_segment(a.vis + (live ? rs : 0) * a.V, live, lane, a.V, a.out_vis + row * a.V, a.pair_wide);
+        pack_segment(a.vis + (live ? ro : 0) * a.V, live, lane, a.V, a.out_vis + (half + row) * a.V, a.pair_wide);
+        if (a.Cc) {
+            pack_segment(a.clip + (live ? rs : 0) * a.Cc, live, lane, a.Cc, a.out_clip + row * a.Cc, a.pair_wide);
+            pack_segment(a.clip + (live ? ro : 0) * a.Cc, live, lane, a.Cc, a.out_clip + (half + row) * a.Cc, a.pair_wide);
+        }
     }
     // box features: lanes 0 (subject-object), 1 (subject), 2 (object) compute, everybody stores zeros for padded frames
     float* const so = a.out_so_box + row * 5;
@@ -206,6 +208,28 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(vrd_gather_args a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[i] = f[i];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// entity-stage rows of a pair batch from per-tracklet rows + window-edge snippets (see vrd_assemble_args); one wave per row
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_pairs_kernel(vrd_assemble_args a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (row >= 2 * (int64_t)a.P * a.T) return;
+    const int e = (int)(row / a.T), t = (int)(row - (int64_t)e * a.T);
+    const int side = e >= a.P, p = e - side * a.P;
+    const int n = a.lens[p];
+    const float* src = nullptr;
+    if (t < n) {
+        const int64_t piece = ((int64_t)side * 2 * a.P + p) * a.L;            // this entity's start piece; its end piece is P pieces on
+        const int end_len = n == a.T ? a.L : a.piece;                          // see vrd_assemble_args
+        if (n <= a.piece || t < a.reach) src = a.snippets + (piece + t) * a.D;
+        else if (t >= n - a.reach) src = a.snippets + (piece + (int64_t)a.P * a.L + (t - (n - end_len))) * a.D;
+        else src = a.streams + (a.stream_row[e] + t) * a.D;
+    }
+    float4* dst = reinterpret_cast<float4*>(a.out + row * a.D);
+    for (int c = lane; c < a.D / 4; c += 64) dst[c] = src ? reinterpret_cast<const float4*>(src)[c] : float4{0.f, 0.f, 0.f, 0.f};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -622,16 +646,31 @@ int vrd_pack_pairs(const vrd_pack_args* a, void* stream) {
 }
 
 int vrd_gather_pairs(const vrd_gather_args* a, void* stream) {
-    VRD_CHECK_ARG(a && a->vis && a->boxes && a->s_row && a->o_row && a->lens && a->out_vis && a->out_so_box && a->out_ent,
+    VRD_CHECK_ARG(a && a->vis && a->boxes && a->s_row && a->o_row && a->lens && a->out_so_box && a->out_ent,
                   "vrd_gather_pairs: null pointer");
     VRD_CHECK_ARG(a->P > 0 && a->T > 0 && a->V > 0 && a->Cc >= 0 && a->stride >= 1 && a->w > 0.f && a->h > 0.f, "vrd_gather_pairs: bad sizes");
-    VRD_CHECK_ARG(a->Cc == 0 || (a->clip && a->out_clip), "vrd_gather_pairs: clip buffers missing");
+    VRD_CHECK_ARG(a->Cc == 0 || !a->out_vis || (a->clip && a->out_clip), "vrd_gather_pairs: clip buffers missing");
     VRD_CHECK_ARG(!a->pair_wide || (a->V % 32 == 0 && a->Cc % 32 == 0), "vrd_gather_pairs: pair rows need widths %% 32 == 0");
     VRD_CHECK_ARG(aligned16(a->boxes), "vrd_gather_pairs: boxes must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t rows = (int64_t)a->P * a->T;
-    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * (2 * a->V + 2 * a->Cc + 21));
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * ((a->out_vis ? 2 * a->V + 2 * a->Cc : 0) + 21));
     hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_assemble_pairs(const vrd_assemble_args* a, void* stream) {
+    VRD_CHECK_ARG(a && a->streams && a->snippets && a->stream_row && a->lens && a->out, "vrd_assemble_pairs: null pointer");
+    VRD_CHECK_ARG(a->P > 0 && a->T > 0 && a->D > 0 && a->D % 4 == 0, "vrd_assemble_pairs: bad sizes");
+    VRD_CHECK_ARG(a->reach >= 0 && a->piece >= 2 * a->reach && a->piece >= 1 && a->L > a->piece && a->T >= a->L,
+                  "vrd_assemble_pairs: pieces of %d frames in buffers of %d (T = %d) cannot cover a reach of %d", a->piece, a->L, a->T, a->reach);
+    VRD_CHECK_ARG(aligned16(a->streams) && aligned16(a->snippets) && aligned16(a->out), "vrd_assemble_pairs: rows must be 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t rows = 2 * (int64_t)a->P * a->T;
+    VRD_CHECK_ARG((rows + 3) / 4 < ((int64_t)1 << 31), "vrd_assemble_pairs: grid too large");
+    vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * a->D);
+    hipLaunchKernelGGL(assemble_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
     VRD_LAUNCH_CHECK();
     return 0;
 }

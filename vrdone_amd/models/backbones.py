@@ -118,13 +118,26 @@ class MaskConvTransformerBackbone(nn.Module):
     def cl_parts(self, vis, clip, so_box, ent, mask):
         """vis (2B, T, V), clip (2B, T, Cc) or None, so_box (B, T, S), ent (2B, T, E): channels-last operand
         buffers (from _unpack or ops.pack_pairs); mask (B, T) bool."""
+        return self.pair_stage(self.entity_stage(vis, clip, ent, torch.cat([mask, mask], dim=0)), so_box, mask)
+
+    def entity_reach(self):
+        """How many frames either side of a frame the entity stage reads (embedding convs, then the first stem block's
+        depthwise conv and attention window), or None when that stage is not local (global attention)."""
+        win = self.mha_win_size[0]
+        if win <= 1 or any(c.kernel_size[0] != 1 for c in self.visual_bbox_fuse.layers):
+            return None
+        return self.arch[0] + 1 + win // 2        # k = 3 embedding convs, k = 3 depthwise conv, half a window
+
+    def entity_stage(self, vis, clip, ent, mask2):
+        """Everything that sees ONE entity's frames only -- embeddings, visual/box fusion and the first stem block, all
+        with weights shared between subject and object (reference backbones.py:172-214): n sequences in, (n, T, D) out.
+        Every op in it is local in time (see entity_reach), which is what lets forward_test run it once per tracklet
+        instead of once per pair."""
         ops = _ops()
-        B, T = mask.shape
+        n, T = mask2.shape
         Cc = self.n_clip
         D = self.s_fuse_norm.num_channels
-        dev = mask.device
-        mask2 = torch.cat([mask, mask], dim=0)
-        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
+        new = lambda *shape: torch.empty(*shape, device=mask2.device, dtype=torch.float32)   # noqa: E731
 
         # concatenation buffers hold two D-wide slabs; in bf16x3 mode both slabs are pair rows (width D)
         pair = ops.pair_mode()
@@ -132,19 +145,33 @@ class MaskConvTransformerBackbone(nn.Module):
 
         # [visual (+clip) | entity box] -> visual_bbox_fuse
         # (ops.join: the slab-filled buffer, or -- under autograd, where ops return fresh tensors -- the concatenation)
-        fuse_in = new(2 * B, T, 2 * D)
+        fuse_in = new(n, T, 2 * D)
         if Cc:
-            vc = new(2 * B, T, 2 * D)
+            vc = new(n, T, 2 * D)
             a = self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
             b = self._embed(clip, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
             a = self.visual_clip_fuse.cl(cat(ops.join(vc, (a, b))), row_mask=mask2, out=fuse_in[..., :D], out_pair=pair)
         else:
             a = self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
         b = self._embed(ent, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
-        so = self.visual_bbox_fuse.cl(cat(ops.join(fuse_in, (a, b))), row_mask=mask2)   # (2B, T, D): subject rows then object rows
+        so = self.visual_bbox_fuse.cl(cat(ops.join(fuse_in, (a, b))), row_mask=mask2)
+        so, _ = self.stem[0].cl(so, mask2)
+        return so
 
-        for stem, s_attn, o_attn in zip(self.stem, self.s_attn, self.o_attn):
-            so, _ = stem.cl(so, mask2)
+    def pair_stage(self, so, so_box, mask):
+        """so: (2B, T, D) entity-stage output, subject rows then object rows; from the first subject<->object attention on."""
+        ops = _ops()
+        B, T = mask.shape
+        D = self.s_fuse_norm.num_channels
+        dev = mask.device
+        mask2 = torch.cat([mask, mask], dim=0)
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)   # noqa: E731
+        pair = ops.pair_mode()
+        cat = (lambda t: ops.Pair(t, D)) if pair else (lambda t: t)          # noqa: E731
+
+        for i, (s_attn, o_attn) in enumerate(zip(self.s_attn, self.o_attn)):
+            if i:
+                so, _ = self.stem[i].cl(so, mask2)
             s, o = so[:B], so[B:]
             nxt = new(2 * B, T, D)
             s2, _ = s_attn.cl(s, o, mask, mask, stream_add=s, out=nxt[:B])         # s + s_attn(s, o)

@@ -8,6 +8,7 @@ Training: `model.train()(input_data)` returns the reference's loss dict (maskvrd
 call is a validation pass on the fused inference kernels (no drop-path sampling).
 """
 import gc
+import math
 
 import torch
 import torch.nn.functional as F
@@ -82,6 +83,7 @@ class MaskVRD(nn.Module):
         # 2*chunk*T*2048 floats = 9.7 GB at 2048 pairs x 288 frames, of 288 GB).  Measured: 256 -> 1024 pairs +15 %,
         # 1024 -> 2048 +2.5 % (fewer launches of the small predictor / pyramid GEMMs, longer tile runs)
         self.pair_chunk = 2048
+        self.share_tracklets = True     # forward_test from a PairSource: entity stage once per tracklet (_entity_streams)
         self.device_matching = True       # Hungarian assignment on the device (vrd_assign); False: scipy on the host
 
     @torch.no_grad()
@@ -318,10 +320,68 @@ class MaskVRD(nn.Module):
                 t_pad[i] = self.max_seq_len if lens[i] <= self.max_seq_len else t_long
         return sorted(range(P), key=lambda i: (t_pad[i], lens[i], i)), t_pad
 
+    def _entity_streams(self, source, ids):
+        """The backbone's entity stage run ONCE PER TRACKLET (per sub-sampling phase) for the pairs `ids` of a
+        proposals.PairSource: (rows (n_streams * Ts, D), stream_row (2, len(ids)) int64 device = row of frame 0 of each
+        pair's subject / object, (piece length, piece buffer length), reach).  None when the stage cannot be shared: no tracklet table, or
+        global attention in the first stem block (backbones.entity_reach)."""
+        import numpy as np
+        bb = self.backbone
+        reach = bb.entity_reach()
+        if not self.share_tracklets or reach is None or source.first_row is None:
+            return None
+        ops = _ops()
+        dev = self.device
+        start, length, stream, j0 = source.stream_plan(ids)
+        chunk = 2 * (bb.mha_win_size[0] // 2)                  # the local attention takes whole chunks (blocks.py:828)
+        unit = math.lcm(32, chunk)
+        Ts = -(-int(length.max()) // unit) * unit
+        stream_row = torch.from_numpy(stream.astype(np.int64) * Ts + j0).to(dev)       # uploads first, kernels after
+        starts, lengths = torch.from_numpy(start).to(dev), torch.from_numpy(length).to(dev)
+        n = len(start)
+        D = bb.s_fuse_norm.num_channels
+        rows = torch.empty(n, Ts, D, device=dev, dtype=torch.float32)
+        step = max(1, (2 * self.pair_chunk * 288) // Ts)
+        for c0 in range(0, n, step):
+            c1 = min(c0 + step, n)
+            # (the gather writes a subject and an object half; a stream is both)
+            vis, clip, _, ent, m = ops.gather_rows(source, starts[c0:c1], starts[c0:c1], lengths[c0:c1], Ts, bb.n_bbox_so,
+                                                   bb.n_bbox_entity, ops.pair_mode())
+            h = c1 - c0
+            rows[c0:c1] = bb.entity_stage(vis[:h], clip[:h] if clip is not None else None, ent[:h], m)
+        piece = -(-2 * reach // chunk) * chunk
+        return rows, stream_row, (piece, piece + chunk), reach
+
+    def _shared_entity_rows(self, source, sel, shared, at, T):
+        """(2B, T, D) entity-stage rows of the pairs `sel` (device indices; positions at.. of the id list the streams were
+        planned for), the pairs' box features (B, T, S) and mask: frames further than `reach` from both window edges come
+        from the per-tracklet rows, the rest from L-frame pieces at the edges run through the same stage."""
+        ops = _ops()
+        bb = self.backbone
+        rows, stream_row, (piece, L), reach = shared
+        B = sel.shape[0]
+        s_row, o_row, lens = source.s_row[sel], source.o_row[sel], source.lens_dev[sel].contiguous()
+        # start pieces: the first `piece` frames.  End pieces: the last `piece` frames followed by padding, as in the pair's
+        # own rows -- or, for a pair that fills its T frames, the last L frames filling the buffer (vrd_assemble_args)
+        end_len = torch.where(lens == T, L, piece).to(torch.int32)
+        end_len = torch.where(lens > piece, end_len, torch.zeros_like(end_len))
+        tail = (lens - end_len).clamp(min=0).long() * source.stride
+        piece_s = torch.cat([s_row, s_row + tail])                  # [start pieces | end pieces]
+        piece_o = torch.cat([o_row, o_row + tail])
+        piece_len = torch.cat([lens.clamp(max=piece), end_len])
+        vis, clip, _, ent, m = ops.gather_rows(source, piece_s, piece_o, piece_len, L, bb.n_bbox_so, bb.n_bbox_entity,
+                                               ops.pair_mode())
+        pieces = bb.entity_stage(vis, clip, ent, torch.cat([m, m], dim=0))                  # (4B, L, D)
+        _, _, so_box, _, mask = ops.gather_rows(source, s_row.contiguous(), o_row.contiguous(), lens, T, bb.n_bbox_so,
+                                                bb.n_bbox_entity, False, boxes_only=True)
+        so = ops.assemble_pairs(rows, pieces, stream_row[:, at:at + B].reshape(-1), lens, T, piece, reach)
+        return so, so_box, mask
+
     def pair_candidates(self, feats, lens, ids, t_pad, k, source=None):
         """Network + per-(pair, query) post-processing kernel for the pairs `ids` (already grouped by padded length).
         source: a proposals.PairSource -- pair rows are then gathered on the device from the per-tracklet features
-        (vrd_gather_pairs) and `feats` is not used.
+        (vrd_gather_pairs) and `feats` is not used; with its tracklet table the entity stage of the backbone runs once
+        per tracklet instead of twice per pair (_entity_streams).
         Returns ONE float32 tensor (len(ids), Q, 2k + 2) = [top-k scores | top-k class ids | first | last frame], the
         three integer fields bit-cast: the compact candidate record that sharded runs exchange (SURVEY 8e option i)."""
         ops = _ops()
@@ -333,9 +393,11 @@ class MaskVRD(nn.Module):
         ints = cand.view(torch.int32)
         # every host->device table goes up before the first kernel is queued (such a copy waits for the queue)
         lens_dev = torch.tensor([lens[i] for i in ids], dtype=torch.int32, device=dev)
+        shared = None
         if source is not None:
             ids_dev = torch.tensor(ids, dtype=torch.int64, device=dev)
             local, tables = None, None
+            shared = self._entity_streams(source, ids)
         else:
             local = [feats[i] for i in ids]
             tables = ops.pair_table(local)      # None unless the features are the dataloader's frame-major matrices
@@ -353,13 +415,17 @@ class MaskVRD(nn.Module):
                 step = self._chunk_size(n)
                 for c0 in range(at, at + n, step):
                     c1 = min(c0 + step, at + n)
-                    if source is not None:
+                    if shared is not None and T > 2 * shared[2][1]:
+                        fm = bb.pair_stage(*self._shared_entity_rows(source, ids_dev[c0:c1], shared, c0, T))
+                    elif source is not None:
                         assert (source.n_visual, source.n_clip) == (bb.n_visual, bb.n_clip)
                         *parts, m2 = ops.gather_pairs(source, ids_dev[c0:c1], T, bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+                        fm = bb.cl_parts(*parts, m2)
                     else:
                         *parts, m2 = ops.pack_pairs(tables[0][c0:c1], tables[1][c0:c1], T, bb.n_visual, bb.n_clip,
                                                     bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
-                    outs.append(self._heads(*bb.cl_parts(*parts, m2), False))
+                        fm = bb.cl_parts(*parts, m2)
+                    outs.append(self._heads(*fm, False))
                 out = self._merge(outs)
             else:
                 x, m = self._batch(local, range(at, at + n), T)

@@ -228,27 +228,54 @@ def gather_pairs(source, sel, T, S, E, pair_wide):
     """Batch the pairs `sel` (device int64 indices into a proposals.PairSource) straight from the per-tracklet rows into
     the backbone's operand buffers, computing the box features on the way (vrd_gather_pairs).
     Returns (vis, clip or None, so_box, ent, mask) like pack_pairs."""
+    return gather_rows(source, source.s_row[sel].contiguous(), source.o_row[sel].contiguous(), source.lens_dev[sel].contiguous(),
+                       T, S, E, pair_wide)
+
+
+def gather_rows(source, s_row, o_row, lens, T, S, E, pair_wide, boxes_only=False):
+    """gather_pairs for explicit tables: sequence p = lens[p] frames starting at rows s_row[p] (subject half of the
+    outputs) and o_row[p] (object half) of the source's per-tracklet arrays, stepping by the source's stride.
+    boxes_only: the wide visual / clip rows are not gathered (returned as None)."""
     assert S == 5 and E == 8, "the reference's box features are 5 (pair) + 8 (entity) channels (utils/misc.py:158-217)"
-    B = sel.shape[0]
+    B = lens.shape[0]
     dev = source.vis.device
     V, Cc = source.n_visual, source.n_clip
+    assert s_row.dtype == o_row.dtype == torch.int64 and lens.dtype == torch.int32 and s_row.shape == o_row.shape == (B,)
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)      # noqa: E731
-    vis, so_box, ent = new(2 * B, T, V), new(B, T, S), new(2 * B, T, E)
-    clip = new(2 * B, T, Cc) if Cc else None
-    s_row, o_row, lens = source.s_row[sel].contiguous(), source.o_row[sel].contiguous(), source.lens_dev[sel].contiguous()
+    so_box, ent = new(B, T, S), new(2 * B, T, E)
+    vis = None if boxes_only else new(2 * B, T, V)
+    clip = new(2 * B, T, Cc) if Cc and not boxes_only else None
     a = _hip.GatherArgs()
     a.vis, a.clip, a.boxes = source.vis.data_ptr(), _ptr(source.clip), source.boxes.data_ptr()
     a.s_row, a.o_row, a.lens = s_row.data_ptr(), o_row.data_ptr(), lens.data_ptr()
     a.P, a.T, a.V, a.Cc, a.stride = B, T, V, Cc, source.stride
     a.w, a.h = source.wh
-    a.out_vis, a.out_clip, a.out_so_box, a.out_ent = vis.data_ptr(), _ptr(clip), so_box.data_ptr(), ent.data_ptr()
+    a.out_vis, a.out_clip, a.out_so_box, a.out_ent = _ptr(vis), _ptr(clip), so_box.data_ptr(), ent.data_ptr()
     a.pair_wide = 1 if pair_wide else 0
     _hip.check(lib.vrd_gather_pairs(C.byref(a), _stream()), "vrd_gather_pairs")
     mask = torch.arange(T, device=dev)[None, :] < lens[:, None]
-    if pair_wide:
+    if pair_wide and not boxes_only:
         vis = Pair(vis, V)
         clip = Pair(clip, Cc) if Cc else None
     return vis, clip, so_box, ent, mask
+
+
+def assemble_pairs(streams, snippets, stream_row, lens, T, piece, reach):
+    """(2P, T, D) entity-stage rows of P pairs from rows computed once per tracklet (`streams`, any shape (..., D);
+    stream_row (2P,) int64 = row of frame 0 of each subject then object) and the window-edge pieces `snippets`
+    (4P, L, D) of `piece` frames; see vrd_assemble_args."""
+    P = lens.shape[0]
+    D = streams.shape[-1]
+    L = snippets.shape[1]
+    assert snippets.shape == (4 * P, L, D) and stream_row.shape == (2 * P,) and stream_row.dtype == torch.int64
+    assert lens.dtype == torch.int32 and streams.is_contiguous() and snippets.is_contiguous()
+    out = torch.empty(2 * P, T, D, device=streams.device, dtype=torch.float32)
+    a = _hip.AssembleArgs()
+    a.streams, a.snippets, a.stream_row, a.lens = streams.data_ptr(), snippets.data_ptr(), stream_row.data_ptr(), lens.data_ptr()
+    a.P, a.T, a.D, a.L, a.piece, a.reach = P, T, D, L, piece, reach
+    a.out = out.data_ptr()
+    _hip.check(lib.vrd_assemble_pairs(C.byref(a), _stream()), "vrd_assemble_pairs")
+    return out
 
 
 def btc_to_bct(x):

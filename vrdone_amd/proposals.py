@@ -20,16 +20,40 @@ class PairSource:
     """Per-tracklet rows on the device + per-pair tables: pair p = `lens[p]` frames, frame t = row s_row[p] + t*stride of
     the subject's tracklet and o_row[p] + t*stride of the object's in the concatenated (sum L, .) arrays."""
 
-    def __init__(self, vis, clip, boxes, s_row, o_row, lens, stride, wh):
+    def __init__(self, vis, clip, boxes, s_row, o_row, lens, stride, wh, first_row=None):
         self.vis, self.clip, self.boxes = vis, clip, boxes
         self.s_row, self.o_row, self.lens_dev = s_row, o_row, lens
         self.lens = lens.tolist()
         self.stride, self.wh = int(stride), (float(wh[0]), float(wh[1]))
         self.n_visual = vis.shape[1]
         self.n_clip = 0 if clip is None else clip.shape[1]
+        # first_row (n_tracklets + 1,): tracklet k owns rows [first_row[k], first_row[k + 1]) -- what lets the model run its
+        # per-entity stage once per tracklet (stream_plan); None: pairs only
+        self.first_row = None if first_row is None else np.asarray(first_row, dtype=np.int64)
+        self._rows_host = None
 
     def __len__(self):
         return len(self.lens)
+
+    def stream_plan(self, ids):
+        """The sub-sampled tracklets ("streams") the pairs `ids` read from.  A pair's subject frames are rows
+        s_row + t*stride of one tracklet: frames phase, phase + stride, ... of it, from frame number j0 on, with
+        phase = (s_row - tracklet start) % stride.  Returns (start row (n,), length (n,)) of the distinct
+        (tracklet, phase) streams, and per pair in `ids` the (stream index, j0) of its subject and of its object:
+        numpy arrays stream (2, len(ids)), j0 (2, len(ids))."""
+        assert self.first_row is not None
+        if self._rows_host is None:
+            self._rows_host = (self.s_row.cpu().numpy(), self.o_row.cpu().numpy())
+        ids = np.asarray(ids, dtype=np.int64)
+        rows = np.stack([self._rows_host[0][ids], self._rows_host[1][ids]])              # (2, n)
+        trk = np.searchsorted(self.first_row, rows, side="right") - 1
+        rel = rows - self.first_row[trk]
+        phase, j0 = rel % self.stride, rel // self.stride
+        key, stream = np.unique(trk * self.stride + phase, return_inverse=True)
+        k_trk, k_phase = key // self.stride, key % self.stride
+        start = self.first_row[k_trk] + k_phase
+        length = -(-(self.first_row[k_trk + 1] - start) // self.stride)
+        return start, length.astype(np.int32), stream.reshape(rows.shape), j0
 
 
 def _clamped(boxes, w, h):
@@ -142,7 +166,7 @@ def prepare_test_proposal(raw, feat_stride, stride_offset, proposal_min_frames, 
         None if clip is None else torch.cat(clip, dim=0).to(device=device, dtype=torch.float32).contiguous(),
         torch.cat(boxes, dim=0).to(device=device, dtype=torch.float32).contiguous(),
         torch.tensor(s_row, dtype=torch.int64, device=device), torch.tensor(o_row, dtype=torch.int64, device=device),
-        torch.tensor(lens, dtype=torch.int32, device=device), feat_stride, (w, h))
+        torch.tensor(lens, dtype=torch.int32, device=device), feat_stride, (w, h), first_row=first_row)
     return {"sids": torch.tensor(sids), "oids": torch.tensor(oids), "cat_ids": raw["cat_ids"], "cat_scores": raw["cat_scores"],
             "traj_durations": raw["traj_durations"], "bboxes_list": boxes,
             "so_offset": torch.full((len(sids),), stride_offset, dtype=torch.int64), "pair_source": src}
