@@ -289,6 +289,11 @@ def test_forward_test_from_tracklet_features_equals_pair_matrices(precision):
     assert a["triplets"] == b["triplets"] and a["pred_durations"] == b["pred_durations"] and a["so_tids"] == b["so_tids"]
     np.testing.assert_allclose(a["triple_scores_avg"], b["triple_scores_avg"], rtol=0, atol=2e-6)
     assert a["so_trajs"] == b["so_trajs"]
+    # the plain-tensor form of the same source (what a dataset returns under the reference's eval loop), moved to the device
+    # the way utils.dict_to_device does
+    flat = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], None)
+    c = model({k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV) if torch.is_tensor(v) else v) for k, v in flat.items()})
+    assert c == b
 
 
 @pytest.mark.parametrize("cfg_name,case,full", [("vidvrd", "vidvrd", False), ("vidvrd", "strided", True), ("vidor_x", "strided", False),

@@ -64,3 +64,23 @@ def test_load_test_video_reads_the_reference_pickle_layout(tmp_path, golden_dir)
         sids, oids, durs, fsum = json.loads(res.stdout.strip().splitlines()[-1])
         assert got["sids"].tolist() == sids and got["oids"].tolist() == oids and got["traj_durations"].tolist() == durs
         assert abs(float(sum(v.double().sum() for v in got["visual_features_list"])) - fsum) < 1e-9
+
+
+def test_plain_tensor_form_passes_the_reference_eval_loop():
+    """prepare_test_proposal(device=None) returns only value types the reference's `utils.dict_to_device`
+    (utils/misc.py:98-112) accepts -- tensors, ints, strings, lists of tensors -- and PairSource.from_fields puts the same
+    source back together."""
+    from vrdone_amd.proposals import PairSource, prepare_test_proposal
+    vid_kw, dl_kw = PROPOSAL_CASES["strided"]
+    raw = P.synth_raw_video(**dict(vid_kw, n_clip=16))
+    flat = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], None)
+    obj = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], "cpu")
+    assert "pair_source" not in flat and set(PairSource.FIELDS) <= set(flat) and "tracklet_clip" in flat
+    for k, v in flat.items():
+        assert isinstance(v, (torch.Tensor, int, str)) or (isinstance(v, list) and all(isinstance(t, torch.Tensor) for t in v)), k
+    a, b = PairSource.from_fields(flat, "cpu"), obj["pair_source"]
+    assert a.lens == b.lens and a.stride == b.stride and a.wh == b.wh and (a.first_row == b.first_row).all()
+    for name in ("vis", "clip", "boxes", "s_row", "o_row"):
+        assert torch.equal(getattr(a, name), getattr(b, name))
+    for k in ("sids", "oids", "so_offset"):
+        assert torch.equal(flat[k], obj[k])

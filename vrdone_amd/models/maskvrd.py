@@ -448,6 +448,9 @@ class MaskVRD(nn.Module):
         from .. import parallel
         dev = self.device
         source = input_data.get('pair_source')          # proposals.prepare_test_proposal: per-tracklet features on the device
+        if source is None and 'tracklet_visual' in input_data:     # ... or its plain-tensor form (PairSource.fields)
+            from ..proposals import PairSource
+            source = PairSource.from_fields(input_data, dev)
         feats = None if source is not None else input_data['so_features_list']
         P = len(input_data['sids'])
         Q, k = self.predictor.num_queries, self.topk

@@ -35,6 +35,27 @@ class PairSource:
     def __len__(self):
         return len(self.lens)
 
+    FIELDS = ("tracklet_visual", "tracklet_boxes", "tracklet_first_row", "pair_s_row", "pair_o_row", "pair_lens", "video_wh")
+
+    def fields(self):
+        """The source as plain proposal entries -- tensors and one int, the only value types the reference's eval loop
+        lets through (`utils.dict_to_device`, utils/misc.py:98-112, raises on anything else): what a dataset running in
+        DataLoader workers returns (CPU tensors); `from_fields` puts the object back together in `forward_test`."""
+        d = {"tracklet_visual": self.vis, "tracklet_boxes": self.boxes, "tracklet_first_row": torch.as_tensor(self.first_row),
+             "pair_s_row": self.s_row, "pair_o_row": self.o_row, "pair_lens": self.lens_dev,
+             "video_wh": torch.tensor(self.wh, dtype=torch.float32), "pair_stride": self.stride}
+        if self.clip is not None:
+            d["tracklet_clip"] = self.clip
+        return d
+
+    @classmethod
+    def from_fields(cls, d, device):
+        to = lambda t: t.to(device)            # noqa: E731
+        w, h = d["video_wh"].tolist()
+        return cls(to(d["tracklet_visual"]), to(d["tracklet_clip"]) if "tracklet_clip" in d else None, to(d["tracklet_boxes"]),
+                   to(d["pair_s_row"]), to(d["pair_o_row"]), to(d["pair_lens"]), int(d["pair_stride"]), (w, h),
+                   first_row=d["tracklet_first_row"].cpu().numpy())
+
     def stream_plan(self, ids):
         """The sub-sampled tracklets ("streams") the pairs `ids` read from.  A pair's subject frames are rows
         s_row + t*stride of one tracklet: frames phase, phase + stride, ... of it, from frame number j0 on, with
@@ -138,7 +159,9 @@ def load_test_video(info_pkl, features_pkl):
 def prepare_test_proposal(raw, feat_stride, stride_offset, proposal_min_frames, device, viou_threshold=0.9):
     """raw: the dict `_prepare_test` hands to `_test_getitem` (sids, oids, cat_ids, cat_scores, bboxes_list,
     traj_durations [start, end), visual_features_list, optional clip_features_list, video_wh).  Returns {} when no pair
-    survives, else the eval proposal with a device-resident `pair_source`."""
+    survives, else the eval proposal with a device-resident `pair_source` -- or, with device=None, with the source as
+    plain CPU tensor entries (PairSource.fields): the form for a dataset's `_test_getitem` under the reference's unmodified
+    eval loop (DataLoader workers, `utils.dict_to_device`)."""
     w, h = raw["video_wh"]
     boxes = [_clamped(b, w, h) for b in raw["bboxes_list"]]
     spans = [(int(a), int(e)) for a, e in raw["traj_durations"].tolist()]
@@ -161,12 +184,19 @@ def prepare_test_proposal(raw, feat_stride, stride_offset, proposal_min_frames, 
     if not sids:
         return {}
     clip = raw.get("clip_features_list")
+    flat = device is None
+    device = "cpu" if flat else device
     src = PairSource(
         torch.cat(raw["visual_features_list"], dim=0).to(device=device, dtype=torch.float32).contiguous(),
         None if clip is None else torch.cat(clip, dim=0).to(device=device, dtype=torch.float32).contiguous(),
         torch.cat(boxes, dim=0).to(device=device, dtype=torch.float32).contiguous(),
         torch.tensor(s_row, dtype=torch.int64, device=device), torch.tensor(o_row, dtype=torch.int64, device=device),
         torch.tensor(lens, dtype=torch.int32, device=device), feat_stride, (w, h), first_row=first_row)
-    return {"sids": torch.tensor(sids), "oids": torch.tensor(oids), "cat_ids": raw["cat_ids"], "cat_scores": raw["cat_scores"],
-            "traj_durations": raw["traj_durations"], "bboxes_list": boxes,
-            "so_offset": torch.full((len(sids),), stride_offset, dtype=torch.int64), "pair_source": src}
+    out = {"sids": torch.tensor(sids), "oids": torch.tensor(oids), "cat_ids": raw["cat_ids"], "cat_scores": raw["cat_scores"],
+           "traj_durations": raw["traj_durations"], "bboxes_list": boxes,
+           "so_offset": torch.full((len(sids),), stride_offset, dtype=torch.int64)}
+    if flat:
+        out.update(src.fields())
+    else:
+        out["pair_source"] = src
+    return out
