@@ -238,6 +238,39 @@ def test_sharded_forward_test_equals_single_process(world, monkeypatch):
         model.shard_pairs(enable=False)
 
 
+def test_sharded_forward_test_from_tracklets(monkeypatch):
+    """The same with a pair_source: every rank runs the entity stage for the tracklets of ITS pairs only
+    (PairSource.stream_plan over its share) and the results still equal the unsharded call."""
+    from golden_cases import PROPOSAL_CASES
+    from oracle import proposal as P
+    from vrdone_amd import parallel
+    from vrdone_amd.proposals import prepare_test_proposal
+    model, mc, ic, _ = get_model("vidvrd")
+    vid_kw, dl_kw = PROPOSAL_CASES["vidvrd"]
+    prop = prepare_test_proposal(P.synth_raw_video(**vid_kw), dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], DEV)
+    src = prop["pair_source"]
+    want = model(prop)
+    order, t_pad = model.eval_plan(src.lens)
+    world = 3
+    per = (len(src) + world - 1) // world
+    try:
+        model.shard_pairs()
+        for rank in range(world):
+            def fake_all_gather(t, w, group=None):
+                parts = []
+                for r in range(w):
+                    c = t if r == rank else model.pair_candidates(None, src.lens, order[r::w], t_pad, model.topk, source=src)
+                    if c.shape[0] < per:
+                        c = torch.cat([c, c.new_zeros(per - c.shape[0], *c.shape[1:])], dim=0)
+                    parts.append(c)
+                return torch.stack(parts)
+            monkeypatch.setattr(parallel, "rank_world", lambda group=None: (rank, world))
+            monkeypatch.setattr(parallel, "_all_gather", fake_all_gather)
+            assert model(prop) == want, rank
+    finally:
+        model.shard_pairs(enable=False)
+
+
 @pytest.mark.parametrize("name", ["vidvrd", "strided"])
 def test_gather_pairs_matches_the_reference_dataloader(name):
     """vrd_gather_pairs (per-tracklet rows on the device -> backbone operand buffers, box features computed on the way)
