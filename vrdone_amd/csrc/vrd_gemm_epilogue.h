@@ -48,7 +48,8 @@ __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw,
 // 16-row pass).   ROWIN: any of row_mask / scale / res / res2 may be set;  ACT: VRD_ACT_NONE or VRD_ACT_GELU.
 // SLAB: rows of the wave's private staging slab `stg`: 64 (both 32-row halves transposed up front) or 32 (the second
 // half is transposed after the first one's passes, into the same slab: DS operations of a wave execute in order).
-template <bool ROWIN, int ACT, int SLAB, typename Transposer>
+// ROWS: 64 (four passes), or 32: one 32-row block, two passes, mw1 unused (the one-block-per-wave kernel, vrd_gemm_x3_row.hip).
+template <bool ROWIN, int ACT, int SLAB, int ROWS, typename Transposer>
 __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Transposer&& transpose_into, float* stg, int64_t mw,
                                                       int64_t mw1, int nw, int lane, const EpiCols& cols) {
     // rows: passes 0-1 are mw .. mw+31, passes 2-3 are mw1 .. mw1+31 (mw1 = mw + 32 unless the tile's 32-row blocks
@@ -91,14 +92,15 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
     };
     // row inputs run two passes ahead (HBM latency under load is several thousand cycles, a pass ~1.5k); the first
     // two requests go out before the transposition
+    constexpr int NPASS = ROWS / 16;
     RowIn q0 = fetch(0), q1 = fetch(1);
     transpose_into(stg, SLAB == 64 ? -1 : 0);            // the wave's 64 x 64 sub-tile (or its upper half), accumulator layout -> slab rows
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         if (SLAB == 32 && pass == 2) transpose_into(stg, 1);
         const RowIn cur = q0;
         q0 = q1;
-        if (pass + 2 < 4) q1 = fetch(pass + 2);
+        if (pass + 2 < NPASS) q1 = fetch(pass + 2);
         float v[4][4];
         const int srow = (SLAB == 64 ? pass : (pass & 1)) * 16 + rb0;
 #pragma unroll
@@ -172,7 +174,7 @@ template <bool ROWIN, int ACT, int SLAB = 64>
 __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* stg, int64_t mw,
                                                    int64_t mw1, int nw, int lane, const EpiCols& cols) {
     const int li = lane & 31, lh = lane >> 5;
-    gemm_epilogue_lean_tr<ROWIN, ACT, SLAB>(
+    gemm_epilogue_lean_tr<ROWIN, ACT, SLAB, 64>(
         p,
         [&](float* slab, int half) {           // half: -1 = both 32-row halves (64-row slab), else that half into rows 0..31
 #pragma unroll
@@ -189,13 +191,30 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
         stg, mw, mw1, nw, lane, cols);
 }
 
+// one 32-row block x 64 columns: two 32 x 32 accumulators side by side, rows mw .. mw+31
+template <bool ROWIN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_lean_rows32(const vrd_gemm_args& p, const f32x16& acc0, const f32x16& acc1, float* stg,
+                                                          int64_t mw, int nw, int lane, const EpiCols& cols) {
+    const int li = lane & 31, lh = lane >> 5;
+    gemm_epilogue_lean_tr<ROWIN, ACT, 32, 32>(
+        p,
+        [&](float* slab, int) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                slab[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + li] = acc0[e];
+                slab[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + 32 + li] = acc1[e];
+            }
+        },
+        stg, mw, mw + 32, nw, lane, cols);
+}
+
 // 16 x 16 accumulators (v_mfma_f32_16x16x32): element j of lane l is C[4 * (l >> 4) + j][l & 15]
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <bool ROWIN, int ACT, int SLAB = 64>
 __device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, const f32x4_t (&acc)[4][4], float* stg, int64_t mw,
                                                      int64_t mw1, int nw, int lane, const EpiCols& cols) {
     const int lc = lane & 15, lq = lane >> 4;
-    gemm_epilogue_lean_tr<ROWIN, ACT, SLAB>(
+    gemm_epilogue_lean_tr<ROWIN, ACT, SLAB, 64>(
         p,
         [&](float* slab, int half) {
 #pragma unroll

@@ -1,0 +1,309 @@
+// Split-precision conv GEMM, 256 x 256 tile, ACTIVATIONS STRAIGHT INTO REGISTERS (see vrd_gemm_x3.hip for the arithmetic
+// and vrd_gemm_x3_big.hip for the kernel this one grew out of).
+//
+// What limits the 256 x 256 LDS-DMA kernel is the issue of its LDS-DMA instructions: a 1-KiB global_load_lds costs the CU
+// ~45 cycles while MFMAs run, a K step of 32 moves 32 KiB of activations + 32 KiB of weights = 64 of them, ~2,900 cycles
+// beside 3,072 cycles of MFMA, and the step takes 4,170.  The activations do not need LDS at all if a wave owns its rows:
+// here the 8 waves split the tile by ROWS -- wave w computes rows 32w .. 32w+31 (one 32-row block of the padding map) times
+// all 256 columns, 1 x 8 accumulators of 32 x 32 -- so an activation row is read by exactly one wave, as ordinary 16-byte
+// global loads that land in MFMA operand layout: a pair row's 128-byte K-step line [32 hi | 32 lo] holds, for lane
+// (row li, k half lh), the four fragments hi/lo x k16 half at bytes lh*16 + {0, 32, 64, 96}.  Only the weights go through
+// LDS (every wave needs all of them): half the DMA instructions per step, the other half replaced by 4 vector loads per
+// lane.  The activations stream from HBM with a latency of several thousand cycles, so their loads run THREE K steps ahead
+// into four rotating register buffers (64 VGPRs; the K loop is unrolled by four, hence K % 128 == 0); weight fragments are
+// read from LDS three MFMA groups ahead into a ring of four.
+//   LDS: W ring 3 x 32 KiB = 96 KiB | epilogue slabs 8 x 8 KiB = 64 KiB (no longer aliased with the ring)
+//   per K step t and wave: MFMA groups q = 0..15 (k16 half q >> 3, column block q & 7, three MFMAs each);
+//   groups 0..3 issue the wave's four DMAs of W(t+2), groups 4..7 its four loads of A(t+3); at group 12 every LDS read of
+//   the step has been issued: wait for them and for the own pieces of W(t+1) (counted vmcnt: A(t+2), W(t+2), A(t+3) stay in
+//   flight), barrier, and groups 13..15 already read the first fragments of step t+1.
+// Same products in the same order as the other split-precision kernels (per K step and k16 half: a_lo*w_hi, a_hi*w_lo,
+// a_hi*w_hi), so results do not depend on which kernel a batch size selects.
+#include "vrd_common.h"
+#include "vrd_gemm_epilogue.h"
+#include <cstdlib>
+#include <type_traits>
+
+#ifndef LAB_STAMP           // the lab harness (scripts/lab/gemm_lab.hip) defines these through vrd_gemm_x3_big.hip
+#define LAB_STAMP(slot)
+#define LAB_REAL(slot)
+#endif
+#ifdef VRD_LAB_STAMP        // lab ablations (timing only): 1 = no activation loads in the loop, 2 = no weight DMAs in the loop
+#define LAB_MODE lab_mode_v
+#else
+#define LAB_MODE 0
+#endif
+
+namespace {
+namespace rowk {       // (own namespace: the lab harness compiles this file and vrd_gemm_x3_big.hip as one unit)
+
+using vrd::f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int TM = 256, TN = 256;
+constexpr int ROWB = 128;                      // bytes of a tile row per K step (32 hi + 32 lo bf16)
+constexpr int W_STAGE = TN * ROWB;
+constexpr int NW_STG = 2;
+constexpr int SLAB_OFF = NW_STG * W_STAGE;     // byte offset of the epilogue slabs
+constexpr size_t ROW_LDS = (size_t)SLAB_OFF + 8 * 32 * vrd::STG_PITCH * sizeof(float);      // 163,840
+constexpr int PER = 4;                         // W DMA instructions per wave and K step (8 rows x 128 B each)
+
+__device__ __attribute__((aligned(128))) uint4 g_row_zero[40];     // 640 zero bytes: four K steps of a padded tap
+__device__ unsigned long long g_row_skipped_kn;                    // as g_big_skipped_kn (vrd_gemm_x3_big.hip)
+
+__device__ constexpr int swz(int row) { return (row >> 1) & 7; }
+
+template <int TAPS>
+__global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, vrd::GemmBatch bb) {
+    if (blockIdx.y) {                                    // uniform selects, no indexed access to the arguments
+        const int z = blockIdx.y;
+        p.A = z == 1 ? bb.A[0] : z == 2 ? bb.A[1] : bb.A[2];
+        p.W_split = z == 1 ? bb.W_split[0] : z == 2 ? bb.W_split[1] : bb.W_split[2];
+        p.bias = z == 1 ? bb.bias[0] : z == 2 ? bb.bias[1] : bb.bias[2];
+        p.C = z == 1 ? bb.C[0] : z == 2 ? bb.C[1] : bb.C[2];
+    }
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int K = p.Cin * TAPS;
+    const int nkt = K / 32;                              // a multiple of 4 (host-checked)
+    const int nwg = tiles_m * tiles_n;
+
+    // ---- tile of this workgroup (XCD-aware renumbering and padding-map block list as in the LDS-DMA 256 x 256 kernel)
+    const int nblk = (int)(p.M >> 5);
+    const int32_t* const rb = p.row_blocks;
+    const int vb = blockIdx.x;
+    const int xcd = vb & 7, qq = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (vb >> 3);
+    const int tm = lid / tiles_n;
+    const int n0 = (lid - tm * tiles_n) * TN;
+    bool contract = true;
+    if (rb) {
+        const int seg_len = p.row_block_seg_len;                          // a multiple of 8 (host-checked)
+        const int seg = (tm * 8) / seg_len;
+        contract = tm * 8 < nblk && tm * 8 - seg * seg_len < p.row_blocks_active[seg];
+    }
+    const int slot = tm * 8 + wave;                      // this wave's 32-row block
+    const int my_blk = slot < nblk ? (rb ? rb[slot] : slot) : -1;
+    if (!contract && tid == 0 && tm * 8 < nblk)
+        atomicAdd(&g_row_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
+
+    LAB_STAMP(0);
+    LAB_REAL(4);
+#ifdef VRD_LAB_STAMP
+    const int lab_mode_v = __builtin_amdgcn_readfirstlane(g_lab_mode);
+#endif
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    if (contract) {
+        // ---- activation rows: lane (li, lh) owns row my_blk*32 + li, bytes lh*16 + {0, 32, 64, 96} of each K-step line:
+        // a scalar base (the block's first row, advanced by 512 bytes per group of four K steps) + one 32-bit lane offset.
+        // (a wave whose block lies outside the matrix reads block 0: its accumulators are never stored)
+        const char* a_base = reinterpret_cast<const char*>(p.A + (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 * p.lda);
+        const unsigned a_off = (unsigned)(li * (int)p.lda * 4 + lh * 16);
+        // fragment i of a K step: 0 = hi of k16 half 0, 1 = hi of half 1, 2 = lo of half 0, 3 = lo of half 1.
+        // The loads are inline assembly on purpose: the compiler's wait-count insertion drains every load in flight at the
+        // head of a loop whose body consumes loads of the previous iteration, which would stop the three-steps-ahead
+        // stream every four steps.  An asm load is invisible to it; the counted waits before the barriers (below) are what
+        // guarantees that a buffer has landed before its step.  "+v": a buffer keeps its registers across the load.
+#define VRD_ROW_LOAD_A(dst, base, u, i) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(a_off), "s"(base), "n"(128 * (u) + 32 * (i)))
+
+        // ---- weight DMA: this wave moves rows wave*32 .. wave*32+31 of the stage, 8 rows x 128 B per instruction; the
+        // 16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7 on the source address (and on the reads): scalar
+        // base of the wave's rows + the lane's offset in an 8-row piece (bit 6 flipped for the odd pieces: rows +8, +24).
+        // (rows beyond N re-read the tile's first rows: those columns are never stored)
+        const int rin = lane >> 3, pch = lane & 7;
+        const int chunk0 = (pch ^ swz(wave * PER * 8 + rin)) * 16;
+        const int w_in = (p.N - n0 - wave * PER * 8 + 7) / 8;              // pieces inside the matrix (N % 64 == 0)
+        const char* const w_base = reinterpret_cast<const char*>(p.W_split) + (int64_t)(n0 + (w_in > 0 ? wave * PER * 8 : 0)) * K * 4;
+        const unsigned w_off[2] = {(unsigned)(rin * K * 4 + chunk0), (unsigned)(rin * K * 4 + chunk0) ^ 64u};
+        const int64_t w_pstride = (int64_t)K * 32;                         // bytes between pieces (8 rows)
+        // (inline assembly too: through the builtin the compiler keeps one 64-bit per-lane pointer per piece, eight VGPRs the
+        // loop does not have; here the piece is a scalar base + the lane offset.  M0 = LDS address of the piece.)
+        const unsigned w_dst = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)lds) + wave * PER * 1024;
+        auto issue_w1 = [&](int kt, int stage, int i) {
+            const char* const src = w_base + (i < w_in ? i * w_pstride : 0) + (int64_t)kt * 128;
+            const unsigned dst = w_dst + stage * W_STAGE + i * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(w_off[i & 1]), "s"(src) : "memory", "m0");
+        };
+        // ---- weight fragments: column block j, k16 half s: row j*32 + li, chunk (2s + lh) hi, +4 lo -- four per-lane
+        // bases (half and hi/lo flip bits 5 and 6 of the swizzled chunk), stage and column block are immediates
+        // The reads are inline assembly with counted waits as well: next to an inline-asm statement the compiler's wait-count
+        // insertion stops counting LDS operations and waits for ALL of them before every use (lgkmcnt(0)), which would expose
+        // the latency of the reads just issued.  A group's fragments were requested three groups earlier; the six reads
+        // issued since may stay in flight: s_waitcnt lgkmcnt(6).
+        const unsigned lds_addr = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)lds);
+        const unsigned w_lane = lds_addr + li * ROWB + ((lh ^ swz(li)) * 16);
+        const unsigned w_hi[2] = {w_lane, w_lane ^ 32};
+        const unsigned w_lo[2] = {w_lane ^ 64, w_lane ^ 96};
+        struct WF { bf16x8 hi, lo; };
+#define VRD_ROW_LOAD_WF(f, stage, q)                                                                                             \
+    do {                                                                                                                         \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((f).hi) : "v"(w_hi[(q) >> 3]), "n"((stage) * W_STAGE + ((q) & 7) * 32 * ROWB)); \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((f).lo) : "v"(w_lo[(q) >> 3]), "n"((stage) * W_STAGE + ((q) & 7) * 32 * ROWB)); \
+    } while (0)
+
+        bf16x8 abuf[4][4];
+        WF wf[4];
+        // ---- prologue: A(0) W(0) A(1) W(1) A(2), and only A(0), W(0) are waited for; every step t then issues A(t+3)
+        // (groups 0..3) and, behind its barrier, W(t+2) (groups 12..15)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) abuf[u][i] = bf16x8{};       // (defined before the asm's read-write operands)
+        LAB_STAMP(6);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[0][i], a_base, 0, i);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) issue_w1(0, 0, i);
+        __builtin_amdgcn_sched_barrier(0);
+        // the memory pipeline of the CU serves requests in arrival order and a CU's share of the HBM stream is ~15 B/clk:
+        // everybody's first stage goes in before anybody's second (this barrier costs ~100 cycles; without it the slowest
+        // wave's first stage sits behind the other waves' look-ahead and the first MFMA starts ~5 k cycles later)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[1][i], a_base, 1, i);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) issue_w1(1, 1, i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[2][i], a_base, 2, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");     // A(0), W(0) landed; A(1), W(1), A(2) in flight
+        LAB_STAMP(7);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) VRD_ROW_LOAD_WF(wf[q], 0, q);
+        LAB_STAMP(1);
+
+        // one K step; u = kt & 3 (register buffer, weight stage u & 1); TAIL: the last four steps (kt = nkt - 4 + u)
+        auto step = [&](int kt, auto u_c, auto tail_c, const char* grp_cur) __attribute__((always_inline)) {
+            constexpr int u = decltype(u_c)::value;
+            constexpr bool TAIL = decltype(tail_c)::value;
+            constexpr int stage = u & 1;
+            constexpr bool last = TAIL && u == 3;
+            constexpr bool has_a3 = !TAIL || u < 1;      // A(kt+3) exists
+            constexpr bool has_w2 = !TAIL || u < 2;      // W(kt+2) exists
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                // fragment reads three groups ahead; groups 13..15 read the next step's first three (behind the barrier)
+                if (q + 3 < 16) VRD_ROW_LOAD_WF(wf[(q + 3) & 3], stage, q + 3);
+                else if (!last) VRD_ROW_LOAD_WF(wf[(q + 3) & 3], stage ^ 1, q + 3 - 16);
+                // this group's fragments (requested at group q - 3) have landed once at most the reads of the three groups
+                // behind them are in flight
+                if (!last || q < 13) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (15 - q)) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const int s2 = q >> 3, j = q & 7;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(abuf[u][2 + s2], wf[q & 3].hi, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(abuf[u][s2], wf[q & 3].lo, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(abuf[u][s2], wf[q & 3].hi, acc[j], 0, 0, 0);
+                if (q < PER && has_a3) {
+                    // A(kt+3) into the buffer step kt-1 used (u + 3 = u - 1 mod 4): step (u + 3) & 3 of its group of four
+                    __builtin_amdgcn_sched_barrier(0);
+                    // (steps 1..3 load steps 0..2 of the NEXT group of four: 512 bytes on)
+                    if (LAB_MODE != 1) VRD_ROW_LOAD_A(abuf[(u + 3) & 3][q], grp_cur, (u == 0 ? 0 : 4) + ((u + 3) & 3), q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (q == 12 && !last) {
+                    // every fragment of stage kt is requested: once they are here the stage is free for W(kt+2).  W(kt+1)
+                    // (own pieces) and with it the older A(kt+1), A(kt+2) must have landed; A(kt+3) stays in flight
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // (in step 0 of the tile A(2) of the prologue is younger than W(1) as well)
+                    if (has_a3 && u == 0 && kt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+                    else if (has_a3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (q >= 12 && has_w2) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (LAB_MODE != 2) issue_w1(kt + 2, stage, q - 12);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the groups apart: the scheduler would pull reads and loads far ahead
+            }
+        };
+        using std::integral_constant;
+        using std::true_type;
+        using std::false_type;
+        // groups of four steps: step kt0 loads A(kt0+3) of its own group, steps kt0+1 .. kt0+3 load A(kt0+4 .. kt0+6) of the
+        // next one; the last group runs with its conditions resolved at compile time
+        auto group = [&](int kt0, auto tail_c, const char* cur) __attribute__((always_inline)) {
+            step(kt0 + 0, integral_constant<int, 0>{}, tail_c, cur);
+            step(kt0 + 1, integral_constant<int, 1>{}, tail_c, cur);
+            step(kt0 + 2, integral_constant<int, 2>{}, tail_c, cur);
+            step(kt0 + 3, integral_constant<int, 3>{}, tail_c, cur);
+        };
+        int kt0 = 0;
+        for (; kt0 + 4 < nkt; kt0 += 4) {
+            group(kt0, false_type{}, a_base);
+            a_base += 512;
+        }
+        group(kt0, true_type{}, a_base);
+    }       // contract
+    LAB_STAMP(2);
+
+    // ---- epilogue: the wave's 32 rows x 256 columns as four 32 x 64 pieces through its private slab (own LDS region: no
+    // barrier, the ring is not touched)
+    if (my_blk < 0) return;
+    float* const stg = smem + SLAB_OFF / 4 + wave * (32 * vrd::STG_PITCH);
+    const int64_t mw = (int64_t)my_blk * 32;
+    const bool rowin = p.row_mask || p.scale || p.res || p.res2;
+    vrd::EpiCols cols[4];                                // bias / scale of the four pieces, requested together
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cols[g] = vrd::load_epi_cols(p, n0 + g * 64, lane);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int nw = n0 + g * 64;
+        if (nw >= p.N) continue;                         // (N % 64 == 0: a piece is inside or entirely outside)
+        if (rowin) vrd::gemm_epilogue_lean_rows32<true, VRD_ACT_NONE>(p, acc[2 * g], acc[2 * g + 1], stg, mw, nw, lane, cols[g]);
+        else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean_rows32<false, VRD_ACT_GELU>(p, acc[2 * g], acc[2 * g + 1], stg, mw, nw, lane, cols[g]);
+        else vrd::gemm_epilogue_lean_rows32<false, VRD_ACT_NONE>(p, acc[2 * g], acc[2 * g + 1], stg, mw, nw, lane, cols[g]);
+    }
+    LAB_STAMP(3);
+    LAB_REAL(5);
+}
+
+}  // namespace rowk
+}  // namespace
+
+namespace vrd {
+
+// the LDS-DMA 256 x 256 kernel's eligibility (checked by the caller), k = 1, and K % 128 == 0 (K loop unrolled by four)
+bool gemm_bf16x3_row_ok(const vrd_gemm_args& a) { return a.taps == 1 && a.Cin % 128 == 0; }
+
+// `count` (1 .. 4) problems that differ only in A, W_split, bias and C, as one launch
+int launch_gemm_bf16x3_row(const vrd_gemm_args* a, int count, hipStream_t s) {
+    GemmBatch bb{};
+    for (int i = 1; i < count; ++i) {
+        bb.A[i - 1] = a[i].A;
+        bb.W_split[i - 1] = a[i].W_split;
+        bb.bias[i - 1] = a[i].bias;
+        bb.C[i - 1] = a[i].C;
+    }
+    const int tiles_m = (int)((a[0].M + rowk::TM - 1) / rowk::TM), tiles_n = (a[0].N + rowk::TN - 1) / rowk::TN;
+    const dim3 grid(tiles_m * tiles_n, count);
+    auto kern = rowk::gemm_bf16x3_row_kernel<1>;         // k = 1 only (a k = 3 conv keeps the LDS-DMA kernel)
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), rowk::ROW_LDS, "vrd_gemm(bf16x3 256x256 row)")) return rc;
+    hipLaunchKernelGGL(kern, grid, dim3(512), rowk::ROW_LDS, s, a[0], tiles_m, tiles_n, bb);
+    return 0;
+}
+
+double take_row_skipped_flops() {
+    unsigned long long v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(rowk::g_row_skipped_kn), sizeof(v)) != hipSuccess) return 0.0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(rowk::g_row_skipped_kn), &zero, sizeof(zero));
+    return 2.0 * rowk::TM * (double)v;
+}
+
+}  // namespace vrd
