@@ -1,24 +1,43 @@
 // Split-precision conv GEMM, 256 x 256 tile, ACTIVATIONS STRAIGHT INTO REGISTERS (see vrd_gemm_x3.hip for the arithmetic
-// and vrd_gemm_x3_big.hip for the kernel this one grew out of).
+// and vrd_gemm_x3_big.hip for the kernel this one grew out of).  OPT-IN (VRD_BIG_ROW=1), k = 1 shapes with Cin % 128 == 0:
+// a study of what the 256 x 256 kernel gains when half of its LDS-DMA traffic disappears; measured result at the end.
 //
 // What limits the 256 x 256 LDS-DMA kernel is the issue of its LDS-DMA instructions: a 1-KiB global_load_lds costs the CU
 // ~45 cycles while MFMAs run, a K step of 32 moves 32 KiB of activations + 32 KiB of weights = 64 of them, ~2,900 cycles
-// beside 3,072 cycles of MFMA, and the step takes 4,170.  The activations do not need LDS at all if a wave owns its rows:
-// here the 8 waves split the tile by ROWS -- wave w computes rows 32w .. 32w+31 (one 32-row block of the padding map) times
-// all 256 columns, 1 x 8 accumulators of 32 x 32 -- so an activation row is read by exactly one wave, as ordinary 16-byte
-// global loads that land in MFMA operand layout: a pair row's 128-byte K-step line [32 hi | 32 lo] holds, for lane
-// (row li, k half lh), the four fragments hi/lo x k16 half at bytes lh*16 + {0, 32, 64, 96}.  Only the weights go through
-// LDS (every wave needs all of them): half the DMA instructions per step, the other half replaced by 4 vector loads per
-// lane.  The activations stream from HBM with a latency of several thousand cycles, so their loads run THREE K steps ahead
-// into four rotating register buffers (64 VGPRs; the K loop is unrolled by four, hence K % 128 == 0); weight fragments are
-// read from LDS three MFMA groups ahead into a ring of four.
-//   LDS: W ring 3 x 32 KiB = 96 KiB | epilogue slabs 8 x 8 KiB = 64 KiB (no longer aliased with the ring)
+// beside 3,072 cycles of MFMA, and the step takes 4,170-4,300.  The activations do not need LDS at all if a wave owns its
+// rows: here the 8 waves split the tile by ROWS -- wave w computes rows 32w .. 32w+31 (one 32-row block of the padding
+// map) times all 256 columns, 1 x 8 accumulators of 32 x 32 -- so an activation row is read by exactly one wave, as
+// ordinary 16-byte global loads that land in MFMA operand layout: a pair row's 128-byte K-step line [32 hi | 32 lo] holds,
+// for lane (row li, k half lh), the four fragments hi/lo x k16 half at bytes lh*16 + {0, 32, 64, 96}.  Only the weights go
+// through LDS (every wave needs all of them): half the DMA instructions per step, the other half replaced by 4 vector
+// loads per lane.  The activations stream from HBM with a latency of several thousand cycles, so their loads run THREE K
+// steps ahead into four rotating register buffers (64 VGPRs; the K loop is unrolled by four, hence K % 128 == 0); weight
+// fragments are read from LDS three MFMA groups ahead into a ring of four.
+//   LDS: W ring 2 x 32 KiB = 64 KiB | epilogue slabs 8 x 8 KiB = 64 KiB (not aliased with the ring)
 //   per K step t and wave: MFMA groups q = 0..15 (k16 half q >> 3, column block q & 7, three MFMAs each);
-//   groups 0..3 issue the wave's four DMAs of W(t+2), groups 4..7 its four loads of A(t+3); at group 12 every LDS read of
-//   the step has been issued: wait for them and for the own pieces of W(t+1) (counted vmcnt: A(t+2), W(t+2), A(t+3) stay in
-//   flight), barrier, and groups 13..15 already read the first fragments of step t+1.
+//   groups 0..3 issue the wave's four loads of A(t+3); at group 12 every LDS read of the step has been issued: wait for
+//   them and for the own pieces of W(t+1) (counted vmcnt: A(t+3) stays in flight), barrier; groups 12..15 then issue the four
+//   DMAs of W(t+2) into the stage just freed and groups 13..15 already read the first fragments of step t+1.
+// Every memory operation of the loop is inline assembly with hand-counted s_waitcnt: with compiler-visible loads the
+// wait-count pass drains all loads at the loop head (the buffers cross the back edge), and next to ANY inline-asm statement
+// it stops counting LDS operations and waits lgkmcnt(0) before every fragment use.
 // Same products in the same order as the other split-precision kernels (per K step and k16 half: a_lo*w_hi, a_hi*w_lo,
-// a_hi*w_hi), so results do not depend on which kernel a batch size selects.
+// a_hi*w_hi), so results do not depend on which kernel a batch size selects (the GPU suite passes with VRD_BIG_ROW=1).
+//
+// Measured (scripts/lab/gemm_lab.hip, per 256 x 256 tile, cycles at ~2.1 GHz; LDS-DMA kernel -> this one):
+//   K step      4,100-4,330 -> 3,600-3,800      (3,500 with either operand's loads removed: barrier and issue overhead)
+//   tile start  4,500-5,500 -> 7,300-11,000     (see below)
+//   epilogue    8,400-9,500 -> 9,500-10,800     (four 32 x 64 pieces instead of two 64 x 64)
+//   GEMM alone  M 147k-590k, N 512 / 2048:  K = 512: +1 .. +4 %,  K = 1024: +7 %,  K = 2048: +8 .. +15 %
+//   whole step  96.3 -> 95.3 ms of this kernel family, 145.0 -> 144.0 ms per step  (+0.7 %)
+// The faster loop needs two activation steps in flight from HBM before it runs at its rate, and a CU's share of the HBM
+// stream is ~15 B/clk: whichever way the first requests are ordered (all three steps up front; first stage alone behind a
+// barrier so that everybody's first stage is served first; first two steps by LDS-DMA into the idle epilogue slab, which is
+// what the code does: gathers touch 32 rows per instruction and are ~3 x slower on first touch), the time until the loop
+// reaches its rate stays ~10 k cycles -- 6 k more than the LDS-DMA kernel's, i.e. what 16 faster K steps save.  A persistent
+// variant (next tile's first requests issued under the epilogue, which works in its own LDS here) was built and measured:
+// tile start 2.2-3 k, but the epilogue then runs with the prefetch registers live on top of 128 accumulators: 52-170
+// spilled VGPRs, epilogue 15-30 k cycles, slower overall; it is not kept.
 #include "vrd_common.h"
 #include "vrd_gemm_epilogue.h"
 #include <cstdlib>
@@ -154,35 +173,50 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
 
         bf16x8 abuf[4][4];
         WF wf[4];
-        // ---- prologue: A(0) W(0) A(1) W(1) A(2), and only A(0), W(0) are waited for; every step t then issues A(t+3)
-        // (groups 0..3) and, behind its barrier, W(t+2) (groups 12..15)
+        // ---- prologue.  The gathers above are slow on first touch (a wave instruction touches 32 rows, 32 bytes of each: ~8 k
+        // cycles until the first stage is there, against ~2.5 k for whole lines by LDS-DMA), so the first TWO activation
+        // steps come by DMA into the wave's epilogue slab (8 KiB, idle until the epilogue) and are read into the register
+        // buffers from there; A(2) is gathered behind them and every step t then issues A(t+3) (groups 0..3) and, behind
+        // its barrier, W(t+2) (groups 12..15).
+        const unsigned a_dma_off = (unsigned)(rin * (int)p.lda * 4 + pch * 16);       // 8 rows x 128 B per instruction
+        const unsigned a_stg = lds_addr + SLAB_OFF + wave * (32 * vrd::STG_PITCH * 4);
+        auto issue_a_dma = [&](int u, int i) {
+            const char* const src = a_base + (int64_t)i * 8 * p.lda * 4 + u * 128;
+            const unsigned dst = a_stg + u * 4096 + i * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(a_dma_off), "s"(src) : "memory", "m0");
+        };
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int i = 0; i < 4; ++i) abuf[u][i] = bf16x8{};       // (defined before the asm's read-write operands)
         LAB_STAMP(6);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[0][i], a_base, 0, i);
+        for (int i = 0; i < 4; ++i) issue_a_dma(0, i);
 #pragma unroll
         for (int i = 0; i < PER; ++i) issue_w1(0, 0, i);
         __builtin_amdgcn_sched_barrier(0);
-        // the memory pipeline of the CU serves requests in arrival order and a CU's share of the HBM stream is ~15 B/clk:
-        // everybody's first stage goes in before anybody's second (this barrier costs ~100 cycles; without it the slowest
-        // wave's first stage sits behind the other waves' look-ahead and the first MFMA starts ~5 k cycles later)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[1][i], a_base, 1, i);
-#pragma unroll
-        for (int i = 0; i < PER; ++i) issue_w1(1, 1, i);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[2][i], a_base, 2, i);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");     // A(0), W(0) landed; A(1), W(1), A(2) in flight
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // A(0), W(0) landed
         LAB_STAMP(7);
+        // the wave's own rows: slab row li, bytes lh*16 + {0, 32, 64, 96} (no barrier needed for these); step 1's follow
+        // behind the barrier of step 0
+        const unsigned a_rd = a_stg + li * ROWB + lh * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(abuf[0][i]) : "v"(a_rd), "n"(32 * i));
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int q = 0; q < 3; ++q) VRD_ROW_LOAD_WF(wf[q], 0, q);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                 // the activation reads (the fragments may stay in flight)
+        // the second stage and A(2) go out only now: whatever is requested before the first stage has arrived delays the
+        // first MFMA (a CU's share of the HBM stream is ~15 B/clk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_a_dma(1, i);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) issue_w1(1, 1, i);
+        __builtin_amdgcn_sched_barrier(0);
+        if (LAB_MODE != 3)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[2][i], a_base, 2, i);
+        __builtin_amdgcn_sched_barrier(0);
         LAB_STAMP(1);
 
         // one K step; u = kt & 3 (register buffer, weight stage u & 1); TAIL: the last four steps (kt = nkt - 4 + u)
@@ -218,13 +252,21 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
                     // every fragment of stage kt is requested: once they are here the stage is free for W(kt+2).  W(kt+1)
                     // (own pieces) and with it the older A(kt+1), A(kt+2) must have landed; A(kt+3) stays in flight
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    // (in step 0 of the tile A(2) of the prologue is younger than W(1) as well)
-                    if (has_a3 && u == 0 && kt == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+                    // (step 0 of the tile: A(2) of the prologue is younger than W(1) as well)
+                    const bool tile_start = has_a3 && u == 0 && kt == 0;
+                    if (tile_start) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
                     else if (has_a3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+                    if (tile_start) {
+                        // step 1's activations came by DMA into the slab (prologue) and have landed with W(1): into registers.
+                        // (four more reads in flight than the counted fragment waits assume: those only wait a little longer)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(abuf[1][i]) : "v"(a_rd), "n"(4096 + 32 * i));
+                    }
                 }
                 if (q >= 12 && has_w2) {
                     __builtin_amdgcn_sched_barrier(0);
