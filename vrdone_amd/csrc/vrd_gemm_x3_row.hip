@@ -68,7 +68,6 @@ constexpr int SLAB_OFF = NW_STG * W_STAGE;     // byte offset of the epilogue sl
 constexpr size_t ROW_LDS = (size_t)SLAB_OFF + 8 * 32 * vrd::STG_PITCH * sizeof(float);      // 163,840
 constexpr int PER = 4;                         // W DMA instructions per wave and K step (8 rows x 128 B each)
 
-__device__ __attribute__((aligned(128))) uint4 g_row_zero[40];     // 640 zero bytes: four K steps of a padded tap
 __device__ unsigned long long g_row_skipped_kn;                    // as g_big_skipped_kn (vrd_gemm_x3_big.hip)
 
 __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
@@ -147,12 +146,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
         const unsigned w_off[2] = {(unsigned)(rin * K * 4 + chunk0), (unsigned)(rin * K * 4 + chunk0) ^ 64u};
         const int64_t w_pstride = (int64_t)K * 32;                         // bytes between pieces (8 rows)
         // (inline assembly too: through the builtin the compiler keeps one 64-bit per-lane pointer per piece, eight VGPRs the
-        // loop does not have; here the piece is a scalar base + the lane offset.  M0 = LDS address of the piece.)
+        // loop does not have; here the piece is a scalar base + the lane offset.  M0 = LDS address of the piece; it is a
+        // reserved register, nothing of the compiler's lives in it across statements.)
         const unsigned w_dst = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)lds) + wave * PER * 1024;
         auto issue_w1 = [&](int kt, int stage, int i) {
             const char* const src = w_base + (i < w_in ? i * w_pstride : 0) + (int64_t)kt * 128;
             const unsigned dst = w_dst + stage * W_STAGE + i * 1024;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(w_off[i & 1]), "s"(src) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(w_off[i & 1]), "s"(src) : "memory");
         };
         // ---- weight fragments: column block j, k16 half s: row j*32 + li, chunk (2s + lh) hi, +4 lo -- four per-lane
         // bases (half and hi/lo flip bits 5 and 6 of the swizzled chunk), stage and column block are immediates
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
         auto issue_a_dma = [&](int u, int i) {
             const char* const src = a_base + (int64_t)i * 8 * p.lda * 4 + u * 128;
             const unsigned dst = a_stg + u * 4096 + i * 1024;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(a_dma_off), "s"(src) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(a_dma_off), "s"(src) : "memory");
         };
 #pragma unroll
         for (int u = 0; u < 4; ++u)
