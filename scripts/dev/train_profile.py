@@ -23,3 +23,10 @@ tot_ms = sum(v["ms"] for v in prof.values()); tot_n = sum(v["launches"] for v in
 print(f"kernel time {tot_ms:.1f} ms over {tot_n} launches of the library")
 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
     if v["launches"]: print(f"  {k:20s} {v['ms']:7.2f} ms {v['launches']:5d} launches")
+# host-side view of the same step
+import cProfile, pstats
+model.zero_grad(set_to_none=True)
+pr = cProfile.Profile(); pr.enable()
+loss = model(data); loss["total_loss"].backward()
+pr.disable(); torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)

@@ -35,11 +35,11 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 
 // ------------------------------------------------------------------------------------------------------------------
 // dW[n, j] += sum_{r in chunk} G[r, n] * X[r + tap(j) - taps/2, ci(j)],  j = tap*Cin + ci, rows outside the length-T
-// sequence of r contribute 0.  One wave per 32 x 32 tile of dW and per chunk of rows: v_mfma_f32_32x32x2_f32 takes
+// sequence of r contribute 0.  One wave per 64 x 64 tile of dW and per chunk of rows: v_mfma_f32_32x32x2_f32 takes
 // the two operands of two rows straight from global memory (a lane holds G[r0 + (lane >> 5)][n0 + (lane & 31)] and
 // X[r0 + (lane >> 5) + shift][ci]: 128-byte row segments), accumulates in f32 and adds its partial tile atomically.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int WG_CHUNK = 512;      // rows per wave
+constexpr int WG_CHUNK = 128;      // rows per wave
 
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
                                                     int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M, int N,
@@ -47,36 +47,113 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = Cin * taps;
     const int tile = blockIdx.x;
-    const int n0 = (tile / tiles_k) * 32, j0 = (tile % tiles_k) * 32;
+    // a wave owns a 64 x 64 tile of dW as 2 x 2 accumulators: two G values and two X values per row feed four MFMAs (with
+    // one 32 x 32 tile per wave every MFMA needed its own two loads and the kernel ran at the rate of its L2 traffic)
+    const int n0 = (tile / tiles_k) * 64, j0 = (tile % tiles_k) * 64;
     const int li = lane & 31, lh = lane >> 5;
-    const int n = n0 + li, j = j0 + li;
-    const int tap = j < K ? j / Cin : 0;
-    const int ci = j < K ? j - tap * Cin : 0;
-    const int shift = tap - taps / 2;
+    int shift[2];
+    const float* xp[2];
+    const float* gp[2];
+    bool a_col[2], b_col[2];
     const int64_t r_begin = ((int64_t)blockIdx.y * 4 + wave) * WG_CHUNK;
-    const int64_t r_end = r_begin + WG_CHUNK < M ? r_begin + WG_CHUNK : M;
-    if (r_begin >= M) return;
-    f32x16 acc;
+    const int64_t r_end = r_begin + WG_CHUNK < M ? r_begin + WG_CHUNK : M;        // (empty for a wave beyond the last row)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += 2) {
-        const int64_t r = r0 + lh;
-        float a = 0.f, b = 0.f;
-        if (r < r_end) {
-            if (n < N && (!row_mask || row_mask[r])) a = G[r * ldg + n];
-            if (j < K) {
-                const int t = (int)(r % T) + shift;
-                if (t >= 0 && t < T) b = X[(r + shift) * ldx + ci];
+    for (int h = 0; h < 2; ++h) {
+        const int n = n0 + 32 * h + li, j = j0 + 32 * h + li;
+        const int tap = j < K ? j / Cin : 0;
+        const int ci = j < K ? j - tap * Cin : 0;
+        shift[h] = tap - taps / 2;
+        a_col[h] = n < N, b_col[h] = j < K;
+        gp[h] = G + (r_begin + lh) * ldg + n;
+        xp[h] = X + (r_begin + lh + shift[h]) * ldx + ci;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int hj = 0; hj < 2; ++hj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[hn][hj][e] = 0.f;
+    // eight rows (four row pairs) per iteration, all sixteen loads requested before the first MFMA: with one row pair per
+    // iteration the loop ran at the latency of its loads (~900 cycles per MFMA on a 4.6 k-row training batch).
+    // The position t of a row in its sequence (k = 3: zero padding at the sequence ends) is carried along instead of a
+    // 64-bit modulo per row.
+    int t = taps == 3 ? (int)((r_begin + lh) % T) : 0;          // position of row r0 + lh
+    const uint8_t* mp = row_mask ? row_mask + r_begin + lh : nullptr;
+    // (the loads of iteration i + 1 are requested before the MFMAs of iteration i: a small batch leaves ~1 wave per SIMD,
+    // nothing else would cover their latency)
+    auto fetch = [&](int64_t r0, float (&a)[4][2], float (&b)[4][2]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = r0 + 2 * u + lh < r_end;
+            const bool live = in && (!mp || mp[2 * u]);
+            int tt = 0;
+            if (taps == 3) {
+                tt = t + 2 * u;
+                while (tt >= T) tt -= T;                        // (at most a few wraps: 8 rows, T >= 1)
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[u][h] = live && a_col[h] ? gp[h][(int64_t)(2 * u) * ldg] : 0.f;
+                const bool ok = in && b_col[h] && (taps == 1 || (tt + shift[h] >= 0 && tt + shift[h] < T));
+                b[u][h] = ok ? xp[h][(int64_t)(2 * u) * ldx] : 0.f;
             }
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) gp[h] += 8 * ldg, xp[h] += 8 * ldx;
+        if (mp) mp += 8;
+        if (taps == 3) {
+            t += 8;
+            while (t >= T) t -= T;
+        }
+    };
+    float a0[4][2], b0[4][2], a1[4][2], b1[4][2];
+    if (r_begin < r_end) fetch(r_begin, a0, b0);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 16) {
+        fetch(r0 + 8, a1, b1);                                  // (past r_end: zeros, no loads)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                for (int hj = 0; hj < 2; ++hj) acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][hn], b0[u][hj], acc[hn][hj], 0, 0, 0);
+        fetch(r0 + 16, a0, b0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                for (int hj = 0; hj < 2; ++hj) acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][hn], b1[u][hj], acc[hn][hj], 0, 0, 0);
     }
-    // element e of lane (li, lh): row (e & 3) + 8 * (e >> 2) + 4 * lh (n index), column li (j index)
-    if (j < K) {
+    // the four waves of the block (four row chunks of the same tile) add up in LDS: one atomic per element and BLOCK, a
+    // plain update when the block covers all rows
+    __shared__ f32x16 red[3][4][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave - 1][q][lane] = acc[q >> 1][q & 1];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x16 v = acc[q >> 1][q & 1];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const f32x16 part = red[o][q][lane];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += part[e];
+        }
+        // element e of lane (li, lh): row (e & 3) + 8 * (e >> 2) + 4 * lh (n index), column li (j index)
+        const int j = j0 + 32 * (q & 1) + li;
+        if (j >= K) continue;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int nn = n0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (nn < N) atomicAdd(dW + (int64_t)nn * K + j, acc[e]);
+            const int nn = n0 + 32 * (q >> 1) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (nn < N) {
+                if (single) dW[(int64_t)nn * K + j] += v[e];         // (dW holds the caller's initial value: zeros)
+                else atomicAdd(dW + (int64_t)nn * K + j, v[e]);
+            }
         }
     }
 }
@@ -86,7 +163,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
 // brow(r): r = s * T + t  ->  s * (bs * T) + bs * t + shift, contributing only if 0 <= bs * t + shift < bs * T.
 // thread = one column; block = 64 rows x 256 columns; one atomic per thread.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int CS_ROWS = 64;
+constexpr int CS_ROWS = 32;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
                                                      int64_t ldb, int bc, int bo, int bs, int shift, int T,
                                                      const uint8_t* __restrict__ mask, const float* __restrict__ rscale,
@@ -95,21 +172,37 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
     if (c >= C) return;
     const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
     const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+    // eight rows per iteration with their loads requested together (one row per iteration ran at the latency of its loads);
+    // the row's (sequence, position) pair is carried along instead of a 64-bit division per row
+    int64_t seq = b ? r0 / T : 0;
+    int tpos = b ? (int)(r0 - seq * T) : 0;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        float f = 1.f;
-        if (mask) {
-            if (!mask[r]) continue;
+    for (int64_t rb = r0; rb < r1; rb += 8) {
+        float av[8], bv[8], fv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = rb + u;
+            bool live = r < r1 && (!mask || mask[r]);
+            av[u] = 0.f, bv[u] = 1.f, fv[u] = 1.f;
+            if (b) {
+                int tq = tpos + u;
+                int64_t sq = seq;
+                while (tq >= T) tq -= T, ++sq;
+                const int tb = bs * tq + shift;
+                live = live && tb >= 0 && tb < bs * T;
+                if (live) bv[u] = b[(sq * (int64_t)bs * T + tb) * ldb + (int64_t)c * bc + bo];
+            }
+            if (live) {
+                av[u] = a[r * lda + c];
+                if (rscale) fv[u] = rscale[r];
+            }
         }
-        if (rscale) f = rscale[r];
-        float bv = 1.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fmaf(av[u] * fv[u], bv[u], s);
         if (b) {
-            const int64_t seq = r / T;
-            const int tb = bs * (int)(r - seq * T) + shift;
-            if (tb < 0 || tb >= bs * T) continue;
-            bv = b[(seq * (int64_t)bs * T + tb) * ldb + (int64_t)c * bc + bo];
+            tpos += 8;
+            while (tpos >= T) tpos -= T, ++seq;
         }
-        s = fmaf(a[r * lda + c] * f, bv, s);
     }
     atomicAdd(out + c, s);
 }
@@ -181,8 +274,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     constexpr float inv_c = 1.0f / (256.0f * NV);
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t r0 = w * LNB_ROWS;
-    if (r0 >= rows) return;
+    const int64_t r0 = w * LNB_ROWS;        // (a wave beyond the last row adds zeros)
     float4 g4[NV], b4[NV], dg[NV], db[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -190,13 +282,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         b4[i] = ld4(beta + i * 256 + lane * 4);
         dg[i] = db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int64_t r = r0; r < r0 + LNB_ROWS && r < rows; ++r) {
+    // the rows of this wave in groups of four, a group's loads requested together (one row at a time ran at the latency of
+    // its loads)
+    for (int h = 0; h < LNB_ROWS / 4; ++h) {
+    const int64_t rh = r0 + 4 * h;
+    if (rh >= rows) break;
+    float4 vr[4][NV], dr[4][NV];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = rh + q < rows ? rh + q : rows - 1;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            vr[q][i] = ld4(x + r * ldx + i * 256 + lane * 4);
+            dr[q][i] = ld4(dy + r * lddy + i * 256 + lane * 4);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = rh + q;
+        if (r >= rows) break;
         float4 v[NV], d[NV];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            v[i] = ld4(x + r * ldx + i * 256 + lane * 4);
-            d[i] = ld4(dy + r * lddy + i * 256 + lane * 4);
+            v[i] = vr[q][i];
+            d[i] = dr[q][i];
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
         const float mean = vrd::wave_sum(s) * inv_c;
@@ -238,14 +348,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             st4(dx + r * lddx + i * 256 + lane * 4, o);
         }
     }
+    }       // groups of four rows
+    // the four waves of the block add their partial sums in LDS; one atomic per channel and BLOCK (the atomics on the 2 C
+    // addresses were what the kernel spent its time on)
+    __shared__ float4 red[2][3][NV][64];
+    const int wv = threadIdx.x >> 6;
+    if (wv > 0) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float* pdg = reinterpret_cast<const float*>(&dg[i]);
-        const float* pdb = reinterpret_cast<const float*>(&db[i]);
+        for (int i = 0; i < NV; ++i) red[0][wv - 1][i][lane] = dg[i], red[1][wv - 1][i][lane] = db[i];
+    }
+    __syncthreads();
+    if (wv == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            atomicAdd(dgamma + i * 256 + lane * 4 + c, pdg[c]);
-            atomicAdd(dbeta + i * 256 + lane * 4 + c, pdb[c]);
+        for (int i = 0; i < NV; ++i) {
+            float4 g = dg[i], b = db[i];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float4 pg = red[0][o][i][lane], pb = red[1][o][i][lane];
+                g.x += pg.x, g.y += pg.y, g.z += pg.z, g.w += pg.w;
+                b.x += pb.x, b.y += pb.y, b.z += pb.z, b.w += pb.w;
+            }
+            float* dgp = dgamma + i * 256 + lane * 4;
+            float* dbp = dbeta + i * 256 + lane * 4;
+            atomicAdd(dgp + 0, g.x), atomicAdd(dgp + 1, g.y), atomicAdd(dgp + 2, g.z), atomicAdd(dgp + 3, g.w);
+            atomicAdd(dbp + 0, b.x), atomicAdd(dbp + 1, b.y), atomicAdd(dbp + 2, b.z), atomicAdd(dbp + 3, b.w);
         }
     }
 }
@@ -506,7 +632,20 @@ __global__ __launch_bounds__(256) void bmm_kernel(BmmArgs p) {
     const float* a = p.A + z0 * p.a0 + z1 * p.a1 + i * p.ai;
     const float* b = p.B + z0 * p.b0 + z1 * p.b1 + n * p.bn;
     float s = 0.f;
-    for (int k = 0; k < p.K; ++k) s = fmaf(a[k * p.ak], b[k * p.bk], s);
+    // eight k at a time with their loads requested together (same summation order; one k per iteration ran at the latency
+    // of its two loads)
+    int k = 0;
+    for (; k + 8 <= p.K; k += 8) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            av[u] = a[(k + u) * p.ak];
+            bv[u] = b[(k + u) * p.bk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s = fmaf(av[u], bv[u], s);
+    }
+    for (; k < p.K; ++k) s = fmaf(a[k * p.ak], b[k * p.bk], s);
     float* c = p.C + z0 * p.c0 + z1 * p.c1 + i * p.ci + n * p.cn;
     *c = p.accumulate ? *c + p.alpha * s : p.alpha * s;
 }
@@ -550,7 +689,7 @@ int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, con
     VRD_CHECK_ARG(ldg >= N && ldx >= Cin, "vrd_gemm_wgrad: leading dimension too small");
     VRD_CHECK_ARG(T > 0 && M % T == 0, "vrd_gemm_wgrad: M (%lld) must be a multiple of T (%d)", (long long)M, T);
     const int K = Cin * taps;
-    const int tiles_n = (N + 31) / 32, tiles_k = (K + 31) / 32;
+    const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
     const int64_t chunks = (M + 4 * WG_CHUNK - 1) / (4 * WG_CHUNK);
     VRD_CHECK_ARG(chunks <= 65535, "vrd_gemm_wgrad: too many rows (%lld)", (long long)M);
     hipStream_t s = static_cast<hipStream_t>(stream);
