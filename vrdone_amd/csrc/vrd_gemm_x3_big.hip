@@ -18,6 +18,7 @@
 #include "vrd_common.h"
 #include "vrd_gemm_epilogue.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -275,19 +276,28 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     AF a_cur = load_a(lds, 0, 0), a_nxt = a_cur;
     LAB_PHASE_DECL;
     // DMA slot d (0..7) of the batch opened by the barrier inside step kt: W(kt+2) pieces 0..3, A(kt+3) pieces 0..3
-    auto dma_slot = [&](int kt_open, int d) {
-        if (d < PER) {
-            if (kt_open + 2 < nkt) issue_w1(cur, kt_open + 2, d);
-        } else {
-            if (kt_open + 3 < nkt) issue_a1(cur, kt_open + 3, d - PER);
-        }
-    };
-    for (int kt = 0; kt < nkt; ++kt) {
+    // Which of these requests exist depends only on where the step stands in the K loop, so the loop body exists in five
+    // copies with the tests resolved at compile time: first step, steady steps (1 .. nkt-3), the step before the last, the
+    // last, and a generic one with run-time tests for K loops of fewer than three steps.  (The per-slot scalar branches of the
+    // generic body cost the steady loop 7 %: 4,300 -> 3,730-4,060 cycles per K step.)
+    enum { POS_GENERIC, POS_FIRST, POS_STEADY, POS_PEN, POS_LAST };
+    auto kstep = [&](int kt, auto pos_c) __attribute__((always_inline)) {
+        constexpr int POS = decltype(pos_c)::value;
+        // W(kt_open+2) pieces / A(kt_open+3) pieces exist?
+        auto has_w = [&](int kt_open) { return POS == POS_GENERIC ? kt_open + 2 < nkt : true; };
+        auto dma_slot = [&](int kt_open, int d, bool w_ok, bool a_ok) {
+            if (d < PER) {
+                if (w_ok) issue_w1(cur, kt_open + 2, d);
+            } else {
+                if (a_ok) issue_a1(cur, kt_open + 3, d - PER);
+            }
+        };
+        (void)has_w;
         const char* sa = lds + (kt % NA_STG) * A_STAGE;
         const char* sw = lds + (kt % NW_STG) * W_STAGE;
         const char* sa1 = lds + ((kt + 1) % NA_STG) * A_STAGE;
         const char* sw1 = lds + ((kt + 1) % NW_STG) * W_STAGE;
-        const bool last = kt + 1 == nkt;
+        const bool last = POS == POS_GENERIC ? kt + 1 == nkt : POS == POS_LAST;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int mi = g & 3;
@@ -319,10 +329,20 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
                     __builtin_amdgcn_sched_barrier(0);
                     // groups 0..6 carry slots 1..7 of the batch opened in step kt-1, group 7 slot 0 of this step's
                     if (g < 7) {
-                        if (kt > 0) dma_slot(kt - 1, g + 1);
-                        else if (g < PER && nkt > 2) issue_a1(cur, 2, g);          // step 0 has no batch of its own yet
+                        // the batch opened in step kt-1: W(kt+1) pieces 1..3, A(kt+2) pieces 0..3
+                        if (POS == POS_GENERIC) {
+                            if (kt > 0) dma_slot(kt - 1, g + 1, kt + 1 < nkt, kt + 2 < nkt);
+                            else if (g < PER && nkt > 2) issue_a1(cur, 2, g);      // step 0 has no batch of its own yet
+                        } else if (POS == POS_FIRST) {
+                            if (g < PER) issue_a1(cur, 2, g);
+                        } else if (POS == POS_STEADY) {
+                            dma_slot(kt - 1, g + 1, true, true);
+                        } else if (POS == POS_PEN) {
+                            dma_slot(kt - 1, g + 1, true, false);
+                        }
                     } else if (!last) {
-                        dma_slot(kt, 0);
+                        // slot 0 of this step's own batch: W(kt+2) piece 0
+                        dma_slot(kt, 0, POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN, false);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
                 // starts reading it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 LAB_PHASE(3);
-                if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                if (POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 LAB_PHASE(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -343,6 +363,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
                 LAB_PHASE(1);
             }
         }
+    };
+    if (nkt >= 3) {
+        kstep(0, std::integral_constant<int, POS_FIRST>{});
+        for (int kt = 1; kt + 2 < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_STEADY>{});
+        kstep(nkt - 2, std::integral_constant<int, POS_PEN>{});
+        kstep(nkt - 1, std::integral_constant<int, POS_LAST>{});
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_GENERIC>{});
     }
     LAB_PHASE_FLUSH(wave >> 2);
     }       // contract
