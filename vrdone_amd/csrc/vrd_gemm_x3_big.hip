@@ -134,23 +134,26 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     const int64_t a_pstride = p.lda * 32, w_pstride = (int64_t)K * 32;  // bytes between pieces (8 rows)
     struct Src {
         const char *a0, *w0;
-        int tseq0, a_in, w_in;
+        int tseq0, a_in, w_in, w_last;
     };
     auto src_of = [&](const Tile& t) {
         const int my_blk = blk_of(t.tm * 8 + wave);          // the block whose A rows this wave stages
         const int64_t a_row = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 + rin;
         Src r;
         r.a0 = reinterpret_cast<const char*>(p.A + a_row * p.lda) + chunk0;
-        r.w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + row0) * K * 4 + chunk0;
         r.tseq0 = (TAPS == 3) ? (int)(a_row % p.T) : 0;
         r.a_in = my_blk < 0 ? 0 : PER;                                   // pieces inside (M % 32 == 0)
         r.w_in = (p.N - t.n0 - wave * PER * 8 + 7) / 8;
+        // weight pieces beyond N re-read the last piece inside (a wave entirely beyond N: the tile's first rows): columns
+        // >= N are never stored, and a uniform minimum costs the loop less than a per-lane select of the zero block
+        r.w_last = (r.w_in > 0 ? (r.w_in < PER ? r.w_in : PER) : 1) - 1;
+        r.w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + (r.w_in > 0 ? row0 : rin)) * K * 4 + chunk0;
         return r;
     };
     // piece i of W(kt) / A(kt): one DMA instruction each
     auto issue_w1 = [&](const Src& c, int kt, int i) {
         char* const dst = lds + W_RING + (kt % NW_STG) * W_STAGE + wave * PER * 1024;
-        const char* src = i < c.w_in ? (c.w0 + i * w_pstride + (int64_t)kt * 128) : zero_src + chunk0;
+        const char* src = c.w0 + (i < c.w_last ? i : c.w_last) * w_pstride + (int64_t)kt * 128;
         if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
         __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
     };
@@ -163,7 +166,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
             ci0 = k0 - tap * p.Cin;
         }
         const int64_t off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 + (int64_t)ci0 * 4;
-        const char* src = i < c.a_in ? c.a0 + i * a_pstride + off : zero_src + chunk0;
+        // (k = 1: a wave whose block lies outside the matrix reads block 0 -- its accumulator rows are never stored)
+        const char* src = TAPS == 1 || i < c.a_in ? c.a0 + i * a_pstride + off : zero_src + chunk0;
         if (TAPS == 3) {
             int tt = c.tseq0 + 8 * i;                   // position of this piece's row in its sequence (T >= 32)
             if (tt >= p.T) tt -= p.T;
