@@ -239,7 +239,9 @@ class DepthwiseConv(Function):
                 for kk in range(k):
                     colsum(dDs[i], gw[g, kk], b=xin, b_cstride=gin, b_coffset=g, b_rstride=s, shift=kk - k // 2, T=Tout,
                            row_mask=ctx.mask_out)
-            grads.append(gw.permute(2, 0, 1).contiguous())                        # (C, gin, k)
+            # (C, gin, k) with the parameter's own strides: for gin = k = 1 `.contiguous()` is a no-op that keeps (1, C, C),
+            # which DDP's bucket views flag as a layout mismatch
+            grads.append(torch.empty(Cout, gin, k, device=dev, dtype=torch.float32).copy_(gw.permute(2, 0, 1)))
             grads.append(colsum(dDs[i], torch.zeros(Cout, device=dev, dtype=torch.float32), row_mask=ctx.mask_out)
                          if ctx.has_bias[i] else None)
         return (dx, dx_up, None, None, *grads)
