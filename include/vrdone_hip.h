@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 16
+#define VRD_ABI_VERSION 17
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -387,6 +387,15 @@ int vrd_assign(const float* cost, int64_t ld, const int32_t* first, const int32_
  * is cut into chunks of 4096 elements: chunk c works on tensor chunk_tensor[c], elements chunk_index[c]*4096 ... */
 int vrd_ema_update(float* const* ema, const float* const* model, const int64_t* numel, const int32_t* chunk_tensor,
                    const int32_t* chunk_index, int n_chunks, float decay, float one_minus_decay, void* stream);
+
+/* The split-precision GEMMs' weight operand (vrd_gemm_args.W_split) from an f32 weight in ONE launch: logical matrix
+ * W'[r][tap*Q + q] = src[r*sr + tap*st + q*sq]  (R rows, K = taps*Q columns, K % 32 == 0; strides in floats, may be negative)
+ * -> out (R, K/32, 2, 32) bf16: per block of 32 columns [32 x hi | 32 x lo], hi = bf16(w), lo = bf16(w - hi).
+ * Forward operand of a Conv1d weight (N, Cin, k): R = N, Q = Cin, sr = Cin*k, st = 1, sq = k.  Operand of its input-gradient
+ * GEMM (autograd of models/blocks.py:91-113; k = 3: taps flipped): R = Cin, Q = N, src = w + (k - 1), sr = k, st = -1,
+ * sq = Cin*k.  In a training step every weight changes every step, so both are rebuilt per step: as tensor expressions that
+ * was ~11 elementwise launches per weight. */
+int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, void* stream);
 
 #ifdef __cplusplus
 }

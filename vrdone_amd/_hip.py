@@ -95,6 +95,7 @@ _SIGNATURES = {
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
     "vrd_gather_pairs": (C.c_int, [C.POINTER(GatherArgs), C.c_void_p]),
     "vrd_assemble_pairs": (C.c_int, [C.POINTER(AssembleArgs), C.c_void_p]),
+    "vrd_split_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_gemm_batch": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "vrd_row_blocks": (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -135,7 +136,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class HipLibraryError(RuntimeError):

@@ -100,3 +100,33 @@ int vrd_ema_update(float* const* ema, const float* const* model, const int64_t* 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// f32 weight (any 3-stride view) -> blocked [hi | lo] bf16 operand of the split-precision GEMMs; thread = one element
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ src, int R, int Q, int taps, int64_t sr, int64_t st,
+                                                           int64_t sq, __bf16* __restrict__ out) {
+    const int K = taps * Q;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)R * K) return;
+    const int r = (int)(idx / K), c = (int)(idx - (int64_t)r * K);
+    const int tap = c / Q, q = c - tap * Q;
+    const float w = src[r * sr + tap * st + q * sq];
+    const __bf16 hi = (__bf16)w;
+    __bf16* o = out + ((int64_t)r * K + (c >> 5) * 32) * 2 + (c & 31);      // block (r, c / 32): [32 hi | 32 lo]
+    o[0] = hi;
+    o[32] = (__bf16)(w - (float)hi);
+}
+}  // namespace
+
+extern "C" int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, void* stream) {
+    VRD_CHECK_ARG(src && out, "vrd_split_weight: null pointer");
+    VRD_CHECK_ARG(R > 0 && Q > 0 && taps > 0 && ((int64_t)taps * Q) % 32 == 0, "vrd_split_weight: K = taps * Q must be a positive multiple of 32");
+    const int64_t n = (int64_t)R * taps * Q;
+    VRD_CHECK_ARG((n + 255) / 256 < ((int64_t)1 << 31), "vrd_split_weight: too large");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, R, Q, taps, sr, st, sq, reinterpret_cast<__bf16*>(out));
+    VRD_LAUNCH_CHECK();
+    return 0;
+}

@@ -164,17 +164,26 @@ def get_precision():
     return _precision
 
 
+def _split_weight(w, offset, R, Q, taps, sr, st, sq):
+    assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and (taps * Q) % 32 == 0
+    out = torch.empty(R, taps * Q // 32, 2, 32, device=w.device, dtype=torch.bfloat16)
+    _hip.check(lib.vrd_split_weight(w.data_ptr() + 4 * offset, R, Q, taps, sr, st, sq, out.data_ptr(), _stream()), "vrd_split_weight")
+    return out
+
+
 def split_conv_weight(w):
     """(N, K/32, 2, 32) bf16 of the tap-major packed weight (K = Cin*k, K % 32 == 0): per block of 32 K positions
     [32 x bf16(W) | 32 x bf16(W - bf16(W))] -- the pair-row block format of vrd_common.h, so one 128-byte line
-    holds what a K step needs from a weight row."""
-    def build():
-        packed = packed_conv_weight(w).detach().reshape(w.shape[0], -1)
-        hi = packed.to(torch.bfloat16)
-        lo = (packed - hi.float()).to(torch.bfloat16)
-        N, K = hi.shape
-        return torch.stack([hi.reshape(N, K // 32, 32), lo.reshape(N, K // 32, 32)], dim=2).contiguous()
-    return _cached(w, "_vrd_split", build)
+    holds what a K step needs from a weight row.  One launch (vrd_split_weight) per weight and weight version."""
+    N, Cin, k = w.shape
+    return _cached(w, "_vrd_split", lambda: _split_weight(w.detach(), 0, N, Cin, k, Cin * k, 1, k))
+
+
+def split_conv_weight_dgrad(w):
+    """The same operand for the input-gradient GEMM of the conv: the (Cin, k*N) matrix [c][tap*N + n] = w[n][c][k-1-tap]
+    (transposed, taps flipped), straight from the parameter."""
+    N, Cin, k = w.shape
+    return _cached(w, "_vrd_split_t", lambda: _split_weight(w.detach(), k - 1, Cin, N, k, k, -1, Cin * k))
 
 
 def bct_to_btc(x, c0, count, out, pair=False):
@@ -328,7 +337,7 @@ def row_blocks(mask):
 
 
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
-              res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None):
+              res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None, _dgrad=False):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
     vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
     out_pair: write the result as pair rows of width N (returns a Pair).
@@ -344,6 +353,8 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
                                   res_masked=res_masked, res2=res2)
     assert row_scale is None, "row_scale (drop-path sampling) exists on the autograd path only"
     N, Cin, k = weight.shape
+    if _dgrad:          # the conv's input gradient: weight (Cin_of_x... = N_w, Cin_w, k) acts as the (Cin_w, N_w, k) flipped conv
+        N, Cin = Cin, N
     x, a_width = _unwrap(x)
     pa, rows, cols, lda = _rows(x)
     assert cols == Cin, f"input has {cols} channels, weight expects {Cin}"
@@ -352,9 +363,16 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
     pc, rows_c, cols_c, ldc = _rows(out)
     assert rows_c == rows and cols_c == N
-    w = packed_conv_weight(weight)
     a = _hip.GemmArgs()
-    a.A, a.lda, a.W, a.bias = pa, lda, _param_ptr(w, x, "conv weight"), _param_ptr(bias, x, "conv bias")
+    if _dgrad:
+        # split-precision only (autograd.Linear checks): the operand is built from the parameter in one launch; the f32
+        # weight pointer is not read by the split-precision kernels and points at the same buffer
+        assert _precision == "bf16x3" and (Cin * k) % 32 == 0 and not a_width
+        wt = split_conv_weight_dgrad(weight)
+        a.W, a.W_split = wt.data_ptr(), wt.data_ptr()
+    else:
+        a.W = _param_ptr(packed_conv_weight(weight), x, "conv weight")
+    a.A, a.lda, a.bias = pa, lda, _param_ptr(bias, x, "conv bias")
     a.C, a.ldc = pc, ldc
     a.M, a.N, a.Cin, a.taps, a.T = rows, N, Cin, k, T
     a.act = act
@@ -362,7 +380,7 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     a.scale = _param_ptr(scale, x, "drop-path scale")
     if a_width:
         assert _precision == "bf16x3" and Cin % 32 == 0, "pair input needs bf16x3 precision and Cin % 32 == 0"
-    if _precision == "bf16x3" and (Cin * k) % 32 == 0:
+    if not _dgrad and _precision == "bf16x3" and (Cin * k) % 32 == 0:
         a.W_split = split_conv_weight(weight).data_ptr()
     a.a_pair_width = a_width
     a.c_pair = 1 if out_pair else 0
