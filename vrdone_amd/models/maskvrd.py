@@ -212,6 +212,18 @@ class MaskVRD(nn.Module):
         batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
         return batch_idx, torch.cat([src for src, _ in indices])
 
+    @staticmethod
+    def _matched_targets(per_pair, indices, dev):
+        """cat([t[j] for t, (_, j) in zip(per_pair, indices)]) -- the reference's gather of every pair's matched relations
+        (maskvrd.py:500-503,520-527) -- with ONE index upload: the per-pair lists are concatenated and indexed with the
+        matcher's columns shifted by each pair's offset (one small host-to-device copy per pair was ~300 per step)."""
+        sizes = [int(t.shape[0]) for t in per_pair]
+        offs = [0]
+        for n in sizes[:-1]:
+            offs.append(offs[-1] + n)
+        j_all = torch.cat([j + o for (_, j), o in zip(indices, offs)]).to(dev)
+        return torch.cat(list(per_pair), dim=0)[j_all]
+
     def _get_tgt_permutation_idx(self, indices):
         batch_idx = torch.cat([torch.full_like(tgt, i) for i, (_, tgt) in enumerate(indices)])
         return batch_idx, torch.cat([tgt for _, tgt in indices])
@@ -222,7 +234,7 @@ class MaskVRD(nn.Module):
         dev = pred_logits.device
         b, q = (t.to(dev) for t in self._get_src_permutation_idx(indices))
         target = torch.zeros(pred_logits.shape[:2], dtype=torch.int64, device=dev)
-        target[b, q] = torch.cat([t[j.to(dev)] for t, (_, j) in zip(gt_preds, indices)])
+        target[b, q] = self._matched_targets(gt_preds, indices, dev)
         ce = F.cross_entropy(pred_logits.transpose(1, 2), target, self.empty_weight.to(dev))
         return {"loss_class": self.loss_factor['loss_class'] * ce}
 
@@ -231,10 +243,10 @@ class MaskVRD(nn.Module):
         valid frames (reference maskvrd.py:515-551)."""
         dev = pred_masks.device
         b, q = (t.to(dev) for t in self._get_src_permutation_idx(indices))
-        target = torch.cat([m[j.to(dev)] for m, (_, j) in zip(gt_masks, indices)])
+        target = self._matched_targets(gt_masks, indices, dev)
         picked = pred_masks[b, q]
         assert picked.shape == target.shape
-        segs = torch.cat([s[j.to(dev)] for s, (_, j) in zip(gt_segs, indices)], dim=0) if self.with_fuzzy else None
+        segs = self._matched_targets(gt_segs, indices, dev) if self.with_fuzzy else None
         focal, dice = losses.matched_losses(picked, target, num_masks, loss_mask, segs,
                                             self.scale_range if self.with_fuzzy else None)
         return {"loss_mask": self.loss_factor['loss_mask'] * focal, "loss_dice": self.loss_factor['loss_dice'] * dice}
