@@ -292,3 +292,28 @@ def test_maxpool_and_mask_head_backward():
     rel_close(seg, sr, 2e-5, "seg")
     rel_close(ed.grad, er.grad, 2e-5, "demb")
     rel_close(fd.grad, fr.grad, 2e-5, "dfeat")
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_split_weight_operands_are_the_tensor_expression_bit_for_bit(k):
+    """vrd_split_weight (one launch from the parameter) against what it replaces: hi = bf16(W), lo = bf16(W - hi) of the
+    tap-major packed weight in blocks of 32, for the forward operand and for the transposed, tap-flipped operand of the
+    input-gradient GEMM."""
+    from vrdone_amd import ops
+
+    def expression(w):              # w: Conv1d weight (N, Cin, k), contiguous
+        packed = w.permute(0, 2, 1).contiguous().reshape(w.shape[0], -1)
+        hi = packed.to(torch.bfloat16)
+        lo = (packed - hi.float()).to(torch.bfloat16)
+        n, kk = hi.shape
+        return torch.stack([hi.reshape(n, kk // 32, 32), lo.reshape(n, kk // 32, 32)], dim=2)
+
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(96, 64, k, generator=g) * 3).to(DEV)
+    assert torch.equal(ops.split_conv_weight(w), expression(w))
+    assert torch.equal(ops.split_conv_weight_dgrad(w), expression(w.flip(2).permute(1, 0, 2).contiguous()))
+    # cached per weight version: an in-place update rebuilds both
+    first = ops.split_conv_weight(w)
+    assert ops.split_conv_weight(w) is first
+    w.mul_(0.5)
+    assert ops.split_conv_weight(w) is not first and torch.equal(ops.split_conv_weight(w), expression(w))
