@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the second run in the other precision mode")
     ap.add_argument("--no-ragged", action="store_true", help="skip the extra run on ragged pair lengths")
     ap.add_argument("--no-forward-test", action="store_true", help="skip the secondary metric (whole eval call on one synthetic video)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the training-step leg (BASELINE config 3: forward + backward on a 24-pair batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=64)
     return ap.parse_args()
@@ -327,6 +328,35 @@ def main():
                                     "note": "host features -> result: prepare = clamp + de-dup + pair tables + upload of each "
                                             "tracklet once; the reference uploads one (L, C_in) matrix per pair"}
 
+    # BASELINE config 3: one training step's forward + backward through the HIP path (vidvrd.yaml, 24 pairs in T_pad 96,
+    # synthetic ground truth; optimizer excluded -- that is the reference's own code).  Rank 0, N = 1 only.
+    train = None
+    if not args.no_train_step and args.config == "vidvrd" and world == 1:
+        sys.path.insert(0, os.path.join(REPO, "scripts"))
+        from train_step import synthetic_batch
+        batch.clear()
+        torch.cuda.empty_cache()
+        ops.set_precision(main_mode)
+        tmodel = synth.load_synthetic_weights(MaskVRD(cfg, device=dev)).to(dev).train()
+        tdata = synthetic_batch(cfg, c_in, dev, seed=0)
+        times = []
+        for it in range(5):
+            tmodel.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = tmodel(tdata)["total_loss"]
+            loss.backward()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        n_grad = sum(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in tmodel.parameters() if p.requires_grad)
+        n_par = sum(p.requires_grad for p in tmodel.parameters())
+        train = {"pairs": len(tdata["so_features_list"]), "t_pad": cfg["max_seq_len"], "ms_forward_backward": 1e3 * sorted(times[2:])[1],
+                 "params_with_finite_grad": f"{n_grad}/{n_par}", "total_loss": float(loss.detach()),
+                 "note": "model.train(): forward_training + total_loss.backward() on the HIP backward kernels, stochastic depth on; "
+                         "median of 3 after 2 warm-up steps"}
+        del tmodel, tdata
+        model.eval()
+
     if rank == 0:
         fpp = FLOPS_PER_PAIR.get((args.config, t_pad))
         line = {
@@ -372,6 +402,8 @@ def main():
             line["ragged_variant"] = ragged
         if ft is not None:
             line["forward_test"] = ft
+        if train is not None:
+            line["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, c_in, args.frames, t_pad, args.cpu_pairs)
