@@ -191,3 +191,64 @@ def write_synth_pickles(directory, video_name="vid0", n_tracklets=6, video_len=6
         with open(path, "wb") as f:
             pickle.dump(obj, f)
     return paths
+
+
+def write_synth_train_files(directory, video_name="vid0", n_tracks=5, video_len=90, n_visual=16, seed=21, wh=(320, 240)):
+    """Write the two per-video files `_prepare_train` reads (dataloaders/vidvrd.py:175-186): <dir>/anno/<name>.json
+    (VidVRD annotation: per-frame trajectories, subject/objects, relation instances) and <dir>/gtfeat/<name>.pkl (RoI
+    features of the ground-truth boxes per 1-based frame id).  The video is built to hit the loader's cases: a trajectory
+    with a gap (two intervals), relation instances of one (subject, object, predicate) that overlap in time (merged),
+    several relations on one pair, boxes that stick out of the frame (clamped), a pair longer than a short max_seq_len.
+    Returns (annotation dir, feature dir, entity name -> id, predicate name -> id)."""
+    import json
+    import os
+    import pickle
+    import numpy as np
+    g = torch.Generator().manual_seed(seed)
+    W, H = wh
+    cats = ["dog", "person", "ball", "bicycle", "sofa"]
+    preds = ["chase", "watch", "ride", "next_to"]
+    spans = []
+    for t in range(n_tracks):
+        a = int(torch.randint(0, video_len // 3, (1,), generator=g))
+        e = int(torch.randint(2 * video_len // 3, video_len + 1, (1,), generator=g))
+        spans.append([(a, e)])
+    a, e = spans[1][0]
+    spans[1] = [(a, a + (e - a) // 2 - 3), (a + (e - a) // 2 + 2, e)]          # trajectory 1 disappears for five frames
+    tids = [3 * t + 2 for t in range(n_tracks)]                                # ids are not 0..n-1
+    trajectories = [[] for _ in range(video_len)]
+    frames = {}
+    for t, tid in enumerate(tids):
+        for (a, e) in spans[t]:
+            for f in range(a, e):
+                xy = torch.rand(2, generator=g) * torch.tensor([W * 0.8, H * 0.8]) - 6.0
+                wh_ = torch.rand(2, generator=g) * torch.tensor([W * 0.35, H * 0.35]) + 10.0
+                x0, y0, x1, y1 = [round(float(v), 2) for v in (xy[0], xy[1], xy[0] + wh_[0], xy[1] + wh_[1])]
+                trajectories[f].append({"tid": tid, "bbox": {"xmin": x0, "ymin": y0, "xmax": x1, "ymax": y1}})
+                rec = frames.setdefault(f + 1, {"frame_id": f + 1, "tids": [], "visual_features": []})
+                rec["tids"].append(tid)
+                rec["visual_features"].append(torch.randn(n_visual, generator=g).numpy())
+    for rec in frames.values():
+        rec["tids"] = np.asarray(rec["tids"])
+        rec["visual_features"] = np.stack(rec["visual_features"], axis=0).astype(np.float32)
+
+    def inst(s, o, p, b, e_):
+        return {"subject_tid": tids[s], "object_tid": tids[o], "predicate": preds[p], "begin_fid": b, "end_fid": e_}
+    lo, hi = max(spans[0][0][0], spans[2][0][0]), min(spans[0][0][1], spans[2][0][1])
+    third = (hi - lo) // 3
+    rel = [inst(0, 2, 0, lo + 1, lo + third), inst(0, 2, 0, lo + third - 2, lo + 2 * third),     # overlap -> one instance
+           inst(0, 2, 1, lo + 2, hi - 1), inst(2, 0, 3, lo, lo + 6),
+           inst(3, 4, 2, max(spans[3][0][0], spans[4][0][0]) + 1, min(spans[3][0][1], spans[4][0][1]) - 1)]
+    b1 = spans[1][1]                                                                          # inside trajectory 1's second interval
+    rel.append(inst(1, 0, 1, max(b1[0], spans[0][0][0]) + 1, min(b1[1], spans[0][0][1]) - 1))
+    anno = {"video_id": video_name, "height": H, "width": W, "trajectories": trajectories,
+            "subject/objects": [{"tid": tid, "category": cats[t % len(cats)]} for t, tid in enumerate(tids)],
+            "relation_instances": rel}
+    anno_dir, feat_dir = os.path.join(directory, "anno"), os.path.join(directory, "gtfeat")
+    os.makedirs(anno_dir, exist_ok=True)
+    os.makedirs(feat_dir, exist_ok=True)
+    with open(os.path.join(anno_dir, video_name + ".json"), "w") as f:
+        json.dump(anno, f)
+    with open(os.path.join(feat_dir, video_name + ".pkl"), "wb") as f:
+        pickle.dump(frames, f)
+    return anno_dir, feat_dir, {c: i + 1 for i, c in enumerate(cats)}, {p_: i + 1 for i, p_ in enumerate(preds)}

@@ -111,7 +111,63 @@ def proposal_case():
     np.savez_compressed(os.path.join(OUT, "proposal.npz"), **arrs)
 
 
+def train_data_case():
+    """Training-side data path: the reference dataloader's own `_prepare_train`, `_train_getitem` (seeded
+    `random`) and `apply_policy` on a synthetic annotation + ground-truth feature file.  Stored: the cache entry (keys,
+    intervals, merged relations, classes, concatenated features / boxes) and, per (feat_stride, max_seq_len) setting, the
+    sample lists in full (C_in is small here)."""
+    import json
+    import random
+    import tempfile
+    from dataloaders.vidvrd import VidVRD
+    from oracle.proposal import write_synth_train_files
+    out = {}
+    arrs = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        anno_dir, feat_dir, ent, pred = write_synth_train_files(tmp)
+        ds = object.__new__(VidVRD)
+        ds.split, ds.video_ann_dir, ds.gt_boxfeatures_dir = "train", anno_dir, feat_dir
+        ds.entity_cat_name_to_id, ds.pred_cat_name_to_id = ent, pred
+        video = ds._prepare_train("vid0")
+        out["relation_keys"] = video["relation_keys"]
+        out["relation_merged"] = [[list(k), v] for k, v in video["relation_merged"].items()]
+        out["traj_intervals"] = {str(k): v for k, v in video["traj_intervals"].items()}
+        out["entity_classes"] = {str(k): v for k, v in video["entity_classes"].items()}
+        out["video_hw"] = list(video["video_hw"])
+        arrs["visual"] = torch.cat([t for k in sorted(video["visual_features"]) for t in video["visual_features"][k]]).numpy()
+        arrs["boxes"] = torch.cat([t for k in sorted(video["entity_bboxes"]) for t in video["entity_bboxes"][k]]).numpy()
+        out["samples"] = {}
+        for name, (stride, max_len, cut, max_preds, dur, seed) in TRAIN_DATA_CASES.items():
+            ds.feat_stride, ds.max_seq_len, ds.cut_max_preds, ds.proposal_max_preds = stride, max_len, cut, max_preds
+            random.seed(seed)
+            sample = ds._train_getitem(video, dur)
+            out["samples"][name] = {"n": len(sample.get("so_features_list", [])),
+                                    "lens": [int(f.shape[1]) for f in sample.get("so_features_list", [])],
+                                    "preds": [p_.tolist() for p_ in sample.get("preds_list", [])],
+                                    "segs": [s_.tolist() for s_ in sample.get("segs_list", [])]}
+            for i, (f, m) in enumerate(zip(sample.get("so_features_list", []), sample.get("masks_list", []))):
+                arrs[f"{name}/feat{i}"], arrs[f"{name}/mask{i}"] = f.numpy(), m.numpy()
+            print("train data case", name, out["samples"][name]["lens"], out["samples"][name]["preds"])
+    ds.video_num_pairs = [["a", 3], ["b", 9], ["c", 1], ["d", 4], ["e", 13], ["f", 2]]
+    ds.num_pairs = 6
+    ds.apply_policy()
+    out["policy"] = {"video_num_pairs": ds.video_num_pairs, "num_pairs": ds.num_pairs, "policy": ds.policy}
+    with open(os.path.join(OUT, "train_data.json"), "w") as f:
+        json.dump(out, f)
+    np.savez_compressed(os.path.join(OUT, "train_data.npz"), **arrs)
+
+
+TRAIN_DATA_CASES = {   # name -> (feat_stride, max_seq_len, cut_max_preds, proposal_max_preds, pair_duration, random seed)
+    "stride1": (1, 96, False, 0, None, 3),
+    "stride1_crop": (1, 24, False, 0, None, 4),          # every pair longer than max_seq_len: random crops
+    "stride4": (4, 96, False, 0, None, 5),               # random sub-sampling offsets
+    "cut": (1, 96, True, 1, (1, 3), 6),                  # pairs with more than one relation dropped, keys 1..2 only
+}
+
+
 def main():
+    if "--only-train-data" in sys.argv:
+        return train_data_case()
     if "--only-proposal" in sys.argv:
         return proposal_case()
     if "--only-global-block" in sys.argv:

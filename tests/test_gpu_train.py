@@ -274,3 +274,26 @@ def test_ema_update_is_one_launch_and_bit_identical():
     ema.set(model)
     for a, b in zip(ema.module.state_dict().values(), model.state_dict().values()):
         assert torch.equal(a, b)
+
+
+def test_training_sample_from_annotation_files_takes_a_step(tmp_path):
+    """The training-side data path end to end: annotation + ground-truth feature files -> cache entry ->
+    sample lists (proposals.load_train_video / train_getitem, pinned against the reference dataloader on the CPU) ->
+    `forward_training` + backward: a finite loss and a finite gradient for every parameter."""
+    import random
+    from oracle import proposal as P
+    from vrdone_amd.models.maskvrd import MaskVRD
+    from vrdone_amd.proposals import load_train_video, train_getitem
+    mc, _, keys = load_case("vidvrd")
+    anno_dir, feat_dir, ent, pred = P.write_synth_train_files(str(tmp_path), n_visual=mc["visual_dim"])
+    video = load_train_video(f"{anno_dir}/vid0.json", f"{feat_dir}/vid0.pkl", ent, pred)
+    random.seed(0)
+    sample = train_getitem(video, 1, mc["max_seq_len"])
+    assert len(sample["so_features_list"]) >= 3
+    model = MaskVRD(mc, device=DEV)
+    model.load_state_dict(O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"]))
+    model = model.to(DEV).train()
+    loss = model({k: [t.to(DEV) for t in v] for k, v in sample.items()})
+    assert np.isfinite(float(loss["total_loss"].detach()))
+    loss["total_loss"].backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.requires_grad)

@@ -84,3 +84,69 @@ def test_plain_tensor_form_passes_the_reference_eval_loop():
         assert torch.equal(getattr(a, name), getattr(b, name))
     for k in ("sids", "oids", "so_offset"):
         assert torch.equal(flat[k], obj[k])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# training side: tests/golden/train_data.* = the reference dataloader's own `_prepare_train`,
+# `_train_getitem` (seeded `random`) and `apply_policy` on the synthetic files of oracle.proposal.write_synth_train_files
+# (scripts/make_golden_r2.py --only-train-data)
+# --------------------------------------------------------------------------------------------------------------------
+TRAIN_DATA_CASES = {   # name -> (feat_stride, max_seq_len, cut_max_preds, proposal_max_preds, pair_duration, random seed)
+    "stride1": (1, 96, False, 0, None, 3),
+    "stride1_crop": (1, 24, False, 0, None, 4),
+    "stride4": (4, 96, False, 0, None, 5),
+    "cut": (1, 96, True, 1, (1, 3), 6),
+}
+
+
+@pytest.fixture(scope="module")
+def train_video(tmp_path_factory):
+    from vrdone_amd.proposals import load_train_video
+    tmp = tmp_path_factory.mktemp("train")
+    anno_dir, feat_dir, ent, pred = P.write_synth_train_files(str(tmp))
+    return load_train_video(f"{anno_dir}/vid0.json", f"{feat_dir}/vid0.pkl", ent, pred)
+
+
+def test_train_cache_entry_matches_the_reference_dataloader(train_video, golden_dir):
+    import json
+    g = json.load(open(f"{golden_dir}/train_data.json"))
+    arrs = np.load(f"{golden_dir}/train_data.npz")
+    v = train_video
+    assert v["relation_keys"] == g["relation_keys"]                      # incl. the set's iteration order (pair_duration indexes it)
+    assert [[list(k), r] for k, r in v["relation_merged"].items()] == g["relation_merged"]
+    assert {str(k): iv for k, iv in v["traj_intervals"].items()} == g["traj_intervals"]
+    assert {str(k): c for k, c in v["entity_classes"].items()} == g["entity_classes"]
+    assert list(v["video_hw"]) == g["video_hw"]
+    assert any(len(iv) > 1 for iv in v["traj_intervals"].values())       # the gapped trajectory became two intervals
+    assert any(len(r) > 1 for r in v["relation_merged"].values())        # several relations on one pair
+    np.testing.assert_array_equal(torch.cat([t for k in sorted(v["visual_features"]) for t in v["visual_features"][k]]).numpy(), arrs["visual"])
+    np.testing.assert_array_equal(torch.cat([t for k in sorted(v["entity_bboxes"]) for t in v["entity_bboxes"][k]]).numpy(), arrs["boxes"])
+
+
+@pytest.mark.parametrize("name", list(TRAIN_DATA_CASES))
+def test_train_samples_match_the_reference_dataloader(name, train_video, golden_dir):
+    """Same draws from `random`, same crops: features, masks, predicates and segments equal the reference's bit for bit."""
+    import json
+    import random
+    from vrdone_amd.proposals import train_getitem
+    stride, max_len, cut, max_preds, dur, seed = TRAIN_DATA_CASES[name]
+    g = json.load(open(f"{golden_dir}/train_data.json"))["samples"][name]
+    arrs = np.load(f"{golden_dir}/train_data.npz")
+    random.seed(seed)
+    got = train_getitem(train_video, stride, max_len, cut, max_preds, dur)
+    assert len(got.get("so_features_list", [])) == g["n"] > 0
+    assert [int(f.shape[1]) for f in got["so_features_list"]] == g["lens"]
+    assert [p.tolist() for p in got["preds_list"]] == g["preds"]
+    assert [s.tolist() for s in got["segs_list"]] == g["segs"]
+    for i, (f, m) in enumerate(zip(got["so_features_list"], got["masks_list"])):
+        np.testing.assert_array_equal(f.numpy(), arrs[f"{name}/feat{i}"])
+        np.testing.assert_array_equal(m.numpy(), arrs[f"{name}/mask{i}"])
+
+
+def test_train_policy_matches_the_reference(golden_dir):
+    import json
+    from vrdone_amd.proposals import train_policy
+    g = json.load(open(f"{golden_dir}/train_data.json"))["policy"]
+    got = train_policy(g["video_num_pairs"], g["num_pairs"])
+    assert [[[n, list(r)] for n, r in step] for step in got] == g["policy"]
+    assert all(sum(r[1] - r[0] for _, r in step) <= g["num_pairs"] for step in got)

@@ -200,3 +200,226 @@ def prepare_test_proposal(raw, feat_stride, stride_offset, proposal_min_frames, 
     else:
         out["pair_source"] = src
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Training side: the per-video ground-truth cache and the per-step sample construction of the reference's
+# training dataloader.  Host code (the sample construction draws from Python's `random`, call for call like the reference,
+# so that a seeded run sees the same crops); the model side takes the resulting lists as `forward_training` input.
+# --------------------------------------------------------------------------------------------------------------------
+def load_train_video(anno_json, gt_features_pkl, entity_cat_name_to_id, pred_cat_name_to_id):
+    """One training video's cache entry; restates `_prepare_train`, dataloaders/vidvrd.py:172-322.
+      anno_json        VidVRD annotation: {'height', 'width', 'trajectories' [per frame: [{'tid', 'bbox': {xmin, ymin, xmax,
+                       ymax}}]], 'subject/objects' [{'tid', 'category'}], 'relation_instances' [{'subject_tid',
+                       'object_tid', 'predicate', 'begin_fid', 'end_fid'}]}
+      gt_features_pkl  {1-based frame id: {'frame_id', 'tids' array, 'visual_features' (n, V) array}} of the ground-truth boxes
+    Trajectories are renumbered 0..n-1 in tid order and cut into intervals of consecutive frames; relation instances of
+    one (subject, object, predicate) that overlap in time are merged; every relation is keyed by (subject, object, subject
+    interval, object interval).  Returns {} for a video without relations, else {'video_hw', 'relation_merged' {key:
+    [{'predicate', 'begin_fid', 'end_fid'}]}, 'relation_keys' [[...]], 'visual_features' / 'entity_bboxes' {index: [per
+    interval tensor]}, 'entity_classes', 'traj_intervals' {index: [[start, end)]}}."""
+    import copy
+    import json
+    import pickle
+    from collections import defaultdict
+    with open(anno_json) as f:
+        anno = json.load(f)
+    if len(anno["relation_instances"]) == 0:
+        return {}
+    with open(gt_features_pkl, "rb") as f:
+        frames = pickle.load(f)
+    present = defaultdict(list)
+    for fid, frame in enumerate(anno["trajectories"]):
+        for box in frame:
+            present[box["tid"]].append(fid)
+    tids = sorted(present)
+    index_of = {tid: i for i, tid in enumerate(tids)}
+    frame_keys = sorted(frames)
+    visual, bboxes, intervals = {}, {}, {}
+    for tid in tids:
+        fids = np.asarray(sorted(present[tid]))
+        cut = np.nonzero(np.diff(fids) > 1)[0]
+        starts = fids[np.concatenate([[0], cut + 1])]
+        ends = fids[np.concatenate([cut, [len(fids) - 1]])] + 1
+        spans = [[int(a), int(e)] for a, e in zip(starts, ends)]
+        idx = index_of[tid]
+        intervals[idx] = spans
+        vis_i, box_i = [], []
+        for a, e in spans:
+            rows = []
+            for k in frame_keys:                         # frame ids in the feature file start at 1
+                if k - 1 < a:
+                    continue
+                if k - 1 >= e:
+                    break
+                rec = frames[k]
+                assert rec["frame_id"] == k
+                at = np.nonzero(np.asarray(rec["tids"]) == tid)[0]
+                assert len(at) == 1
+                rows.append(np.asarray(rec["visual_features"])[at])
+            vis_i.append(torch.tensor(np.concatenate(rows, axis=0)))
+            bb = [[b["bbox"]["xmin"], b["bbox"]["ymin"], b["bbox"]["xmax"], b["bbox"]["ymax"]]
+                  for frame in anno["trajectories"][a:e] for b in frame if b["tid"] == tid]
+            assert len(bb) == e - a
+            box_i.append(torch.tensor(bb, dtype=torch.float32))
+        visual[idx], bboxes[idx] = vis_i, box_i
+    classes = {index_of[so["tid"]]: entity_cat_name_to_id[so["category"]] for so in anno["subject/objects"]}
+
+    # merge instances of the same (subject, object, predicate) that overlap in time, in order of their first frame
+    insts = sorted(copy.deepcopy(anno["relation_instances"]), key=lambda r: r["begin_fid"])
+    merged, seen = [], [False] * len(insts)
+    for i, base in enumerate(insts):
+        if seen[i]:
+            continue
+        seen[i] = True
+        for j in range(i + 1, len(insts)):
+            other = insts[j]
+            if (other["subject_tid"], other["object_tid"], other["predicate"]) != (base["subject_tid"], base["object_tid"], base["predicate"]):
+                continue
+            assert other["begin_fid"] > base["begin_fid"]
+            if other["begin_fid"] <= base["end_fid"]:
+                assert other["end_fid"] > base["end_fid"]
+                base["end_fid"] = other["end_fid"]
+                seen[j] = True
+        merged.append(copy.deepcopy(base))
+    merged.sort(key=lambda r: r["begin_fid"])
+
+    # (the keys are collected in a set and listed in ITS iteration order, like the reference: `pair_duration` slices index
+    # that list, and for tuples of ints the order is a deterministic function of the insertions)
+    relation_merged, keys = defaultdict(list), set()
+    for r in merged:
+        s, o = index_of[r["subject_tid"]], index_of[r["object_tid"]]
+        bf, ef = r["begin_fid"], r["end_fid"]
+        s_iv = [k for k, (a, e) in enumerate(intervals[s]) if a <= bf and e >= ef]
+        o_iv = [k for k, (a, e) in enumerate(intervals[o]) if a <= bf and e >= ef]
+        assert len(s_iv) == 1 and len(o_iv) == 1, "a relation must lie inside one interval of each trajectory"
+        key = (s, o, s_iv[0], o_iv[0])
+        assert max(intervals[s][s_iv[0]][0], intervals[o][o_iv[0]][0]) < min(intervals[s][s_iv[0]][1], intervals[o][o_iv[0]][1])
+        relation_merged[key].append({"predicate": pred_cat_name_to_id[r["predicate"]], "begin_fid": bf, "end_fid": ef})
+        keys.add(key)
+    return {"video_hw": (anno["height"], anno["width"]), "relation_merged": relation_merged,
+            "relation_keys": [list(k) for k in keys], "visual_features": visual, "entity_bboxes": bboxes,
+            "entity_classes": classes, "traj_intervals": intervals}
+
+
+def truncate_feats(so_feat, pred, segment, max_seq_len, trunc_thresh=0.5, max_times=10, rng=None):
+    """Random max_seq_len crop of a pair that keeps at least one relation >= trunc_thresh inside (reference
+    utils/misc.py:219-273, which derives from ActionFormer); None when ten draws find none.  so_feat (C, L), segment
+    (N, 2) in feature steps.  Draws `rng.randint(0, L - max_seq_len)` per try, like the reference's `random.randint`."""
+    import random
+    rng = rng or random
+    L = so_feat.shape[1]
+    if L <= max_seq_len:
+        return so_feat, pred, segment
+    for _ in range(max_times):
+        st = rng.randint(0, L - max_seq_len)
+        ed = st + max_seq_len
+        left = torch.clamp(segment[:, 0], min=st).float()
+        right = torch.clamp(segment[:, 1], max=ed).float()
+        inter = (right - left).clamp(min=0)
+        keep = inter / (segment[:, 1] - segment[:, 0]).abs() >= trunc_thresh
+        if int(keep.sum()) > 0:
+            return so_feat[:, st:ed], pred[keep], torch.stack((left[keep], right[keep]), dim=1) - st
+    return None
+
+
+def _so_box_features(sb, ob):
+    """utils/misc.py:158-178 (what vrd_gather_pairs computes on the device for the eval path)."""
+    s_cx, s_cy = (sb[:, 2] + sb[:, 0]) / 2, (sb[:, 3] + sb[:, 1]) / 2
+    o_cx, o_cy = (ob[:, 2] + ob[:, 0]) / 2, (ob[:, 3] + ob[:, 1]) / 2
+    s_w, s_h, o_w, o_h = sb[:, 2] - sb[:, 0], sb[:, 3] - sb[:, 1], ob[:, 2] - ob[:, 0], ob[:, 3] - ob[:, 1]
+    return torch.stack([(s_cx - o_cx) / o_cx, (s_cy - o_cy) / o_cy, torch.log(s_w / o_w), torch.log(s_h / o_h),
+                        torch.log(s_w * s_h / (o_w * o_h))], dim=1)
+
+
+def _entity_box_features(b, w, h):
+    """utils/misc.py:181-217: normalised centre / size and their frame-to-frame differences (first frame extrapolated)."""
+    x0, x1, y0, y1 = b[:, 0] / w, b[:, 2] / w, b[:, 1] / h, b[:, 3] / h
+    geo = torch.stack([(x1 + x0) / 2, (y1 + y0) / 2, x1 - x0, y1 - y0], dim=1)
+    d = geo[1:] - geo[:-1]
+    first = d[0:1] - (d[1:2] - d[0:1]) if len(d) > 1 else d[0:1]
+    d = torch.cat([first, d], dim=0)
+    return torch.stack([geo[:, 0], d[:, 0], geo[:, 1], d[:, 1], geo[:, 2], d[:, 2], geo[:, 3], d[:, 3]], dim=1)
+
+
+def train_getitem(video, feat_stride, max_seq_len, cut_max_preds=False, proposal_max_preds=0, pair_duration=None, rng=None):
+    """The training sample of one video (or of its relation keys [pair_duration[0], pair_duration[1])): restates
+    `_train_getitem`, dataloaders/vidvrd.py:324-457.  Per relation key: a random sub-sampling offset, the subject / object
+    features of the frames both intervals share, the 21 box-feature channels, the relations as [ceil((fid - start -
+    offset) / stride)] segments, a random max_seq_len crop, 0/1 masks.  Returns {} when nothing survives, else
+    {'so_features_list' [(C_in, L)], 'preds_list', 'masks_list' [(N, max_seq_len)], 'segs_list'}."""
+    import copy
+    import random
+    rng = rng or random
+    if not video:
+        return {}
+    video = copy.deepcopy(video)
+    merged, keys = video["relation_merged"], video["relation_keys"]
+    if pair_duration is not None:
+        keys = keys[pair_duration[0]:pair_duration[1]]
+        merged = {k: v for k, v in merged.items() if list(k) in keys}
+    h, w = video["video_hw"]
+    boxes = {t: [_clamped(b, w, h) for b in per] for t, per in video["entity_bboxes"].items()}
+    feats_out, preds_out, masks_out, segs_out = [], [], [], []
+    for key in merged:
+        offset = rng.randint(0, feat_stride - 1)
+        s, o, si, oi = key
+        if cut_max_preds and proposal_max_preds < len(merged[key]):
+            continue
+        s_iv, o_iv = video["traj_intervals"][s][si], video["traj_intervals"][o][oi]
+        lo, hi = max(s_iv[0], o_iv[0]), min(s_iv[1], o_iv[1])
+        pick = lambda per, iv: per[lo - iv[0]:hi - iv[0]][offset::feat_stride]      # noqa: E731
+        s_feat, o_feat = pick(video["visual_features"][s][si], s_iv), pick(video["visual_features"][o][oi], o_iv)
+        if s_feat.shape[0] < 2:
+            continue
+        sb, ob = pick(boxes[s][si], s_iv), pick(boxes[o][oi], o_iv)
+        so_feat = torch.cat([s_feat, o_feat, _so_box_features(sb, ob), _entity_box_features(sb, w, h),
+                             _entity_box_features(ob, w, h)], dim=-1).permute(1, 0)
+        preds, segs = [], []
+        for r in merged[key]:
+            left = np.ceil((r["begin_fid"] - lo - offset) / feat_stride)
+            right = np.ceil((r["end_fid"] - lo - offset) / feat_stride)
+            if left < right:
+                preds.append(r["predicate"])
+                segs.append([left, right])
+        if not preds:
+            continue
+        cropped = truncate_feats(so_feat, torch.tensor(preds, dtype=torch.int64), torch.tensor(np.array(segs), dtype=torch.int64),
+                                 max_seq_len, rng=rng)
+        if cropped is None:
+            continue
+        so_feat, preds, segs = cropped
+        segs_out.append(segs)
+        masks = torch.zeros(len(segs), max_seq_len, dtype=torch.float32)
+        for m, (a, e) in zip(masks, segs.to(torch.int64).tolist()):
+            assert 0 <= a < e <= max_seq_len
+            m[a:e] = 1
+        feats_out.append(so_feat)
+        preds_out.append(preds)
+        masks_out.append(masks)
+    if not feats_out:
+        return {}
+    return {"so_features_list": feats_out, "preds_list": preds_out, "masks_list": masks_out, "segs_list": segs_out}
+
+
+def train_policy(video_num_pairs, num_pairs):
+    """Steps of at most num_pairs relation keys, videos cut across steps where needed: [[(video, (first, last))]] per step;
+    restates `apply_policy`, dataloaders/vidvrd.py:100-135."""
+    policy, current = [[]], 0
+    for name, n in video_num_pairs:
+        if n + current < num_pairs:
+            policy[-1].append([name, (0, n)])
+            current += n
+            continue
+        start = 0
+        while n + current >= num_pairs:
+            take = num_pairs - current
+            policy[-1].append([name, (start, start + take)])
+            n -= take
+            start += take
+            current = 0
+            policy.append([])
+        if n > 0:
+            policy[-1].append([name, (start, start + n)])
+            current += n
+    return policy
