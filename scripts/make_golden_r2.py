@@ -148,6 +148,20 @@ def train_data_case():
             for i, (f, m) in enumerate(zip(sample.get("so_features_list", []), sample.get("masks_list", []))):
                 arrs[f"{name}/feat{i}"], arrs[f"{name}/mask{i}"] = f.numpy(), m.numpy()
             print("train data case", name, out["samples"][name]["lens"], out["samples"][name]["preds"])
+        # the VidOR loader's sample construction with CLIP features (dataloaders/vidor.py:335-478) on the same cache entry
+        from dataloaders.vidor import VidOR
+        g = torch.Generator().manual_seed(77)
+        video["clip_features"] = {k: [torch.randn(t.shape[0], 8, generator=g) for t in per] for k, per in video["visual_features"].items()}
+        dv = object.__new__(VidOR)
+        dv.feat_stride, dv.max_seq_len, dv.cut_max_preds, dv.proposal_max_preds, dv.with_clip_feature = 4, 96, False, 0, True
+        random.seed(8)
+        sample = dv._train_getitem(video, None)
+        out["samples"]["vidor_clip"] = {"n": len(sample["so_features_list"]), "lens": [int(f.shape[1]) for f in sample["so_features_list"]],
+                                        "preds": [p_.tolist() for p_ in sample["preds_list"]], "segs": None}
+        for i, (f, m) in enumerate(zip(sample["so_features_list"], sample["masks_list"])):
+            arrs[f"vidor_clip/feat{i}"], arrs[f"vidor_clip/mask{i}"] = f.numpy(), m.numpy()
+        arrs["clip"] = torch.cat([t for k in sorted(video["clip_features"]) for t in video["clip_features"][k]]).numpy()
+        print("train data case vidor_clip", out["samples"]["vidor_clip"]["lens"], "C_in", sample["so_features_list"][0].shape[0])
     ds.video_num_pairs = [["a", 3], ["b", 9], ["c", 1], ["d", 4], ["e", 13], ["f", 2]]
     ds.num_pairs = 6
     ds.apply_policy()

@@ -347,7 +347,9 @@ def train_getitem(video, feat_stride, max_seq_len, cut_max_preds=False, proposal
     `_train_getitem`, dataloaders/vidvrd.py:324-457.  Per relation key: a random sub-sampling offset, the subject / object
     features of the frames both intervals share, the 21 box-feature channels, the relations as [ceil((fid - start -
     offset) / stride)] segments, a random max_seq_len crop, 0/1 masks.  Returns {} when nothing survives, else
-    {'so_features_list' [(C_in, L)], 'preds_list', 'masks_list' [(N, max_seq_len)], 'segs_list'}."""
+    {'so_features_list' [(C_in, L)], 'preds_list', 'masks_list' [(N, max_seq_len)], 'segs_list'}.  A cache entry with
+    'clip_features' {index: [per interval (L, Cc)]} (the VidOR loader with CLIP features, dataloaders/vidor.py:346-415) puts
+    the subject / object CLIP rows behind the visual ones."""
     import copy
     import random
     rng = rng or random
@@ -373,8 +375,10 @@ def train_getitem(video, feat_stride, max_seq_len, cut_max_preds=False, proposal
         if s_feat.shape[0] < 2:
             continue
         sb, ob = pick(boxes[s][si], s_iv), pick(boxes[o][oi], o_iv)
-        so_feat = torch.cat([s_feat, o_feat, _so_box_features(sb, ob), _entity_box_features(sb, w, h),
-                             _entity_box_features(ob, w, h)], dim=-1).permute(1, 0)
+        clip = video.get("clip_features")
+        wide = [s_feat, o_feat] if clip is None else [s_feat, o_feat, pick(clip[s][si], s_iv), pick(clip[o][oi], o_iv)]
+        so_feat = torch.cat(wide + [_so_box_features(sb, ob), _entity_box_features(sb, w, h), _entity_box_features(ob, w, h)],
+                            dim=-1).permute(1, 0)
         preds, segs = [], []
         for r in merged[key]:
             left = np.ceil((r["begin_fid"] - lo - offset) / feat_stride)
