@@ -46,6 +46,17 @@ def channel_ln(x, weight, bias):
     return d / torch.sqrt(var + LN_EPS) * weight + bias
 
 
+def sinusoid_encoding(n_position, d_hid):
+    """models/blocks.py:161-172 -- (1, C, T) table: channel 2i = sin(t / 10000^(2i/C)), channel 2i+1 = cos of the same angle;
+    computed in float64 and rounded to float32 like the reference's numpy table."""
+    import numpy as np
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    angle = pos / np.power(10000.0, 2 * (j // 2) / d_hid)
+    table = np.where(j % 2 == 0, np.sin(angle), np.cos(angle))
+    return torch.tensor(table, dtype=torch.float32).unsqueeze(0).transpose(1, 2)
+
+
 def _split_heads(x, n_head):
     B, C, T = x.shape
     return x.view(B, n_head, C // n_head, T).transpose(2, 3)   # (B, H, T, hd)
@@ -210,7 +221,7 @@ def backbone(sd, cfg, x, mask):
     n_conv, n_stem, n_branch = cfg["backbone_arch"]
     assert x.shape[1] == 2 * V + 2 * Cc + S + 2 * E
     assert cfg["fuse_qx_stride"] == 1 and cfg["fuse_kv_stride"] == 1 and cfg["embd_with_ln"]
-    assert not cfg["use_abs_pe"] and not cfg["use_rel_pe"]
+    assert not cfg["use_rel_pe"]
     mf = mask.to(x.dtype)
     P = "backbone"
     o0 = 2 * V + 2 * Cc
@@ -233,6 +244,14 @@ def backbone(sd, cfg, x, mask):
         clips = embed("clip_embd", clips)
         streams = [conv_mlp(sd, f"{P}.visual_clip_fuse", torch.cat([f, c], 1)) * mf
                    for f, c in zip(streams, clips)]
+    if cfg["use_abs_pe"]:
+        # backbones.py:180-196 / 368-384 (eval): the sinusoid table / sqrt(C), linearly re-interpolated to T frames once
+        # T reaches max_len, added on the valid frames of both streams
+        T = x.shape[-1]
+        pe = sinusoid_encoding(cfg["max_seq_len"], cfg["embd_dim"]) / cfg["embd_dim"] ** 0.5
+        if T >= cfg["max_seq_len"]:
+            pe = F.interpolate(pe, T, mode="linear", align_corners=False)
+        streams = [f + pe[:, :, :T].to(f.dtype) * mf for f in streams]
     boxes = []
     for b in ent_box:
         b, _ = masked_conv1d(b, mask, sd[f"{P}.bbox_entity_embd.conv.weight"], sd[f"{P}.bbox_entity_embd.conv.bias"])

@@ -179,7 +179,32 @@ TRAIN_DATA_CASES = {   # name -> (feat_stride, max_seq_len, cut_max_preds, propo
 }
 
 
+ABS_PE_CASES = {   # name -> (config file, [(B, T, lengths)])
+    "vidvrd": ("vidvrd.yaml", [(3, 96, [96, 50, 7]), (3, 288, [288, 201, 30])]),          # T = max_len and T > max_len: interpolated table
+    "vidor_x": ("vidor_x.yaml", [(2, 128, [128, 77])]),                                       # T < max_len, CLIP backbone
+}
+
+
+def abs_pe_case():
+    """`use_abs_pe: True` (no shipped config sets it): the reference's `_mask_vrd` with the sinusoid position table added behind
+    the visual embedding (backbones.py:180-196; CLIP variant :368-384) -- logits / masks of the last layer."""
+    arrs = {}
+    for name, (fname, shapes) in ABS_PE_CASES.items():
+        cfg, mc = load_cfg(fname)
+        mc = dict(mc, use_abs_pe=True)
+        model, _, _ = build(mc)
+        for (B, T, lens) in shapes:
+            x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=4321 + T)
+            out = model._mask_vrd(x, m)
+            arrs[f"{name}/T{T}_pred_logits"] = out["pred_logits"].numpy()
+            arrs[f"{name}/T{T}_pred_masks"] = out["pred_masks"].numpy()
+            print("abs pe case", name, T, "logits std", float(out["pred_logits"].std()))
+    np.savez_compressed(os.path.join(OUT, "abs_pe.npz"), **arrs)
+
+
 def main():
+    if "--only-abs-pe" in sys.argv:
+        return abs_pe_case()
     if "--only-train-data" in sys.argv:
         return train_data_case()
     if "--only-proposal" in sys.argv:

@@ -202,6 +202,31 @@ def test_mask_vrd_b256_matches_reference_golden(precision):
         assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
 
 
+@pytest.mark.parametrize("name,B,T,lens", [("vidvrd", 3, 96, [96, 50, 7]), ("vidvrd", 3, 288, [288, 201, 30]), ("vidor_x", 2, 128, [128, 77])])
+def test_absolute_position_encoding_matches_reference_golden(name, B, T, lens, precision):
+    """`use_abs_pe: True` (no shipped config): position rows added in the last visual-embedding LayerNorm launch (CLIP variant:
+    as a residual of the visual/CLIP fusion GEMM); table as is below max_len, re-interpolated from it on.  Eval and -- same
+    values, differentiable path -- train mode with stochastic depth off."""
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, ic, keys = load_case(name)
+    mc = dict(mc, use_abs_pe=True)
+    model = MaskVRD(mc, device=DEV)
+    model.load_state_dict(O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"]), strict=True)
+    model = model.to(DEV).eval()
+    g = np.load(os.path.join(GOLDEN, "abs_pe.npz"))
+    x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=4321 + T)
+    out = model._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
+    close(out["pred_logits"], g[f"{name}/T{T}_pred_logits"], LOGIT_TOL)
+    close(out["pred_masks"], g[f"{name}/T{T}_pred_masks"], MASK_TOL)
+    assert model.backbone.entity_reach() is None          # position rows count the pair's frames: nothing to share per tracklet
+    if T <= mc["max_seq_len"]:
+        # the autograd path (fresh tensors, torch.cat joins) computes the same numbers
+        with torch.enable_grad():
+            xg = x.to(DEV).requires_grad_(True)
+            out2 = model._mask_vrd(xg, m.to(DEV), with_aux=False)
+        close(out2["pred_logits"], g[f"{name}/T{T}_pred_logits"], LOGIT_TOL)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_forward_test_equals_single_process(world, monkeypatch):
     """MaskVRD.shard_pairs(): every rank runs its round-robin share of the length-sorted pairs and the ranks exchange

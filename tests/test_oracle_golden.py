@@ -380,3 +380,22 @@ def test_pair_construction_matches_reference_dataloader(name):
     np.testing.assert_array_equal(torch.cat([f[-21:].T for f in feats], dim=0).numpy(), g[f"{name}/box_feats"])   # same torch ops: bit-equal
     sums = np.asarray([[float(f[:-21].double().sum()), float(f[:-21].double().abs().sum())] for f in feats])
     np.testing.assert_array_equal(sums, g[f"{name}/vis_sums"])
+
+
+ABS_PE_CASES = [("vidvrd", 3, 96, [96, 50, 7]), ("vidvrd", 3, 288, [288, 201, 30]), ("vidor_x", 2, 128, [128, 77])]
+
+
+@pytest.mark.parametrize("name,B,T,lens", ABS_PE_CASES)
+def test_absolute_position_encoding_matches_reference(name, B, T, lens, weights):
+    """`use_abs_pe: True` (scripts/make_golden_r2.py --only-abs-pe): the sinusoid table behind the visual embedding, as is
+    below max_len, linearly re-interpolated from it on (vidvrd T = 96 and 288), CLIP variant behind the visual/CLIP fusion."""
+    mc, _, sd = weights(name)
+    mc = dict(mc, use_abs_pe=True)
+    g = np.load(os.path.join(GOLDEN, "abs_pe.npz"))
+    x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=4321 + T)
+    out = O.mask_vrd(sd, mc, x, m, with_aux=False)
+    np.testing.assert_allclose(out["pred_logits"].numpy(), g[f"{name}/T{T}_pred_logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["pred_masks"].numpy(), g[f"{name}/T{T}_pred_masks"], atol=MASK_TOL, rtol=0)
+    # and the encoding matters: without it the outputs are somewhere else
+    off = O.mask_vrd(sd, dict(mc, use_abs_pe=False), x, m, with_aux=False)
+    assert float((off["pred_logits"] - out["pred_logits"]).abs().max()) > 100 * LOGIT_TOL

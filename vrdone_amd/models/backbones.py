@@ -10,7 +10,7 @@ materialised -- producers write into column slabs of the consumer's input buffer
 import torch
 from torch import nn
 
-from .blocks import ConvMLP, LayerNorm, MaskedConv1D, TransformerBlock, _from_cl, _mask2d, _ops
+from .blocks import ConvMLP, LayerNorm, MaskedConv1D, TransformerBlock, _from_cl, _mask2d, _ops, get_sinusoid_encoding
 from .local_transformer import MaskedConvTransformerDecoderLayer
 
 
@@ -21,8 +21,7 @@ class MaskConvTransformerBackbone(nn.Module):
                  use_rel_pe=False, use_local=True):
         super().__init__()
         assert len(arch) == 3 and len(mha_win_size) == 1 + arch[-1]
-        assert with_ln and not use_abs_pe and not use_rel_pe, \
-            "built for the shipped configs: embd_with_ln=True, no absolute/relative position encodings"
+        assert with_ln and not use_rel_pe, "built for embd_with_ln=True and no relative position encoding"
         assert scale_factor == 2 and n_embd_ks == 3
         self.n_visual, self.n_bbox_entity, self.n_bbox_so = n_visual, n_bbox_entity, n_bbox_so
         self.n_clip = 0
@@ -30,6 +29,8 @@ class MaskConvTransformerBackbone(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.scale_factor, self.use_abs_pe, self.use_rel_pe = scale_factor, use_abs_pe, use_rel_pe
 
+        if use_abs_pe:      # reference backbones.py:70-72 (not part of the checkpoint)
+            self.register_buffer("pos_embd", get_sinusoid_encoding(max_len, n_embd) / (n_embd ** 0.5), persistent=False)
         self.visual_embd, self.visual_embd_norm = self._embedding(n_visual, n_embd, n_embd_ks, arch[0])
         self.bbox_entity_embd = MaskedConv1D(n_bbox_entity, n_embd, n_embd_ks, stride=1, padding=n_embd_ks // 2)
         self.bbox_entity_norm = LayerNorm(n_embd)
@@ -99,14 +100,14 @@ class MaskConvTransformerBackbone(nn.Module):
         return (stacked(0, V, pair), stacked(2 * V, Cc, pair) if Cc else None, so_box, stacked(o0 + S, E, False))
 
     @staticmethod
-    def _embed(h, convs, norms, mask2, out):
+    def _embed(h, convs, norms, mask2, out, post_add=None):
         """k=3 conv * mask -> LN -> ReLU stack on 2B stacked sequences; the last LN writes into `out`, a column
         slab of the consumer GEMM's input buffer (pair rows in bf16x3 mode)."""
         ops = _ops()
         last = len(convs) - 1
         for i, (conv, norm) in enumerate(zip(convs, norms)):
             h = ops.conv_gemm(h, conv.conv.weight, conv.conv.bias, row_mask=mask2)
-            h = norm.cl(h, relu=True, out=out if i == last else None, pair=ops.pair_mode())
+            h = norm.cl(h, relu=True, out=out if i == last else None, pair=ops.pair_mode(), post_add=post_add if i == last else None)
         return h
 
     def cl(self, x, mask):
@@ -124,9 +125,23 @@ class MaskConvTransformerBackbone(nn.Module):
         """How many frames either side of a frame the entity stage reads (embedding convs, then the first stem block's
         depthwise conv and attention window), or None when that stage is not local (global attention)."""
         win = self.mha_win_size[0]
+        if self.use_abs_pe:          # the position rows count frames of the PAIR's window
+            return None
         if win <= 1 or any(c.kernel_size[0] != 1 for c in self.visual_bbox_fuse.layers):
             return None
         return self.arch[0] + 1 + win // 2        # k = 3 embedding convs, k = 3 depthwise conv, half a window
+
+    def _position_rows(self, mask2):
+        """Absolute position encoding as one row per (sequence, frame): the table's first T frames (linearly re-interpolated
+        to T frames once T reaches max_len, eval only) on valid frames, zeros on padded ones (reference backbones.py:180-196)."""
+        n, T = mask2.shape
+        pe = self.pos_embd
+        if self.training:
+            assert T <= self.max_len, "Reached max length."
+        elif T >= self.max_len:
+            pe = torch.nn.functional.interpolate(pe, T, mode='linear', align_corners=False)
+        rows = pe[0, :, :T].t()                                              # (T, D)
+        return (rows[None] * mask2[..., None].to(rows.dtype)).reshape(n * T, -1).contiguous()
 
     def entity_stage(self, vis, clip, ent, mask2):
         """Everything that sees ONE entity's frames only -- embeddings, visual/box fusion and the first stem block, all
@@ -146,13 +161,15 @@ class MaskConvTransformerBackbone(nn.Module):
         # [visual (+clip) | entity box] -> visual_bbox_fuse
         # (ops.join: the slab-filled buffer, or -- under autograd, where ops return fresh tensors -- the concatenation)
         fuse_in = new(n, T, 2 * D)
+        pe = self._position_rows(mask2) if self.use_abs_pe else None        # (n * T, D): pe[t] on valid frames, 0 on padded ones
         if Cc:
             vc = new(n, T, 2 * D)
             a = self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, vc[..., :D])
             b = self._embed(clip, self.clip_embd, self.clip_embd_norm, mask2, vc[..., D:])
-            a = self.visual_clip_fuse.cl(cat(ops.join(vc, (a, b))), row_mask=mask2, out=fuse_in[..., :D], out_pair=pair)
+            # (CLIP variant: the position rows are added behind the visual / CLIP fusion, backbones.py:362-384)
+            a = self.visual_clip_fuse.cl(cat(ops.join(vc, (a, b))), row_mask=mask2, out=fuse_in[..., :D], out_pair=pair, res=pe)
         else:
-            a = self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D])
+            a = self._embed(vis, self.visual_embd, self.visual_embd_norm, mask2, fuse_in[..., :D], post_add=pe)
         b = self._embed(ent, [self.bbox_entity_embd], [self.bbox_entity_norm], mask2, fuse_in[..., D:])
         so = self.visual_bbox_fuse.cl(cat(ops.join(fuse_in, (a, b))), row_mask=mask2)
         so, _ = self.stem[0].cl(so, mask2)

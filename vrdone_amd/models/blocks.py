@@ -92,6 +92,16 @@ class LayerNorm(nn.Module):
         return _from_cl(self.cl(_to_cl(x)))
 
 
+def get_sinusoid_encoding(n_position, d_hid):
+    """(1, C, T) sinusoid position table (reference models/blocks.py:161-172): channel 2i = sin(t / 10000^(2i/C)), channel
+    2i+1 = cos of the same angle, computed in float64 and rounded to float32."""
+    import numpy as np
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    j = np.arange(d_hid)[None, :]
+    angle = pos / np.power(10000.0, 2 * (j // 2) / d_hid)
+    return torch.tensor(np.where(j % 2 == 0, np.sin(angle), np.cos(angle)), dtype=torch.float32).unsqueeze(0).transpose(1, 2)
+
+
 class ConvMLP(nn.Module):
     """1x1-conv MLP with GELU between layers; reference models/blocks.py:37-61."""
 
@@ -106,15 +116,16 @@ class ConvMLP(nn.Module):
             if layer.bias is not None:
                 nn.init.zeros_(layer.bias)
 
-    def cl(self, x, row_mask=None, out=None, out_pair=False):
-        """x: tensor or ops.Pair.  Hidden activations only feed the next GEMM, so they travel as pair rows."""
+    def cl(self, x, row_mask=None, out=None, out_pair=False, res=None):
+        """x: tensor or ops.Pair.  Hidden activations only feed the next GEMM, so they travel as pair rows.
+        res: rows added to the (masked) output of the last layer."""
         ops = _ops()
         last = self.num_layers - 1
         for i, layer in enumerate(self.layers):
             if i < last:
                 x = ops.conv_gemm(x, layer.weight, layer.bias, act=ops.ACT_GELU, out_pair=ops.pair_mode(), skip_rows=row_mask)
             else:
-                x = ops.conv_gemm(x, layer.weight, layer.bias, row_mask=row_mask, out=out, out_pair=out_pair)
+                x = ops.conv_gemm(x, layer.weight, layer.bias, row_mask=row_mask, out=out, out_pair=out_pair, res=res)
         return x
 
     def forward(self, x):
