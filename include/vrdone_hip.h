@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 17
+#define VRD_ABI_VERSION 18
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -246,9 +246,11 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
 
 /* ---- banded (local-window) attention, models/blocks.py:950-986 ---------------------------
  * query t attends keys j in [t-half_win, t+half_win] within [0,T); masked keys get -1e4,
- * masked query rows give 0.  q is scaled by head_dim^-0.5 inside.  C = n_head*head_dim = 512. */
+ * masked query rows give 0.  q is scaled by head_dim^-0.5 inside.  C = n_head*head_dim = 512.
+ * rel_pe: NULL, or the relative position bias [n_head][2*half_win+1] added to the scaled scores
+ * before the key mask (`use_rel_pe`, models/blocks.py:739-743,957-958). */
 int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld,
-                   const uint8_t* mask, int B, int T, int C, int n_head, int half_win,
+                   const uint8_t* mask, const float* rel_pe, int B, int T, int C, int n_head, int half_win,
                    float* out, int64_t ldo, int out_pair, void* stream);
 
 /* ---- global masked attention, models/local_transformer.py:163-183 and :44-63 -------------
@@ -345,9 +347,11 @@ typedef struct {
 int vrd_dwconv_bwd(const vrd_dwconv_bwd_args* a, void* stream);
 
 /* Banded attention backward (vrd_local_attn; models/blocks.py:950-986): dq, dk, dv (leading dimension ldd) from the
- * forward inputs and dO.  scratch: 2 * B*T * n_head * (2*half_win+1) floats. */
+ * forward inputs and dO.  scratch: 2 * B*T * n_head * (2*half_win+1) floats; on return its second half holds dS
+ * [B*T][n_head][2*half_win+1], the gradient w.r.t. the biased scores: d rel_pe is its sum over the rows. */
 int vrd_local_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dO, int64_t lddo,
-                       const uint8_t* mask, int B, int T, int C, int n_head, int half_win, float* dq, float* dk, float* dv,
+                       const uint8_t* mask, const float* rel_pe, int B, int T, int C, int n_head, int half_win,
+                       float* dq, float* dk, float* dv,
                        int64_t ldd, float* scratch, void* stream);
 
 /* Global attention backward, first half (vrd_attention; models/local_transformer.py:44-63,163-183): the probabilities

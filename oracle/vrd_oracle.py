@@ -78,11 +78,12 @@ def full_attention(q, k, v, kv_mask, n_head):
     return _merge_heads(out)
 
 
-def banded_attention(q, k, v, kv_mask, n_head, half_win):
+def banded_attention(q, k, v, kv_mask, n_head, half_win, rel_pe=None):
     """models/blocks.py:950-986 (sliding-chunk trick at :819-918) restated as the
     banded attention it computes: query t sees keys j in [t-w, t+w] inside [0, T);
     masked keys get -1e4 added, out-of-range keys -inf, masked query rows are
-    zeroed after the softmax."""
+    zeroed after the softmax.  rel_pe (1, 1, n_head, 2w+1), `use_rel_pe`: a bias per (head, window
+    slot) added to the scaled scores before the masks (:957-958)."""
     q, k, v = _split_heads(q, n_head), _split_heads(k, n_head), _split_heads(v, n_head)
     B, H, T, hd = q.shape
     w = half_win
@@ -90,6 +91,8 @@ def banded_attention(q, k, v, kv_mask, n_head, half_win):
     kp = F.pad(k, (0, 0, w, w)).unfold(2, 2 * w + 1, 1)        # (B,H,T,hd,2w+1)
     vp = F.pad(v, (0, 0, w, w)).unfold(2, 2 * w + 1, 1)
     s = torch.einsum("bhtd,bhtdw->bhtw", q, kp)
+    if rel_pe is not None:
+        s = s + rel_pe.reshape(1, H, 1, 2 * w + 1)
     pos = torch.arange(T)[:, None] + torch.arange(-w, w + 1)[None, :]        # (T, 2w+1)
     inside = (pos >= 0) & (pos < T)
     key_ok = kv_mask[:, 0][:, pos.clamp(0, T - 1)]                             # (B,T,2w+1)
@@ -127,7 +130,7 @@ def local_mhca(sd, pre, x, mask, n_head, win, stride):
     q, qm = _qkv_branch(sd, pre, "query", x, mask, stride)
     k, km = _qkv_branch(sd, pre, "key", x, mask, stride)
     v, _ = _qkv_branch(sd, pre, "value", x, mask, stride)
-    o = banded_attention(q, k, v, km, n_head, win // 2)
+    o = banded_attention(q, k, v, km, n_head, win // 2, rel_pe=sd.get(f"{pre}.rel_pe"))
     o = F.conv1d(o, sd[f"{pre}.proj.weight"], sd[f"{pre}.proj.bias"])
     return o * qm.to(o.dtype), qm
 
@@ -152,7 +155,7 @@ def mhca_qkv(sd, pre, q_in, k_in, v_in, q_mask, kv_mask, n_head, half_win=None):
     if half_win is None:
         o = full_attention(q, k, v, km, n_head)
     else:
-        o = banded_attention(q, k, v, km, n_head, half_win)
+        o = banded_attention(q, k, v, km, n_head, half_win, rel_pe=sd.get(f"{pre}.rel_pe"))
     o = F.conv1d(o, sd[f"{pre}.proj.weight"], sd[f"{pre}.proj.bias"])
     return o * qm.to(o.dtype), qm
 
@@ -221,7 +224,6 @@ def backbone(sd, cfg, x, mask):
     n_conv, n_stem, n_branch = cfg["backbone_arch"]
     assert x.shape[1] == 2 * V + 2 * Cc + S + 2 * E
     assert cfg["fuse_qx_stride"] == 1 and cfg["fuse_kv_stride"] == 1 and cfg["embd_with_ln"]
-    assert not cfg["use_rel_pe"]
     mf = mask.to(x.dtype)
     P = "backbone"
     o0 = 2 * V + 2 * Cc
@@ -582,6 +584,8 @@ def synth_tensor(name, shape, ln_bias_std=0.1):
     is_ln = len(shape) == 3 and shape[0] == 1 and shape[2] == 1
     if leaf == "scale":
         return torch.rand(shape, generator=g) + 0.5
+    if leaf == "rel_pe":                # O(1), so that the bias visibly reshapes the window softmax
+        return torch.randn(shape, generator=g)
     if is_ln and leaf == "weight":
         return 1.0 + 0.1 * torch.randn(shape, generator=g)
     if is_ln and leaf == "bias":

@@ -202,7 +202,36 @@ def abs_pe_case():
     np.savez_compressed(os.path.join(OUT, "abs_pe.npz"), **arrs)
 
 
+REL_PE_CASES = {   # name -> (config file, [(B, T, lengths)])
+    "vidvrd": ("vidvrd.yaml", [(3, 96, [96, 50, 7])]),               # stem / branch blocks (LocalMaskedMHCA)
+    "vidor_local": ("vidor_local.yaml", [(2, 128, [128, 77])]),      # + the fusion layers' local q/k/v attention
+}
+
+
+def rel_pe_case():
+    """`use_rel_pe: True` (no shipped config sets it): a learnable bias per (head, window slot) on the banded attention's
+    scores (blocks.py:739-743,957-958; local_transformer.py:373-376,591-592).  The extra parameters' names and shapes go to
+    rel_pe_keys.json; their values are the name-seeded synthetic ones like every other parameter."""
+    arrs, extra = {}, {}
+    for name, (fname, shapes) in REL_PE_CASES.items():
+        cfg, mc = load_cfg(fname)
+        mc = dict(mc, use_rel_pe=True)
+        model, keys, _ = build(mc)
+        extra[name] = [k for k in keys if k[0].endswith("rel_pe")]
+        for (B, T, lens) in shapes:
+            x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=8765 + T)
+            out = model._mask_vrd(x, m)
+            arrs[f"{name}/T{T}_pred_logits"] = out["pred_logits"].numpy()
+            arrs[f"{name}/T{T}_pred_masks"] = out["pred_masks"].numpy()
+            print("rel pe case", name, T, len(extra[name]), "tables; logits std", float(out["pred_logits"].std()))
+    np.savez_compressed(os.path.join(OUT, "rel_pe.npz"), **arrs)
+    with open(os.path.join(OUT, "rel_pe_keys.json"), "w") as f:
+        json.dump(extra, f)
+
+
 def main():
+    if "--only-rel-pe" in sys.argv:
+        return rel_pe_case()
     if "--only-abs-pe" in sys.argv:
         return abs_pe_case()
     if "--only-train-data" in sys.argv:

@@ -221,23 +221,30 @@ def test_dwconv_ln_backward(case):
 
 
 # ---------------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("with_rel", [False, True])
 @pytest.mark.parametrize("n_head,half_win", [(4, 3), (8, 4)])
-def test_local_attention_backward(n_head, half_win):
+def test_local_attention_backward(n_head, half_win, with_rel):
+    """with_rel: the `use_rel_pe` bias (1, 1, n_head, window) on the scores; its gradient is the sum of dS over the rows."""
     from vrdone_amd import ops
     g = torch.Generator().manual_seed(n_head)
     B, T, C = 3, 24, 512
     m = mask_for(B, T, [24, 13, 2])
     q, k, v, dO = (torch.randn(B, C, T, generator=g) for _ in range(4))
+    rel = torch.randn(1, 1, n_head, 2 * half_win + 1, generator=g) if with_rel else None
     qr, kr, vr = ref64(q), ref64(k), ref64(v)
-    outr = O.banded_attention(qr, kr, vr, m[:, None], n_head, half_win)
+    relr = ref64(rel) if with_rel else None
+    outr = O.banded_attention(qr, kr, vr, m[:, None], n_head, half_win, rel_pe=relr)
     outr.backward(dO.double())
     qd, kd, vd = leaf(cl(q)), leaf(cl(k)), leaf(cl(v))
+    reld = leaf(rel) if with_rel else None
     with torch.enable_grad():
-        out = ops.local_attention(qd, kd, vd, m.to(DEV), n_head, half_win)
+        out = ops.local_attention(qd, kd, vd, m.to(DEV), n_head, half_win, rel_pe=reld)
     out.backward(cl(dO).to(DEV))
     rel_close(out, cl(outr), 2e-5, "out")
     for name, a, r in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
         rel_close(a, cl(r), 2e-5, name)
+    if with_rel:
+        rel_close(reld.grad, relr.grad, 2e-5, "d rel_pe")
 
 
 @pytest.mark.parametrize("n_head,C,Tq,Tk,masked", [(4, 512, 96, 96, True), (8, 512, 40, 64, True), (4, 256, 9, 12, True), (4, 256, 9, 9, False)])

@@ -276,6 +276,12 @@ def test_local_attention_kernel(H, w):
     close(got, want, 2e-5)
     got_pair = ops.local_attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, w, pair=True)
     assert float((got_pair.float() - got).abs().max()) <= 2 ** -15 * float(got.abs().max())
+    # relative position bias (use_rel_pe): strip kernel and, VRD_LOCAL_STRIP=0 aside, the same arithmetic per row
+    rel = torch.randn(1, 1, H, 2 * w + 1, generator=gen)
+    want_rel = O.banded_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H, w, rel_pe=rel).transpose(1, 2)
+    got_rel = ops.local_attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, w, rel_pe=rel.to(DEV))
+    close(got_rel, want_rel, 2e-5)
+    assert float((want_rel - want).abs().max()) > 0.1
 
 
 @pytest.mark.parametrize("algo", [1, 2])

@@ -399,3 +399,22 @@ def test_absolute_position_encoding_matches_reference(name, B, T, lens, weights)
     # and the encoding matters: without it the outputs are somewhere else
     off = O.mask_vrd(sd, dict(mc, use_abs_pe=False), x, m, with_aux=False)
     assert float((off["pred_logits"] - out["pred_logits"]).abs().max()) > 100 * LOGIT_TOL
+
+
+@pytest.mark.parametrize("name,B,T,lens", [("vidvrd", 3, 96, [96, 50, 7]), ("vidor_local", 2, 128, [128, 77])])
+def test_relative_position_encoding_matches_reference(name, B, T, lens, weights):
+    """`use_rel_pe: True` (scripts/make_golden_r2.py --only-rel-pe): one bias per (head, window slot) on the scores of every
+    stem / branch block's banded attention; the extra parameters are listed in rel_pe_keys.json."""
+    mc, _, sd = weights(name)
+    with open(os.path.join(GOLDEN, "rel_pe_keys.json")) as f:
+        extra = json.load(f)[name]
+    assert len(extra) == mc["backbone_arch"][1] + mc["backbone_arch"][2]
+    sd = dict(sd, **O.synth_state_dict(extra))
+    mc = dict(mc, use_rel_pe=True)
+    g = np.load(os.path.join(GOLDEN, "rel_pe.npz"))
+    x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=8765 + T)
+    out = O.mask_vrd(sd, mc, x, m, with_aux=False)
+    np.testing.assert_allclose(out["pred_logits"].numpy(), g[f"{name}/T{T}_pred_logits"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out["pred_masks"].numpy(), g[f"{name}/T{T}_pred_masks"], atol=MASK_TOL, rtol=0)
+    off = O.mask_vrd({k: v for k, v in sd.items() if not k.endswith("rel_pe")}, mc, x, m, with_aux=False)
+    assert float((off["pred_logits"] - out["pred_logits"]).abs().max()) > 100 * LOGIT_TOL

@@ -102,8 +102,8 @@ _SIGNATURES = {
     "vrd_layernorm": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int,
                                 c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_dwconv_ln": (C.c_int, [C.POINTER(DwconvLnArgs), C.c_void_p]),
-    "vrd_local_attn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+    "vrd_local_attn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_u8p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_attention": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_attention_pair": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,
@@ -125,8 +125,8 @@ _SIGNATURES = {
     "vrd_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p,
                                     C.c_int64, c_f32p, c_f32p, C.c_void_p]),
     "vrd_dwconv_bwd": (C.c_int, [C.POINTER(DwconvBwdArgs), C.c_void_p]),
-    "vrd_local_attn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "vrd_local_attn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, c_f32p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "vrd_attn_bwd_probs": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p]),
     "vrd_bmm": (C.c_int, [C.POINTER(BmmArgs), C.c_void_p]),
@@ -136,7 +136,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class HipLibraryError(RuntimeError):

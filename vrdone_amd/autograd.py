@@ -260,15 +260,16 @@ class DepthwiseConv(Function):
 
 class LocalAttention(Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, n_head, half_win):
-        out = ops.local_attention(q, k, v, mask, n_head, half_win)
-        ctx.save_for_backward(q, k, v)
+    def forward(ctx, q, k, v, mask, n_head, half_win, rel_pe=None):
+        rel = None if rel_pe is None else rel_pe.detach()
+        out = ops.local_attention(q, k, v, mask, n_head, half_win, rel_pe=rel)
+        ctx.save_for_backward(q, k, v, rel)
         ctx.mask, ctx.n_head, ctx.half_win = mask, n_head, half_win
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        q, k, v = ctx.saved_tensors
+        q, k, v, rel = ctx.saved_tensors
         dO = _dense(dO)
         B, T, Cc = q.shape
         q, k, v = (t if t.stride(-2) == Cc and t.is_contiguous() else t.contiguous() for t in (q, k, v))
@@ -276,9 +277,13 @@ class LocalAttention(Function):
         dq, dk, dv = (torch.empty(B, T, Cc, device=q.device, dtype=torch.float32) for _ in range(3))
         scratch = torch.empty(2 * B * T * ctx.n_head * W, device=q.device, dtype=torch.float32)
         check(lib.vrd_local_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), Cc, dO.data_ptr(), Cc, _mask_ptr(ctx.mask, B * T),
-                                     B, T, Cc, ctx.n_head, ctx.half_win, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), Cc,
-                                     scratch.data_ptr(), _stream()), "vrd_local_attn_bwd")
-        return dq, dk, dv, None, None, None
+                                     ops._rel_pe_ptr(rel, q, ctx.n_head, ctx.half_win), B, T, Cc, ctx.n_head, ctx.half_win,
+                                     dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), Cc, scratch.data_ptr(), _stream()),
+              "vrd_local_attn_bwd")
+        d_rel = None
+        if rel is not None and ctx.needs_input_grad[6]:      # the bias is added to every row's scores: d rel_pe = sum of dS
+            d_rel = scratch[B * T * ctx.n_head * W:].view(B * T, ctx.n_head, W).sum(0).view(rel.shape)
+        return dq, dk, dv, None, None, None, d_rel
 
 
 class Attention(Function):

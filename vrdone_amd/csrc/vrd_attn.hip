@@ -24,10 +24,13 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a
 // ------------------------------------------------------------------------------------------
 // banded attention.  C = 512: lane l owns channels [8l, 8l+8); GROUP = head_dim / 8 lanes per head
 // ------------------------------------------------------------------------------------------
-template <int W, int GROUP>
+// REL: the learnable per-(head, window slot) bias `rel_pe` (n_head x W) is added to the scaled scores before the key mask
+// (blocks.py:957-958); a separate instantiation, so that the default path carries no extra instruction
+template <int W, int GROUP, bool REL>
 __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                          const float* __restrict__ v, int64_t ld,
-                                                         const uint8_t* __restrict__ mask, int B, int T, float scale,
+                                                         const uint8_t* __restrict__ mask, const float* __restrict__ rel,
+                                                         int B, int T, float scale,
                                                          float* __restrict__ out, int64_t ldo, int pair) {
     constexpr int HW = W / 2;
     const int lane = threadIdx.x & 63;
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
         float d = dot4(q0, ld4(kr)) + dot4(q1, ld4(kr + 4));
 #pragma unroll
         for (int off = GROUP / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        if (REL) d += rel[(lane / GROUP) * W + j];
         s[j] = d + (mask[row + j - HW] ? 0.f : -1e4f);
         m = fmaxf(m, s[j]);
     }
@@ -90,10 +94,11 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
 // rows of the moving window in registers (a ring of W + 1 slots, the row entering the window next already requested),
 // so every K / V row is read W + 1 -> (RW + W - 1) / RW times from the L1 instead of W times.  The ring is indexed with
 // compile-time slots: the row loop runs in rounds of R = W + 1 unrolled phases.
-template <int W, int GROUP, int RW>
+template <int W, int GROUP, int RW, bool REL>
 __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, int64_t ld,
-                                                               const uint8_t* __restrict__ mask, int B, int T, int strips_per_seq,
+                                                               const uint8_t* __restrict__ mask, const float* __restrict__ rel,
+                                                               int B, int T, int strips_per_seq,
                                                                float scale, float* __restrict__ out, int64_t ldo, int pair) {
     constexpr int HW = W / 2, R = W + 1;
     const int lane = threadIdx.x & 63;
@@ -129,6 +134,9 @@ __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __re
         }
         return r;
     };
+    float rb[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) rb[j] = REL ? rel[(lane / GROUP) * W + j] : 0.f;
     Row kr[R], vr[R];
 #pragma unroll
     for (int i = 0; i < W; ++i) {          // window of the first query row: rows t0 - HW .. t0 + HW in slots 0 .. W-1
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __re
                 float d = dot4(q0, kk.a) + dot4(q1, kk.b);
 #pragma unroll
                 for (int off = GROUP / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+                if (REL) d += rb[j];
                 sc[j] = d + (((live >> (bit0 + j)) & 1ull) ? 0.f : -1e4f);
                 m = fmaxf(m, sc[j]);
             }
@@ -420,8 +429,8 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 
 extern "C" {
 
-int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, const uint8_t* mask, int B, int T, int C,
-                   int n_head, int half_win, float* out, int64_t ldo, int out_pair, void* stream) {
+int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, const uint8_t* mask, const float* rel_pe,
+                   int B, int T, int C, int n_head, int half_win, float* out, int64_t ldo, int out_pair, void* stream) {
     VRD_CHECK_ARG(q && k && v && mask && out, "vrd_local_attn: null pointer");
     VRD_CHECK_ARG(C == 512, "vrd_local_attn: built for C = 512 (got %d)", C);
     VRD_CHECK_ARG(n_head == 4 || n_head == 8, "vrd_local_attn: n_head must be 4 or 8 (got %d)", n_head);
@@ -440,7 +449,15 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
         constexpr int RW = 16;
         const int strips = (T + RW - 1) / RW;
         dim3 grid((unsigned)(((int64_t)B * strips + 3) / 4)), block(256);
-#define VRD_LS(Wn, G) hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW>), grid, block, 0, s, q, k, v, ld, mask, B, T, strips, scale, out, ldo, out_pair)
+#define VRD_LS(Wn, G)                                                                                                     \
+    do {                                                                                                                  \
+        if (rel_pe)                                                                                                       \
+            hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW, true>), grid, block, 0, s, q, k, v, ld, mask, rel_pe,   \
+                               B, T, strips, scale, out, ldo, out_pair);                                                  \
+        else                                                                                                              \
+            hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW, false>), grid, block, 0, s, q, k, v, ld, mask, rel_pe,  \
+                               B, T, strips, scale, out, ldo, out_pair);                                                  \
+    } while (0)
         if (half_win == 3 && n_head == 4) VRD_LS(7, 16);
         else if (half_win == 3) VRD_LS(7, 8);
         else if (n_head == 4) VRD_LS(9, 16);
@@ -450,7 +467,15 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
         return 0;
     }
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define VRD_LA(Wn, G) hipLaunchKernelGGL((local_attn_kernel<Wn, G>), grid, block, 0, s, q, k, v, ld, mask, B, T, scale, out, ldo, out_pair)
+#define VRD_LA(Wn, G)                                                                                                     \
+    do {                                                                                                                  \
+        if (rel_pe)                                                                                                       \
+            hipLaunchKernelGGL((local_attn_kernel<Wn, G, true>), grid, block, 0, s, q, k, v, ld, mask, rel_pe, B, T,      \
+                               scale, out, ldo, out_pair);                                                                \
+        else                                                                                                              \
+            hipLaunchKernelGGL((local_attn_kernel<Wn, G, false>), grid, block, 0, s, q, k, v, ld, mask, rel_pe, B, T,     \
+                               scale, out, ldo, out_pair);                                                                \
+    } while (0)
     if (half_win == 3 && n_head == 4) VRD_LA(7, 16);
     else if (half_win == 3) VRD_LA(7, 8);
     else if (n_head == 4) VRD_LA(9, 16);

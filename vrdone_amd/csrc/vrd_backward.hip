@@ -453,7 +453,8 @@ template <int GROUP>
 __global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, int64_t ld,
                                                                const float* __restrict__ dO, int64_t lddo,
-                                                               const uint8_t* __restrict__ mask, int B, int T, int W, float scale,
+                                                               const uint8_t* __restrict__ mask, const float* __restrict__ rel,
+                                                               int B, int T, int W, float scale,
                                                                float* __restrict__ dq, int64_t lddq, float* __restrict__ P,
                                                                float* __restrict__ dS) {
     const int HW = W / 2;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void local_attn_bwd_q_kernel(const float* __re
         const float* vr = v + (row + j - HW) * ld + lane * 8;
         const float d = head_sum<GROUP>(dot8(q0, q1, ld4(kr), ld4(kr + 4))) * scale;
         dp[j] = head_sum<GROUP>(dot8(o0, o1, ld4(vr), ld4(vr + 4)));
-        s[j] = d + (mask[row + j - HW] ? 0.f : -1e4f);
+        s[j] = (rel ? d + rel[head * W + j] : d) + (mask[row + j - HW] ? 0.f : -1e4f);
         m = fmaxf(m, s[j]);
     }
     float den = 0.f;
@@ -785,8 +786,8 @@ int vrd_dwconv_bwd(const vrd_dwconv_bwd_args* a, void* stream) {
 }
 
 int vrd_local_attn_bwd(const float* q, const float* k, const float* v, int64_t ld, const float* dO, int64_t lddo,
-                       const uint8_t* mask, int B, int T, int C, int n_head, int half_win, float* dq, float* dk, float* dv,
-                       int64_t ldd, float* scratch, void* stream) {
+                       const uint8_t* mask, const float* rel_pe, int B, int T, int C, int n_head, int half_win,
+                       float* dq, float* dk, float* dv, int64_t ldd, float* scratch, void* stream) {
     VRD_CHECK_ARG(q && k && v && dO && mask && dq && dk && dv && scratch, "vrd_local_attn_bwd: null pointer");
     VRD_CHECK_ARG(C == 512 && (n_head == 4 || n_head == 8), "vrd_local_attn_bwd: built for C = 512 with 4 or 8 heads");
     const int W = 2 * half_win + 1;
@@ -802,10 +803,10 @@ int vrd_local_attn_bwd(const float* q, const float* k, const float* v, int64_t l
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * 8);
     dim3 grid((unsigned)((rows + 3) / 4));
     if (n_head == 4) {
-        hipLaunchKernelGGL(local_attn_bwd_q_kernel<16>, grid, dim3(256), 0, s, q, k, v, ld, dO, lddo, mask, B, T, W, scale, dq, ldd, P, dS);
+        hipLaunchKernelGGL(local_attn_bwd_q_kernel<16>, grid, dim3(256), 0, s, q, k, v, ld, dO, lddo, mask, rel_pe, B, T, W, scale, dq, ldd, P, dS);
         hipLaunchKernelGGL(local_attn_bwd_kv_kernel<16>, grid, dim3(256), 0, s, q, ld, dO, lddo, B, T, W, scale, P, dS, dk, dv, ldd);
     } else {
-        hipLaunchKernelGGL(local_attn_bwd_q_kernel<8>, grid, dim3(256), 0, s, q, k, v, ld, dO, lddo, mask, B, T, W, scale, dq, ldd, P, dS);
+        hipLaunchKernelGGL(local_attn_bwd_q_kernel<8>, grid, dim3(256), 0, s, q, k, v, ld, dO, lddo, mask, rel_pe, B, T, W, scale, dq, ldd, P, dS);
         hipLaunchKernelGGL(local_attn_bwd_kv_kernel<8>, grid, dim3(256), 0, s, q, ld, dO, lddo, B, T, W, scale, P, dS, dk, dv, ldd);
     }
     VRD_LAUNCH_CHECK();

@@ -21,7 +21,7 @@ class MaskConvTransformerBackbone(nn.Module):
                  use_rel_pe=False, use_local=True):
         super().__init__()
         assert len(arch) == 3 and len(mha_win_size) == 1 + arch[-1]
-        assert with_ln and not use_rel_pe, "built for embd_with_ln=True and no relative position encoding"
+        assert with_ln, "built for embd_with_ln=True"
         assert scale_factor == 2 and n_embd_ks == 3
         self.n_visual, self.n_bbox_entity, self.n_bbox_so = n_visual, n_bbox_entity, n_bbox_so
         self.n_clip = 0

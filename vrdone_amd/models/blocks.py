@@ -233,13 +233,21 @@ class _ConvAttention(nn.Module):
             ((v, self.value.weight, self.value.bias), dict(out_pair=out_pair, skip_rows=kv_mask))]))
 
 
+def make_rel_pe(n_embd, n_head, window_size):
+    """The learnable bias of the window scores, one value per (head, window slot): shape and initialisation of reference
+    models/blocks.py:739-743 (truncated normal, std sqrt(2 / n_embd), cut at +-2)."""
+    rel_pe = nn.Parameter(torch.zeros(1, 1, n_head, window_size))
+    nn.init.trunc_normal_(rel_pe, std=(2.0 / n_embd) ** 0.5)
+    return rel_pe
+
+
 class LocalMaskedMHCA(_ConvAttention):
     """Banded-window conv attention; reference models/blocks.py:656-989."""
 
     def __init__(self, n_embd, n_head, window_size, n_qx_stride=1, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0,
                  use_rel_pe=False):
         super().__init__()
-        assert window_size > 1 and window_size % 2 == 1 and not use_rel_pe
+        assert window_size > 1 and window_size % 2 == 1
         assert n_qx_stride == n_kv_stride and n_kv_stride in (1, 2)
         assert attn_pdrop == 0.0 and proj_pdrop == 0.0
         self.window_size, self.window_overlap = window_size, window_size // 2
@@ -247,6 +255,7 @@ class LocalMaskedMHCA(_ConvAttention):
         self.n_qx_stride, self.n_kv_stride = n_qx_stride, n_kv_stride
         ks = n_kv_stride + 1 if n_kv_stride > 1 else 3
         self._build(n_embd, n_head, ks, ks, n_kv_stride)
+        self.rel_pe = make_rel_pe(n_embd, n_head, window_size) if use_rel_pe else None
 
     def cl(self, x, mask, mask_out=None, pre_ln=None, **epilogue):
         """x = LN1 output (B, T, C), or the block input with pre_ln = (ln1.weight, ln1.bias) applied inside the
@@ -258,7 +267,8 @@ class LocalMaskedMHCA(_ConvAttention):
         assert (x.shape[1] // s) % (2 * self.window_overlap) == 0      # reference blocks.py:828
         q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s, pre_ln=pre_ln)
         q, k, v = self._project(q, k, v, q_mask=mask_out, kv_mask=mask_out)
-        att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap, pair=ops.pair_mode())
+        att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap, pair=ops.pair_mode(),
+                                  rel_pe=self.rel_pe)
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
 
     def forward(self, x, mask):

@@ -7,7 +7,7 @@ from typing import Optional
 import torch
 from torch import nn, Tensor
 
-from .blocks import (AffineDropPath, LayerNorm, MaskedMHA, _ConvAttention, _from_cl, _mask2d, _ops,
+from .blocks import (make_rel_pe, AffineDropPath, LayerNorm, MaskedMHA, _ConvAttention, _from_cl, _mask2d, _ops,
                      _to_cl)
 from .transformer import _get_clones
 
@@ -49,7 +49,8 @@ class MaskedMHCA_QKV(_ConvAttention):
             att = ops.attention(q, k, v, kv_mask, self.n_head, pair=ops.pair_mode(), q_mask=q_mask)
         else:
             assert q.shape[1] == k.shape[1]
-            att = ops.local_attention(q, k, v, kv_mask, self.n_head, self._half_win, pair=ops.pair_mode())
+            att = ops.local_attention(q, k, v, kv_mask, self.n_head, self._half_win, pair=ops.pair_mode(),
+                                      rel_pe=getattr(self, "rel_pe", None))
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=q_mask, **epilogue), q_mask
 
     def forward(self, q, k, v, _qx_mask, _kv_mask, _attn_mask=None):
@@ -70,10 +71,11 @@ class LocalMaskedMHCA_QKV(MaskedMHCA_QKV):
     def __init__(self, n_embd, n_head, window_size, n_qx_stride=0, n_kv_stride=1, attn_pdrop=0.0, proj_pdrop=0.0,
                  use_rel_pe=False):
         super().__init__(n_embd, n_head, n_qx_stride, n_kv_stride, attn_pdrop, proj_pdrop)
-        assert window_size > 1 and window_size % 2 == 1 and not use_rel_pe
+        assert window_size > 1 and window_size % 2 == 1
         self.window_size, self.window_overlap = window_size, window_size // 2
         self.use_rel_pe = use_rel_pe
         self._half_win = self.window_overlap
+        self.rel_pe = make_rel_pe(n_embd, n_head, window_size) if use_rel_pe else None
 
 
 class MaskedConvTransformerDecoderLayer(nn.Module):

@@ -506,17 +506,27 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
     return outs
 
 
-def local_attention(q, k, v, mask, n_head, half_win, pair=False):
-    if recording(q, k, v):
+def _rel_pe_ptr(rel_pe, like, n_head, half_win):
+    if rel_pe is None:
+        return None
+    assert rel_pe.numel() == n_head * (2 * half_win + 1) and rel_pe.dtype == torch.float32 and rel_pe.is_contiguous()
+    assert rel_pe.device == like.device
+    return rel_pe.data_ptr()
+
+
+def local_attention(q, k, v, mask, n_head, half_win, pair=False, rel_pe=None):
+    """rel_pe: None or the module's (1, 1, n_head, window) relative position bias (reference blocks.py:739-743)."""
+    if recording(q, k, v, rel_pe):
         from . import autograd
-        return autograd.LocalAttention.apply(q, k, v, mask, n_head, half_win)
+        return autograd.LocalAttention.apply(q, k, v, mask, n_head, half_win, rel_pe)
     B, T, Cc = q.shape
+    rel = _rel_pe_ptr(rel_pe, q, n_head, half_win)
     pq, rows, cols, ld = _rows(q)
     pk, _, _, ldk = _rows(k)
     pv, _, _, ldv = _rows(v)
     assert ld == ldk == ldv
     out = torch.empty(B, T, Cc, device=q.device, dtype=torch.float32)
-    _hip.check(lib.vrd_local_attn(pq, pk, pv, ld, _mask_ptr(mask, rows), B, T, Cc, n_head, half_win,
+    _hip.check(lib.vrd_local_attn(pq, pk, pv, ld, _mask_ptr(mask, rows), rel, B, T, Cc, n_head, half_win,
                                   out.data_ptr(), Cc, 1 if pair else 0, _stream()), "vrd_local_attn")
     return Pair(out, Cc) if pair else out
 
