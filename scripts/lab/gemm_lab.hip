@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
         vrd_gemm_args a = {};
         a.A = A; a.lda = sh.Cin; a.W = nullptr; a.bias = bias; a.C = C; a.ldc = sh.N; a.M = sh.M; a.N = sh.N; a.Cin = sh.Cin;
         a.taps = sh.taps; a.T = T; a.act = 0; a.W_split = (const uint16_t*)W; a.a_pair_width = sh.Cin; a.c_pair = 0;
-        for (int var : {11, 12}) {
+        for (int var : {11, 12, 14}) {
             char env[8];
             snprintf(env, sizeof env, "%d", var);
             hipEvent_t e0, e1;
@@ -44,13 +44,14 @@ int main(int argc, char** argv) {
             float ms = 0;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
-                int rc = var == 12 ? vrd::launch_gemm_bf16x3_row(&a, 1, 0) : var == 11 ? vrd::launch_gemm_bf16x3_big(a, 0) : vrd::launch_gemm_bf16x3_dma_variant(a, 0, var);
+                int rc = var == 14 ? vrd::launch_gemm_bf16x3_row_nw(&a, vrd::GemmBatch{}, 1, 4, 0) : var == 12 ? vrd::launch_gemm_bf16x3_row_nw(&a, vrd::GemmBatch{}, 1, 8, 0) : var == 11 ? vrd::launch_gemm_bf16x3_big(a, 0) : vrd::launch_gemm_bf16x3_dma_variant(a, 0, var);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 if (rc) { printf("launch failed: %s\n", vrd_last_error()); return 1; }
                 hipEventElapsedTime(&ms, e0, e1);
             }
-            const int tiles = (int)((sh.M + (var >= 11 ? 255 : 127)) / (var >= 11 ? 256 : 128)) * ((sh.N + 255) / 256);
+            const int tm_rows = var == 14 ? 128 : var >= 11 ? 256 : 128;
+            const int tiles = (int)((sh.M + tm_rows - 1) / tm_rows) * ((sh.N + 255) / 256);
 
             const int n = std::min(tiles, 65536);
             std::vector<unsigned long long> st((size_t)n * 8);
@@ -68,7 +69,7 @@ int main(int argc, char** argv) {
             printf("%-20s K=%5d N=%4d var %d: %7.3f ms  %6.1f TF/s | per tile (wave 0): setup %6.0f  loop %7.0f (%5.0f/kstep)  epilogue %6.0f  total %7.0f cyc @ %.2f GHz | tiles/CU %.1f -> busy %.3f ms\n",
                    sh.label, K, sh.N, var, ms, 2.0 * sh.M * sh.N * K / ms / 1e9, median(pro), median(loop), median(loop) / nkt, median(epi),
                    median(tot), ghz, tiles / 256.0, tiles / 256.0 * median(tot) / ghz * 1e-6);
-            if (var == 12) {
+            if (var == 12 || var == 14) {
                 std::vector<double> t6, t7, tb;
                 for (int i = 0; i < n; ++i) {
                     const unsigned long long* s_ = &st[(size_t)i * 8];

@@ -38,6 +38,16 @@
 // variant (next tile's first requests issued under the epilogue, which works in its own LDS here) was built and measured:
 // tile start 2.2-3 k, but the epilogue then runs with the prefetch registers live on top of 128 accumulators: 52-170
 // spilled VGPRs, epilogue 15-30 k cycles, slower overall; it is not kept.
+//
+// Two workgroups per CU (VRD_BIG_ROW=2, NWV = 4 below): the other way to put one tile's start and epilogue under another
+// tile's K loop -- 128 x 256 tiles of 4 waves x (32 rows x 256 columns), 64 KiB of LDS each (the epilogue slabs alias the
+// ring), 246 VGPRs, no spills; the two workgroups of a CU run out of phase by themselves.  Measured (same harness, K = 512,
+// M = 590k): K step 3,840 cycles PER WORKGROUP -- the two waves a SIMD now holds from independent workgroups share the
+// MFMA pipe exactly as the two of one workgroup did, 3,072 cycles of MFMA per 256 x 256 of work in ~3,850 -- but tile start
+// 14.7 k and epilogue 13.1 k cycles while the neighbour computes (8.5 k / 10.4 k alone), and a workgroup that has the CU's
+// MFMA pipes to itself during those phases does not run its loop faster: 89 k cycles per 128 x 256 tile, two at a time, =
+// 0.798 ms against 0.727 ms of the LDS-DMA kernel and 0.771 ms of the 8-wave form; K = 2048: 0.630 / 0.650 / 0.644 ms.
+// Whole step 144.0 ms (LDS-DMA kernel 141.2, 8-wave form 141.9).  Bit-identical results (GPU suite green); stays opt-in.
 #include "vrd_common.h"
 #include "vrd_gemm_epilogue.h"
 #include <cstdlib>
@@ -60,20 +70,33 @@ using vrd::f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int TM = 256, TN = 256;
+constexpr int TN = 256;
 constexpr int ROWB = 128;                      // bytes of a tile row per K step (32 hi + 32 lo bf16)
 constexpr int W_STAGE = TN * ROWB;
 constexpr int NW_STG = 2;
-constexpr int SLAB_OFF = NW_STG * W_STAGE;     // byte offset of the epilogue slabs
-constexpr size_t ROW_LDS = (size_t)SLAB_OFF + 8 * 32 * vrd::STG_PITCH * sizeof(float);      // 163,840
-constexpr int PER = 4;                         // W DMA instructions per wave and K step (8 rows x 128 B each)
+constexpr int NA = 4;                          // activation loads per lane and K step
+// NWV waves, each 32 rows x 256 columns.  8: one 256 x 256 workgroup per CU, epilogue slabs behind the ring.
+// 4: 128 x 256 tiles, TWO workgroups per CU (64 KiB of LDS and 4 x 256 VGPRs each): the two run out of phase, so one's
+// tile start and epilogue overlap the other's K loop; the epilogue slabs then alias the ring (a barrier after the last
+// step), and only A(0) comes by DMA -- into the wave's 4 KiB of ring stage 1, which W(1) overwrites behind the barrier.
+template <int NWV>
+struct RowGeo {
+    static constexpr int TM = 32 * NWV;
+    static constexpr int PER = 32 / NWV;       // W DMA instructions per wave and K step (8 rows x 128 B each)
+    static constexpr bool ALIAS = NWV == 4;
+    static constexpr int SLAB_OFF = ALIAS ? 0 : NW_STG * W_STAGE;     // byte offset of the epilogue slabs
+    static constexpr size_t LDS = ALIAS ? (size_t)NW_STG * W_STAGE : (size_t)SLAB_OFF + 8 * 32 * vrd::STG_PITCH * sizeof(float);
+};
 
 __device__ unsigned long long g_row_skipped_kn;                    // as g_big_skipped_kn (vrd_gemm_x3_big.hip)
 
 __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
 
-template <int TAPS>
-__global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, vrd::GemmBatch bb) {
+template <int TAPS, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void gemm_bf16x3_row_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, vrd::GemmBatch bb) {
+    using G = RowGeo<NWV>;
+    constexpr int PER = G::PER, SLAB_OFF = G::SLAB_OFF;
+    constexpr bool ALIAS = G::ALIAS;
     if (blockIdx.y) {                                    // uniform selects, no indexed access to the arguments
         const int z = blockIdx.y;
         p.A = z == 1 ? bb.A[0] : z == 2 ? bb.A[1] : bb.A[2];
@@ -102,13 +125,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
     bool contract = true;
     if (rb) {
         const int seg_len = p.row_block_seg_len;                          // a multiple of 8 (host-checked)
-        const int seg = (tm * 8) / seg_len;
-        contract = tm * 8 < nblk && tm * 8 - seg * seg_len < p.row_blocks_active[seg];
+        const int seg = (tm * NWV) / seg_len;
+        contract = tm * NWV < nblk && tm * NWV - seg * seg_len < p.row_blocks_active[seg];
     }
-    const int slot = tm * 8 + wave;                      // this wave's 32-row block
+    const int slot = tm * NWV + wave;                    // this wave's 32-row block
     const int my_blk = slot < nblk ? (rb ? rb[slot] : slot) : -1;
-    if (!contract && tid == 0 && tm * 8 < nblk)
-        atomicAdd(&g_row_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
+    if (!contract && tid == 0 && tm * NWV < nblk)
+        atomicAdd(&g_row_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN) * NWV);
 
     LAB_STAMP(0);
     LAB_REAL(4);
@@ -179,7 +202,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
         // buffers from there; A(2) is gathered behind them and every step t then issues A(t+3) (groups 0..3) and, behind
         // its barrier, W(t+2) (groups 12..15).
         const unsigned a_dma_off = (unsigned)(rin * (int)p.lda * 4 + pch * 16);       // 8 rows x 128 B per instruction
-        const unsigned a_stg = lds_addr + SLAB_OFF + wave * (32 * vrd::STG_PITCH * 4);
+        // (ALIAS: the wave's 4 KiB of ring stage 1 -- free until W(1) is issued behind the first barrier)
+        const unsigned a_stg = ALIAS ? lds_addr + W_STAGE + wave * 4096 : lds_addr + SLAB_OFF + wave * (32 * vrd::STG_PITCH * 4);
         auto issue_a_dma = [&](int u, int i) {
             const char* const src = a_base + (int64_t)i * 8 * p.lda * 4 + u * 128;
             const unsigned dst = a_stg + u * 4096 + i * 1024;
@@ -202,17 +226,24 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
         const unsigned a_rd = a_stg + li * ROWB + lh * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(abuf[0][i]) : "v"(a_rd), "n"(32 * i));
+        if (ALIAS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // out of stage 1 before anybody's W(1) goes there
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int q = 0; q < 3; ++q) VRD_ROW_LOAD_WF(wf[q], 0, q);
         asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");                 // the activation reads (the fragments may stay in flight)
         // the second stage and A(2) go out only now: whatever is requested before the first stage has arrived delays the
         // first MFMA (a CU's share of the HBM stream is ~15 B/clk)
+        if (!ALIAS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue_a_dma(1, i);
+            for (int i = 0; i < 4; ++i) issue_a_dma(1, i);
+        }
 #pragma unroll
         for (int i = 0; i < PER; ++i) issue_w1(1, 1, i);
         __builtin_amdgcn_sched_barrier(0);
+        if (ALIAS) {                  // no slab outside the ring: A(1) is gathered like A(2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[1][i], a_base, 1, i);
+        }
         if (LAB_MODE != 3)
 #pragma unroll
         for (int i = 0; i < 4; ++i) VRD_ROW_LOAD_A(abuf[2][i], a_base, 2, i);
@@ -241,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(abuf[u][2 + s2], wf[q & 3].hi, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(abuf[u][s2], wf[q & 3].lo, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(abuf[u][s2], wf[q & 3].hi, acc[j], 0, 0, 0);
-                if (q < PER && has_a3) {
+                if (q < NA && has_a3) {
                     // A(kt+3) into the buffer step kt-1 used (u + 3 = u - 1 mod 4): step (u + 3) & 3 of its group of four
                     __builtin_amdgcn_sched_barrier(0);
                     // (steps 1..3 load steps 0..2 of the NEXT group of four: 512 bytes on)
@@ -254,13 +285,13 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     // (step 0 of the tile: A(2) of the prologue is younger than W(1) as well)
                     const bool tile_start = has_a3 && u == 0 && kt == 0;
-                    if (tile_start) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-                    else if (has_a3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                    if (tile_start) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NA) : "memory");
+                    else if (has_a3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (tile_start) {
+                    if (tile_start && !ALIAS) {
                         // step 1's activations came by DMA into the slab (prologue) and have landed with W(1): into registers.
                         // (four more reads in flight than the counted fragment waits assume: those only wait a little longer)
 #pragma unroll
@@ -270,7 +301,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
                 }
                 if (q >= 12 && has_w2) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (LAB_MODE != 2) issue_w1(kt + 2, stage, q - 12);
+                    if (LAB_MODE != 2) {
+#pragma unroll
+                        for (int i = 0; i < PER / 4; ++i) issue_w1(kt + 2, stage, (q - 12) * (PER / 4) + i);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the groups apart: the scheduler would pull reads and loads far ahead
             }
@@ -294,11 +328,15 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_row_kernel(vrd_gemm_args p, i
         group(kt0, true_type{}, a_base);
     }       // contract
     LAB_STAMP(2);
+    if (ALIAS) {                      // the slabs lie in the ring: every wave's last fragment reads first
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 
     // ---- epilogue: the wave's 32 rows x 256 columns as four 32 x 64 pieces through its private slab (own LDS region: no
     // barrier, the ring is not touched)
     if (my_blk < 0) return;
-    float* const stg = smem + SLAB_OFF / 4 + wave * (32 * vrd::STG_PITCH);
+    float* const stg = smem + SLAB_OFF / 4 + wave * (32 * vrd::STG_PITCH);       // (8 KiB per wave)
     const int64_t mw = (int64_t)my_blk * 32;
     const bool rowin = p.row_mask || p.scale || p.res || p.res2;
     vrd::EpiCols cols[4];                                // bias / scale of the four pieces, requested together
@@ -324,6 +362,8 @@ namespace vrd {
 // the LDS-DMA 256 x 256 kernel's eligibility (checked by the caller), k = 1, and K % 128 == 0 (K loop unrolled by four)
 bool gemm_bf16x3_row_ok(const vrd_gemm_args& a) { return a.taps == 1 && a.Cin % 128 == 0; }
 
+int launch_gemm_bf16x3_row_nw(const vrd_gemm_args* a, const GemmBatch& bb, int count, int nwv, hipStream_t s);
+
 // `count` (1 .. 4) problems that differ only in A, W_split, bias and C, as one launch
 int launch_gemm_bf16x3_row(const vrd_gemm_args* a, int count, hipStream_t s) {
     GemmBatch bb{};
@@ -333,11 +373,25 @@ int launch_gemm_bf16x3_row(const vrd_gemm_args* a, int count, hipStream_t s) {
         bb.bias[i - 1] = a[i].bias;
         bb.C[i - 1] = a[i].C;
     }
-    const int tiles_m = (int)((a[0].M + rowk::TM - 1) / rowk::TM), tiles_n = (a[0].N + rowk::TN - 1) / rowk::TN;
+    // VRD_BIG_ROW=1: 8 waves, one 256 x 256 workgroup per CU; =2: 4 waves, two 128 x 256 workgroups per CU
+    static const int nwv = [] { const char* e = getenv("VRD_BIG_ROW"); return e && atoi(e) == 2 ? 4 : 8; }();
+    return launch_gemm_bf16x3_row_nw(a, bb, count, nwv, s);
+}
+
+int launch_gemm_bf16x3_row_nw(const vrd_gemm_args* a, const GemmBatch& bb, int count, int nwv, hipStream_t s) {
+    const int tm_rows = 32 * nwv;
+    const int tiles_m = (int)((a[0].M + tm_rows - 1) / tm_rows), tiles_n = (a[0].N + rowk::TN - 1) / rowk::TN;
     const dim3 grid(tiles_m * tiles_n, count);
-    auto kern = rowk::gemm_bf16x3_row_kernel<1>;         // k = 1 only (a k = 3 conv keeps the LDS-DMA kernel)
-    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), rowk::ROW_LDS, "vrd_gemm(bf16x3 256x256 row)")) return rc;
-    hipLaunchKernelGGL(kern, grid, dim3(512), rowk::ROW_LDS, s, a[0], tiles_m, tiles_n, bb);
+    // k = 1 only (a k = 3 conv keeps the LDS-DMA kernel)
+    if (nwv == 4) {
+        auto kern = rowk::gemm_bf16x3_row_kernel<1, 4>;
+        if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), rowk::RowGeo<4>::LDS, "vrd_gemm(bf16x3 128x256 row)")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), rowk::RowGeo<4>::LDS, s, a[0], tiles_m, tiles_n, bb);
+    } else {
+        auto kern = rowk::gemm_bf16x3_row_kernel<1, 8>;
+        if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), rowk::RowGeo<8>::LDS, "vrd_gemm(bf16x3 256x256 row)")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(512), rowk::RowGeo<8>::LDS, s, a[0], tiles_m, tiles_n, bb);
+    }
     return 0;
 }
 
@@ -345,7 +399,7 @@ double take_row_skipped_flops() {
     unsigned long long v = 0, zero = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(rowk::g_row_skipped_kn), sizeof(v)) != hipSuccess) return 0.0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(rowk::g_row_skipped_kn), &zero, sizeof(zero));
-    return 2.0 * rowk::TM * (double)v;
+    return 2.0 * 32 * (double)v;
 }
 
 }  // namespace vrd
