@@ -459,15 +459,17 @@ def test_forward_test_matches_oracle_small():
 
 
 def test_full_size_properties():
-    """North-star shape (2048 pairs x T_pad 288 is the bench; here 512 pairs to bound memory/time):
-    finite outputs, masked frames filled with -10, and rows equal to a small-batch run."""
+    """The north-star shape itself (BASELINE metric: 2048 pairs x 256 frames, T_pad 288 -- the bench workload): finite outputs,
+    masked frames filled with -10, rows equal to a small-batch run (other kernels: no 256 x 256 tiles, no padding maps), and
+    -- batch-composition independence at full size -- the reversed batch gives the reversed outputs BIT FOR BIT."""
     model, mc, _, _ = get_model("vidvrd")
-    B, T = 512, 288
+    B, T = 2048, 288
     gen = torch.Generator(device=DEV).manual_seed(5)
-    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(6))
-    lens[:4] = torch.tensor([288, 201, 97, 2])
+    lens = torch.randint(2, 257, (B,), generator=torch.Generator().manual_seed(6))
+    lens[:4] = torch.tensor([256, 201, 97, 2])
+    lens[-1] = 288
     m = (torch.arange(T)[None] < lens[:, None])[:, None].to(DEV)
-    x = torch.randn(B, c_in(mc), T, device=DEV, generator=gen) * m
+    x = torch.randn(B, c_in(mc), T, device=DEV, generator=gen).mul_(m)
     out = model._mask_vrd(x, m, with_aux=False)
     assert out["pred_logits"].shape == (B, 9, 133) and out["pred_masks"].shape == (B, 9, T)
     assert bool(torch.isfinite(out["pred_logits"]).all()) and bool(torch.isfinite(out["pred_masks"]).all())
@@ -475,19 +477,22 @@ def test_full_size_properties():
     small = model._mask_vrd(x[:4].contiguous(), m[:4].contiguous(), with_aux=False)
     close(small["pred_logits"], out["pred_logits"][:4], 1e-5)
     close(small["pred_masks"], out["pred_masks"][:4], 1e-4)
+    rev = model._mask_vrd(x.flip(0), m.flip(0), with_aux=False)
+    assert torch.equal(rev["pred_logits"].flip(0), out["pred_logits"])
+    assert torch.equal(rev["pred_masks"].flip(0), out["pred_masks"])
 
 
-def test_full_size_properties_vidor_x():
-    """BASELINE config 5 shape class (vidor_x.yaml: C_in 3093 with the CLIP slabs, 8 heads, window 9, T = 512): 384 pairs x
-    512 frames -- enough rows (393k stacked) for the 256 x 256 GEMM kernel, the padding maps and the batched q/k/v
-    launches -- finite outputs, -10 on masked frames, and rows equal to a 3-pair run of the small-shape kernels."""
+@pytest.mark.parametrize("B,T", [(384, 512), (4096, 512)])
+def test_full_size_properties_vidor_x(B, T):
+    """BASELINE config 5 (vidor_x.yaml: C_in 3093 with the CLIP slabs, 8 heads, window 9), at its full 4096 pairs x 512
+    frames (26 GB of input, two 2048-pair chunks) and at 384 pairs: finite outputs, -10 on masked frames, and rows equal to a
+    3-pair run of the small-shape kernels."""
     model, mc, _, _ = get_model("vidor_x")
-    B, T = 384, 512
     gen = torch.Generator(device=DEV).manual_seed(15)
     lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(16))
     lens[:3] = torch.tensor([512, 333, 65])
     m = (torch.arange(T)[None] < lens[:, None])[:, None].to(DEV)
-    x = torch.randn(B, c_in(mc), T, device=DEV, generator=gen) * m
+    x = torch.randn(B, c_in(mc), T, device=DEV, generator=gen).mul_(m)
     out = model._mask_vrd(x, m, with_aux=False)
     Q = mc["predictor"]["num_queries"]
     assert out["pred_logits"].shape == (B, Q, mc["num_classes"] + 1) and out["pred_masks"].shape == (B, Q, T)
@@ -496,6 +501,46 @@ def test_full_size_properties_vidor_x():
     small = model._mask_vrd(x[:3].contiguous(), m[:3].contiguous(), with_aux=False)
     close(small["pred_logits"], out["pred_logits"][:3], 1e-5)
     close(small["pred_masks"], out["pred_masks"][:3], 1e-4)
+    del x, out
+    torch.cuda.empty_cache()
+
+
+def test_sharded_forward_test_at_the_8_gpu_job_size(monkeypatch):
+    """BASELINE config 4's job (8192 pairs x 256 frames over 8 ranks; here 91 tracklets = 8190 ordered pairs minus the vIoU
+    duplicates, 1024 per rank): the 8 ranks run one after another in this process on one GPU (each rank's candidates computed
+    once; the collective itself is covered on gloo and by scripts/sharded_eval_check.py), every rank's result equal to the
+    unsharded call."""
+    from vrdone_amd import parallel, synth
+    from vrdone_amd.proposals import prepare_test_proposal
+    model, mc, ic, _ = get_model("vidvrd")
+    raw = synth.synth_raw_video(91, mc["visual_dim"], 200, 256, seed=11)
+    prop = prepare_test_proposal(raw, 1, 0, 2, DEV)
+    src = prop["pair_source"]
+    assert len(src) > 8000
+    want = model(prop)
+    assert want is not None and len(want["triplets"]) > 0
+    order, t_pad = model.eval_plan(src.lens)
+    world = 8
+    per = (len(src) + world - 1) // world
+    cands = {}
+
+    def share(r):
+        if r not in cands:
+            c = model.pair_candidates(None, src.lens, order[r::world], t_pad, model.topk, source=src)
+            if c.shape[0] < per:
+                c = torch.cat([c, c.new_zeros(per - c.shape[0], *c.shape[1:])], dim=0)
+            cands[r] = c
+        return cands[r]
+    try:
+        model.shard_pairs()
+        for rank in range(world):
+            def fake_all_gather(t, w, group=None):
+                return torch.stack([t if r == rank else share(r) for r in range(w)])
+            monkeypatch.setattr(parallel, "rank_world", lambda group=None: (rank, world))
+            monkeypatch.setattr(parallel, "_all_gather", fake_all_gather)
+            assert model(prop) == want, rank
+    finally:
+        model.shard_pairs(enable=False)
 
 
 def test_extension_is_loaded_and_profiled():
