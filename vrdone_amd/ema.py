@@ -6,7 +6,6 @@ values.  The reference walks the state dict and launches three elementwise kerne
 522 entries of vidvrd.yaml); here a table of device pointers is built once and `vrd_ema_update` sweeps every
 floating-point entry in a single launch.  The tables are rebuilt when a tensor of either model is re-allocated (`.to()`,
 `load_state_dict` keeps storage and needs nothing)."""
-import ctypes as C
 from copy import deepcopy
 
 import torch
