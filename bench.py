@@ -339,21 +339,30 @@ def main():
         ops.set_precision(main_mode)
         tmodel = synth.load_synthetic_weights(MaskVRD(cfg, device=dev)).to(dev).train()
         tdata = synthetic_batch(cfg, c_in, dev, seed=0)
-        times = []
-        for it in range(5):
-            tmodel.zero_grad(set_to_none=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            loss = tmodel(tdata)["total_loss"]
-            loss.backward()
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
+        def fwd_bwd(n):
+            times = []
+            for it in range(n):
+                tmodel.zero_grad(set_to_none=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loss = tmodel(tdata)["total_loss"]
+                loss.backward()
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            return 1e3 * sorted(times[2:])[(n - 2) // 2], loss
+        eager_ms, loss = fwd_bwd(5)
         n_grad = sum(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in tmodel.parameters() if p.requires_grad)
         n_par = sum(p.requires_grad for p in tmodel.parameters())
-        train = {"pairs": len(tdata["so_features_list"]), "t_pad": cfg["max_seq_len"], "ms_forward_backward": 1e3 * sorted(times[2:])[1],
-                 "params_with_finite_grad": f"{n_grad}/{n_par}", "total_loss": float(loss.detach()),
+        tmodel.enable_training_graphs()                      # the network's forward / backward as two HIP-graph replays
+        graph_ms, _ = fwd_bwd(6)                             # (the first of these records them)
+        n_grad_g = sum(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in tmodel.parameters() if p.requires_grad)
+        train = {"pairs": len(tdata["so_features_list"]), "t_pad": cfg["max_seq_len"], "ms_forward_backward": eager_ms,
+                 "ms_forward_backward_hip_graphs": graph_ms,
+                 "params_with_finite_grad": f"{n_grad}/{n_par}", "params_with_finite_grad_hip_graphs": f"{n_grad_g}/{n_par}",
+                 "total_loss": float(loss.detach()),
                  "note": "model.train(): forward_training + total_loss.backward() on the HIP backward kernels, stochastic depth on; "
-                         "median of 3 after 2 warm-up steps"}
+                         "median after 2 warm-up steps; hip_graphs: MaskVRD.enable_training_graphs() (vrdone_amd/train_graph.py), "
+                         "batching / matching / losses still eager"}
         del tmodel, tdata
         model.eval()
 

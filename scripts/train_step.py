@@ -52,7 +52,8 @@ def synthetic_batch(cfg, c_in, device, n_pairs=24, seed=0):
             "preds_list": to(preds), "masks_list": to(masks), "segs_list": to(segs)}
 
 
-def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, ema_decay=0.999, verbose=True, drop_path=True):
+def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, ema_decay=0.999, verbose=True, drop_path=True,
+        graphs=False):
     from vrdone_amd import configs, synth
     from vrdone_amd.models.maskvrd import MaskVRD
     cfg = configs.model_config("vidvrd")
@@ -63,6 +64,8 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
         for mod in model.modules():
             if isinstance(mod, AffineDropPath):
                 mod.drop_prob = 0.0
+    if graphs:
+        model.enable_training_graphs()        # forward + backward of the network as two HIP-graph replays (train_graph.py)
     from vrdone_amd.ema import ModelEma
     ema = ModelEma(model, decay=ema_decay)                                # one-launch EMA (vrd_ema_update), same values
     opt = torch.optim.AdamW(param_groups(model, weight_decay), lr=lr)
@@ -99,5 +102,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--graphs", action="store_true", help="replay the network's forward / backward as HIP graphs")
     args = ap.parse_args()
-    print(json.dumps(run(steps=args.steps, seed=args.seed)))
+    print(json.dumps(run(steps=args.steps, seed=args.seed, graphs=args.graphs)))

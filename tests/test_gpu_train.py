@@ -208,6 +208,59 @@ def test_optimisation_steps_reduce_the_loss():
     assert log["param_delta_norm"] > 0 and 0 < log["ema_delta_norm"] < log["param_delta_norm"]
 
 
+def test_training_graphs_take_the_same_steps():
+    """MaskVRD.enable_training_graphs() (vrdone_amd/train_graph.py): the network's forward and backward recorded as two HIP
+    graphs and replayed.  Four optimisation steps with and without (stochastic depth off): the same losses and the same
+    parameter movement -- the weights change between the steps, so a replay that used operands derived from the weights at
+    recording time (the per-weight caches of ops.py) would show from step 1 on; a second batch shape records its own
+    graphs; eval and no_grad calls stay eager."""
+    import importlib.util
+    from vrdone_amd import train_graph
+    spec = importlib.util.spec_from_file_location("train_step", os.path.join(os.path.dirname(GOLDEN), "..", "scripts", "train_step.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    eager = ts.run(steps=4, seed=0, device=DEV, verbose=False, lr=2e-5, drop_path=False)
+    graphed = ts.run(steps=4, seed=0, device=DEV, verbose=False, lr=2e-5, drop_path=False, graphs=True)
+    np.testing.assert_allclose(graphed["total_loss"], eager["total_loss"], rtol=2e-5)
+    assert graphed["total_loss"][-1] < graphed["total_loss"][0]
+    assert graphed["params_without_grad"] == [] and graphed["nonfinite_grads"] == []
+    np.testing.assert_allclose(graphed["param_delta_norm"], eager["param_delta_norm"], rtol=1e-3)
+    np.testing.assert_allclose(graphed["ema_delta_norm"], eager["ema_delta_norm"], rtol=1e-3)
+
+    # gradients of one step, graph against eager, on two batch shapes
+    from vrdone_amd import configs, synth
+    from vrdone_amd.models.blocks import AffineDropPath
+    from vrdone_amd.models.maskvrd import MaskVRD
+    cfg = configs.model_config("vidvrd")
+    model = synth.load_synthetic_weights(MaskVRD(cfg, device=DEV)).to(DEV).train()
+    for mod in model.modules():
+        if isinstance(mod, AffineDropPath):
+            mod.drop_prob = 0.0
+    for n_pairs in (24, 7, 24):
+        data = ts.synthetic_batch(cfg, configs.input_channels(cfg), DEV, n_pairs=n_pairs, seed=3 + n_pairs)
+        grads = []
+        for on in (False, True):
+            model.enable_training_graphs(on)
+            model.zero_grad(set_to_none=True)
+            loss = model(data)["total_loss"]
+            loss.backward()
+            grads.append((float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        assert abs(grads[0][0] - grads[1][0]) <= 2e-5 * abs(grads[0][0])
+        floor = 1e-6 * max(float(g.abs().max()) for g in grads[0][1].values())      # (atomics order: rounding-level noise)
+        for k, g in grads[0][1].items():
+            assert float((grads[1][1][k] - g).abs().max()) <= 2e-4 * float(g.abs().max()) + floor, k
+        with torch.no_grad():                   # weights move: the next replay must see them
+            for p in model.parameters():
+                p.mul_(1.01)
+    assert len(train_graph.recordings(model)) == 2          # 24 pairs, 7 pairs; the third batch replayed the first recording
+    with torch.no_grad():
+        assert np.isfinite(float(model(data)["total_loss"]))          # validation pass: eager, fused kernels
+    model.enable_training_graphs(False)
+    assert not train_graph.enabled(model)
+    train_graph.forget(model)
+    assert not train_graph.recordings(model)
+
+
 def test_device_assignment_equals_scipy():
     """vrd_assign (one thread per pair, Hungarian with potentials) against scipy.optimize.linear_sum_assignment -- what the
     reference's matcher calls per pair (models/maskvrd.py:492) -- on random cost blocks of every size N <= Q, Q = 9, 10, 16."""

@@ -16,6 +16,7 @@ from torch import nn
 
 from .backbones import MaskConvTransformerBackbone, MaskConvTransformerBackboneWithCLIP
 from .blocks import _ops
+from .. import train_graph
 from . import losses
 from .fpns import FPN1D_Fuse
 from .predictor import MaskedTransformerPredictor
@@ -143,8 +144,17 @@ class MaskVRD(nn.Module):
         vrdone_amd/autograd.py, AffineDropPath samples per-sample keep factors, and total_loss.backward() reaches
         every parameter.  Under torch.no_grad() it is the validation loss on the fused inference kernels."""
         x, m = self._train_batch(input_data['so_features_list'])
-        predictions = self._mask_vrd(x, m, with_aux=self.deep_supervision)
+        if torch.is_grad_enabled() and self.training and train_graph.enabled(self):
+            predictions = train_graph.mask_vrd(self, x, m)        # two HIP-graph replays instead of ~2,000 launches
+        else:
+            predictions = self._mask_vrd(x, m, with_aux=self.deep_supervision)
         return self.criterion(predictions, input_data)
+
+    def enable_training_graphs(self, enable=True):
+        """Training steps replay the network's forward and backward as HIP graphs, recorded once per batch shape
+        (vrdone_amd/train_graph.py: what is recorded, and the limits -- one backward per forward, no DDP)."""
+        train_graph.enable(self, enable)
+        return self
 
     @torch.no_grad()
     def forward_loss(self, input_data):

@@ -123,7 +123,30 @@ def _mask_ptr(m, rows):
 
 # Derived weight layouts are cached ON the parameter object (so they die with it and can never be
 # confused with another tensor that later reuses the same address), keyed on (data_ptr, version).
+_capture_keep = []
+
+
+def _capturing():
+    """True while the current stream records a HIP graph (vrdone_amd/train_graph.py): derived operands are then built
+    inside the graph on every replay -- a cache hit would leave their kernels out of the recording, and every replay
+    would see the operand of the weights (or mask) as they were at capture time."""
+    on = torch.cuda.is_current_stream_capturing()
+    if not on and _capture_keep:
+        _capture_keep.clear()
+    return on
+
+
+def _keep_for_capture(val):
+    """Operands built during a capture stay referenced until it is over: call sites hand their addresses to a launch and
+    drop the tensor, which the cache normally keeps alive -- freed inside a capture, the pool would give the memory to the
+    next allocation before the launch that reads it."""
+    _capture_keep.append(val)
+    return val
+
+
 def _cached(w, slot, build):
+    if _capturing():
+        return _keep_for_capture(build())
     key = (w.data_ptr(), w._version)
     hit = getattr(w, slot, None)
     if hit is not None and hit[0] == key:
@@ -319,7 +342,8 @@ def row_blocks(mask):
     the mask tensor object (keyed on its address and version counter), so it dies with it."""
     hit = getattr(mask, "_vrd_row_blocks", None)
     key = (mask.data_ptr(), mask._version)
-    if hit is not None and hit[0] == key:
+    capturing = _capturing()
+    if hit is not None and hit[0] == key and not capturing:
         return hit[1]
     rows = mask.numel()
     val = None
@@ -332,6 +356,8 @@ def row_blocks(mask):
         _hip.check(lib.vrd_row_blocks(mask.data_ptr(), rows, seg_len, order.data_ptr(), count.data_ptr(), _stream()),
                    "vrd_row_blocks")
         val = (order, count, seg_len)
+    if capturing:
+        return _keep_for_capture(val)
     mask._vrd_row_blocks = (key, val)
     return val
 
@@ -450,11 +476,14 @@ def _dwconv_block(w, bias, gamma, beta):
     parts = (w, bias, gamma, beta)
     key = tuple((t.data_ptr(), t._version) if t is not None else None for t in parts)
     hit = getattr(w, "_vrd_dw_block", None)
-    if hit is not None and hit[0] == key:
+    capturing = _capturing()
+    if hit is not None and hit[0] == key and not capturing:
         return hit[1]
     Cout, g, k = w.shape
     one = lambda t, fill: torch.full((Cout,), fill, device=w.device, dtype=torch.float32) if t is None else t.detach().float().reshape(-1)  # noqa: E731
     val = torch.cat([w.detach().float().permute(1, 2, 0).reshape(-1), one(bias, 0.0), one(gamma, 1.0), one(beta, 0.0)]).contiguous()
+    if capturing:
+        return _keep_for_capture(val)
     w._vrd_dw_block = (key, val)
     return val
 
