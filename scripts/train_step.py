@@ -78,11 +78,11 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
         loss_dict = model(data)                                           # train.py:182
         opt.zero_grad(set_to_none=True)
         loss_dict["total_loss"].backward()                                # train.py:186
-        for name, p in model.named_parameters():
-            if p.grad is None:
-                log["params_without_grad"].append(name)
-            elif not bool(torch.isfinite(p.grad).all()):
-                log["nonfinite_grads"].append(name)
+        named = list(model.named_parameters())
+        log["params_without_grad"] += [name for name, p in named if p.grad is None]
+        with_grad = [(name, p.grad) for name, p in named if p.grad is not None]
+        norms = torch.stack(torch._foreach_norm([g for _, g in with_grad]))       # one multi-tensor launch, one sync
+        log["nonfinite_grads"] += [with_grad[i][0] for i in torch.nonzero(~torch.isfinite(norms)).flatten().tolist()]
         if clip > 0:
             torch.nn.utils.clip_grad_norm_(model.parameters(), clip)     # train.py:187-188
         opt.step()
