@@ -299,6 +299,39 @@ def test_device_matching_gives_the_host_matchings():
         assert sorted(aj.tolist()) == sorted(bj.tolist()) and len(set(ai.tolist())) == len(ai)
 
 
+def test_criterion_on_device_equals_the_host_round_trip():
+    """MaskVRD._criterion_on_device (losses straight from the device assignment, relations in batch order) against
+    bipartite_match + loss (indices to the host and back, matched rows in the reference's per-pair query order): same
+    keys in the same order, same values, same gradients -- on the 24-pair training batch with all auxiliary layers."""
+    import importlib.util
+    from vrdone_amd import configs, synth
+    from vrdone_amd.models.blocks import AffineDropPath
+    from vrdone_amd.models.maskvrd import MaskVRD
+    spec = importlib.util.spec_from_file_location("train_step", os.path.join(os.path.dirname(GOLDEN), "..", "scripts", "train_step.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    cfg = configs.model_config("vidvrd")
+    model = synth.load_synthetic_weights(MaskVRD(cfg, device=DEV)).to(DEV).train()
+    for mod in model.modules():
+        if isinstance(mod, AffineDropPath):
+            mod.drop_prob = 0.0
+    data = ts.synthetic_batch(cfg, configs.input_channels(cfg), DEV, seed=5)
+    runs = []
+    for on in (False, True):
+        model.device_criterion = on
+        model.zero_grad(set_to_none=True)
+        losses = model(data)
+        losses["total_loss"].backward()
+        runs.append(({k: float(v.detach()) for k, v in losses.items()}, {k: p.grad.clone() for k, p in model.named_parameters()}))
+    (host, g_host), (devc, g_dev) = runs
+    assert list(host) == list(devc) and len(host) == 3 * cfg["predictor"]["num_layers"] + 1
+    for k in host:
+        assert abs(host[k] - devc[k]) <= 2e-6 * abs(host[k]) + 1e-7, (k, host[k], devc[k])
+    floor = 1e-6 * max(float(g.abs().max()) for g in g_host.values())
+    for k, g in g_host.items():
+        assert float((g_dev[k] - g).abs().max()) <= 2e-4 * float(g.abs().max()) + floor, k
+
+
 def test_ema_update_is_one_launch_and_bit_identical():
     """vrdone_amd.ema.ModelEma.update (vrd_ema_update over a pointer table) vs the reference's per-tensor expression
     decay * e + (1 - decay) * m (utils/train_utils.py:21-29), three updates in a row."""

@@ -86,6 +86,7 @@ class MaskVRD(nn.Module):
         self.pair_chunk = 2048
         self.share_tracklets = True     # forward_test from a PairSource: entity stage once per tracklet (_entity_streams)
         self.device_matching = True       # Hungarian assignment on the device (vrd_assign); False: scipy on the host
+        self.device_criterion = True      # ... and the losses straight from its result, no trip to the host (_criterion_on_device)
 
     @torch.no_grad()
     def _config_eval(self, infer_config):
@@ -174,12 +175,63 @@ class MaskVRD(nn.Module):
         if gt_segs is not None:
             gt_segs = [t.to(dev) for t in gt_segs]
         pred_logits, pred_masks, out_mask = predictions['pred_logits'], predictions['pred_masks'], predictions['output_mask']
-        indices, loss_mask = self.bipartite_match(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask=out_mask)
-        loss_dict = self.loss(indices, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, _mask=out_mask,
-                              loss_mask=loss_mask,
-                              aux_outputs=predictions['aux_outputs'] if self.deep_supervision else None)
+        aux = predictions['aux_outputs'] if self.deep_supervision else None
+        sizes = [len(p) for p in gt_preds]
+        Q = pred_logits.shape[1]
+        if (self.device_matching and self.device_criterion and pred_logits.is_cuda and sizes and 0 < max(sizes) <= Q <= 16
+                and 'bipartite_match' not in self.__dict__):          # (tests pin the matching by replacing the method)
+            loss_dict = self._criterion_on_device(pred_logits, pred_masks, out_mask, aux, sizes, gt_preds, gt_masks, gt_segs)
+        else:
+            indices, loss_mask = self.bipartite_match(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask=out_mask)
+            loss_dict = self.loss(indices, pred_logits, pred_masks, gt_preds, gt_masks, gt_segs, _mask=out_mask,
+                                  loss_mask=loss_mask, aux_outputs=aux)
         loss_dict['total_loss'] = torch.stack(list(loss_dict.values())).sum()
         return loss_dict
+
+    def _criterion_on_device(self, pred_logits, pred_masks, out_mask, aux_outputs, sizes, gt_preds, gt_masks, gt_segs):
+        """The loss dict of `bipartite_match` + `loss` without a trip to the host: the device assignment (vrd_assign) gives
+        the query of every relation, which is all the losses need -- target[pair of g, query of g] = class of g, and the
+        matched mask rows in relation order (the reference gathers them pair by pair in query order, maskvrd.py:500-527:
+        the same rows, so the same sums up to their order).  The host never waits for the predictions, so the eager loss
+        launches queue up behind the network instead of starting when it has finished; the relation tables (owner,
+        offsets) are built once for the final head and the auxiliary layers."""
+        dev = pred_logits.device
+        ops = _ops()
+        G = sum(sizes)
+        owner = torch.repeat_interleave(torch.arange(len(sizes), device=dev), torch.tensor(sizes, device=dev), output_size=G)
+        tables = ops.assign_tables(sizes, dev)
+        ids, tgt_masks = torch.cat(gt_preds, dim=0), torch.cat(gt_masks, dim=0)
+        valid = out_mask[:, 0]
+        assert tgt_masks.shape == (G, valid.shape[-1])
+        segs, scale_range = self._fuzzy(gt_segs)
+        loss_mask = valid[owner]
+        num_masks = float(max(G, 1))
+        weight = self.empty_weight.to(dev)
+
+        def layer(logits, masks):
+            with torch.no_grad():
+                c_class, c_mask, c_dice = losses.pair_costs(logits, masks, valid, ids, tgt_masks, owner, segs, scale_range)
+                cost = (self.cost_factor['cost_class'] * c_class + self.cost_factor['cost_mask'] * c_mask +
+                        self.cost_factor['cost_dice'] * c_dice)
+                q_of = ops.assign(cost.contiguous(), sizes, tables).long()
+            terms = {}
+            if "labels" in self.loss_types:
+                target = torch.zeros(logits.shape[:2], dtype=torch.int64, device=dev)
+                target[owner, q_of] = ids
+                terms["loss_class"] = self.loss_factor['loss_class'] * F.cross_entropy(logits.transpose(1, 2), target, weight)
+            if "masks" in self.loss_types:
+                focal, dice = losses.matched_losses(masks[owner, q_of], tgt_masks, num_masks, loss_mask, segs, scale_range)
+                terms["loss_mask"] = self.loss_factor['loss_mask'] * focal
+                terms["loss_dice"] = self.loss_factor['loss_dice'] * dice
+            return terms
+        names = {"labels": ["loss_class"], "masks": ["loss_mask", "loss_dice"]}
+        keys = [k for name in self.loss_types for k in names[name]]          # the reference's order of terms
+        terms = layer(pred_logits, pred_masks)
+        out = {k: terms[k] for k in keys}
+        for i, aux in enumerate(aux_outputs or []):
+            terms = layer(aux['pred_logits'], aux['pred_masks'])
+            out.update({f"{k}_{i}": terms[k] for k in keys})
+        return out
 
     # ---- matching and losses (reference maskvrd.py:417-588) ----
     def _fuzzy(self, gt_segs):

@@ -626,20 +626,24 @@ def mask_head(emb, feat, out_mask, fill=-10.0):
     return seg
 
 
-def assign(cost, sizes):
-    """Minimum-cost assignment of every pair's relations to its queries on the device (vrd_assign): cost (sum N, Q) f32,
-    rows grouped pair by pair, sizes = [N_p] (each <= Q <= 16).  Returns the query of every relation, (sum N,) int32."""
-    assert cost.is_cuda and cost.dtype == torch.float32 and cost.dim() == 2 and cost.stride(1) == 1
-    G, Q = cost.shape
-    assert sum(sizes) == G and max(sizes) <= Q <= 16
+def assign_tables(sizes, dev):
+    """(first row, relation count) of every pair as device int32 tensors: what vrd_assign walks."""
     first, at = [], 0
     for n in sizes:
         first.append(at)
         at += n
-    dev = cost.device
-    first_d = torch.tensor(first, dtype=torch.int32, device=dev)
-    count_d = torch.tensor(sizes, dtype=torch.int32, device=dev)
-    out = torch.full((G,), -1, dtype=torch.int32, device=dev)
+    return torch.tensor(first, dtype=torch.int32, device=dev), torch.tensor(sizes, dtype=torch.int32, device=dev)
+
+
+def assign(cost, sizes, tables=None):
+    """Minimum-cost assignment of every pair's relations to its queries on the device (vrd_assign): cost (sum N, Q) f32,
+    rows grouped pair by pair, sizes = [N_p] (each <= Q <= 16); tables = assign_tables(sizes, device) when the caller
+    assigns several cost matrices of the same batch.  Returns the query of every relation, (sum N,) int32."""
+    assert cost.is_cuda and cost.dtype == torch.float32 and cost.dim() == 2 and cost.stride(1) == 1
+    G, Q = cost.shape
+    assert sum(sizes) == G and max(sizes) <= Q <= 16
+    first_d, count_d = tables if tables is not None else assign_tables(sizes, cost.device)
+    out = torch.full((G,), -1, dtype=torch.int32, device=cost.device)
     _hip.check(lib.vrd_assign(cost.data_ptr(), cost.stride(0), first_d.data_ptr(), count_d.data_ptr(), len(sizes), Q,
                               out.data_ptr(), _stream()), "vrd_assign")
     return out
