@@ -229,7 +229,36 @@ def rel_pe_case():
         json.dump(extra, f)
 
 
+def vidor_case():
+    """configs/vidor.yaml -- the fourth shipped config: the plain backbone at the VidOR settings (8 heads, window 9, T 512,
+    9 queries, global SOS attention, no CLIP slabs) -- in the format of scripts/make_golden.py's cases: state keys + config,
+    `_mask_vrd` outputs with the auxiliary layers, channel-subsampled backbone / pyramid features."""
+    from make_golden import sub
+    cfg, mc = load_cfg("vidor.yaml")
+    model, keys, sd = build(mc)
+    with open(os.path.join(OUT, "state_keys_vidor.json"), "w") as f:
+        json.dump({"keys": keys, "n_params": int(sum(v.numel() for v in sd.values())),
+                   "model_config": mc, "inference_config": cfg["inference_config"]}, f)
+    B, T, lens = 2, 512, [512, 301]
+    x, m = O.synth_pairs(B, c_in(mc), T, lens, seed=1234 + T)
+    feats, masks = model.backbone(x, m)
+    fpn, _ = model.neck(feats, masks)
+    out = model.predictor(feats[-1], fpn, masks[-1], output_mask=masks[0])
+    tag = f"T{T}"
+    arrs = {f"{tag}_lengths": np.asarray(lens), f"{tag}_pred_logits": out["pred_logits"].numpy(),
+            f"{tag}_pred_masks": out["pred_masks"].numpy(), f"{tag}_fpn": sub(fpn, 8)}
+    for i, a in enumerate(out["aux_outputs"]):
+        arrs[f"{tag}_aux{i}_pred_logits"] = a["pred_logits"].numpy()
+        arrs[f"{tag}_aux{i}_pred_masks"] = a["pred_masks"].numpy()
+    for l, ft in enumerate(feats):
+        arrs[f"{tag}_feat{l}"] = sub(ft)
+    np.savez_compressed(os.path.join(OUT, "mask_vrd_vidor.npz"), **arrs)
+    print("vidor case: logits std", float(out["pred_logits"].std()), "masks std", float(out["pred_masks"].std()))
+
+
 def main():
+    if "--only-vidor" in sys.argv:
+        return vidor_case()
     if "--only-rel-pe" in sys.argv:
         return rel_pe_case()
     if "--only-abs-pe" in sys.argv:

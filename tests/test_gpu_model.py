@@ -61,7 +61,7 @@ def precision(request):
 
 
 @pytest.mark.parametrize("name,T", [("vidvrd", 96), ("vidvrd", 144), ("vidvrd", 288),
-                                    ("vidor_x", 512), ("vidor_local", 512)])
+                                    ("vidor_x", 512), ("vidor_local", 512), ("vidor", 512)])
 def test_mask_vrd_matches_reference_golden(name, T, precision):
     model, mc, _, _ = get_model(name)
     g = np.load(os.path.join(GOLDEN, f"mask_vrd_{name}.npz"))

@@ -45,7 +45,7 @@ def test_param_checksums(name, weights):
 
 
 @pytest.mark.parametrize("name,T", [("vidvrd", 96), ("vidvrd", 144), ("vidvrd", 288),
-                                    ("vidor_x", 512), ("vidor_local", 512)])
+                                    ("vidor_x", 512), ("vidor_local", 512), ("vidor", 512)])
 def test_mask_vrd_matches_reference(name, T, weights):
     mc, _, sd = weights(name)
     g = np.load(os.path.join(GOLDEN, f"mask_vrd_{name}.npz"))
