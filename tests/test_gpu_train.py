@@ -255,6 +255,15 @@ def test_training_graphs_take_the_same_steps():
     assert len(train_graph.recordings(model)) == 2          # 24 pairs, 7 pairs; the third batch replayed the first recording
     with torch.no_grad():
         assert np.isfinite(float(model(data)["total_loss"]))          # validation pass: eager, fused kernels
+    # parameters that move to new memory invalidate the recordings (re-recorded on the next step)
+    model.enable_training_graphs(True)
+    with torch.no_grad():
+        model.backbone.stem[0].mlp[0].weight.data = model.backbone.stem[0].mlp[0].weight.data.clone()
+    model.zero_grad(set_to_none=True)
+    loss = model(data)["total_loss"]
+    loss.backward()
+    assert len(train_graph.recordings(model)) == 1 and np.isfinite(float(loss.detach()))
+    assert model.backbone.stem[0].mlp[0].weight.grad is not None
     model.enable_training_graphs(False)
     assert not train_graph.enabled(model)
     train_graph.forget(model)

@@ -39,11 +39,18 @@ WARMUP_ITERS = 3
 _GRAPHS = weakref.WeakKeyDictionary()          # model -> {on, recordings: {(batch shape, deep supervision, precision mode): _Recording}}
 
 
+def _storage_key(model):
+    """What a recording is tied to: the parameter objects that take gradients and the memory they live in (a model moved
+    with .to(), cast, or given new parameter tensors needs new graphs; in-place updates and load_state_dict do not)."""
+    return tuple((id(p), p.data_ptr()) for p in model.parameters() if p.requires_grad)
+
+
 class _Recording:
     """Forward and backward graph of `model._mask_vrd` for one batch shape."""
 
     def __init__(self, model, x, m):
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.storage = _storage_key(model)
         aliases = [nn.Parameter(p.detach()) for p in self.params]             # same storage, no autograd history
         by_id = {id(p): a for p, a in zip(self.params, aliases)}
         slots = [(mod, name, p) for mod in model.modules() for name, p in mod._parameters.items() if id(p) in by_id]
@@ -140,6 +147,9 @@ def mask_vrd(model, x, m):
     graphs = _GRAPHS[model]["recordings"]
     key = (tuple(x.shape), tuple(m.shape), bool(model.deep_supervision), ops.get_precision())
     rec = graphs.get(key)
+    if rec is not None and rec.storage != _storage_key(model):
+        graphs.clear()                         # the parameters were replaced or moved: every recording is stale
+        rec = None
     if rec is None:
         if len(graphs) >= MAX_SHAPES:
             return model._mask_vrd(x, m, with_aux=model.deep_supervision)
