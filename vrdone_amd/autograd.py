@@ -17,6 +17,8 @@ of a tensor used twice); the arithmetic of every forward and backward op is a ke
 """
 import ctypes as C
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -84,6 +86,44 @@ def bmm(A, a_strides, B, b_strides, Cmat, c_strides, Z0, Z1, M, N, K, alpha=1.0,
 
 
 # ------------------------------------------------------------------------------------------------------ Functions
+class _ZeroArena:
+    """Zero-initialised accumulators for the gradient kernels (weight / bias / LayerNorm / scale gradients are summed with
+    atomics into their output), carved out of 16 MiB blocks: one fill per block instead of one `torch.zeros` per gradient
+    (~500 of the ~930 fills of a training step on the 24-pair batch).  A block is never handed out twice; it lives as long
+    as a gradient that points into it.  A block opened during a graph capture belongs to the graph's pool and is dropped
+    when the capture state changes."""
+    BLOCK = 4 << 20            # floats
+
+    def __init__(self):
+        self.block, self.at, self.capturing = None, 0, False
+
+    def take(self, n, device):
+        capturing = torch.cuda.is_current_stream_capturing()
+        padded = -(-n // 64) * 64                      # keep every slice 256-byte aligned
+        if (self.block is None or self.block.device != device or capturing != self.capturing or
+                self.at + padded > self.block.numel()):
+            self.block = torch.zeros(max(self.BLOCK, padded), device=device, dtype=torch.float32)
+            self.at, self.capturing = 0, capturing
+        out = self.block[self.at:self.at + n]
+        self.at += padded
+        return out
+
+
+_arena = _ZeroArena()
+
+
+_USE_ARENA = os.environ.get("VRD_ZERO_ARENA", "1") != "0"
+
+
+def _zeros(*shape, device):
+    if not _USE_ARENA:
+        return torch.zeros(*shape, device=device, dtype=torch.float32)
+    n = 1
+    for d in shape:
+        n *= d
+    return _arena.take(n, torch.device(device)).view(*shape)
+
+
 class Linear(Function):
     """y = Conv1d(x; W (N, Cin, k), b) * row_mask, k in {1, 3}, on channels-last rows (vrd_gemm without epilogue terms)."""
 
@@ -121,14 +161,14 @@ class Linear(Function):
                 else:
                     dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None)
         if ctx.needs_input_grad[1]:
-            packed = torch.zeros(N, k * Cin, device=dy.device, dtype=torch.float32)
+            packed = _zeros(N, k * Cin, device=dy.device)
             px, _, _, ldx = _rows(x)
             check(lib.vrd_gemm_wgrad(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(), _stream()),
                   "vrd_gemm_wgrad")
             # tap-major -> the Conv1d layout (N, Cin, k), with the parameter's own strides (DDP's bucket views expect them)
             dw = packed.view(N, Cin, 1) if k == 1 else packed.view(N, k, Cin).permute(0, 2, 1).contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, torch.zeros(N, device=dy.device, dtype=torch.float32), row_mask=mask)
+            db = colsum(dy, _zeros(N, device=dy.device), row_mask=mask)
         return dx, dw, db, None
 
 
@@ -164,7 +204,7 @@ class ScaleResidual(Function):
         if ctx.needs_input_grad[0]:
             dv = rowcol_scale(dy, col_scale=scale, row_scale=ctx.row_scale, row_mask=ctx.row_mask)
         if scale is not None and ctx.needs_input_grad[1]:
-            ds = colsum(dy, torch.zeros(v.shape[-1], device=dy.device, dtype=torch.float32), b=v, T=1,
+            ds = colsum(dy, _zeros(v.shape[-1], device=dy.device), b=v, T=1,
                         row_mask=ctx.row_mask, row_scale=ctx.row_scale).view_as(scale)
         if ctx.needs_input_grad[4]:
             dres = rowcol_scale(dy, row_mask=ctx.row_mask) if (ctx.res_masked and ctx.row_mask is not None) else dy
@@ -191,15 +231,15 @@ class LayerNormFn(Function):
         pd, _, _, ldd = _rows(dy)
         dx = _new_like_rows(x)
         pdx, _, _, lddx = _rows(dx)
-        dg = torch.zeros(cols, device=x.device, dtype=torch.float32)
-        db = torch.zeros(cols, device=x.device, dtype=torch.float32)
+        dg = _zeros(cols, device=x.device)
+        db = _zeros(cols, device=x.device)
         check(lib.vrd_layernorm_bwd(px, ldx, pd, ldd, rows, cols, gamma.data_ptr(), beta.data_ptr(), 1 if ctx.relu else 0,
                                     pdx, lddx, dg.data_ptr(), db.data_ptr(), _stream()), "vrd_layernorm_bwd")
         dpost = None
         if ctx.period is not None and ctx.needs_input_grad[4]:
             # y[r] += post_add[r % period]: sum dy over the rows of each residue = column sums of the (rows/period, period*C) view
             dpost = colsum(dy.reshape(rows // ctx.period, ctx.period * cols),
-                           torch.zeros(ctx.period * cols, device=x.device, dtype=torch.float32)).view(ctx.period, cols)
+                           _zeros(ctx.period * cols, device=x.device)).view(ctx.period, cols)
         return dx, dg.view_as(gamma), db.view_as(beta), None, dpost
 
 
@@ -245,7 +285,7 @@ class DepthwiseConv(Function):
         xin = x if x_up is None else rowcol_scale(x, res2=x_up.repeat_interleave(2, dim=1))
         grads = []
         for i in range(n):
-            gw = torch.zeros(gin, k, Cout, device=dev, dtype=torch.float32)
+            gw = _zeros(gin, k, Cout, device=dev)
             for g in range(gin):
                 for kk in range(k):
                     colsum(dDs[i], gw[g, kk], b=xin, b_cstride=gin, b_coffset=g, b_rstride=s, shift=kk - k // 2, T=Tout,
@@ -253,7 +293,7 @@ class DepthwiseConv(Function):
             # (C, gin, k) with the parameter's own strides: for gin = k = 1 `.contiguous()` is a no-op that keeps (1, C, C),
             # which DDP's bucket views flag as a layout mismatch
             grads.append(torch.empty(Cout, gin, k, device=dev, dtype=torch.float32).copy_(gw.permute(2, 0, 1)))
-            grads.append(colsum(dDs[i], torch.zeros(Cout, device=dev, dtype=torch.float32), row_mask=ctx.mask_out)
+            grads.append(colsum(dDs[i], _zeros(Cout, device=dev), row_mask=ctx.mask_out)
                          if ctx.has_bias[i] else None)
         return (dx, dx_up, None, None, *grads)
 
