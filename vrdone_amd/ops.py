@@ -470,6 +470,19 @@ def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False
     return Pair(out, cols) if pair else out
 
 
+_CONST_ROWS = {}
+
+
+def _const_row(n, fill, device):
+    """A constant vector (the stand-in of an absent bias / LayerNorm affine in a parameter image), made once per size: in a
+    training step the images are rebuilt for every weight, which was ~170 fill launches per step."""
+    key = (n, float(fill), str(device))
+    t = _CONST_ROWS.get(key)
+    if t is None:
+        t = _CONST_ROWS[key] = torch.full((n,), fill, device=device, dtype=torch.float32)
+    return t
+
+
 def _dwconv_block(w, bias, gamma, beta):
     """The on-chip parameter image of one dwconv_ln set (vrd_dwconv_ln_args.packed): taps tap-major | bias | gamma |
     beta.  Cached on the weight, keyed on the (address, version) of all four tensors."""
@@ -480,7 +493,7 @@ def _dwconv_block(w, bias, gamma, beta):
     if hit is not None and hit[0] == key and not capturing:
         return hit[1]
     Cout, g, k = w.shape
-    one = lambda t, fill: torch.full((Cout,), fill, device=w.device, dtype=torch.float32) if t is None else t.detach().float().reshape(-1)  # noqa: E731
+    one = lambda t, fill: _const_row(Cout, fill, w.device) if t is None else t.detach().float().reshape(-1)  # noqa: E731
     val = torch.cat([w.detach().float().permute(1, 2, 0).reshape(-1), one(bias, 0.0), one(gamma, 1.0), one(beta, 0.0)]).contiguous()
     if capturing:
         return _keep_for_capture(val)
