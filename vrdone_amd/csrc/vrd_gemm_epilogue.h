@@ -429,4 +429,25 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
     }
 }
 
+// One 32 x 32 accumulator straight from its register layout (lane = column, registers = rows): the epilogue of the
+// 64 x 64-tile kernels, whose problems are small enough for its 16 stores of 128-byte row pieces per lane not to matter.
+__device__ __forceinline__ void gemm_epilogue_tile32(const vrd_gemm_args& p, const f32x16& acc, int64_t mw, int nw, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = nw + li;
+    if (n >= p.N) return;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float scale = p.scale ? p.scale[n] : 1.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int64_t m = mw + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
+        const float r1 = p.res ? p.res[m * p.ldres + n] : 0.f;
+        const float r2 = p.res2 ? p.res2[m * p.ldres2 + n] : 0.f;
+        const float v = epilogue_value(p, acc[e] + bias, mk, scale, r1, p.res_masked ? mk : 1.f, r2);
+        if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v);
+        else p.C[m * p.ldc + n] = v;
+    }
+}
+
 }  // namespace vrd

@@ -18,6 +18,7 @@
 // per step.
 #include "vrd_common.h"
 #include "vrd_gemm_epilogue.h"
+#include <cstdlib>
 
 namespace {
 
@@ -25,13 +26,27 @@ using vrd::f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BK = 32;
 constexpr int XP = 40;                                   // row pitch in bf16 elements (80 B)
-constexpr int TILE = BM * XP;                            // elements per operand tile
-constexpr size_t X3_LDS = 2 * 4 * TILE * sizeof(__bf16); // 2 buffers x (a_hi, a_lo, w_hi, w_lo) = 81920 B
+// SMALL: 64 x 64 tiles, one 32 x 32 accumulator per wave -- for problems whose 128 x 128 tiles would leave most of the
+// chip idle (a training batch, the predictor's 9 queries per pair: 2.3 k rows x 512 columns are 72 tiles for 256 CUs, each a
+// serial 16-step K loop of 24 MFMAs per wave): four times the workgroups, a quarter of the MFMA time per wave.  Same
+// products in the same order per output element, so the same bits.
+template <bool SMALL>
+struct X3Geo {
+    static constexpr int BM = SMALL ? 64 : 128, BN = BM;
+    static constexpr int WT = BM / 2;                                    // rows / columns of a wave's sub-tile
+    static constexpr int NT = WT / 32;                                   // 32 x 32 accumulators per wave and dimension
+    static constexpr int TILE = BM * XP;                                 // elements per operand tile
+    static constexpr size_t LDS = 2 * 4 * TILE * sizeof(__bf16);         // 2 buffers x (a_hi, a_lo, w_hi, w_lo): 80 / 40 KiB
+    static constexpr int NPA = BM / 32, NPAP = BM / 64, NPW = BN / 64;   // staging pieces per thread: f32 A, pair A, W
+};
 
-template <int TAPS, bool STAGED, bool APAIR>
+template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+    using G = X3Geo<SMALL>;
+    constexpr int BM = G::BM, BN = G::BN, TILE = G::TILE, WT = G::WT, NT = G::NT;
+    constexpr int NPA = G::NPA, NPAP = G::NPAP, NPW = G::NPW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* const lds = reinterpret_cast<__bf16*>(smem);      // buffer b: lds + b*4*TILE; tiles a_hi, a_lo, w_hi, w_lo
 
@@ -53,20 +68,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
 
     // A staging: 4 float4 pieces per thread, piece i = (row = (tid + 256 i) / 8, k = 4 * ((tid + 256 i) % 8))
     // W staging: 2 x (hi, lo) 16-byte pieces per thread, piece i = (row = (tid + 256 i) / 4, k = 8 * (f % 4))
-    int st[4];
+    int st[NPA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPA; ++i) {
         const int64_t r = m0 + ((tid + 256 * i) >> 3);
         st[i] = (TAPS == 3 && r < p.M) ? (int)(r % p.T) : 0;
     }
     float4 ra[4];                   // f32 A pieces (APAIR: reinterpreted as hi[2] | lo[2] 16-byte pieces)
-    uint4 rwh[2], rwl[2];
+    uint4 rwh[NPW], rwl[NPW];
 
     auto fetch = [&](int kt) {
         if (APAIR) {
             // piece i = (row = (tid + 256 i) / 4, 8 consecutive k): one 16-byte load from each plane
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NPAP; ++i) {
                 const int f = tid + 256 * i;
                 const int64_t r = m0 + (f >> 2);
                 const int k = kt * BK + (f & 3) * 8;
@@ -92,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             }
         } else
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             const int f = tid + 256 * i;
             const int64_t r = m0 + (f >> 3);
             const int k = kt * BK + (f & 7) * 4;
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             ra[i] = v;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NPW; ++i) {
             const int f = tid + 256 * i;
             const int n = n0 + (f >> 2);
             const int k = kt * BK + (f & 3) * 8;
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
         __bf16* w_lo = w_hi + TILE;
         if (APAIR) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NPAP; ++i) {
                 const int f = tid + 256 * i;
                 const int off = (f >> 2) * XP + (f & 3) * 8;
                 *reinterpret_cast<float4*>(a_hi + off) = ra[i];
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             }
         } else
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             const int f = tid + 256 * i;
             const int off = (f >> 3) * XP + (f & 7) * 4;
             const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             *reinterpret_cast<bf16x4*>(a_lo + off) = l;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NPW; ++i) {
             const int f = tid + 256 * i;
             const int off = (f >> 2) * XP + (f & 3) * 8;
             *reinterpret_cast<uint4*>(w_hi + off) = rwh[i];
@@ -162,11 +177,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
     stage(0);
     if (nkt > 1) fetch(1);
     __syncthreads();
-    const int arow = (wm * 64 + li) * XP + 8 * lh, wrow = (wn * 64 + li) * XP + 8 * lh;
+    const int arow = (wm * WT + li) * XP + 8 * lh, wrow = (wn * WT + li) * XP + 8 * lh;
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const __bf16* a_hi = lds + cur * 4 * TILE;
@@ -183,18 +198,18 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
         const __bf16* w_lo = w_hi + TILE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[2], al[2], wh[2], wl[2];
+            bf16x8 ah[NT], al[NT], wh[NT], wl[NT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 ah[t] = *reinterpret_cast<const bf16x8*>(a_hi + arow + t * 32 * XP + 16 * s);
                 al[t] = *reinterpret_cast<const bf16x8*>(a_lo + arow + t * 32 * XP + 16 * s);
                 wh[t] = *reinterpret_cast<const bf16x8*>(w_hi + wrow + t * 32 * XP + 16 * s);
                 wl[t] = *reinterpret_cast<const bf16x8*>(w_lo + wrow + t * 32 * XP + 16 * s);
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < NT; ++mi)
 #pragma unroll
-                for (int nj = 0; nj < 2; ++nj) {
+                for (int nj = 0; nj < NT; ++nj) {
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], wh[nj], acc[mi][nj], 0, 0, 0);
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
                     acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
@@ -208,7 +223,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
         }
         __syncthreads();
     }
-    vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
+    if constexpr (SMALL) vrd::gemm_epilogue_tile32(p, acc[0][0], m0 + wm * 32, n0 + wn * 32, lane);
+    else vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
 }
 
 }  // namespace
@@ -216,25 +232,32 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
 namespace vrd {
 
 // called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
-template <int TAPS, bool STAGED, bool APAIR>
+template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false>
 static int launch_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t s) {
-    auto kern = gemm_bf16x3_kernel<TAPS, STAGED, APAIR>;
-    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), X3_LDS, "vrd_gemm(bf16x3)")) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), X3_LDS, s, a, tiles_m, tiles_n);
+    auto kern = gemm_bf16x3_kernel<TAPS, STAGED, APAIR, SMALL>;
+    constexpr size_t lds = X3Geo<SMALL>::LDS;
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3)")) return rc;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);
     return 0;
 }
 
 template <int TAPS>
-static int launch_taps(const vrd_gemm_args& a, bool staged, int tiles_m, int tiles_n, hipStream_t s) {
+static int launch_taps(const vrd_gemm_args& a, bool staged, int tiles_m, int tiles_n, hipStream_t s, bool small) {
     const bool apair = a.a_pair_width > 0;
+    if (small) return apair ? launch_one<TAPS, false, true, true>(a, tiles_m, tiles_n, s) : launch_one<TAPS, false, false, true>(a, tiles_m, tiles_n, s);
     if (staged) return apair ? launch_one<TAPS, true, true>(a, tiles_m, tiles_n, s) : launch_one<TAPS, true, false>(a, tiles_m, tiles_n, s);
     return apair ? launch_one<TAPS, false, true>(a, tiles_m, tiles_n, s) : launch_one<TAPS, false, false>(a, tiles_m, tiles_n, s);
 }
 
 // called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
 int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s) {
-    const int tiles_m = (int)((a.M + BM - 1) / BM), tiles_n = (a.N + BN - 1) / BN;
-    return a.taps == 1 ? launch_taps<1>(a, staged, tiles_m, tiles_n, s) : launch_taps<3>(a, staged, tiles_m, tiles_n, s);
+    // 64 x 64 tiles while the 128 x 128 ones would not give every CU a workgroup (VRD_X3_SMALL=0: never)
+    static const int small_env = [] { const char* e = getenv("VRD_X3_SMALL"); return e ? atoi(e) : 1; }();
+    const int64_t tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool small = small_env && tiles128 < 256;
+    const int bm = small ? 64 : 128;
+    const int tiles_m = (int)((a.M + bm - 1) / bm), tiles_n = (a.N + bm - 1) / bm;
+    return a.taps == 1 ? launch_taps<1>(a, staged, tiles_m, tiles_n, s, small) : launch_taps<3>(a, staged, tiles_m, tiles_n, s, small);
 }
 
 }  // namespace vrd
