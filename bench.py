@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-forward-test", action="store_true", help="skip the secondary metric (whole eval call on one synthetic video)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step leg (BASELINE config 3: forward + backward on a 24-pair batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-projection", action="store_true",
+                    help="skip timing the 1/2, 1/4, 1/8 per-rank shares of the batch on this one GPU (N = 1 only)")
     ap.add_argument("--cpu-pairs", type=int, default=64)
     return ap.parse_args()
 
@@ -149,8 +151,28 @@ def cpu_baseline(model_cfg, sd_cpu, c_in, frames, t_pad, n_pairs):
                       f"{med:.2f} s/run"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks the way the driver would
+    (`python -m torch.distributed.run --nproc-per-node N bench.py ...`) as a CHILD process -- this process has not touched
+    the GPU and never does -- relay the child's output (its rank 0 prints the JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -273,6 +295,38 @@ def main():
         r_elapsed, _ = run(main_mode, 1, args.steps)
         ragged = {"lengths": f"U[2, {args.frames}] (seed 1235), mean {float(lens.float().mean()):.1f}, T_pad {t_pad}",
                   "value": args.pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps}
+
+    # What a rank of an N-GPU run computes per step, timed here on ONE GPU: the first pairs/N pairs of the batch for
+    # N = 2, 4, 8 (strong scaling: the global batch is fixed).  A projection of the scaling curve, not a measurement of
+    # it: it leaves out the all-gather (payload below, < 1 ms over xGMI) and rank-to-rank skew.
+    projection = None
+    if world == 1 and not args.no_shard_projection:
+        if ragged is not None or "x" not in batch:          # the ragged leg replaced the full-length batch
+            batch.clear()
+            full_x, full_m = synth.synth_pairs(args.pairs, c_in, t_pad, [args.frames] * args.pairs, seed=1234, device=dev)
+        else:
+            full_x, full_m = batch["x"], batch["m"]
+        shares = {}
+        for n in (2, 4, 8):
+            if args.pairs % n:
+                continue
+            batch["x"], batch["m"] = full_x[:args.pairs // n].contiguous(), full_m[:args.pairs // n].contiguous()
+            ops.set_precision(main_mode)
+            with torch.no_grad():
+                step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(max(args.steps, 3)):
+                    step()
+                torch.cuda.synchronize()
+            shares[str(n)] = {"pairs_per_rank": args.pairs // n, "ms_per_step": 1e3 * (time.perf_counter() - t0) / max(args.steps, 3)}
+        q, k1 = cfg["predictor"]["num_queries"], cfg["num_classes"] + 1
+        one = 1e3 * elapsed / args.steps
+        projection = {"kind": "projection, not a measurement: per-rank share of the same batch timed on one GPU; no collective, no skew",
+                      "ms_per_step_n1": one, "ranks": shares,
+                      "projected_speedup": {n: round(one / v["ms_per_step"], 2) for n, v in shares.items()},
+                      "allgather_payload_bytes_per_step": args.pairs * (q * k1 + q * t_pad) * 4}
+        del full_x, full_m
 
     ft = None
     if not args.no_forward_test and args.config == "vidvrd":
@@ -409,6 +463,8 @@ def main():
                 line["alt_precision"]["roofline"] = roofline(alt_mode, a_prof)
         if ragged is not None:
             line["ragged_variant"] = ragged
+        if projection is not None:
+            line["shard_projection"] = projection
         if ft is not None:
             line["forward_test"] = ft
         if train is not None:

@@ -17,6 +17,8 @@
 #include "vrd_common.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -294,6 +296,670 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Round 3: one wave per SIMD, 64 queries per wave (attn_flash_x3_w64_kernel).
+//
+// The kernel above is latency-bound: at 247 registers and two waves per SIMD nothing can be read ahead, a wave's tile is a
+// serial chain S^T (24 dependent MFMAs) -> softmax (~190 VALU) -> O^T (24 MFMAs behind 32 transposed reads), and each of
+// the two workgroups of a CU streams its own copy of K / V (profiles/r02_sq_counters.json: MFMA pipe busy 0.29).
+// Here a workgroup is 4 waves = 256 queries of one (b, h) -- at the benchmark shape all valid queries, so K / V are
+// streamed ONCE -- and a wave owns the whole register file of its SIMD (launch bounds 256 x 1 -> 512 registers):
+//   * two 32-query blocks per wave: every K fragment (ds_read_b128) and V^T fragment (ds_read_b64_tr_b16) feeds six MFMAs
+//     instead of three, and the two blocks' accumulation chains are independent;
+//   * software pipeline across key tiles: the S^T MFMAs of tile t+1 are issued between the softmax instructions of tile t
+//     (a wave issues in order: vector instructions only overlap ITS OWN MFMAs if they sit between them in program order,
+//     ~5 per 32-cycle MFMA), then the O^T MFMAs of tile t between the second half of the softmax and the next requests;
+//   * register file by hand: the Q^T fragments (a[0:127] at head_dim 128) and the O^T accumulators (a[128:255]) live in the
+//     accumulator half (an MFMA takes A / B / C / D from either half), scores, probabilities and K / V fragments in the
+//     architectural half.  The compiler cannot be talked into that split -- with "a" operand constraints it keeps the values
+//     in the architectural half and copies them over before every MFMA (+680 v_accvgpr_write, 366 spills) -- so the
+//     accumulator half is addressed by literal register names inside the asm statements and the compiler owns none of it
+//     (checked after every edit: no v_accvgpr_* outside ASMSTART / ASMEND, no scratch);
+//   * a 4-stage LDS ring (32 KiB per 32-key tile at head_dim 128): two tiles in flight behind the two being read, one
+//     barrier per tile, counted vmcnt waits, 8 LDS-DMA instructions per wave and tile (half the other kernel's), each a
+//     scalar base + a per-lane offset that never changes (no vector address arithmetic in the loop).
+// Arithmetic per element is the other kernel's (same products, same accumulation order per accumulator), except that the
+// exponentials are taken in base 2 with log2(e) folded into the score scale (one FMA per score instead of FMA + multiply).
+//
+// What the compiler does not do for the asm MFMAs (cdna_hip_programming.md 5.7): wait states between a vector instruction
+// that writes an operand and the MFMA reading it (the first MFMA behind a split carries an s_nop 1), and between an MFMA
+// and a vector instruction reading its result (scores are read one pipeline stage later; the accumulators behind an
+// explicit s_nop block).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+#define VRD_ALL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+#define VRD_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef VRD_W64_ABL
+#define VRD_W64_ABL 0
+#endif
+#ifndef VRD_W64_THR
+#define VRD_W64_THR 16.0f
+#endif
+// (VRD_PIN(x): an empty volatile asm through which x passes.  Volatile asm statements keep their order, so nothing computed
+//  from x is placed above the MFMA statement in front of it: that is what holds a piece in its gap -- `sched_barrier`
+//  alone does not, pure arithmetic is hoisted across it before instruction scheduling runs.)
+#define VRD_PIN(x) asm volatile("" : "+v"(x))
+
+template <int I>
+using ic = std::integral_constant<int, I>;
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(ic<Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// The value of lane l ^ 32 combined with this lane's.  v_permlane32_swap exchanges the upper 32 lanes of its first register with
+// the lower 32 of its second; as inline assembly, because hipcc (ROCm 7.2) returns the FIRST result for both elements of
+// __builtin_amdgcn_permlane32_swap's result pair (measured: the row maximum / sum came out as that of one half-row).
+// The s_nop 1 in front: a vector write of the register needs two wait states before a permlane reads it.
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xchg32_max(float v) {
+    float a = v, b = v;
+    swap32(a, b);               // a = lower half-row's value in both halves, b = the upper's
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float xchg32_sum(float v) {
+    float a = v, b = v;
+    swap32(a, b);
+    return a + b;
+}
+// (p0, p1) -> packed bf16 hi pair and lo pair (lo = bf16(p - hi))
+__device__ __forceinline__ void split_pair(float p0, float p1, unsigned& hi, unsigned& lo) {
+    const bf16x2 h = {(__bf16)p0, (__bf16)p1};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)(p0 - h0), (__bf16)(p1 - h1)};
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// a[R0 .. R0+N-1] *= alpha
+template <int R0, int N>
+__device__ __forceinline__ void agpr_scale(float alpha) {
+    if constexpr (N > 0) {
+        float t;
+        asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c2, %0"
+                     : "=&v"(t) : "v"(alpha), "n"(R0));
+        agpr_scale<R0 + 1, N - 1>(alpha);
+    }
+}
+
+// softmax state of one 32-query block while a tile is in the pipeline
+struct SmBlock {
+    float x[16];                // scaled scores, then probabilities
+    float mx, mu, alpha, sum, pend;
+    u32x4 ph[2], pl[2];         // P^T fragments: k16 step s -> hi / lo (bf16x8 as four dwords)
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* __restrict__ q, int64_t ldq,
+                                                                  const float* __restrict__ k, const float* __restrict__ v,
+                                                                  int64_t ldkv, const uint8_t* __restrict__ kv_mask,
+                                                                  const uint8_t* __restrict__ q_mask, int Tq, int Tk, int width,
+                                                                  float scale_log2e, float* __restrict__ out, int64_t ldo,
+                                                                  int pair_out, int q_blocks, int n_head_) {
+    using G = AG<HD>;
+    constexpr int KS = HD / 16;                   // k16 steps of the S^T contraction
+    constexpr int DT = HD / 32;                   // 32-row d tiles of O^T
+    constexpr int NS = 4;                         // ring stages
+    constexpr int PER_WAVE = G::N_DMA / 4;        // LDS-DMA instructions per wave and tile (8 or 4)
+    constexpr int PPP = 32 / G::RPI;              // pieces per plane (8 or 4)
+    constexpr int NG_S = 6 * KS;                  // MFMAs (= gaps) of the S^T phase
+    constexpr int NG_O = 12 * DT;                 // MFMAs of the O^T phase
+    constexpr int HPG_S = 48 / NG_S, HPG_O = 48 / NG_O;       // softmax half-pieces per gap (1 or 2)
+    // accumulator-half map: Q^T fragment (block qb, k16 step s): hi a[AQ .. AQ+3], lo a[AQ+4 .. AQ+7]; O^T accumulator
+    // (block qb, d tile d): a[AO .. AO+15]
+#define VRD_AQ(qb, s) (8 * ((qb) * KS + (s)))
+#define VRD_AO(qb, d) (128 + 16 * ((qb) * DT + (d)))
+    static_assert(G::N_DMA % 4 == 0 && NG_S >= 24 && NG_O >= 24 && VRD_AQ(1, KS - 1) + 8 <= 128, "layout assumptions");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    float* const kbias = reinterpret_cast<float*>(lds + NS * G::STAGE);      // [32 * nkt]: 0 or -inf per key
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
+    const int h = lid % n_head_, b = lid / n_head_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    // One workgroup per (b, h) walks the 256-query blocks of the sequence.  (A grid with one workgroup per block made the
+    // blocks of pure padding -- rows 256 .. 287 at the benchmark shape -- cost 22 us each: a workgroup of this size has a CU
+    // to itself, so even one that leaves at once waits for the CU to drain.  Measured: 1.92 ms per launch against 1.2.)
+    for (int qblk = 0; qblk < q_blocks; ++qblk) {
+    if (qblk) __syncthreads();                    // the ring and the output slabs of the previous block are no longer in use
+    const int q0 = qblk * 256 + wave * 64;        // the wave's two blocks: q0 .. q0+31, q0+32 .. q0+63
+    const char* kb = reinterpret_cast<const char*>(k + (int64_t)b * Tk * ldkv) + h * HD * 4;
+    const char* vb = reinterpret_cast<const char*>(v + (int64_t)b * Tk * ldkv) + h * HD * 4;
+
+    auto row_live = [&](int tq) { return tq < Tq && (!q_mask || q_mask[(int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)] != 0); };
+    const bool live0 = __any(row_live(q0 + li)), live1 = __any(row_live(q0 + 32 + li));
+    const bool q_live = live0 || live1;
+    if (!__syncthreads_or(q_live)) {              // no live query in these 256 rows: zeros, K / V are not streamed
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int tq = q0 + 32 * qb + li;
+            if (tq < Tq) {
+                float* orow = out + ((int64_t)b * Tq + tq) * ldo + h * HD;
+                for (int c = lh * 4; c < HD; c += 8) *reinterpret_cast<float4*>(orow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        continue;
+    }
+    // every accumulator-half register is named in a clobber list once: that is what makes the kernel descriptor allocate them
+    asm volatile("" ::: VRD_ALL_AGPRS);
+    // Q^T fragments of both blocks: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo.  All loads
+    // first (volatile asm statements keep their order: a load next to its register write would make 32 serial round trips)
+    u32x4 qtmp[2][KS][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int tq = q0 + 32 * qb + li;
+        const char* qr = reinterpret_cast<const char*>(q + ((int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)) * ldq) + h * HD * 4;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int off = vrd::pair_index(16 * s + 8 * lh) * 2;
+            if constexpr ((VRD_W64_ABL & 128) != 0) {
+                qtmp[qb][s][0] = qtmp[qb][s][1] = u32x4{(unsigned)off, 1u, 2u, 3u};
+                continue;
+            }
+            qtmp[qb][s][0] = *reinterpret_cast<const u32x4*>(qr + off);
+            qtmp[qb][s][1] = *reinterpret_cast<const u32x4*>(qr + off + 64);
+        }
+    }
+    // O^T accumulators = 0
+    static_for<2 * DT * 16>([&](auto r_c) {
+        asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "n"(128 + decltype(r_c)::value));
+    });
+
+    // ---- LDS-DMA.  Piece i (0 .. PER_WAVE-1) of a tile: plane (wave + 4i) / PPP (k_hi, k_lo, v_hi, v_lo), row block
+    // rb = (wave + 4i) % PPP, key row rb * RPI + rin.  Row blocks differ by multiples of 4 rows (head_dim 128: by 16), which
+    // leaves both swizzles unchanged, so a lane has ONE source offset for the K planes and one for the V planes; plane,
+    // row block and tile are added to the scalar base.
+    const int rin = lane / G::CPR, pch = lane % G::CPR;
+    const int row0 = (wave % PPP) * G::RPI + rin;                      // key row of this lane in piece 0 (and in every even piece)
+    const int rowbytes = (int)(ldkv * 4);                              // (host-checked: a (b) slab of K / V is below 2 GiB)
+    auto chunk_of = [&](int row, bool is_v) {
+        const int lc = pch ^ (is_v ? G::vswz(row) : G::kswz(row));     // logical 16-byte chunk of the plane row
+        return (lc >> 2) * 128 + (lc & 3) * 16;
+    };
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)lds);
+    constexpr int HALF_ROWS = HD == 128 ? 16 : 0;                      // rows between an even piece and the odd piece behind it
+    // what the pieces of one tile share: scalar bases of the K and V slabs at the tile, per-lane offsets for even / odd pieces
+    struct Req {
+        const char *kbase, *vbase;
+        unsigned vk[2], vv[2];
+        int half;                                                      // bytes from an even piece's rows to the odd piece's
+    };
+    auto req_of = [&](int kt) {
+        Req r;
+        if (kt * 32 + 32 <= Tk) {
+            r.kbase = kb + (int64_t)kt * 32 * rowbytes;
+            r.vbase = vb + (int64_t)kt * 32 * rowbytes;
+            r.vk[0] = r.vk[1] = (unsigned)(row0 * rowbytes) + chunk_of(row0, false);
+            r.vv[0] = r.vv[1] = (unsigned)(row0 * rowbytes) + chunk_of(row0, true);
+            r.half = HALF_ROWS * rowbytes;
+        } else {        // the last, partial tile: keys past Tk re-read key Tk-1 (finite values; their scores get -inf, their P is 0)
+            r.kbase = kb;
+            r.vbase = vb;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int key = kt * 32 + row0 + HALF_ROWS * u;
+                key = key < Tk ? key : Tk - 1;
+                r.vk[u] = (unsigned)(key * rowbytes) + chunk_of(row0, false);
+                r.vv[u] = (unsigned)(key * rowbytes) + chunk_of(row0, true);
+            }
+            r.half = 0;
+        }
+        return r;
+    };
+    auto issue1 = [&](const Req& r, int buf, auto i_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        constexpr int u = HD == 128 ? (i & 1) : 0;
+        const int j = wave + 4 * i;
+        const int plane = j / PPP, rb = j % PPP;                        // plane is the same for every wave: i / 2 or i
+        const unsigned dst = lds_base + buf * G::STAGE + plane * G::PLANE + rb * 1024;
+        const char* sbase = (plane < 2 ? r.kbase : r.vbase) + ((plane & 1) ? 64 : 0) + (u ? r.half : 0);
+        const unsigned voff = plane < 2 ? r.vk[u] : r.vv[u];
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory");
+    };
+
+    const int nkt = (Tk + 31) / 32;
+    int* const tile_on = reinterpret_cast<int*>(kbias + nkt * 32);
+    for (int key = tid; key < nkt * 32; key += 256) {
+        const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
+        kbias[key] = ok ? 0.f : -INFINITY;
+        const unsigned long long bal = __ballot(ok);
+        if ((lane & 31) == 0) tile_on[key >> 5] = ((bal >> (lane & 32)) & 0xffffffffull) != 0ull;
+    }
+    __syncthreads();
+    unsigned long long act = ~0ull;                      // rows of more than 64 tiles: every tile is visited
+    if (nkt <= 64) act = __ballot(lane < nkt && tile_on[lane < nkt ? lane : 0] != 0);
+    auto next_on = [&](int from) {                       // first tile >= from that has a valid key, or nkt
+        if (from >= nkt) return nkt;
+        if (nkt > 64) return from;
+        const unsigned long long m = act & (~0ull << from);
+        return m ? (int)__builtin_ctzll(m) : nkt;
+    };
+    const int n_act = nkt <= 64 ? (int)__builtin_popcountll(act) : nkt;      // tiles that are visited
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 16)
+    float* const stamps = reinterpret_cast<float*>(lds + NS * G::STAGE + 8192);      // LDS: no effect on the vmcnt counting
+    int n_stamp = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#define VRD_STAMP() do { if (n_stamp < 64 && tid == 0) stamps[n_stamp] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start); ++n_stamp; } while (0)
+#else
+#define VRD_STAMP() do {} while (0)
+#endif
+
+    float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
+
+    const int krow = li * G::ROWB;
+    const int vq = (lane >> 2) & 3, vp = lane & 3;
+    const int vcol0 = 16 * ((lane >> 4) & 1) + 4 * vp;          // column inside a 32-wide d tile
+
+    struct KF { bf16x8 h, l; };
+    auto load_k = [&](const char* st, int s) __attribute__((always_inline)) {
+        KF f;
+        const int off = krow + (((2 * s + lh) ^ G::kswz(li)) * 16);
+        f.h = *reinterpret_cast<const bf16x8*>(st + off);
+        f.l = *reinterpret_cast<const bf16x8*>(st + G::PLANE + off);
+        return f;
+    };
+    // V^T fragment (s, d) of the tile in stage `st`: two transposed reads per plane
+    auto load_v = [&](const char* st, int s, int d) __attribute__((always_inline)) {
+        KF f;
+        s16x8 rh, rl;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int row = 16 * s + 8 * part + 4 * lh + vq;                  // key row this lane addresses
+            const int col = 32 * d + vcol0;                                   // first of its 4 columns
+            const int off = row * G::ROWB + ((((col * 2) >> 4) ^ G::vswz(row)) * 16) + ((col * 2) & 15);
+            const s16x4 th = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(st + 2 * G::PLANE + off));
+            const s16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(st + 3 * G::PLANE + off));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rh[4 * part + j] = th[j];
+                rl[4 * part + j] = tl[j];
+            }
+        }
+        f.h = __builtin_bit_cast(bf16x8, rh);
+        f.l = __builtin_bit_cast(bf16x8, rl);
+        return f;
+    };
+
+    // ---- the softmax of one tile as 2 x 48 half-pieces, run in the gaps between MFMAs (one per gap at head_dim 128, two at 64).
+    // S^T phase of the NEXT tile:   0..15 scale + bias + running maximum of score e; 16/17 exchange with the other half-row;
+    //                               18/19 new maximum and alpha; 20..35 exponentials of scores 0..7 (k16 step 0 of P^T);
+    //                               36..43 their hi / lo split.
+    // first half of the O^T phase:  0..15 exponentials of scores 8..15; 16..23 their split (k16 step 1, used by the second
+    //                               half of the phase); 24 the running sums.
+    float bias[16];
+    SmBlock A, B;
+    auto half_s = [&](auto hp_c, const f32x16& sa, const f32x16& sb) __attribute__((always_inline)) {
+        constexpr int hp = decltype(hp_c)::value;
+        if constexpr (hp < 16) {
+            constexpr int e = hp;
+            float a = sa[e], bq = sb[e];
+            VRD_PIN(a);
+            VRD_PIN(bq);
+            A.x[e] = fmaf(a, scale_log2e, bias[e]);
+            B.x[e] = fmaf(bq, scale_log2e, bias[e]);
+            A.mx = e ? fmaxf(A.mx, A.x[e]) : A.x[e];
+            B.mx = e ? fmaxf(B.mx, B.x[e]) : B.x[e];
+        } else if constexpr (hp == 16) {
+            VRD_PIN(A.mx);
+            A.mx = xchg32_max(A.mx);
+            A.sum = A.pend = 0.f;
+        } else if constexpr (hp == 17) {
+            VRD_PIN(B.mx);
+            B.mx = xchg32_max(B.mx);
+            B.sum = B.pend = 0.f;
+        } else if constexpr (hp == 18 || hp == 19) {
+            // The reference point of the exponentials moves only when the row maximum has grown by more than VRD_W64_THR
+            // (log2 units) since it was set: probabilities then reach 2^THR instead of 1, which costs nothing here (they are
+            // split into hi + lo relative to their own magnitude and accumulated in f32), and the running output -- 64
+            // accumulator-half registers per block, three instructions each -- is rescaled in the first tile or two only
+            // instead of in nearly every tile (some query of the 32 almost always finds a slightly larger score).
+            SmBlock& X = (hp & 1) ? B : A;
+            VRD_PIN(X.mx);
+            const float m_old = m_run[hp & 1];
+            const float mn = (X.mx - m_old > VRD_W64_THR) ? X.mx : m_old;       // (m_old = -inf: always; mx = -inf cannot happen in a visited tile)
+            X.mu = (mn == -INFINITY) ? 0.f : mn;
+            X.alpha = __builtin_amdgcn_exp2f(m_old - X.mu);                     // exactly 1 where the reference stays
+            m_run[hp & 1] = mn;
+        } else if constexpr (hp < 36) {
+            constexpr int e = (hp - 20) >> 1;
+            SmBlock& X = (hp & 1) ? B : A;
+            VRD_PIN(X.x[e]);
+            X.sum += X.pend;                     // the previous exponential (not the one just issued: no dependent stall)
+            X.x[e] = __builtin_amdgcn_exp2f(X.x[e] - X.mu);
+            X.pend = X.x[e];
+        } else if constexpr (hp < 44) {
+            constexpr int j = (hp - 36) >> 1;
+            SmBlock& X = (hp & 1) ? B : A;
+            VRD_PIN(X.x[2 * j]);
+            VRD_PIN(X.x[2 * j + 1]);
+            unsigned hi, lo;
+            split_pair(X.x[2 * j], X.x[2 * j + 1], hi, lo);
+            X.ph[0][j] = hi;
+            X.pl[0][j] = lo;
+        }
+    };
+    auto half_o = [&](auto hp_c) __attribute__((always_inline)) {
+        constexpr int hp = decltype(hp_c)::value;
+        if constexpr (hp < 16) {
+            constexpr int e = 8 + (hp >> 1);
+            SmBlock& X = (hp & 1) ? B : A;
+            VRD_PIN(X.x[e]);
+            X.sum += X.pend;
+            X.x[e] = __builtin_amdgcn_exp2f(X.x[e] - X.mu);
+            X.pend = X.x[e];
+        } else if constexpr (hp < 24) {
+            constexpr int j = (hp - 16) >> 1;
+            SmBlock& X = (hp & 1) ? B : A;
+            VRD_PIN(X.x[8 + 2 * j]);
+            VRD_PIN(X.x[8 + 2 * j + 1]);
+            unsigned hi, lo;
+            split_pair(X.x[8 + 2 * j], X.x[8 + 2 * j + 1], hi, lo);
+            X.ph[1][j] = hi;
+            X.pl[1][j] = lo;
+        } else if constexpr (hp == 24) {
+            VRD_PIN(A.sum);
+            VRD_PIN(B.sum);
+            l_part[0] = l_part[0] * A.alpha + (A.sum + A.pend);
+            l_part[1] = l_part[1] * B.alpha + (B.sum + B.pend);
+        }
+    };
+
+    // S^T MFMA j (0..5) of k16 step s: both blocks take the three products in the order (k_lo q_hi), (k_hi q_lo), (k_hi q_hi);
+    // the first one of a chain starts from 0
+    auto mfma_s = [&](auto s_c, auto j_c, const KF& kf, f32x16& sa, f32x16& sb) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_c)::value, j = decltype(j_c)::value, qb = j & 1;
+        f32x16& acc = qb ? sb : sa;
+        constexpr int aq = VRD_AQ(qb, s) + (j >= 2 && j < 4 ? 4 : 0);          // q_lo for the middle product
+        if constexpr (s == 0 && j < 2) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(kf.l), "n"(aq), "n"(aq + 3));
+        } else if constexpr (j < 2) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(kf.l), "n"(aq), "n"(aq + 3));
+        } else {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(kf.h), "n"(aq), "n"(aq + 3));
+        }
+    };
+    // O^T MFMA j (0..5) of group g = (k16 step s, d tile d): (v_lo p_hi), (v_hi p_lo), (v_hi p_hi) for both blocks
+    auto mfma_o = [&](auto g_c, auto j_c, const KF& vf) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_c)::value, j = decltype(j_c)::value, qb = j & 1, s = g / DT, d = g % DT;
+        constexpr int ao = VRD_AO(qb, d);
+        const SmBlock& X = qb ? B : A;
+        if constexpr (j < 2) {
+            if constexpr (d == 0 && j == 0)      // the fragments of this k16 step were written by vector instructions just now
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.l), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
+            else
+                asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.l), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
+        } else if constexpr (j < 4) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.h), "v"(X.pl[s]), "n"(ao), "n"(ao + 15));
+        } else {
+            asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.h), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
+        }
+    };
+    // running output of block qb *= alpha (rare: only when some query's maximum moved)
+    auto rescale = [&](auto qb_c, float alpha) __attribute__((always_inline)) {
+        agpr_scale<VRD_AO(decltype(qb_c)::value, 0), 16 * DT>(alpha);
+    };
+
+    // One pipeline step.  In: the raw scores of tile `it` (sa_c, sb_c; stage st), out: the raw scores of tile it+1 (WITH_S;
+    // stage st1) and tile it's contribution to the outputs.  do_req: the pieces of tile kt_req are requested into stage
+    // buf_req during the second half of the O^T phase.
+    auto tile = [&](auto with_s_c, const f32x16& sa_c, const f32x16& sb_c, f32x16& sa_n, f32x16& sb_n, const char* st,
+                    const char* st1, const float* kbs, bool do_req, const Req& req, int buf_req, bool first) __attribute__((always_inline)) {
+        constexpr bool WITH_S = decltype(with_s_c)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(kbs + 8 * g + 4 * lh);
+            bias[4 * g + 0] = bv.x;
+            bias[4 * g + 1] = bv.y;
+            bias[4 * g + 2] = bv.z;
+            bias[4 * g + 3] = bv.w;
+        }
+        KF kf{}, kn{}, vf{}, vn{};
+        if (WITH_S) kf = load_k(st1, 0);
+        VRD_SB();
+        static_for<KS>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            static_for<6>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value, gap = 6 * s + j;
+                if constexpr (WITH_S && !(VRD_W64_ABL & 1)) mfma_s(s_c, j_c, kf, sa_n, sb_n);
+                if constexpr (j == 0 && WITH_S && s + 1 < KS) kn = load_k(st1, s + 1);
+                if constexpr (gap == NG_S - 4) vf = load_v(st, 0, 0);
+                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_S>([&](auto u_c) { half_s(ic<gap * HPG_S + decltype(u_c)::value>{}, sa_c, sb_c); });
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 4)
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+                VRD_SB();
+            });
+            kf = kn;
+        });
+        VRD_STAMP();                                     // 4 + 5 it: S^T phase done
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 2)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        rescale(ic<0>{}, A.alpha);
+        rescale(ic<1>{}, B.alpha);
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#else
+        if (!first && __any(A.alpha != 1.0f)) rescale(ic<0>{}, A.alpha);
+        if (!first && __any(B.alpha != 1.0f)) rescale(ic<1>{}, B.alpha);
+#endif
+        VRD_SB();
+        VRD_STAMP();                                     // 5 + 5 it: rescale done
+        // ---- O^T += V^T . P^T for both blocks: each V^T fragment pair feeds six MFMAs, fragments one group ahead
+        static_for<2 * DT>([&](auto g_c) {
+            constexpr int g = decltype(g_c)::value;
+            static_for<6>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value, gap = 6 * g + j;
+                if constexpr (!(VRD_W64_ABL & 2)) mfma_o(g_c, j_c, vf);
+                if constexpr (j == 0 && g + 1 < 2 * DT) vn = load_v(st, (g + 1) / DT, (g + 1) % DT);
+                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_O>([&](auto u_c) { half_o(ic<gap * HPG_O + decltype(u_c)::value>{}); });
+                constexpr int rq = gap - NG_O / 2 - 1;
+                if constexpr (rq >= 0 && rq % 3 == 0 && rq / 3 < PER_WAVE) {
+                    if (do_req && !(VRD_W64_ABL & 8)) issue1(req, buf_req, ic<rq / 3>{});
+                }
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 4)
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+                VRD_SB();
+            });
+            vf = vn;
+        });
+        VRD_STAMP();                                     // 6 + 5 it: O^T phase done
+    };
+
+    // ---- prologue: the first NS-1 visited tiles are requested, S^T of the first one is formed
+    int kt_iss = -1;                                     // last tile requested
+    int issued = 0;                                      // tiles requested so far (sequence numbers 0 .. issued-1)
+    auto request_next = [&](int buf) {
+        if (issued < n_act) {
+            kt_iss = next_on(kt_iss + 1);
+            const Req r = req_of(kt_iss);
+            static_for<PER_WAVE>([&](auto i_c) { issue1(r, buf, i_c); });
+            ++issued;
+        }
+    };
+    request_next(0);
+    // the Q^T fragments move to their accumulator-half registers.  The vector-memory counter is in order and the compiler does
+    // not see the asm requests: its waits for the Q loads (issued before them) also cover tile 0 -- which is needed now
+    // anyway -- so the tiles behind it are requested after the moves
+    static_for<2>([&](auto qb_c) {
+        constexpr int qb = decltype(qb_c)::value;
+        static_for<KS>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            static_for<2>([&](auto l_c) {
+                constexpr int r = VRD_AQ(qb, s) + 4 * decltype(l_c)::value;
+                const u32x4 t = qtmp[qb][s][decltype(l_c)::value];
+                asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\t"
+                             "v_accvgpr_write_b32 a%c7, %3"
+                             :: "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "n"(r), "n"(r + 1), "n"(r + 2), "n"(r + 3));
+            });
+        });
+    });
+#pragma unroll
+    for (int jq = 1; jq < NS - 1; ++jq) request_next(jq);
+    if constexpr ((VRD_W64_ABL & 64) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    VRD_STAMP();                                         // 0: requests and Q moves done
+    int kt_cur = next_on(0);                             // tile whose raw scores the next step consumes
+    f32x16 s0a, s0b, s1a, s1b;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s0a[e] = s0b[e] = s1a[e] = s1b[e] = 0.f;
+    if (n_act > 0) {
+        // tile 0 has landed when at most the requests of the tiles behind it are outstanding
+        if (n_act >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+        else if (n_act == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (q_live) {
+            KF kf = load_k(lds, 0), kn = kf;
+            static_for<KS>([&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                if constexpr (s + 1 < KS) kn = load_k(lds, s + 1);
+                static_for<6>([&](auto j_c) { mfma_s(s_c, j_c, kf, s0a, s0b); });
+                kf = kn;
+            });
+            asm volatile("s_nop 15" : "+v"(s0a), "+v"(s0b));       // MFMA result -> vector read: wait states by hand
+        }
+    }
+    VRD_STAMP();                                         // 1: first S^T done
+    // a step: wait for tile it+1, barrier, pipeline step (scores of tile `it` in (ca, cb), of tile it+1 into (na, nb))
+    int it = 0;
+    auto step = [&](f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) __attribute__((always_inline)) {
+        const bool has_next = it + 1 < n_act;
+        const int kt_next = has_next ? next_on(kt_cur + 1) : nkt;
+        // tile it+1 landed (mine: counted wait; everybody's: the barrier); the barrier also says that nobody reads the
+        // stage of tile it-1 any more, which the request for tile it+3 refills
+        if (has_next) {
+            if (it + 2 < issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        VRD_STAMP();                                     // 2 + 5 it: counted wait done
+        __builtin_amdgcn_s_barrier();
+        VRD_STAMP();                                     // 3 + 5 it: barrier passed
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 1)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+        const bool do_req = issued < n_act;
+        if (do_req) {
+            kt_iss = next_on(kt_iss + 1);
+            ++issued;
+        }
+        const Req req = req_of(do_req ? kt_iss : 0);
+        const char* st = lds + (it & (NS - 1)) * G::STAGE;
+        const char* st1 = lds + ((it + 1) & (NS - 1)) * G::STAGE;
+        const float* kbs = kbias + kt_cur * 32;
+        const int buf_req = (it + NS - 1) & (NS - 1);
+        if (q_live) {
+            if (has_next) tile(std::true_type{}, ca, cb, na, nb, st, st1, kbs, do_req, req, buf_req, it == 0);
+            else tile(std::false_type{}, ca, cb, na, nb, st, st1, kbs, do_req, req, buf_req, it == 0);
+        } else if (do_req) {
+            static_for<PER_WAVE>([&](auto i_c) { issue1(req, buf_req, i_c); });
+        }
+        kt_cur = kt_next;
+        ++it;
+    };
+    while (it < n_act) {
+        step(s0a, s0b, s1a, s1b);
+        if (it >= n_act) break;
+        step(s1a, s1b, s0a, s0b);
+    }
+
+    // ---- epilogue.  MFMA result -> v_accvgpr_read: wait states by hand (the compiler does not know the asm statements are
+    // MFMAs).  The outputs go through LDS: a lane holds 4 channels of ONE query per register quad, so stores straight from
+    // the accumulators touch 32 rows per instruction, 32 bytes of each (8 k cycles per workgroup, measured); staged, an
+    // instruction writes whole 512-byte rows.  The ring is free once every wave has passed the barrier (the last tile's V):
+    // wave w's 64 x HD f32 slab is the ring's bytes [w * 64 * HD * 4, ...).  16-byte chunk c of row r is stored at chunk
+    // c ^ (r % chunks) (conflict-free writes -- lanes are rows -- and reads -- lanes are chunks).
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int CH = HD / 4;                                       // 16-byte chunks per output row of this head
+    char* const slab = lds + wave * (64 * HD * 4);
+    static_for<2>([&](auto qb_c) {
+        constexpr int qb = decltype(qb_c)::value;
+        const float l_tot = xchg32_sum(l_part[qb]);
+        const float inv = (qb ? live1 : live0) ? 1.0f / l_tot : 0.f;
+        static_for<DT>([&](auto d_c) {
+            constexpr int d = decltype(d_c)::value;
+            static_for<4>([&](auto g_c) {
+                constexpr int g = decltype(g_c)::value, r = VRD_AO(qb, d) + 4 * g;
+                float4 val;                                        // registers 4g..4g+3 are d = 32d + 8g + 4lh + 0..3
+                asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\t"
+                             "v_accvgpr_read_b32 %3, a%c7"
+                             : "=v"(val.x), "=v"(val.y), "=v"(val.z), "=v"(val.w) : "n"(r), "n"(r + 1), "n"(r + 2), "n"(r + 3));
+                val.x *= inv;
+                val.y *= inv;
+                val.z *= inv;
+                val.w *= inv;
+                const int c16 = 8 * d + 2 * g + lh;
+                *reinterpret_cast<float4*>(slab + (32 * qb + li) * (HD * 4) + ((c16 ^ (li & (CH - 1))) * 16)) = val;
+            });
+        });
+    });
+    // (wave-private slab: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt wait)
+    {
+        constexpr int ROWS_PI = 64 / CH;                             // rows per wave instruction (2 or 4)
+        const int rr = lane / CH, cj = lane % CH;
+#pragma unroll 4
+        for (int t = 0; t < 64 / ROWS_PI; ++t) {
+            const int r = t * ROWS_PI + rr;                          // row of the wave's 64
+            const float4 val = *reinterpret_cast<const float4*>(slab + r * (HD * 4) + ((cj ^ (r & (CH - 1))) * 16));
+            const int tq = q0 + r;
+            if (tq < Tq) {
+                float* orow = out + ((int64_t)b * Tq + tq) * ldo;
+                const int c = h * HD + 4 * cj;
+                if (pair_out) vrd::store_pair4(orow, c, width, val);
+                else *reinterpret_cast<float4*>(orow + c) = val;
+            }
+        }
+    }
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 16)
+    VRD_STAMP();                                         // last: stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) {
+        float* dbg = out + ((int64_t)b * Tq + qblk * 256) * ldo + h * HD;          // row 0 of the block, this head's columns
+        for (int i = 0; i < 64 && i < HD; ++i) dbg[i] = i < n_stamp ? stamps[i] : -1.f;
+    }
+#endif
+    }       // 256-query blocks
+#undef VRD_AQ
+#undef VRD_AO
+}
+
+template <int HD>
+int launch_w64(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, const uint8_t* q_mask, int B,
+               int Tq, int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
+    auto kern = attn_flash_x3_w64_kernel<HD>;
+    constexpr size_t lds_max = 4 * AG<HD>::STAGE + (4096 + 128) * sizeof(float);       // key bias + tile flags for Tk <= 4096
+    const size_t lds = 4 * AG<HD>::STAGE + (size_t)((Tk + 31) / 32) * 33 * sizeof(float);
+    if (lds > lds_max) {
+        vrd::set_error("vrd_attention_pair: Tk = %d exceeds the 4096 keys the key-bias row is sized for", Tk);
+        return -1;
+    }
+    if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds_max, "vrd_attention_pair(w64)")) return rc;
+    const int q_blocks = (Tq + 255) / 256;
+#if defined(VRD_W64_DBG)
+    const size_t lds_launch = lds_max;          // the stamp buffer of the diagnostic build lives behind the key-bias row
+#else
+    const size_t lds_launch = lds;
+#endif
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_head * B), dim3(256), lds_launch, s, q, ldq, k, v, ldkv, kv_mask, q_mask, Tq, Tk,
+                       n_head * HD, scale * 1.44269504088896340736f, out, ldo, pair_out, q_blocks, n_head);
+    return 0;
+}
+
 template <int HD, int NW>
 int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq,
            int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
@@ -338,8 +1004,16 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     // barrier for a tile.
     static const int nw_env = [] { const char* e = getenv("VRD_FLASH_NW"); return e ? atoi(e) : 0; }();
     const int nw = nw_env == 3 || nw_env == 4 ? nw_env : 4;
+    // 64 queries per wave, one wave per SIMD (attn_flash_x3_w64_kernel) once a (b, h) has more than 128 query rows: below
+    // that a 256-query workgroup would leave half of its waves without rows.  VRD_FLASH_W64=0 / 1 forces the choice.
+    const char* const w64_e = getenv("VRD_FLASH_W64");                  // (read per call: tests compare the two kernels in one process)
+    const int w64_env = w64_e ? atoi(w64_e) : -1;
+    // (its LDS-DMA offsets are 32-bit: a batch element's K / V slab has to stay below 2 GiB)
+    const bool w64 = (w64_env >= 0 ? w64_env != 0 : Tq > 128) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31);
     int rc;
-    if (head_dim == 128) rc = nw == 3 ? launch<128, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
+    if (w64) rc = head_dim == 128 ? launch_w64<128>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
+                                  : launch_w64<64>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
+    else if (head_dim == 128) rc = nw == 3 ? launch<128, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
                                       : launch<128, 4>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
     else rc = nw == 3 ? launch<64, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
                       : launch<64, 4>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
