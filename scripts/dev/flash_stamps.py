@@ -18,7 +18,7 @@ med = st.median(dim=0).values.tolist()
 names = ["prologue done", "first S done"]
 for it in range(8):
     names += [f"it{it} wait", f"it{it} barrier", f"it{it} S-phase", f"it{it} rescale", f"it{it} O-phase"]
-names += ["stores issued"]
+names += ["epi barrier", "outputs in LDS", "stores issued"]
 prev = 0
 for i, n in enumerate(names):
     print(f"{i:2d} {n:16s} {med[i]:9.0f}  (+{med[i]-prev:7.0f})")

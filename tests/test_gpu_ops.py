@@ -545,6 +545,41 @@ def test_flash_attention_pair_rows(H, hd, Tq, Tk, precision):
     assert bool((masked[~tile_live.to(DEV)] == 0).all())
 
 
+@pytest.mark.parametrize("H,hd,Tq,Tk", [(4, 128, 288, 288), (4, 128, 40, 77), (8, 64, 144, 144), (8, 64, 512, 512), (4, 128, 600, 330)])
+def test_flash_attention_one_wave_per_simd_kernel(H, hd, Tq, Tk, precision, monkeypatch):
+    """The 64-queries-per-wave kernel (vrd_attn_x3.hip, attn_flash_x3_w64_kernel) forced on every shape -- partial last key
+    tile, several 256-query blocks, blocks of padding only, a dominant late key (the deferred rescale) -- against the oracle
+    and against the 32-queries-per-wave kernel."""
+    if precision != "bf16x3":
+        pytest.skip("pair rows exist in bf16x3 mode only")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(3 * H + hd + Tq + Tk)
+    B, C = 3, H * hd
+    q = torch.randn(B, Tq, C, generator=gen) * 2.0
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    k[:, min(70, Tk - 1), :hd] = q[:, 5, :hd] * 2.0          # a dominant late key: the reference point of the exponentials moves
+    k[:, Tk - 1, hd:2 * hd] = q[:, 33, hd:2 * hd] * 3.0
+    lens = torch.tensor([Tk, max(1, Tk // 3), 1])
+    mask = torch.arange(Tk)[None] < lens[:, None]
+    want = O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H).transpose(1, 2)
+    qp, kp, vp = (_to_pair(t.to(DEV)) for t in (q, k, v))
+    qlens = torch.tensor([Tq, min(Tq, 33), 1])
+    qm = (torch.arange(Tq)[None] < qlens[:, None])
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VRD_FLASH_W64", flag)
+        got = ops.attention(qp, kp, vp, mask.to(DEV), H)
+        close(got, want, 2e-4)
+        close(ops.attention(qp, kp, vp, mask.to(DEV), H, pair=True).float(), want, 2e-4)
+        masked = ops.attention(qp, kp, vp, mask.to(DEV), H, q_mask=qm.to(DEV))
+        tile_live = torch.nn.functional.pad(qm, (0, (-Tq) % 32)).reshape(B, -1, 32).any(-1).repeat_interleave(32, dim=1)[:, :Tq]
+        assert torch.equal(masked[tile_live.to(DEV)], got[tile_live.to(DEV)])
+        assert bool((masked[~tile_live.to(DEV)] == 0).all())
+        out[flag] = got
+    close(out["1"], out["0"], 5e-5)
+
+
 def test_row_blocks_padding_map():
     """vrd_row_blocks: the 32-row blocks dealt into segments (about eight, whole 256-row tiles, the last one shorter);
     inside a segment the blocks holding a valid row first (ascending), the fully padded ones after (ascending); every

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
                                                                   int64_t ldkv, const uint8_t* __restrict__ kv_mask,
                                                                   const uint8_t* __restrict__ q_mask, int Tq, int Tk, int width,
                                                                   float scale_log2e, float* __restrict__ out, int64_t ldo,
-                                                                  int pair_out, int q_blocks, int n_head_) {
+                                                                  int pair_out, int q_blocks, int n_head_, int n_batch) {
     using G = AG<HD>;
     constexpr int KS = HD / 16;                   // k16 steps of the S^T contraction
     constexpr int DT = HD / 32;                   // 32-row d tiles of O^T
@@ -421,13 +421,16 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     char* const lds = reinterpret_cast<char*>(smem);
     float* const kbias = reinterpret_cast<float*>(lds + NS * G::STAGE);      // [32 * nkt]: 0 or -inf per key
 
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
-    const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
-    const int h = lid % n_head_, b = lid / n_head_;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    // Persistent workgroups (one per CU: the grid is min(items, CUs)) walk the (b, h) items blockIdx.x, + gridDim.x, ...: a
+    // workgroup of this size has its CU to itself, so every dispatch is a drained CU (measured: ~9 us per workgroup between
+    // the end of one and the first instruction of the next).
+    const int n_items = n_head_ * n_batch;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    if (item != (int)blockIdx.x) __syncthreads();       // ring, key-bias row and output slabs of the previous item are free
+    const int h = item % n_head_, b = item / n_head_;
     // One workgroup per (b, h) walks the 256-query blocks of the sequence.  (A grid with one workgroup per block made the
     // blocks of pure padding -- rows 256 .. 287 at the benchmark shape -- cost 22 us each: a workgroup of this size has a CU
     // to itself, so even one that leaves at once waits for the CU to drain.  Measured: 1.92 ms per launch against 1.2.)
@@ -884,6 +887,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     // c ^ (r % chunks) (conflict-free writes -- lanes are rows -- and reads -- lanes are chunks).
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    VRD_STAMP();                                         // after the last step: barrier passed
     constexpr int CH = HD / 4;                                       // 16-byte chunks per output row of this head
     char* const slab = lds + wave * (64 * HD * 4);
     static_for<2>([&](auto qb_c) {
@@ -907,20 +911,42 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             });
         });
     });
+    VRD_STAMP();                                         // outputs in LDS
     // (wave-private slab: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt wait)
+    // Rows leave in batches of eight wave instructions: the reads of a batch together, then its stores; the row pointer
+    // advances by a constant (no 64-bit multiply per row), and the rows-inside-the-sequence test is per wave unless the
+    // wave's 64 rows straddle Tq.
     {
         constexpr int ROWS_PI = 64 / CH;                             // rows per wave instruction (2 or 4)
+        constexpr int NT = 64 / ROWS_PI, BATCH = 8;
         const int rr = lane / CH, cj = lane % CH;
-#pragma unroll 4
-        for (int t = 0; t < 64 / ROWS_PI; ++t) {
-            const int r = t * ROWS_PI + rr;                          // row of the wave's 64
-            const float4 val = *reinterpret_cast<const float4*>(slab + r * (HD * 4) + ((cj ^ (r & (CH - 1))) * 16));
-            const int tq = q0 + r;
-            if (tq < Tq) {
-                float* orow = out + ((int64_t)b * Tq + tq) * ldo;
-                const int c = h * HD + 4 * cj;
-                if (pair_out) vrd::store_pair4(orow, c, width, val);
-                else *reinterpret_cast<float4*>(orow + c) = val;
+        const bool all_rows = q0 + 64 <= Tq;                         // wave-uniform
+        char* gp = reinterpret_cast<char*>(out + ((int64_t)b * Tq + (q0 + rr < Tq ? q0 + rr : Tq - 1)) * ldo) +
+                   (pair_out ? vrd::pair_index(h * HD + 4 * cj) * 2 : (h * HD + 4 * cj) * 4);
+        const int64_t gstep = ldo * 4 * ROWS_PI;
+#pragma unroll 1
+        for (int t0 = 0; t0 < NT; t0 += BATCH) {
+            float4 val[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int r = (t0 + u) * ROWS_PI + rr;               // row of the wave's 64
+                val[u] = *reinterpret_cast<const float4*>(slab + r * (HD * 4) + ((cj ^ (r & (CH - 1))) * 16));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int r = (t0 + u) * ROWS_PI + rr;
+                if (all_rows || q0 + r < Tq) {
+                    if (pair_out) {
+                        unsigned h01, l01, h23, l23;
+                        split_pair(val[u].x, val[u].y, h01, l01);
+                        split_pair(val[u].z, val[u].w, h23, l23);
+                        *reinterpret_cast<uint2*>(gp) = make_uint2(h01, h23);
+                        *reinterpret_cast<uint2*>(gp + 64) = make_uint2(l01, l23);
+                    } else {
+                        *reinterpret_cast<float4*>(gp) = val[u];
+                    }
+                }
+                gp += gstep;
             }
         }
     }
@@ -934,6 +960,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     }
 #endif
     }       // 256-query blocks
+    }       // items
 #undef VRD_AQ
 #undef VRD_AO
 }
@@ -955,8 +982,14 @@ int launch_w64(const float* q, int64_t ldq, const float* k, const float* v, int6
 #else
     const size_t lds_launch = lds;
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_head * B), dim3(256), lds_launch, s, q, ldq, k, v, ldkv, kv_mask, q_mask, Tq, Tk,
-                       n_head * HD, scale * 1.44269504088896340736f, out, ldo, pair_out, q_blocks, n_head);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int n_items = n_head * B;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(n_items < n_cu ? n_items : n_cu)), dim3(256), lds_launch, s, q, ldq, k, v, ldkv, kv_mask, q_mask,
+                       Tq, Tk, n_head * HD, scale * 1.44269504088896340736f, out, ldo, pair_out, q_blocks, n_head, B);
     return 0;
 }
 
@@ -1004,12 +1037,15 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     // barrier for a tile.
     static const int nw_env = [] { const char* e = getenv("VRD_FLASH_NW"); return e ? atoi(e) : 0; }();
     const int nw = nw_env == 3 || nw_env == 4 ? nw_env : 4;
-    // 64 queries per wave, one wave per SIMD (attn_flash_x3_w64_kernel) once a (b, h) has more than 128 query rows: below
-    // that a 256-query workgroup would leave half of its waves without rows.  VRD_FLASH_W64=0 / 1 forces the choice.
-    const char* const w64_e = getenv("VRD_FLASH_W64");                  // (read per call: tests compare the two kernels in one process)
+    // 64 queries per wave, one wave per SIMD (attn_flash_x3_w64_kernel): head_dim 128 with at least one nearly full block of
+    // 256 query rows.  Measured per launch (scripts/flash_bench.py, MI355X): 4 heads x 128, 2048 sequences x 288 rows (256
+    // valid) 1.18 ms against 1.25-1.33 ms; at head_dim 64 the kernel has half the MFMAs per softmax instruction and loses
+    // (8 heads x 64, 512 x 512 rows: 1.10 against 0.95 ms), as it does with short sequences (192 rows: 0.39 against 0.36).
+    // VRD_FLASH_W64=0 / 1 forces the choice (read per call: tests compare the two kernels in one process).
+    const char* const w64_e = getenv("VRD_FLASH_W64");
     const int w64_env = w64_e ? atoi(w64_e) : -1;
     // (its LDS-DMA offsets are 32-bit: a batch element's K / V slab has to stay below 2 GiB)
-    const bool w64 = (w64_env >= 0 ? w64_env != 0 : Tq > 128) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31);
+    const bool w64 = (w64_env >= 0 ? w64_env != 0 : (head_dim == 128 && Tq >= 224)) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31);
     int rc;
     if (w64) rc = head_dim == 128 ? launch_w64<128>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
                                   : launch_w64<64>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
