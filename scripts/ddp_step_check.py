@@ -8,6 +8,8 @@ One-GPU rehearsal (ranks share the card, gradient all-reduce on gloo):
     BENCH_REHEARSAL=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
         --master-port 29513 scripts/ddp_step_check.py
 Multi-GPU node: drop BENCH_REHEARSAL (RCCL).  Launch from a shell (a process that has not touched the GPU).
+`--graphs`: additionally take three DDP steps with MaskVRD.enable_training_graphs() (forward / backward of the network as
+HIP-graph replays, vrdone_amd/train_graph.py) and compare their all-reduced gradients with the eager DDP step's.
 """
 import json
 import os
@@ -57,6 +59,20 @@ def main():
     ddp = DDP(model, device_ids=None if rehearsal else [dev_index], find_unused_parameters=False)
     loss = ddp(shard(rank))["total_loss"]
     loss.backward()
+    graph_worst = None
+    if "--graphs" in sys.argv:
+        # the same step with the network's forward / backward replayed from HIP graphs (MaskVRD.enable_training_graphs):
+        # the recording differentiates aliases of the parameters, the replaying autograd.Function hands the gradients to the
+        # real ones, so DDP's reducer hooks fire outside the graphs and all-reduce as in the eager step
+        eager = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        model.enable_training_graphs()
+        for _ in range(3):                           # the first of these records
+            model.zero_grad(set_to_none=True)
+            ddp(shard(rank))["total_loss"].backward()
+        from vrdone_amd import train_graph
+        assert len(train_graph.recordings(model)) == 1
+        graph_worst = max(float((p.grad - eager[n]).norm()) / (float(eager[n].norm()) + 1e-4 * max(float(g.norm()) for g in eager.values()))
+                          for n, p in model.named_parameters())
     worst, missing = 0.0, []
     scale = max(float(g.norm()) for g in want.values())
     for n, p in model.named_parameters():
@@ -65,14 +81,15 @@ def main():
             continue
         worst = max(worst, float((p.grad - want[n]).norm()) / (float(want[n].norm()) + 1e-4 * scale))
     flags = [None] * world
-    dist.all_gather_object(flags, (worst, missing))
+    dist.all_gather_object(flags, (worst, missing, graph_worst))
     if rank == 0:
         print(json.dumps({"check": "DDP-averaged gradients == gradient of the mean shard loss; every parameter used",
                           "world_size": world, "backend": dist.get_backend(), "rehearsal_on_one_gpu": rehearsal,
                           "worst_relative_gradient_error_per_rank": [f[0] for f in flags],
-                          "parameters_without_gradient": [f[1] for f in flags], "loss_rank0": float(loss.detach())}), flush=True)
+                          "parameters_without_gradient": [f[1] for f in flags], "loss_rank0": float(loss.detach()),
+                          "graph_replayed_ddp_step_vs_eager_ddp_step": [f[2] for f in flags]}), flush=True)
     dist.destroy_process_group()
-    if any(f[0] > 1e-4 or f[1] for f in flags):
+    if any(f[0] > 1e-4 or f[1] or (f[2] is not None and f[2] > 2e-4) for f in flags):
         sys.exit(1)
 
 

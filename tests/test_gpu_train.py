@@ -291,6 +291,42 @@ def test_device_assignment_equals_scipy():
             at += n
 
 
+def test_device_assignment_terminates_on_nan_and_infinite_costs():
+    """A diverged step hands the matcher NaN / infinite costs.  scipy's linear_sum_assignment raises ValueError on such a
+    matrix; vrd_assign has to come back (its augmenting search used to spin for ever there) with those pairs unassigned,
+    the pairs around them solved as usual."""
+    from scipy.optimize import linear_sum_assignment
+    from vrdone_amd import ops
+    g = torch.Generator().manual_seed(1)
+    Q, sizes = 9, [3, 4, 9, 2, 5, 1]
+    cost = torch.randn(sum(sizes), Q, generator=g)
+    first = [0, 3, 7, 16, 18, 23]
+    cost[first[1] + 2] = float("nan")                       # pair 1: one relation's whole row
+    cost[first[2]:first[2] + 9] = float("inf")              # pair 2: everything
+    cost[first[4] + 1, 3] = float("nan")                    # pair 4: a single entry (may or may not block the search)
+    got = ops.assign(cost.to(DEV), sizes)
+    torch.cuda.synchronize()                                # returns at all
+    got = got.cpu()
+    assert bool((got[first[1]:first[1] + 4] == -1).all()) and bool((got[first[2]:first[2] + 9] == -1).all())
+    for p in (0, 3, 5):
+        n, at = sizes[p], first[p]
+        rows, cols = linear_sum_assignment(cost[at:at + n].T.numpy())
+        want = torch.empty(n, dtype=torch.int32)
+        want[torch.as_tensor(cols)] = torch.as_tensor(rows, dtype=torch.int32)
+        assert torch.equal(got[at:at + n], want)
+    blk = got[first[4]:first[4] + 5]
+    assert bool((blk == -1).all()) or (len(set(blk.tolist())) == 5 and int(blk.min()) >= 0)
+    # the matcher's host form raises like scipy does
+    model, mc, _ = build()
+    lens, x, m, data = train_batch(mc, c_in(mc), device=DEV)
+    with torch.no_grad():
+        out = model.eval()._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
+        logits = out["pred_logits"].clone()
+        logits[1] = float("nan")
+        with pytest.raises(ValueError):
+            model.bipartite_match(logits, data["preds_list"], out["pred_masks"], data["masks_list"], data["segs_list"], out["output_mask"])
+
+
 def test_device_matching_gives_the_host_matchings():
     """MaskVRD.bipartite_match with the device assignment vs the scipy path on the training batch's predictions."""
     model, mc, _ = build()
@@ -369,6 +405,31 @@ def test_ema_update_is_one_launch_and_bit_identical():
     ema.set(model)
     for a, b in zip(ema.module.state_dict().values(), model.state_dict().values()):
         assert torch.equal(a, b)
+
+
+def test_ema_module_forward_follows_its_updates():
+    """The update kernel writes the averaged weights through raw pointers.  ops caches derived operands on the parameter
+    objects (split bf16 weights, packed k = 3 weights) keyed on their version counters: a forward of ema.module AFTER an
+    update has to see the new weights -- i.e. equal a fresh model loaded from ema.module.state_dict()."""
+    from vrdone_amd import synth
+    from vrdone_amd.ema import ModelEma
+    from vrdone_amd.models.maskvrd import MaskVRD
+    model, mc, _ = build()
+    ema = ModelEma(model, decay=0.5)
+    lens, x, m, _ = train_batch(mc, c_in(mc), device=DEV)
+    x, m = x.to(DEV), m.to(DEV)
+    with torch.no_grad():
+        before = ema.module._mask_vrd(x, m, with_aux=False)["pred_logits"].clone()      # fills the derived-operand caches
+        g = torch.Generator(device=DEV).manual_seed(5)
+        for p in model.parameters():
+            p.add_(torch.randn(p.shape, device=DEV, generator=g) * 0.05)
+        ema.update(model)
+        after = ema.module._mask_vrd(x, m, with_aux=False)["pred_logits"]
+        fresh = MaskVRD(mc, device=DEV).to(DEV).eval()
+        fresh.load_state_dict(ema.module.state_dict())
+        want = fresh._mask_vrd(x, m, with_aux=False)["pred_logits"]
+    assert float((after - before).abs().max()) > 1e-3          # the update is visible at all
+    assert torch.equal(after, want)
 
 
 def test_training_sample_from_annotation_files_takes_a_step(tmp_path):

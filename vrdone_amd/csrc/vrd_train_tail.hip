@@ -46,6 +46,14 @@ __global__ __launch_bounds__(64) void assign_kernel(const float* __restrict__ co
                 if (cur < minv[j]) minv[j] = cur, way[j] = j0;
                 if (minv[j] < delta) delta = minv[j], j1 = j;
             }
+            // No usable column: every remaining cost of the row is NaN or infinite (a diverged step).  `cur < minv[j]` is then
+            // never true, j1 stays 0 and -- column 0 being the row under assignment -- the search would spin for ever.  The
+            // pair's relations are marked unassigned (-1) instead; the host raises like scipy's linear_sum_assignment does on
+            // such a matrix (ops.assign / MaskVRD.bipartite_match).
+            if (j1 == 0 || !(delta < 1e300)) {
+                for (int r = 0; r < n; ++r) query_of[r0 + r] = -1;
+                return;
+            }
             for (int j = 0; j <= Q; ++j) {
                 if (used[j]) u[match[j]] += delta, v[j] -= delta;
                 else minv[j] -= delta;

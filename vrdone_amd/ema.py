@@ -63,6 +63,12 @@ class ModelEma(torch.nn.Module):
             _hip.check(_hip.lib.vrd_ema_update(t["ema"].data_ptr(), t["model"].data_ptr(), t["numel"].data_ptr(),
                                                t["chunk_tensor"].data_ptr(), t["chunk_index"].data_ptr(),
                                                t["chunk_tensor"].numel(), d32, om32, _stream()), "vrd_ema_update")
+            # The kernel wrote through raw pointers: tell autograd's version counters (the reference's ema_v.copy_() does).
+            # ops caches derived operands on parameters -- split bf16 hi / lo weights, packed k = 3 weights -- keyed on
+            # (data_ptr, _version); without the bump a forward of ema.module after an update would reuse stale ones.
+            for e, m in pairs:
+                if self._on_kernel(e, m):
+                    torch.autograd.graph.increment_version(e)
         for e, m in pairs:                     # whatever the kernel does not cover (other dtypes / devices): the reference's form
             if self._on_kernel(e, m):
                 continue

@@ -214,15 +214,21 @@ class MaskVRD(nn.Module):
                 cost = (self.cost_factor['cost_class'] * c_class + self.cost_factor['cost_mask'] * c_mask +
                         self.cost_factor['cost_dice'] * c_dice)
                 q_of = ops.assign(cost.contiguous(), sizes, tables).long()
+                # a pair whose costs are NaN / infinite comes back unassigned (-1).  The reference's scipy call raises there;
+                # this path never waits for the device, so it poisons the layer's losses instead (they are NaN anyway: the
+                # costs come from the same logits) and indexes with a valid query
+                failed = (q_of < 0).any()
+                q_of = q_of.clamp_min(0)
+            poison = torch.where(failed, torch.full((), float("nan"), device=dev), torch.zeros((), device=dev))
             terms = {}
             if "labels" in self.loss_types:
                 target = torch.zeros(logits.shape[:2], dtype=torch.int64, device=dev)
                 target[owner, q_of] = ids
-                terms["loss_class"] = self.loss_factor['loss_class'] * F.cross_entropy(logits.transpose(1, 2), target, weight)
+                terms["loss_class"] = self.loss_factor['loss_class'] * F.cross_entropy(logits.transpose(1, 2), target, weight) + poison
             if "masks" in self.loss_types:
                 focal, dice = losses.matched_losses(masks[owner, q_of], tgt_masks, num_masks, loss_mask, segs, scale_range)
-                terms["loss_mask"] = self.loss_factor['loss_mask'] * focal
-                terms["loss_dice"] = self.loss_factor['loss_dice'] * dice
+                terms["loss_mask"] = self.loss_factor['loss_mask'] * focal + poison
+                terms["loss_dice"] = self.loss_factor['loss_dice'] * dice + poison
             return terms
         names = {"labels": ["loss_class"], "masks": ["loss_mask", "loss_dice"]}
         keys = [k for name in self.loss_types for k in names[name]]          # the reference's order of terms
@@ -261,6 +267,8 @@ class MaskVRD(nn.Module):
             # every pair's assignment on the device (vrd_assign); one small copy brings the result back in the reference's
             # format: per pair (query indices ascending, the relation each one got)
             q_of = _ops().assign(cost.contiguous(), sizes).cpu().long()
+            if bool((q_of < 0).any()):          # NaN / infinite costs: scipy's linear_sum_assignment raises the same way
+                raise ValueError("matrix contains invalid numeric entries")
             for block in q_of.split(sizes):
                 rows, order = torch.sort(block)
                 indices.append((rows, order))

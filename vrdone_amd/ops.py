@@ -372,12 +372,15 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     no valid row ever reads a padded one: projections feeding masked attention, an MLP's hidden layer).
     row_scale (rows,): per-row factor on the branch term (stochastic depth, blocks.py:1107-1120); autograd path only.
     Under autograd (`recording`) the op runs as autograd.conv_gemm and returns a fresh tensor (`out` is ignored)."""
-    if _launch is None and not isinstance(x, Pair) and recording(x, weight, bias, scale, res, res2):
+    # row_scale (stochastic depth, sampled whenever the model trains) lives in the autograd form's epilogue: it goes there even
+    # when nothing of this call needs a gradient (a frozen sub-module under requires_grad_(False), reference blocks.py:1107-1120
+    # drops paths regardless)
+    if _launch is None and not isinstance(x, Pair) and (recording(x, weight, bias, scale, res, res2) or row_scale is not None):
         from . import autograd
         assert not out_pair
         return autograd.conv_gemm(x, weight, bias, act=act, row_mask=row_mask, scale=scale, row_scale=row_scale, res=res,
                                   res_masked=res_masked, res2=res2)
-    assert row_scale is None, "row_scale (drop-path sampling) exists on the autograd path only"
+    assert row_scale is None, "row_scale (drop-path sampling) exists for plain f32 rows only"
     N, Cin, k = weight.shape
     if _dgrad:          # the conv's input gradient: weight (Cin_of_x... = N_w, Cin_w, k) acts as the (Cin_w, N_w, k) flipped conv
         N, Cin = Cin, N

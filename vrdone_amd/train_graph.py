@@ -19,10 +19,16 @@ that node on the default stream, and an event wait on the default stream in the 
 The aliases have no autograd history, the graphs read and write the same memory, and the replaying Function hands the
 gradients to the real parameters.
 
-Limits: one backward per forward (parameter gradients come back in the recording's own buffers, as with
-make_graphed_callables); no DistributedDataParallel (its reducer hooks are not captured); the per-kernel profiler
-(`_hip.prof_*`) sees nothing inside a replay; at most `MAX_SHAPES` batch shapes are recorded per model, any further shape
-runs eagerly.
+DistributedDataParallel (how the reference's train.py:103-108 always wraps the model) works around it unchanged: the
+recording differentiates the aliases, so no reducer hook runs inside a capture, and the replaying Function's backward hands
+every gradient to the real parameters at once -- their AccumulateGrad hooks then fire outside the graphs and the reducer
+all-reduces its buckets as in an eager step (scripts/ddp_step_check.py --graphs: graph-replayed DDP steps on two ranks
+give the eager DDP step's averaged gradients, profiles/r03_ddp_graph_step_check.json).
+
+Limits: one backward per forward, and gradients are not accumulated across steps -- they come back in the recording's own
+buffers, which `.grad` then aliases (as with make_graphed_callables): call `zero_grad(set_to_none=True)` (torch's default)
+between steps; the per-kernel profiler (`_hip.prof_*`) sees nothing inside a replay; at most `MAX_SHAPES` batch shapes are
+recorded per model, any further shape runs eagerly.
 """
 import weakref
 
@@ -145,7 +151,14 @@ def mask_vrd(model, x, m):
     """`model._mask_vrd(x, m, with_aux=model.deep_supervision)` through the recorded graphs (recorded on the first use of a
     batch shape; that call replays them too and returns real predictions)."""
     graphs = _GRAPHS[model]["recordings"]
-    key = (tuple(x.shape), tuple(m.shape), bool(model.deep_supervision), ops.get_precision())
+    # everything that shapes the captured launch sequence besides the batch shape: precision mode, launch-wave size, the
+    # stochastic-depth probabilities and pinned keep vectors of every AffineDropPath, which parameters train
+    from .models.blocks import AffineDropPath
+    drops = tuple((mod.drop_prob, None if mod.keep is None else mod.keep.data_ptr()) for mod in model.modules()
+                  if isinstance(mod, AffineDropPath))
+    trainable = tuple(p.requires_grad for p in model.parameters())
+    key = (tuple(x.shape), tuple(m.shape), bool(model.deep_supervision), ops.get_precision(), int(model.pair_chunk), drops,
+           trainable)
     rec = graphs.get(key)
     if rec is not None and rec.storage != _storage_key(model):
         graphs.clear()                         # the parameters were replaced or moved: every recording is stale
