@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 18
+#define VRD_ABI_VERSION 19
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -391,6 +391,46 @@ int vrd_assign(const float* cost, int64_t ld, const int32_t* first, const int32_
  * is cut into chunks of 4096 elements: chunk c works on tensor chunk_tensor[c], elements chunk_index[c]*4096 ... */
 int vrd_ema_update(float* const* ema, const float* const* model, const int64_t* numel, const int32_t* chunk_tensor,
                    const int32_t* chunk_index, int n_chunks, float decay, float one_minus_decay, void* stream);
+
+/* ---- the training criterion for all decoder layers of a step --------------------------------------------
+ * Replaces the tensor code of models/maskvrd.py:417-496 (bipartite_match: the three cost matrices), :498-588 (loss_labels,
+ * loss_masks on the final head and the auxiliary heads) and models/losses.py:4-354 (masked focal / dice, plain and fuzzy
+ * targets).  Layer l's predictions: logits[l] (B, Q, K1), masks[l] (B, Q, T), contiguous f32.  Ground truth of the batch:
+ * G relations; owner[g] = pair of relation g; tgt_ids[g] its predicate class; tgt_masks (G, T) 0/1; out_valid (B, T) the
+ * pairs' valid frames; segs (G, 2) [start, end) frames -- non-null selects the fuzzy targets of losses.py:214-227 with
+ * scale_range.  alpha < 0 switches the focal weighting off, like the reference's. */
+typedef struct {
+    const float* logits[4];
+    const float* masks[4];
+    int32_t n_layers, B, Q, K1, T, G;
+    const uint8_t* out_valid;
+    const int64_t* tgt_ids;
+    const float* tgt_masks;
+    const int32_t* owner;
+    const int32_t* segs;
+    float scale_range, alpha, gamma;
+    float w_class, w_mask, w_dice;            /* cost weights (vrd_criterion_costs only) */
+} vrd_criterion_args;
+
+typedef struct {
+    float* logits[4];                         /* (B, Q, K1) each, every element written */
+    float* masks[4];                          /* (B, Q, T) each, every element written (0 on unmatched rows / padded frames) */
+} vrd_criterion_grads;
+
+/* cost (n_layers, G, Q): w_class * (-log softmax(logits_l[owner[g], q])[tgt_ids[g]]) + w_mask * focal cost + w_dice * dice cost
+ * of giving relation g to query q of its own pair (entry [owner[g]*Q + q, g] of the reference's matrices, maskvrd.py:447-481).
+ * Feed it to vrd_assign with the pair tables repeated per layer. */
+int vrd_criterion_costs(const vrd_criterion_args* a, float* cost, void* stream);
+/* out (n_layers, 4): [class-weighted cross-entropy over all (pair, query) rows (target = the matched relation's class, else 0;
+ * F.cross_entropy(..., weight=class_weight)), sum_g focal_g / num_masks, sum_g dice_g / num_masks, sum of the class weights
+ * (the backward's normaliser)] for query_of (n_layers, G) = the assignment (entries < 0 are read as query 0).  Sums run in a
+ * fixed order: the result does not depend on scheduling. */
+int vrd_criterion_losses(const vrd_criterion_args* a, const int32_t* query_of, const float* class_weight, float num_masks, float* out,
+                         void* stream);
+/* Gradients of sum_l (gout[l][0] * class_l + gout[l][1] * focal_l + gout[l][2] * dice_l) with respect to every layer's logits and
+ * masks; gout (n_layers, 3), fwd_out = vrd_criterion_losses' output for the same arguments. */
+int vrd_criterion_backward(const vrd_criterion_args* a, const int32_t* query_of, const float* class_weight, float num_masks,
+                           const float* fwd_out, const float* gout, const vrd_criterion_grads* grads, void* stream);
 
 /* The split-precision GEMMs' weight operand (vrd_gemm_args.W_split) from an f32 weight in ONE launch: logical matrix
  * W'[r][tap*Q + q] = src[r*sr + tap*st + q*sq]  (R rows, K = taps*Q columns, K % 32 == 0; strides in floats, may be negative)

@@ -327,6 +327,66 @@ def test_device_assignment_terminates_on_nan_and_infinite_costs():
             model.bipartite_match(logits, data["preds_list"], out["pred_masks"], data["masks_list"], data["segs_list"], out["output_mask"])
 
 
+@pytest.mark.parametrize("fuzzy", [False, True])
+@pytest.mark.parametrize("L,Q,K1,T", [(4, 9, 133, 96), (2, 10, 51, 200)])
+def test_fused_criterion_equals_the_tensor_form(fuzzy, L, Q, K1, T):
+    """csrc/vrd_criterion.hip (costs -> vrd_assign -> losses, and the gradient kernel) against the tensor code of
+    models/losses.py, which the reference goldens pin: same assignments as scipy on the tensor costs, same loss values, same
+    gradients with respect to every layer's logits and masks (hard and fuzzy targets, ragged valid lengths)."""
+    from scipy.optimize import linear_sum_assignment
+    from vrdone_amd.models import losses
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(7 + L + Q + int(fuzzy))
+    B = 7
+    sizes = [3, 1, 0, Q, 2, 4, 1]
+    G = sum(sizes)
+    lens = torch.tensor([T, T - 5, 40, T, 17, T // 2, 3])
+    valid = (torch.arange(T)[None] < lens[:, None])
+    owner = torch.repeat_interleave(torch.arange(B), torch.tensor(sizes))
+    ids = torch.randint(1, K1, (G,), generator=g)
+    segs = torch.zeros(G, 2, dtype=torch.int64)
+    tgt = torch.zeros(G, T)
+    for i in range(G):
+        n = int(lens[owner[i]])
+        a = int(torch.randint(0, max(n - 1, 1), (1,), generator=g))
+        b = int(torch.randint(a + 1, n + 1, (1,), generator=g))
+        segs[i] = torch.tensor([a, b])
+        tgt[i, a:b] = 1.0
+    weight = torch.ones(K1)
+    weight[0] = 0.1
+    cost_w = (2.0, 5.0, 5.0)
+    layers = [(torch.randn(B, Q, K1, generator=g).to(DEV).requires_grad_(True), (2.0 * torch.randn(B, Q, T, generator=g)).to(DEV).requires_grad_(True))
+              for _ in range(L)]
+    seg_d = segs.to(DEV) if fuzzy else None
+    vals, q_of, failed = losses.device_criterion(layers, valid.to(DEV), sizes, ids.to(DEV), tgt.to(DEV), seg_d, 0.85, weight, cost_w)
+    assert not bool(failed)
+    coef = torch.randn(L, 3, generator=g).to(DEV)
+    (vals * coef).sum().backward()
+    got_grads = [(lg.grad.clone(), mk.grad.clone()) for lg, mk in layers]
+    for l, (lg, mk) in enumerate(layers):
+        lg.grad = mk.grad = None
+        with torch.no_grad():
+            cc, cm, cd = losses.pair_costs(lg, mk, valid.to(DEV), ids.to(DEV), tgt.to(DEV), owner.to(DEV), seg_d, 0.85)
+            cost = (cost_w[0] * cc + cost_w[1] * cm + cost_w[2] * cd).cpu()
+        want_q = torch.empty(G, dtype=torch.int64)
+        at = 0
+        for n in sizes:
+            if n:
+                rows, cols = linear_sum_assignment(cost[at:at + n].T.numpy())
+                want_q[at + torch.as_tensor(cols)] = torch.as_tensor(rows)
+            at += n
+        assert torch.equal(q_of[l].cpu().long(), want_q), l
+        target = torch.zeros(B, Q, dtype=torch.int64, device=DEV)
+        target[owner.to(DEV), want_q.to(DEV)] = ids.to(DEV)
+        ce = F.cross_entropy(lg.transpose(1, 2), target, weight.to(DEV))
+        focal, dice = losses.matched_losses(mk[owner.to(DEV), want_q.to(DEV)], tgt.to(DEV), float(G), valid.to(DEV)[owner.to(DEV)], seg_d, 0.85)
+        want = torch.stack([ce, focal, dice])
+        assert float((vals[l] - want).detach().abs().max()) < 2e-6 * max(1.0, float(want.detach().abs().max())), (l, vals[l], want)
+        (want * coef[l]).sum().backward()
+        for a, b in zip(got_grads[l], (lg.grad, mk.grad)):
+            assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())) + 1e-7, l
+
+
 def test_device_matching_gives_the_host_matchings():
     """MaskVRD.bipartite_match with the device assignment vs the scipy path on the training batch's predictions."""
     model, mc, _ = build()

@@ -93,7 +93,8 @@ def test_ctypes_struct_layout_matches_header():
     """Field order of the ctypes mirrors vs the C structs in the header."""
     from vrdone_amd import _hip
     header = open(os.path.join(REPO, "include", "vrdone_hip.h")).read()
-    for cname, cls in (("vrd_gemm_args", _hip.GemmArgs), ("vrd_dwconv_ln_args", _hip.DwconvLnArgs)):
+    for cname, cls in (("vrd_gemm_args", _hip.GemmArgs), ("vrd_dwconv_ln_args", _hip.DwconvLnArgs),
+                       ("vrd_criterion_args", _hip.CriterionArgs), ("vrd_criterion_grads", _hip.CriterionGrads)):
         body = re.search(r"typedef struct \{([^}]*)\} " + cname, header).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

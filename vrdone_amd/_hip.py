@@ -24,6 +24,18 @@ c_u8p = C.c_void_p
 c_i32p = C.c_void_p
 
 
+class CriterionArgs(C.Structure):                     # vrd_criterion_args
+    _fields_ = [("logits", C.c_void_p * 4), ("masks", C.c_void_p * 4),
+                ("n_layers", C.c_int32), ("B", C.c_int32), ("Q", C.c_int32), ("K1", C.c_int32), ("T", C.c_int32), ("G", C.c_int32),
+                ("out_valid", C.c_void_p), ("tgt_ids", C.c_void_p), ("tgt_masks", C.c_void_p), ("owner", C.c_void_p),
+                ("segs", C.c_void_p), ("scale_range", C.c_float), ("alpha", C.c_float), ("gamma", C.c_float),
+                ("w_class", C.c_float), ("w_mask", C.c_float), ("w_dice", C.c_float)]
+
+
+class CriterionGrads(C.Structure):                    # vrd_criterion_grads
+    _fields_ = [("logits", C.c_void_p * 4), ("masks", C.c_void_p * 4)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("A", c_f32p), ("lda", C.c_int64), ("W", c_f32p), ("bias", c_f32p),
                 ("C", c_f32p), ("ldc", C.c_int64),
@@ -132,11 +144,14 @@ _SIGNATURES = {
     "vrd_bmm": (C.c_int, [C.POINTER(BmmArgs), C.c_void_p]),
     "vrd_assign": (C.c_int, [c_f32p, C.c_int64, c_i32p, c_i32p, C.c_int, C.c_int, c_i32p, C.c_void_p]),
     "vrd_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i32p, c_i32p, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "vrd_criterion_costs": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
+    "vrd_criterion_losses": (C.c_int, [C.c_void_p, c_i32p, c_f32p, C.c_float, c_f32p, C.c_void_p]),
+    "vrd_criterion_backward": (C.c_int, [C.c_void_p, c_i32p, c_f32p, C.c_float, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "vrd_maxpool_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p, C.c_int64,
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class HipLibraryError(RuntimeError):

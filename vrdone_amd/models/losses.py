@@ -7,7 +7,9 @@ block-diagonal is what is computed: a relation is priced against the Q queries o
 reference's names and argument meaning for callers that use them directly; all of them are thin wrappers around
 the three helpers below.  Tensors stay on the device of the predictions; arithmetic is fp32 like the reference.
 
-Forward values only: nothing here is differentiated (the HIP path has no backward kernels yet).
+`device_criterion` is the fused form the training step uses on the GPU: matching costs, assignment, losses and their
+gradients for all decoder layers as four kernel launches (csrc/vrd_criterion.hip, vrd_assign); the tensor functions above
+stay as its CPU / fallback form and as what the tests compare it with.
 """
 import math
 
@@ -163,3 +165,84 @@ def masked_sigmoid_focal_fuzzy_loss(inputs, targets, num_masks, loss_mask, tgt_s
 
 def masked_dice_fuzzy_loss(inputs, targets, num_masks, loss_mask, tgt_segs, scale_range: float = 0.8):
     return matched_losses(inputs, targets, num_masks, loss_mask, tgt_segs, scale_range)[1]
+
+
+# ------------------------------------------------------------------------------------- fused device criterion
+class _Criterion(torch.autograd.Function):
+    """(n_layers, 3) losses [class, focal, dice] of the given assignment; backward = vrd_criterion_backward."""
+
+    @staticmethod
+    def forward(ctx, pack, q_of, *preds):
+        from .. import _hip
+        from ..ops import _stream
+        args, keep, class_weight, num_masks = pack
+        L = args.n_layers
+        out = torch.empty(L, 4, device=q_of.device, dtype=torch.float32)
+        _hip.check(_hip.lib.vrd_criterion_losses(_hip.C.byref(args), q_of.data_ptr(), class_weight.data_ptr(), num_masks, out.data_ptr(),
+                                                 _stream()), "vrd_criterion_losses")
+        ctx.pack, ctx.shapes = pack, [p.shape for p in preds]
+        ctx.save_for_backward(q_of, out, *preds)
+        return out[:, :3].clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        from .. import _hip
+        from ..ops import _stream
+        args, keep, class_weight, num_masks = ctx.pack
+        q_of, out, *preds = ctx.saved_tensors
+        grads = [torch.empty_like(p) for p in preds]
+        gr = _hip.CriterionGrads()
+        L = args.n_layers
+        for l in range(L):
+            gr.logits[l], gr.masks[l] = grads[l].data_ptr(), grads[L + l].data_ptr()
+        gout = gout.contiguous().float()
+        _hip.check(_hip.lib.vrd_criterion_backward(_hip.C.byref(args), q_of.data_ptr(), class_weight.data_ptr(), num_masks, out.data_ptr(),
+                                                   gout.data_ptr(), _hip.C.byref(gr), _stream()), "vrd_criterion_backward")
+        return (None, None) + tuple(grads)
+
+
+def device_criterion(layers, out_valid, sizes, tgt_ids, tgt_masks, segs, scale_range, class_weight, cost_w, alpha=0.25, gamma=2.0):
+    """Matching + losses of up to four decoder layers on the device.
+    layers: [(pred_logits (B, Q, K1), pred_masks (B, Q, T))], final head first; out_valid (B, T) bool; sizes [N_p] relations
+    per pair; tgt_ids (G,) int64, tgt_masks (G, T) f32, segs (G, 2) or None (fuzzy targets with scale_range);
+    class_weight (K1,); cost_w = (w_class, w_mask, w_dice).
+    Returns (losses (n_layers, 3) [class, focal, dice] -- differentiable with respect to the predictions --,
+    query_of (n_layers, G) int32, failed: 0-d bool tensor, true when some pair's costs were NaN / infinite)."""
+    from .. import _hip, ops
+    from ..ops import _stream
+    L = len(layers)
+    assert 1 <= L <= 4
+    logits = [lg.contiguous().float() for lg, _ in layers]
+    masks = [mk.contiguous().float() for _, mk in layers]
+    B, Q, K1 = logits[0].shape
+    T = masks[0].shape[-1]
+    dev = logits[0].device
+    G = sum(sizes)
+    a = _hip.CriterionArgs()
+    for l in range(L):
+        assert logits[l].shape == (B, Q, K1) and masks[l].shape == (B, Q, T)
+        a.logits[l], a.masks[l] = logits[l].data_ptr(), masks[l].data_ptr()
+    valid_u8 = out_valid.contiguous().view(torch.uint8) if out_valid.dtype == torch.bool else out_valid.contiguous()
+    owner = torch.repeat_interleave(torch.arange(len(sizes), device=dev, dtype=torch.int32),
+                                    torch.tensor(sizes, device=dev), output_size=G)
+    tgt_ids = tgt_ids.contiguous().long()
+    tgt_masks = tgt_masks.contiguous().float()
+    segs32 = None if segs is None else segs.to(torch.int32).contiguous()
+    assert tgt_masks.shape == (G, T) and valid_u8.shape == (B, T)
+    a.n_layers, a.B, a.Q, a.K1, a.T, a.G = L, B, Q, K1, T, G
+    a.out_valid, a.tgt_ids, a.tgt_masks, a.owner = valid_u8.data_ptr(), tgt_ids.data_ptr(), tgt_masks.data_ptr(), owner.data_ptr()
+    a.segs = None if segs32 is None else segs32.data_ptr()
+    a.scale_range = float(scale_range) if segs32 is not None else 1.0
+    a.alpha, a.gamma = float(alpha), float(gamma)
+    a.w_class, a.w_mask, a.w_dice = (float(w) for w in cost_w)
+    keep = (valid_u8, owner, tgt_ids, tgt_masks, segs32, logits, masks)          # what the argument struct points into
+    with torch.no_grad():
+        cost = torch.empty(L, G, Q, device=dev, dtype=torch.float32)
+        _hip.check(_hip.lib.vrd_criterion_costs(_hip.C.byref(a), cost.data_ptr(), _stream()), "vrd_criterion_costs")
+        q_of = ops.assign(cost.view(L * G, Q), list(sizes) * L)                    # every layer's pairs in one launch
+        failed = (q_of < 0).any()
+    class_weight = class_weight.to(device=dev, dtype=torch.float32).contiguous()
+    num_masks = float(max(G, 1))
+    losses = _Criterion.apply((a, keep, class_weight, num_masks), q_of, *logits, *masks)
+    return losses, q_of.view(L, G), failed

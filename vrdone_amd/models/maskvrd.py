@@ -198,12 +198,30 @@ class MaskVRD(nn.Module):
         dev = pred_logits.device
         ops = _ops()
         G = sum(sizes)
-        owner = torch.repeat_interleave(torch.arange(len(sizes), device=dev), torch.tensor(sizes, device=dev), output_size=G)
-        tables = ops.assign_tables(sizes, dev)
         ids, tgt_masks = torch.cat(gt_preds, dim=0), torch.cat(gt_masks, dim=0)
         valid = out_mask[:, 0]
         assert tgt_masks.shape == (G, valid.shape[-1])
         segs, scale_range = self._fuzzy(gt_segs)
+        names = {"labels": ["loss_class"], "masks": ["loss_mask", "loss_dice"]}
+        keys = [k for name in self.loss_types for k in names[name]]          # the reference's order of terms
+        layers = [(pred_logits, pred_masks)] + [(aux['pred_logits'], aux['pred_masks']) for aux in (aux_outputs or [])]
+        if len(layers) <= 4:
+            # four launches for all layers: costs, assignment, losses (+ one for their gradients) -- csrc/vrd_criterion.hip
+            vals, _, failed = losses.device_criterion(layers, valid, sizes, ids, tgt_masks, segs, scale_range, self.empty_weight,
+                                                      (self.cost_factor['cost_class'], self.cost_factor['cost_mask'],
+                                                       self.cost_factor['cost_dice']))
+            # a pair whose costs are NaN / infinite comes back unassigned.  The reference's scipy call raises there; this path
+            # never waits for the device, so it poisons the losses instead (they are NaN anyway: same logits)
+            vals = vals + torch.where(failed, torch.full((), float("nan"), device=dev), torch.zeros((), device=dev))
+            factor = {"loss_class": self.loss_factor['loss_class'], "loss_mask": self.loss_factor['loss_mask'],
+                      "loss_dice": self.loss_factor['loss_dice']}
+            col = {"loss_class": 0, "loss_mask": 1, "loss_dice": 2}
+            out = {k: factor[k] * vals[0, col[k]] for k in keys}
+            for i in range(len(layers) - 1):
+                out.update({f"{k}_{i}": factor[k] * vals[i + 1, col[k]] for k in keys})
+            return out
+        owner = torch.repeat_interleave(torch.arange(len(sizes), device=dev), torch.tensor(sizes, device=dev), output_size=G)
+        tables = ops.assign_tables(sizes, dev)
         loss_mask = valid[owner]
         num_masks = float(max(G, 1))
         weight = self.empty_weight.to(dev)
@@ -214,9 +232,6 @@ class MaskVRD(nn.Module):
                 cost = (self.cost_factor['cost_class'] * c_class + self.cost_factor['cost_mask'] * c_mask +
                         self.cost_factor['cost_dice'] * c_dice)
                 q_of = ops.assign(cost.contiguous(), sizes, tables).long()
-                # a pair whose costs are NaN / infinite comes back unassigned (-1).  The reference's scipy call raises there;
-                # this path never waits for the device, so it poisons the layer's losses instead (they are NaN anyway: the
-                # costs come from the same logits) and indexes with a valid query
                 failed = (q_of < 0).any()
                 q_of = q_of.clamp_min(0)
             poison = torch.where(failed, torch.full((), float("nan"), device=dev), torch.zeros((), device=dev))
@@ -230,8 +245,6 @@ class MaskVRD(nn.Module):
                 terms["loss_mask"] = self.loss_factor['loss_mask'] * focal + poison
                 terms["loss_dice"] = self.loss_factor['loss_dice'] * dice + poison
             return terms
-        names = {"labels": ["loss_class"], "masks": ["loss_mask", "loss_dice"]}
-        keys = [k for name in self.loss_types for k in names[name]]          # the reference's order of terms
         terms = layer(pred_logits, pred_masks)
         out = {k: terms[k] for k in keys}
         for i, aux in enumerate(aux_outputs or []):
