@@ -405,6 +405,19 @@ def main():
                 times.append(time.perf_counter() - t0)
             return 1e3 * sorted(times[2:])[(n - 2) // 2], loss
         eager_ms, loss = fwd_bwd(5)
+        # launches of one eager forward + backward, by who issues them (torch.profiler; device events)
+        launches = None
+        try:
+            from torch.profiler import profile, ProfilerActivity
+            tmodel.zero_grad(set_to_none=True)
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as tp:
+                tmodel(tdata)["total_loss"].backward()
+                torch.cuda.synchronize()
+            dev_ev = [e for e in tp.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+            mine = sum("anonymous namespace" in e.name and "at::native" not in e.name for e in dev_ev)
+            launches = {"device_events": len(dev_ev), "library_kernels": mine, "aten_and_copies": len(dev_ev) - mine}
+        except Exception as exc:          # profiling is a report, never a reason to lose the line
+            launches = {"error": repr(exc)[:200]}
         n_grad = sum(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in tmodel.parameters() if p.requires_grad)
         n_par = sum(p.requires_grad for p in tmodel.parameters())
         tmodel.enable_training_graphs()                      # the network's forward / backward as two HIP-graph replays
@@ -413,10 +426,10 @@ def main():
         train = {"pairs": len(tdata["so_features_list"]), "t_pad": cfg["max_seq_len"], "ms_forward_backward": eager_ms,
                  "ms_forward_backward_hip_graphs": graph_ms,
                  "params_with_finite_grad": f"{n_grad}/{n_par}", "params_with_finite_grad_hip_graphs": f"{n_grad_g}/{n_par}",
-                 "total_loss": float(loss.detach()),
+                 "total_loss": float(loss.detach()), "launches_forward_backward": launches,
                  "note": "model.train(): forward_training + total_loss.backward() on the HIP backward kernels, stochastic depth on; "
                          "median after 2 warm-up steps; hip_graphs: MaskVRD.enable_training_graphs() (vrdone_amd/train_graph.py), "
-                         "batching / matching / losses still eager"}
+                         "batching eager, criterion = vrd_criterion_* (costs, assignment, losses, gradients: 4 launches for all layers)"}
         del tmodel, tdata
         model.eval()
 

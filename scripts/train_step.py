@@ -92,9 +92,10 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
         log["total_loss"].append(float(loss_dict["total_loss"].detach()))
         if verbose:
             print(f"step {step}: total_loss {log['total_loss'][-1]:.4f}  ({log['step_ms'][-1]:.1f} ms)", flush=True)
-    with torch.no_grad():
-        log["param_delta_norm"] = float(torch.sqrt(sum(((p - s) ** 2).sum() for p, s in zip(model.parameters(), start))))
-        log["ema_delta_norm"] = float(torch.sqrt(sum(((p - s) ** 2).sum() for p, s in zip(ema.module.parameters(), start))))
+    with torch.no_grad():          # (multi-tensor ops: a per-parameter expression here was 3 x 521 x 2 launches in the step profile)
+        for key, params in (("param_delta_norm", model.parameters()), ("ema_delta_norm", ema.module.parameters())):
+            norms = torch._foreach_norm(torch._foreach_sub([p.detach() for p in params], start))
+            log[key] = float(torch.linalg.vector_norm(torch.stack(norms)))
     return log
 
 
