@@ -5,6 +5,8 @@ whose helpers this reuses; nothing already committed is regenerated):
   forward_test_vidvrd_slices.json   forward_test on > 2 * max_so_pair pairs (3 slices of the reference's slice loop
                                     models/maskvrd.py:208-227, each padding its long pairs to its OWN longest)
   forward_test_vidor_x.json         forward_test under vidor_x.yaml (Q = 10, topk 6, feat_stride 4) with so_offset != 0
+  mask_vrd_vidvrd_cfg2.npz          (round 3, --only-cfg2) _mask_vrd on 1024 pairs x 128 frames (T_pad 144): BASELINE config 2 at
+                                    its size; logits / masks of every 64th pair
   mask_vrd_vidvrd_b256.npz          _mask_vrd on 256 pairs x T_pad 288 (the batch size that selects the 256 x 256 GEMM
                                     kernel and the padding maps); logits / masks of every 16th pair
 
@@ -29,6 +31,7 @@ torch.set_grad_enabled(False)
 SLICES = dict(n_tracklets=23, min_len=30, max_len=250, seed=2718, sort_by_length=True)
 VIDOR_X = dict(n_tracklets=5, min_len=150, max_len=800, seed=1618, feat_stride=4, random_offset=True)
 B256 = dict(B=256, T=288, seed=31415, every=16)
+CFG2 = dict(B=1024, T=144, frames=128, seed=27182, every=64)       # BASELINE config 2 at its size: 1024 pairs x 128 frames -> T_pad 144
 
 
 def digest(res, data):
@@ -44,6 +47,27 @@ def b256_lengths():
     lens = torch.randint(2, B256["T"] + 1, (B256["B"],), generator=g)
     lens[::16] = torch.tensor([288, 287, 256, 255, 200, 129, 97, 96, 64, 33, 32, 31, 17, 3, 2, 288])
     return lens.tolist()
+
+
+def cfg2_lengths():
+    lens = [CFG2["frames"]] * CFG2["B"]
+    for i, n in zip(range(0, CFG2["B"], CFG2["every"]), [128, 127, 144, 143, 97, 96, 65, 64, 33, 32, 2, 128, 100, 113, 129, 140]):
+        lens[i] = n
+    return lens
+
+
+def cfg2_case():
+    """BASELINE config 2 at its size (round 3): `_mask_vrd` of the reference on 1024 pairs x 128 frames, which its eval batching
+    pads to T_pad 144 (not a multiple of 32); logits / masks of every 64th pair (those carry the special lengths)."""
+    cfg, mc = load_cfg("vidvrd.yaml")
+    model, _, _ = build(mc)
+    t0 = time.time()
+    x, m = O.synth_pairs(CFG2["B"], c_in(mc), CFG2["T"], cfg2_lengths(), seed=CFG2["seed"])
+    out = model._mask_vrd(x, m)
+    e = CFG2["every"]
+    np.savez_compressed(os.path.join(OUT, "mask_vrd_vidvrd_cfg2.npz"), lengths=np.asarray(cfg2_lengths()),
+                        pred_logits=out["pred_logits"][::e].numpy(), pred_masks=out["pred_masks"][::e].numpy())
+    print("cfg2 case:", tuple(out["pred_logits"].shape), f"{time.time() - t0:.0f} s")
 
 
 def global_block_case():
@@ -257,6 +281,8 @@ def vidor_case():
 
 
 def main():
+    if "--only-cfg2" in sys.argv:
+        return cfg2_case()
     if "--only-vidor" in sys.argv:
         return vidor_case()
     if "--only-rel-pe" in sys.argv:

@@ -5,6 +5,14 @@ import torch
 SLICES = dict(n_tracklets=23, min_len=30, max_len=250, seed=2718, sort_by_length=True)
 VIDOR_X = dict(n_tracklets=5, min_len=150, max_len=800, seed=1618, feat_stride=4, random_offset=True)
 B256 = dict(B=256, T=288, seed=31415, every=16)
+CFG2 = dict(B=1024, T=144, frames=128, seed=27182, every=64)       # scripts/make_golden_r2.py --only-cfg2
+
+
+def cfg2_lengths():
+    lens = [CFG2["frames"]] * CFG2["B"]
+    for i, n in zip(range(0, CFG2["B"], CFG2["every"]), [128, 127, 144, 143, 97, 96, 65, 64, 33, 32, 2, 128, 100, 113, 129, 140]):
+        lens[i] = n
+    return lens
 
 
 def b256_lengths():
@@ -71,16 +79,21 @@ def replay_matching(model, recorded):
     return differing
 
 
-def compare_grads(named_grads, golden_npz, meta, case, rtol, atol_frac=1e-6, median_tol=None):
+def compare_grads(named_grads, golden_npz, meta, case, rtol, atol_frac=1e-6, median_tol=None, outlier_tol=None, max_outliers=3,
+                  outlier_scope=None):
     """Every parameter's gradient against the stored reference gradient: full tensor when it has <= 2048 elements, the
     stride-`sample_stride` sample otherwise; error measured relative to the l2 norm of the stored entries (plus
     atol_frac of the largest gradient norm of the model, for gradients that are ~0).  rtol bounds the worst parameter,
-    median_tol the median over parameters.  Returns (worst, median) relative error."""
+    median_tol the median over parameters; at most `max_outliers` parameters may exceed `outlier_tol` (the worst-case bound
+    has to leave room for a max-pool arg-max that flips on a rounding difference; this one keeps that room from hiding a
+    systematic error); `outlier_scope`: regular expression of the parameter names that count applies to (default: all).
+    Returns (worst, median) relative error."""
+    import re
     import numpy as np
     stride = meta["sample_stride"]
     stats = meta["cases"][case]["grad_stats"]
     biggest = max(s[2] for s in stats.values())
-    worst, worst_name, errs = 0.0, None, []
+    worst, worst_name, errs, outliers = 0.0, None, [], []
     for name, g in named_grads:
         assert g is not None, f"{name} received no gradient"
         g = g.detach().float().cpu()
@@ -90,6 +103,8 @@ def compare_grads(named_grads, golden_npz, meta, case, rtol, atol_frac=1e-6, med
         assert got.shape == want.shape, name
         err = float(np.linalg.norm(got.astype(np.float64) - want)) / (float(np.linalg.norm(want)) + atol_frac * biggest)
         errs.append(err)
+        if outlier_tol is not None and err > outlier_tol and (outlier_scope is None or re.match(outlier_scope, name)):
+            outliers.append((name, err))
         if err > worst:
             worst, worst_name = err, name
         # whole-tensor checksum: the l2 norm of the full gradient
@@ -98,6 +113,8 @@ def compare_grads(named_grads, golden_npz, meta, case, rtol, atol_frac=1e-6, med
     assert worst <= rtol, f"{worst_name}: relative gradient error {worst:.3e} > {rtol:.1e}"
     median = float(np.median(errs))
     assert median_tol is None or median <= median_tol, f"median relative gradient error {median:.3e} > {median_tol:.1e}"
+    assert len(outliers) <= max_outliers, (f"{len(outliers)} parameters exceed a relative gradient error of {outlier_tol:.1e} "
+                                           f"(allowed: {max_outliers}): {outliers[:8]}")
     return worst, median
 
 

@@ -202,6 +202,51 @@ def test_mask_vrd_b256_matches_reference_golden(precision):
         assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
 
 
+def test_mask_vrd_cfg2_at_size_matches_reference_golden(precision):
+    """BASELINE config 2 at its size: 1024 pairs x 128 frames, which the eval batching pads to T_pad 144 -- not a multiple of
+    32, so the last 32-row block of every pair straddles two sequences in the flat row space, the flash kernels see a
+    partial last key tile and the banded kernel a ragged last strip.  Every 64th pair against the REFERENCE's output for
+    the same batch; all pairs: finite, -10 on padded frames, independent of the batch composition (first 64 pairs alone)."""
+    from golden_cases import CFG2, cfg2_lengths
+    model, mc, _, _ = get_model("vidvrd")
+    g = np.load(os.path.join(GOLDEN, "mask_vrd_vidvrd_cfg2.npz"))
+    lens = cfg2_lengths()
+    x, m = O.synth_pairs(CFG2["B"], c_in(mc), CFG2["T"], lens, seed=CFG2["seed"])
+    x, m = x.to(DEV), m.to(DEV)
+    out = model._mask_vrd(x, m, with_aux=False)
+    e = CFG2["every"]
+    close(out["pred_logits"][::e], g["pred_logits"], LOGIT_TOL)
+    close(out["pred_masks"][::e], g["pred_masks"], MASK_TOL)
+    assert bool(torch.isfinite(out["pred_logits"]).all()) and bool(torch.isfinite(out["pred_masks"]).all())
+    assert bool((out["pred_masks"].transpose(1, 2)[~m[:, 0]] == -10.0).all())
+    part = model._mask_vrd(x[:64].contiguous(), m[:64].contiguous(), with_aux=False)
+    # (a 64-pair batch runs the small-tile GEMM kernels and the 32-query flash kernel: same products, other summation order)
+    assert float((part["pred_logits"] - out["pred_logits"][:64]).abs().max()) <= 5e-5
+    assert float((part["pred_masks"] - out["pred_masks"][:64]).abs().max()) <= 5e-4
+
+
+def test_sharded_forward_test_with_real_processes():
+    """Two fresh `torchrun` ranks (gloo, sharing the GPU) run scripts/sharded_eval_check.py: MaskVRD.shard_pairs() with the
+    REAL all-gather on device tensors against the single-process forward_test, every field on every rank.  The ranks are
+    child processes of this one (never an exec of a process that has touched the GPU)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, BENCH_REHEARSAL="1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VRDONE_PRECISION", None)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(repo, "scripts", "sharded_eval_check.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["world_size"] == 2 and line["equal_on_rank"] == [True, True] and line["triplets"] > 0
+
+
 @pytest.mark.parametrize("name,B,T,lens", [("vidvrd", 3, 96, [96, 50, 7]), ("vidvrd", 3, 288, [288, 201, 30]), ("vidor_x", 2, 128, [128, 77])])
 def test_absolute_position_encoding_matches_reference_golden(name, B, T, lens, precision):
     """`use_abs_pe: True` (no shipped config): position rows added in the last visual-embedding LayerNorm launch (CLIP variant:

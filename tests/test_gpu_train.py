@@ -135,6 +135,19 @@ def test_sos_decoder_layer_forward_backward_vs_oracle(precision):
     check_param_grads(layer, {k: v.grad for k, v in sd64.items()}, "sos.", tol)
 
 
+# Parameters whose gradient does not pass through a max-pool of the branch blocks on its way back from the loss.  Why the
+# "at most three parameters beyond 1e-3" bound of the pinned case is restricted to them: a max-pool arg-max between two frames
+# whose values differ by less than the forward's rounding error (~1e-6 relative) can resolve differently than in the reference,
+# which moves one element's gradient from one frame to another -- 1.7e-4 of the gradient arriving at branch.0's output -- and the
+# subject / object LayerNorms in front of the fusion MLP shrink the gradient norm 250-fold there (55 -> 0.22), so every parameter
+# further upstream sees that one flip at 1e-3 .. 6e-3.  Measured for the pinned case in f32 mode: sequence 21, frames 21 / 23,
+# branch.1's skip pool (scripts/dev/pinned_bisect4.py against float64 gradients of the reference at every block output;
+# branch.1 alone on the same tensors agrees with float64 autograd to 8e-7).  The reference's own f32 gradients sit 1e-6 from its
+# float64 ones, so the golden is exact at this level; which precision mode meets a flip on a given batch is chance (the bf16x3
+# mode does for other drop patterns).  The worst-case bound (3e-2) and the median bound stay on every parameter.
+POOL_FREE = r"(backbone\.branch\.[12]\.|neck\.|predictor\.)"
+
+
 @pytest.mark.parametrize("case", ["nodrop", "pinned"])
 def test_training_step_matches_reference_gradients(case, precision):
     """model.train()(batch) -> total_loss.backward() on the HIP path vs the reference's own training step."""
@@ -168,7 +181,8 @@ def test_training_step_matches_reference_gradients(case, precision):
     # replayed the losses agree to 1e-6, so a flipped assignment is a tie, not a different prediction
     assert all(len(call) <= 6 for call in differing), differing
     worst, median = compare_grads(((n, p.grad) for n, p in model.named_parameters()), g, meta, case,
-                                  rtol=3e-2, atol_frac=1e-4, median_tol=2e-5 if precision == "f32" else 5e-4)
+                                  rtol=3e-2, atol_frac=1e-4, median_tol=2e-5 if precision == "f32" else 5e-4, outlier_tol=1e-3,
+                                  max_outliers=3, outlier_scope=None if case == "nodrop" else POOL_FREE)
     print(f"[{case}/{precision}] relative gradient error: worst {worst:.2e}, median {median:.2e}")
 
 

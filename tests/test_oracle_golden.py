@@ -188,6 +188,21 @@ def test_mask_vrd_b256_matches_reference(weights):
     np.testing.assert_allclose(out["pred_masks"].numpy(), g["pred_masks"], atol=2e-4, rtol=0)
 
 
+def test_mask_vrd_cfg2_matches_reference(weights):
+    """BASELINE config 2 at its size: the reference ran 1024 pairs x 128 frames (T_pad 144); the oracle recomputes the 16
+    stored pairs (every 64th: the ones with the special lengths)."""
+    from golden_cases import CFG2, cfg2_lengths
+    mc, _, sd = weights("vidvrd")
+    g = np.load(os.path.join(GOLDEN, "mask_vrd_vidvrd_cfg2.npz"))
+    lens = cfg2_lengths()
+    assert g["lengths"].tolist() == lens
+    x, m = O.synth_pairs(CFG2["B"], c_in(mc), CFG2["T"], lens, seed=CFG2["seed"])
+    e = CFG2["every"]
+    out = O.mask_vrd(sd, mc, x[::e].contiguous(), m[::e].contiguous(), with_aux=False)
+    np.testing.assert_allclose(out["pred_logits"].numpy(), g["pred_logits"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["pred_masks"].numpy(), g["pred_masks"], atol=2e-4, rtol=0)
+
+
 def test_training_step_gradients_match_reference(weights):
     """One training step's losses and parameter gradients (reference forward_training + autograd, stochastic depth off,
     tests/golden/train_step_vidvrd.*) against autograd through the oracle's network and the product's criterion
