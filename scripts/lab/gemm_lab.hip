@@ -4,7 +4,7 @@
 #include "../../vrdone_amd/csrc/vrd_runtime.hip"
 #include "../../vrdone_amd/csrc/vrd_gemm_x3_dma.hip"
 #include "../../vrdone_amd/csrc/vrd_gemm_x3_big.hip"
-#include "../../vrdone_amd/csrc/vrd_gemm_x3_row.hip"
+#include "vrd_gemm_x3_row.hip"
 #include <algorithm>
 #include <vector>
 

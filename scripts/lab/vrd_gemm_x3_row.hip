@@ -1,5 +1,5 @@
 // Split-precision conv GEMM, 256 x 256 tile, ACTIVATIONS STRAIGHT INTO REGISTERS (see vrd_gemm_x3.hip for the arithmetic
-// and vrd_gemm_x3_big.hip for the kernel this one grew out of).  OPT-IN (VRD_BIG_ROW=1), k = 1 shapes with Cin % 128 == 0:
+// and vrd_gemm_x3_big.hip for the kernel this one grew out of).  LAB ONLY since round 3 (scripts/lab/gemm_lab.hip; it used to be an opt-in of the library, VRD_BIG_ROW=1), k = 1 shapes with Cin % 128 == 0:
 // a study of what the 256 x 256 kernel gains when half of its LDS-DMA traffic disappears; measured result at the end.
 //
 // What limits the 256 x 256 LDS-DMA kernel is the issue of its LDS-DMA instructions: a 1-KiB global_load_lds costs the CU
@@ -48,8 +48,8 @@
 // MFMA pipes to itself during those phases does not run its loop faster: 89 k cycles per 128 x 256 tile, two at a time, =
 // 0.798 ms against 0.727 ms of the LDS-DMA kernel and 0.771 ms of the 8-wave form; K = 2048: 0.630 / 0.650 / 0.644 ms.
 // Whole step 144.0 ms (LDS-DMA kernel 141.2, 8-wave form 141.9).  Bit-identical results (GPU suite green); stays opt-in.
-#include "vrd_common.h"
-#include "vrd_gemm_epilogue.h"
+#include "../../vrdone_amd/csrc/vrd_common.h"
+#include "../../vrdone_amd/csrc/vrd_gemm_epilogue.h"
 #include <cstdlib>
 #include <type_traits>
 

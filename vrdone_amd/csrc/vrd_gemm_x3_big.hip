@@ -446,14 +446,6 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
 
 namespace vrd {
 
-bool gemm_bf16x3_row_ok(const vrd_gemm_args& a);                                         // vrd_gemm_x3_row.hip
-int launch_gemm_bf16x3_row(const vrd_gemm_args* a, int count, hipStream_t s);
-// VRD_BIG_ROW=1: the activations-in-registers 256 x 256 kernel for the shapes it takes (K % 128 == 0)
-static bool use_row_kernel(const vrd_gemm_args& a) {
-    static const int row = [] { const char* e = getenv("VRD_BIG_ROW"); return e ? atoi(e) : 0; }();
-    return row && gemm_bf16x3_row_ok(a);
-}
-
 template <int TAPS, bool M16, bool PERSIST>
 static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch& bb = BigBatch{}, int count = 1) {
     auto kern = gemm_bf16x3_big_kernel<TAPS, M16, PERSIST>;
@@ -466,7 +458,6 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch&
 
 // `count` (2 .. 4) problems that differ only in A, W_split, bias and C, as one launch of the default kernel
 int launch_gemm_bf16x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
-    if (use_row_kernel(a[0])) return launch_gemm_bf16x3_row(a, count, s);
     BigBatch bb{};
     for (int i = 1; i < count; ++i) {
         bb.A[i - 1] = a[i].A;
@@ -494,7 +485,6 @@ int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s) {
     static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
     // VRD_BIG_PERSIST=1: one workgroup per CU walking its tiles, the next tile's first stage requested under the epilogue
     static const int persist = [] { const char* e = getenv("VRD_BIG_PERSIST"); return e ? atoi(e) : 0; }();
-    if (use_row_kernel(a)) return launch_gemm_bf16x3_row(&a, 1, s);
     if (m16) return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
     if (persist) return a.taps == 1 ? launch_big_one<1, false, true>(a, s) : launch_big_one<3, false, true>(a, s);
     return a.taps == 1 ? launch_big_one<1, false, false>(a, s) : launch_big_one<3, false, false>(a, s);

@@ -374,259 +374,10 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// Wave-specialised variant: the same 128 x 256 x 32 tile and 3-stage ring, but the 48 DMA instructions of a
-// stage are issued by a ninth wave instead of six by each MFMA wave.
-//
-// Why: the CU's address unit takes ~30 cycles per 1-KiB DMA instruction, so a stage costs ~1,500 cycles of
-// issue -- as much as its MFMAs.  When every wave issues its six DMAs ahead of its MFMAs, the waves queue up
-// behind that unit (measured: the first wave is through in ~400 cycles, the last in ~1,500), each then runs
-// its MFMAs, and the step ends at the slowest wave: issue time and MFMA time add.  Here the MFMA waves never
-// touch the address unit:
-//     producer (wave 8):   [wait: stage t landed] -> barrier t -> issue stage t+2 (buffer of stage t-1)
-//     consumers (0..7):                              barrier t -> ds_read + MFMA of stage t
-// The consumers finished reading stage t-1 before they arrived at barrier t, so its buffer is free after it;
-// stage t is visible to them because the only wave that issued it waited for it (counted vmcnt: the 48 newer
-// DMAs stay in flight) before the same barrier.  All nine waves execute nkt + 1 barriers.
-template <int TAPS, bool BLK, int NPROD, int NCONS>
-__global__ __launch_bounds__(64 * (NCONS + NPROD)) void gemm_bf16x3_ws_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
-    using G = Geo<32, 128, 3, BLK>;
-    // consumers: 2 (M) x NCONS/2 (N) waves, each 64 rows x NJ*32 columns
-    constexpr int CWN = NCONS / 2, NJ = (DBN / CWN) / 32, KSUB = 2;
-    static_assert(NCONS == 8 || NCONS == 4, "8 consumers of 64 x 64 or 4 of 64 x 128");
-    constexpr int ROWB = G::ROWB, A_PLANE = G::A_PLANE, W_PLANE = G::W_PLANE, STAGE = G::STAGE;
-    constexpr int A_INSTR = G::A_INSTR, W_INSTR = G::W_INSTR, NPL = G::NPL;
-    constexpr int NDMA = NPL * (A_INSTR + W_INSTR);           // 48 per stage
-    constexpr int PER = NDMA / NPROD;                         // DMA instructions per producer wave and stage
-    static_assert(NDMA % NPROD == 0 && PER <= 63, "a producer's share of a stage must fit the vmcnt counter");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-    LAB_MODE_DECL;
-    LAB_STAMP(0);
-    LAB_REAL(4);
-
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int64_t m0 = (int64_t)tm * 128;
-    const int n0 = tn * DBN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = p.Cin * TAPS;
-    const int nkt = K / 32;
-    const int PW = p.a_pair_width;
-
-    if (wave >= NCONS) {
-        // ------------------------------------------------------------------ producers
-        // flat list of a stage's DMA instructions: [planes x A row blocks | planes x W row blocks]; producer pw
-        // issues entries [pw * PER, (pw + 1) * PER)
-        const int pw = wave - NCONS;
-        // producers issue few instructions but each gates a kilobyte: let them win issue arbitration against
-        // the MFMA waves they share a SIMD with (the arbiter otherwise favours the older, always-ready waves)
-        __builtin_amdgcn_s_setprio(3);
-        const char* Whi = reinterpret_cast<const char*>(p.W_split);
-        const int rin = lane / G::CPR, pch = lane % G::CPR;
-        const char* zero_src = reinterpret_cast<const char*>(g_zero_block);
-        const int64_t wrow_bytes = BLK ? (int64_t)K * 4 : (int64_t)K * 2;
-        const int64_t wplane = BLK ? 0 : (int64_t)p.N * K * 2;
-        const bool w_ragged = n0 + DBN > p.N;
-        auto produce = [&](auto pw_c) {
-            constexpr int PWC = decltype(pw_c)::value;
-            constexpr int J0 = PWC * PER, J1 = J0 + PER;
-            constexpr int NA = NPL * A_INSTR;
-            // per-lane source rows of the A entries this producer owns
-            const char* arow[A_INSTR];
-            int tseq[A_INSTR], achunk[A_INSTR];
-#pragma unroll
-            for (int rb = 0; rb < A_INSTR; ++rb) {
-                bool mine = false;
-#pragma unroll
-                for (int pl = 0; pl < NPL; ++pl) mine |= (pl * A_INSTR + rb >= J0 && pl * A_INSTR + rb < J1);
-                if (!mine) continue;
-                int64_t r = (LAB_MODE(8) ? (m0 & 1023) : m0) + rb * G::RPI + rin;   // lab: every tile reads the same rows
-                if (r >= p.M) r = p.M - 1;
-                achunk[rb] = (pch ^ G::swz(rb * G::RPI + rin)) * 16;
-                arow[rb] = reinterpret_cast<const char*>(p.A + r * p.lda) + achunk[rb];
-                tseq[rb] = (TAPS == 3) ? (int)(r % p.T) : 0;
-            }
-            // ... and of the W entries (row pointers are per tile; a K step only adds a wave-uniform offset)
-            constexpr int NWMINE = (J1 > NA ? J1 - (J0 > NA ? J0 : NA) : 0);
-            const char* wrow[NWMINE > 0 ? NWMINE : 1];
-#pragma unroll
-            for (int j = (J0 > NA ? J0 : NA); j < J1; ++j) {
-                const int pl = (j - NA) / W_INSTR, rb = (j - NA) % W_INSTR;
-                int n = n0 + rb * G::RPI + rin;
-                if (w_ragged && n >= p.N) n = p.N - 1;
-                wrow[j - (J0 > NA ? J0 : NA)] = Whi + pl * wplane + (int64_t)n * wrow_bytes + (pch ^ G::swz(rb * G::RPI + rin)) * 16;
-            }
-            auto issue = [&](int kt) {
-                const int buf = kt % 3;
-                const int k0 = kt * 32;
-                int tap = 0, ci0 = k0;
-                if (TAPS == 3) {
-                    tap = (k0 >= p.Cin) + (k0 >= 2 * p.Cin);
-                    ci0 = k0 - tap * p.Cin;
-                }
-                const int slab = ci0 / PW;
-                const int64_t a_off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 +
-                                      (BLK ? (int64_t)ci0 * 4 : (int64_t)(2 * slab * PW + (ci0 - slab * PW)) * 2);
-                const int64_t w_off = BLK ? (int64_t)k0 * 4 : (int64_t)k0 * 2;
-                char* const sbase = lds + buf * STAGE;
-#pragma unroll
-                for (int j = J0; j < J1; ++j) {
-                    if (j < NA) {
-                        const int pl = j / A_INSTR, rb = j % A_INSTR;
-                        const char* src = arow[rb] + a_off + (pl ? (int64_t)PW * 2 : 0);
-                        if (TAPS == 3) {
-                            const int tt = tseq[rb] + tap - 1;
-                            if (tt < 0 || tt >= p.T) src = zero_src + achunk[rb];
-                        }
-                        if (!LAB_MODE(2)) __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(sbase + pl * A_PLANE + rb * 1024), 16, 0, 0);
-                    } else {
-                        const int pl = (j - NA) / W_INSTR, rb = (j - NA) % W_INSTR;
-                        const char* src = wrow[j - (J0 > NA ? J0 : NA)] + w_off;
-                        if (!LAB_MODE(4)) __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(sbase + NPL * A_PLANE + pl * W_PLANE + rb * 1024), 16, 0, 0);
-                    }
-                }
-            };
-            issue(0);
-            if (nkt > 1) issue(1);
-            LAB_STAMP(1);
-            LAB_PHASE_DECL;
-            for (int kt = 0; kt < nkt; ++kt) {
-                if (LAB_MODE(6)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // timing experiments only
-                else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                LAB_PHASE(0);
-                __builtin_amdgcn_s_barrier();
-                LAB_PHASE(1);
-                if (kt + 2 < nkt) issue(kt + 2);
-                LAB_PHASE(2);
-            }
-            if (PWC == NPROD - 1) LAB_PHASE_FLUSH2(1);
-            __builtin_amdgcn_s_barrier();
-        };
-        if (NPROD == 1 || pw == 0) produce(std::integral_constant<int, 0>{});
-        else if (NPROD >= 2 && pw == 1) produce(std::integral_constant<int, (NPROD >= 2 ? 1 : 0)>{});
-        else if (NPROD >= 3 && pw == 2) produce(std::integral_constant<int, (NPROD >= 3 ? 2 : 0)>{});
-        else if (NPROD >= 4) produce(std::integral_constant<int, (NPROD >= 4 ? 3 : 0)>{});
-        return;
-    }
-
-    // ---------------------------------------------------------------------- consumers
-    // Software-pipelined by half steps: while the MFMAs of one k16 half run, the fragments of the next half are
-    // on their way from LDS, so the only LDS latency a wave ever waits for is hidden behind 6*NJ MFMAs:
-    //     [frags(t, s=0) ready]  read frags(t, s=1) | MFMA(t, 0) | lgkmcnt(0) | barrier t+1 |
-    //                            read frags(t+1, s=0) | MFMA(t, 1)
-    // The lgkmcnt(0) ahead of barrier t+1 retires this wave's last reads of stage t, which is what lets the
-    // producers refill that buffer after the barrier.
-    const int wm = wave / CWN, wn = wave % CWN;
-    const int li = lane & 31, lh = lane >> 5;
-    constexpr int LO_A = BLK ? 0 : A_PLANE, LO_W = BLK ? 0 : W_PLANE, LO_CH = BLK ? 4 : 0;
-    int a_rd[2][KSUB], w_rd[NJ][KSUB], a_rl[2][KSUB], w_rl[NJ][KSUB];
-#pragma unroll
-    for (int s = 0; s < KSUB; ++s) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int ra = wm * 64 + t * 32 + li;
-            a_rd[t][s] = ra * ROWB + (((2 * s + lh) ^ G::swz(ra)) * 16);
-            a_rl[t][s] = LO_A + ra * ROWB + (((LO_CH + 2 * s + lh) ^ G::swz(ra)) * 16);
-        }
-#pragma unroll
-        for (int t = 0; t < NJ; ++t) {
-            const int rw = wn * (32 * NJ) + t * 32 + li;
-            w_rd[t][s] = NPL * A_PLANE + rw * ROWB + (((2 * s + lh) ^ G::swz(rw)) * 16);
-            w_rl[t][s] = NPL * A_PLANE + LO_W + rw * ROWB + (((LO_CH + 2 * s + lh) ^ G::swz(rw)) * 16);
-        }
-    }
-    f32x16 acc[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    struct Frags {
-        bf16x8 ah[2], al[2], wh[NJ], wl[NJ];
-    };
-    auto load = [&](Frags& f, const char* st, int s) {
-        if (LAB_MODE(16)) {                 // lab: no LDS reads (fragments are whatever the registers hold)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(f.ah[t]), "+v"(f.al[t]));
-#pragma unroll
-            for (int t = 0; t < NJ; ++t) asm volatile("" : "+v"(f.wh[t]), "+v"(f.wl[t]));
-            return;
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f.ah[t] = *reinterpret_cast<const bf16x8*>(st + a_rd[t][s]);
-            f.al[t] = *reinterpret_cast<const bf16x8*>(st + a_rl[t][s]);
-        }
-#pragma unroll
-        for (int t = 0; t < NJ; ++t) {
-            f.wh[t] = *reinterpret_cast<const bf16x8*>(st + w_rd[t][s]);
-            f.wl[t] = *reinterpret_cast<const bf16x8*>(st + w_rl[t][s]);
-        }
-    };
-    auto mfma = [&](const Frags& f) {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < NJ; ++nj) {
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.wh[nj], acc[mi][nj], 0, 0, 0);
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.wl[nj], acc[mi][nj], 0, 0, 0);
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.wh[nj], acc[mi][nj], 0, 0, 0);
-            }
-    };
-    LAB_STAMP(1);
-    Frags f0, f1;
-    __builtin_amdgcn_s_barrier();                                  // stage 0 is visible
-    load(f0, lds, 0);
-    LAB_PHASE_DECL;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const char* st = lds + (kt % 3) * STAGE;
-        load(f1, st, 1);
-        if (!LAB_MODE(1)) mfma(f0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave is done reading stage kt
-        __builtin_amdgcn_sched_barrier(0);
 #ifdef VRD_LAB_STAMP
-        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][NJ - 1][15]));
+// (lab builds only: the wave-specialised schedule of the study in LABNOTES.md, measured and not kept)
+#include "../../scripts/lab/vrd_gemm_x3_ws.inc"
 #endif
-        LAB_PHASE(0);
-        if (kt + 1 < nkt) {
-            __builtin_amdgcn_s_barrier();                          // stage kt+1 is visible
-            LAB_PHASE(1);
-            __builtin_amdgcn_sched_barrier(0);
-            load(f0, lds + ((kt + 1) % 3) * STAGE, 0);
-        }
-        if (!LAB_MODE(1)) mfma(f1);
-#ifdef VRD_LAB_STAMP
-        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][NJ - 1][15]));
-#endif
-        LAB_PHASE(2);
-    }
-    if (wave == 0) LAB_PHASE_FLUSH2(0);
-    // every consumer must be done with the ring before it is reused as epilogue staging
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    LAB_STAMP(2);
-#pragma unroll
-    for (int hn = 0; hn < NJ / 2; ++hn) {
-        f32x16 part[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) part[i][j] = acc[i][2 * hn + j];
-        vrd::gemm_epilogue<true, 64>(p, part, smem, m0 + wm * 64, n0 + wn * (32 * NJ) + hn * 64, wave, lane);
-    }
-    LAB_STAMP(3);
-    LAB_REAL(5);
-}
-
 }  // namespace
 
 namespace vrd {
@@ -642,6 +393,7 @@ static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
     return 0;
 }
 
+#ifdef VRD_LAB_STAMP
 template <int TAPS, bool BLK, int NPROD, int NCONS = 8>
 static int launch_ws_one(const vrd_gemm_args& a, hipStream_t s) {
     auto kern = gemm_bf16x3_ws_kernel<TAPS, BLK, NPROD, NCONS>;
@@ -651,6 +403,8 @@ static int launch_ws_one(const vrd_gemm_args& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(64 * (NCONS + NPROD)), lds, s, a, tiles_m, tiles_n);
     return 0;
 }
+
+#endif
 
 // eligibility: pair-row A whose slab width and Cin are multiples of 32, 16-byte aligned output rows
 bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged) {

@@ -23,7 +23,9 @@ static double g_ms[VRD_K_COUNT], g_flops[VRD_K_COUNT], g_bytes[VRD_K_COUNT];
 static int64_t g_launches[VRD_K_COUNT];
 static double g_skipped[VRD_K_COUNT];        // launched-but-skipped FLOPs (padding maps), folded in by drain()
 double take_big_skipped_flops();             // vrd_gemm_x3_big.hip
-double take_row_skipped_flops();             // vrd_gemm_x3_row.hip
+#ifdef VRD_LAB_STAMP
+double take_row_skipped_flops();             // scripts/lab/vrd_gemm_x3_row.hip (lab harness only)
+#endif
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -96,7 +98,10 @@ static void drain() {
         g_free_events.push_back(r.e1);
     }
     g_recs.clear();
-    g_skipped[VRD_K_GEMM_X3_BIG] += take_big_skipped_flops() + take_row_skipped_flops();     // synchronous copy: every launch above has finished
+    g_skipped[VRD_K_GEMM_X3_BIG] += take_big_skipped_flops();     // synchronous copy: every launch above has finished
+#ifdef VRD_LAB_STAMP
+    g_skipped[VRD_K_GEMM_X3_BIG] += take_row_skipped_flops();
+#endif
 }
 
 }  // namespace vrd
