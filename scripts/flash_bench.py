@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--hd", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--pair", action="store_true", help="pair-row output (what the model asks for)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     ops.set_precision("bf16x3")
@@ -42,18 +43,20 @@ def main():
         for name, flag in (("w32 (2 waves/SIMD)", "0"), ("w64 (1 wave/SIMD)", "1"), ("w32 again", "0"), ("w64 again", "1")):
             os.environ["VRD_FLASH_W64"] = flag
             for _ in range(3):
-                out = ops.attention(q, k, v, mask, a.heads, pair=False, q_mask=mask)
+                out = ops.attention(q, k, v, mask, a.heads, pair=a.pair, q_mask=mask)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.iters):
-                out = ops.attention(q, k, v, mask, a.heads, pair=False, q_mask=mask)
+                out = ops.attention(q, k, v, mask, a.heads, pair=a.pair, q_mask=mask)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             flops = 4.0 * a.B * a.heads * a.valid * a.valid * a.hd
             print(f"{name:22s} {ms:8.3f} ms / launch   {flops / ms / 1e9:7.1f} TFLOP/s executed", flush=True)
             res[flag] = out
+    if a.pair:
+        res = {k: v.float() for k, v in res.items()}
     d = (res["0"] - res["1"]).abs().max().item()
     print(f"max |w32 - w64| = {d:.3e}   (outputs are O(1))")
     # an f32 reference on a few sequences

@@ -35,7 +35,11 @@ int main(int argc, char** argv) {
         vrd_gemm_args a = {};
         a.A = A; a.lda = sh.Cin; a.W = nullptr; a.bias = bias; a.C = C; a.ldc = sh.N; a.M = sh.M; a.N = sh.N; a.Cin = sh.Cin;
         a.taps = sh.taps; a.T = T; a.act = 0; a.W_split = (const uint16_t*)W; a.a_pair_width = sh.Cin; a.c_pair = 0;
-        for (int var : {11, 12, 14}) {
+        // GEMM_LAB_VARS=11: only the product's 256 x 256 kernel (e.g. for the -DVRD_LAB_VALU=... synthetic-load builds)
+        const char* vars_env = getenv("GEMM_LAB_VARS");
+        std::vector<int> vars = {11, 12, 14};
+        if (vars_env) vars = {atoi(vars_env)};
+        for (int var : vars) {
             char env[8];
             snprintf(env, sizeof env, "%d", var);
             hipEvent_t e0, e1;

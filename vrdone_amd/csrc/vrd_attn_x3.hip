@@ -915,14 +915,46 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     // (wave-private slab: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt wait)
     // Rows leave in batches of eight wave instructions: the reads of a batch together, then its stores; the row pointer
     // advances by a constant (no 64-bit multiply per row), and the rows-inside-the-sequence test is per wave unless the
-    // wave's 64 rows straddle Tq.
-    {
+    // wave's 64 rows straddle Tq.  f32 output: a lane stores one 16-byte chunk (4 channels); pair-row output: a lane takes
+    // two chunks (8 channels) and stores 16 bytes of hi and 16 bytes of lo (8-byte stores run at ~0.6 of the 16-byte rate).
+    const bool all_rows = q0 + 64 <= Tq;                             // wave-uniform
+    if (pair_out) {
+        constexpr int LPR = CH / 2;                                  // lanes per row (16 or 8)
+        constexpr int ROWS_PI = 64 / LPR;                            // rows per wave instruction (4 or 8)
+        constexpr int NT = 64 / ROWS_PI, BATCH = 4;
+        const int rr = lane / LPR, cj = lane % LPR;                  // chunks 2 cj, 2 cj + 1 = channels 8 cj .. 8 cj + 7
+        char* gp = reinterpret_cast<char*>(out + ((int64_t)b * Tq + (q0 + rr < Tq ? q0 + rr : Tq - 1)) * ldo) +
+                   vrd::pair_index(h * HD + 8 * cj) * 2;
+        const int64_t gstep = ldo * 4 * ROWS_PI;
+#pragma unroll 1
+        for (int t0 = 0; t0 < NT; t0 += BATCH) {
+            float4 va[BATCH], vb[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int r = (t0 + u) * ROWS_PI + rr;
+                va[u] = *reinterpret_cast<const float4*>(slab + r * (HD * 4) + (((2 * cj) ^ (r & (CH - 1))) * 16));
+                vb[u] = *reinterpret_cast<const float4*>(slab + r * (HD * 4) + (((2 * cj + 1) ^ (r & (CH - 1))) * 16));
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int r = (t0 + u) * ROWS_PI + rr;
+                if (all_rows || q0 + r < Tq) {
+                    uint4 hi, lo;
+                    split_pair(va[u].x, va[u].y, hi.x, lo.x);
+                    split_pair(va[u].z, va[u].w, hi.y, lo.y);
+                    split_pair(vb[u].x, vb[u].y, hi.z, lo.z);
+                    split_pair(vb[u].z, vb[u].w, hi.w, lo.w);
+                    *reinterpret_cast<uint4*>(gp) = hi;
+                    *reinterpret_cast<uint4*>(gp + 64) = lo;
+                }
+                gp += gstep;
+            }
+        }
+    } else {
         constexpr int ROWS_PI = 64 / CH;                             // rows per wave instruction (2 or 4)
         constexpr int NT = 64 / ROWS_PI, BATCH = 8;
         const int rr = lane / CH, cj = lane % CH;
-        const bool all_rows = q0 + 64 <= Tq;                         // wave-uniform
-        char* gp = reinterpret_cast<char*>(out + ((int64_t)b * Tq + (q0 + rr < Tq ? q0 + rr : Tq - 1)) * ldo) +
-                   (pair_out ? vrd::pair_index(h * HD + 4 * cj) * 2 : (h * HD + 4 * cj) * 4);
+        char* gp = reinterpret_cast<char*>(out + ((int64_t)b * Tq + (q0 + rr < Tq ? q0 + rr : Tq - 1)) * ldo) + (h * HD + 4 * cj) * 4;
         const int64_t gstep = ldo * 4 * ROWS_PI;
 #pragma unroll 1
         for (int t0 = 0; t0 < NT; t0 += BATCH) {
@@ -935,17 +967,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const int r = (t0 + u) * ROWS_PI + rr;
-                if (all_rows || q0 + r < Tq) {
-                    if (pair_out) {
-                        unsigned h01, l01, h23, l23;
-                        split_pair(val[u].x, val[u].y, h01, l01);
-                        split_pair(val[u].z, val[u].w, h23, l23);
-                        *reinterpret_cast<uint2*>(gp) = make_uint2(h01, h23);
-                        *reinterpret_cast<uint2*>(gp + 64) = make_uint2(l01, l23);
-                    } else {
-                        *reinterpret_cast<float4*>(gp) = val[u];
-                    }
-                }
+                if (all_rows || q0 + r < Tq) *reinterpret_cast<float4*>(gp) = val[u];
                 gp += gstep;
             }
         }

@@ -351,6 +351,26 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if defined(VRD_LAB_STAMP) && defined(VRD_LAB_VALU)
+            // lab only (round 3, LABNOTES.md "producing the q / k / v operands inside the projection GEMM"): what the K loop
+            // pays for VRD_LAB_VALU extra vector instructions (and VRD_LAB_LDSR extra 16-byte LDS reads) per wave and K step,
+            // an eighth of them behind each MFMA group -- the in-loop LayerNorm -> depthwise conv -> LayerNorm -> hi / lo split
+            // of a fused attention-input stage would need ~210 + ~36 per K step
+            {
+                static_assert(VRD_LAB_VALU % 8 == 0 && VRD_LAB_LDSR % 8 == 0, "per group");
+                float d0 = acc[0][0][0] * 0.f + 1.f, d1 = 2.f, d2 = 3.f, d3 = 4.f;
+#pragma unroll
+                for (int i = 0; i < VRD_LAB_VALU / 8 / 4; ++i)
+                    asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %2, %2, %3, %0\n\tv_fma_f32 %3, %3, %0, %1"
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+#pragma unroll
+                for (int i = 0; i < VRD_LAB_LDSR / 8; ++i) {
+                    vrd::f32x4_t t = *reinterpret_cast<const vrd::f32x4_t*>(sa + ((a_base + i * 2048) & (A_STAGE - 16)));
+                    asm volatile("" ::"v"(t));
+                }
+                asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
+            }
+#endif
             a_cur = a_nxt;
             if ((!M16 && g == 3) || g == 7) w_cur = w_nxt;
             if (g == 6 && !last) {
