@@ -431,6 +431,20 @@ def main():
                          "median after 2 warm-up steps; hip_graphs: MaskVRD.enable_training_graphs() (vrdone_amd/train_graph.py), "
                          "batching eager, criterion = vrd_criterion_* (costs, assignment, losses, gradients: 4 launches for all layers)"}
         del tmodel, tdata
+        # ... and at the largest shipped training shape: configs/vidor.yaml, 48 pairs x 512 frames x 8 heads (eager)
+        try:
+            torch.cuda.empty_cache()
+            vcfg = configs.model_config("vidor")
+            tmodel = synth.load_synthetic_weights(MaskVRD(vcfg, device=dev)).to(dev).train()
+            tdata = synthetic_batch(vcfg, configs.input_channels(vcfg), dev, n_pairs=48, seed=0)
+            v_ms, v_loss = fwd_bwd(5)
+            train["vidor_48x512"] = {"pairs": 48, "t_pad": vcfg["max_seq_len"], "ms_forward_backward": v_ms,
+                                     "total_loss": float(v_loss.detach()),
+                                     "note": "attention backward as five matrix-core products (vrd_bmm) + a softmax / dS row kernel"}
+            del tmodel, tdata
+        except Exception as exc:
+            train["vidor_48x512"] = {"error": repr(exc)[:200]}
+        torch.cuda.empty_cache()
         model.eval()
 
     if rank == 0:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 19
+#define VRD_ABI_VERSION 20
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -360,9 +360,15 @@ int vrd_local_attn_bwd(const float* q, const float* k, const float* v, int64_t l
 int vrd_attn_bwd_probs(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* dO, int64_t lddo,
                        const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim, float* P, float* dS, void* stream);
 
+/* Second half of the same on matrices (long sequences; round 3): with P = head_dim^-0.5 * Q K^T and dS = dO V^T already formed by
+ * two vrd_bmm products (both (B, n_head, Tq, Tk)), turn them in place into P = softmax_j(P | kv_mask) (masked keys: 0) and
+ * dS = P * (dS - sum_j P dS).  Tk <= 1024. */
+int vrd_attn_bwd_softmax(float* P, float* dS, const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, void* stream);
+
 /* Strided batched matmul, f32: C[z][i][n] (= or +=) alpha * sum_k A[z][i][k] * B[z][k][n], z = (z0 < Z0, z1 < Z1); every
  * operand is addressed by (stride of z0, stride of z1, stride of its row index, stride of its column index) in floats.
- * Fastest when B and C are contiguous along n. */
+ * Products of at least 32 x 32 x 16 run as 64 x 64 tiles on the matrix cores (exact f32 MFMA, k ascending per output); smaller
+ * ones one thread per output (fastest when B and C are contiguous along n). */
 typedef struct {
     const float* A;  int64_t a_z0, a_z1, a_row, a_col;
     const float* B;  int64_t b_z0, b_z1, b_row, b_col;

@@ -53,10 +53,10 @@ def synthetic_batch(cfg, c_in, device, n_pairs=24, seed=0):
 
 
 def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, ema_decay=0.999, verbose=True, drop_path=True,
-        graphs=False):
-    from vrdone_amd import configs, synth
+        graphs=False, config="vidvrd", n_pairs=24, profile=False):
+    from vrdone_amd import _hip, configs, synth
     from vrdone_amd.models.maskvrd import MaskVRD
-    cfg = configs.model_config("vidvrd")
+    cfg = configs.model_config(config)
     torch.manual_seed(seed)
     model = synth.load_synthetic_weights(MaskVRD(cfg, device=device)).to(device).train()
     if not drop_path:
@@ -69,10 +69,13 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
     from vrdone_amd.ema import ModelEma
     ema = ModelEma(model, decay=ema_decay)                                # one-launch EMA (vrd_ema_update), same values
     opt = torch.optim.AdamW(param_groups(model, weight_decay), lr=lr)
-    data = synthetic_batch(cfg, configs.input_channels(cfg), device, seed=seed)
+    data = synthetic_batch(cfg, configs.input_channels(cfg), device, n_pairs=n_pairs, seed=seed)
     start = [p.detach().clone() for p in model.parameters()]
     log = {"total_loss": [], "step_ms": [], "params_without_grad": [], "nonfinite_grads": []}
     for step in range(steps):
+        if profile and step == steps - 1:                                 # per-kernel-family time of the last step (HIP events)
+            _hip.prof_enable(True)
+            _hip.prof_reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss_dict = model(data)                                           # train.py:182
@@ -92,6 +95,11 @@ def run(steps=3, seed=0, device="cuda", lr=1e-4, weight_decay=0.05, clip=1.0, em
         log["total_loss"].append(float(loss_dict["total_loss"].detach()))
         if verbose:
             print(f"step {step}: total_loss {log['total_loss'][-1]:.4f}  ({log['step_ms'][-1]:.1f} ms)", flush=True)
+    if profile:
+        prof = _hip.prof_read()
+        _hip.prof_enable(False)
+        log["kernel_ms_last_step"] = {k: round(v["ms"], 3) for k, v in prof.items() if v["launches"]}
+        log["kernel_launches_last_step"] = {k: v["launches"] for k, v in prof.items() if v["launches"]}
     with torch.no_grad():          # (multi-tensor ops: a per-parameter expression here was 3 x 521 x 2 launches in the step profile)
         for key, params in (("param_delta_norm", model.parameters()), ("ema_delta_norm", ema.module.parameters())):
             norms = torch._foreach_norm(torch._foreach_sub([p.detach() for p in params], start))
@@ -104,5 +112,8 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graphs", action="store_true", help="replay the network's forward / backward as HIP graphs")
+    ap.add_argument("--config", default="vidvrd", help="vidvrd (24 pairs x 96 frames) | vidor (48 pairs x 512 frames: --pairs 48)")
+    ap.add_argument("--pairs", type=int, default=24)
+    ap.add_argument("--profile", action="store_true", help="per-kernel-family HIP-event time of the last step")
     args = ap.parse_args()
-    print(json.dumps(run(steps=args.steps, seed=args.seed, graphs=args.graphs)))
+    print(json.dumps(run(steps=args.steps, seed=args.seed, graphs=args.graphs, config=args.config, n_pairs=args.pairs, profile=args.profile)))

@@ -144,6 +144,7 @@ _SIGNATURES = {
     "vrd_bmm": (C.c_int, [C.POINTER(BmmArgs), C.c_void_p]),
     "vrd_assign": (C.c_int, [c_f32p, C.c_int64, c_i32p, c_i32p, C.c_int, C.c_int, c_i32p, C.c_void_p]),
     "vrd_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i32p, c_i32p, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "vrd_attn_bwd_softmax": (C.c_int, [c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "vrd_criterion_costs": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
     "vrd_criterion_losses": (C.c_int, [C.c_void_p, c_i32p, c_f32p, C.c_float, c_f32p, C.c_void_p]),
     "vrd_criterion_backward": (C.c_int, [C.c_void_p, c_i32p, c_f32p, C.c_float, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
@@ -151,7 +152,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class HipLibraryError(RuntimeError):

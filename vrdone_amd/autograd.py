@@ -346,13 +346,20 @@ class Attention(Function):
         dev = q.device
         P = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)
         dS = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)
-        check(lib.vrd_attn_bwd_probs(q.data_ptr(), Cc, k.data_ptr(), v.data_ptr(), Cc, dO.data_ptr(), Cc,
-                                     _mask_ptr(ctx.kv_mask, B * Tk), B, Tq, Tk, H, hd, P.data_ptr(), dS.data_ptr(), _stream()),
-              "vrd_attn_bwd_probs")
         scale = hd ** -0.5
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         sc = (H * Tq * Tk, Tq * Tk)                   # z strides of P / dS
         row_q, row_k = (Tq * Cc, hd), (Tk * Cc, hd)   # z strides of (B, T, H*hd) operands
+        if Tq >= 32 and Tk >= 32:
+            # long sequences: scores and dP as matrix products on the matrix cores (vrd_bmm), then softmax / dS row by row
+            bmm(q, (*row_q, Cc, 1), k, (*row_k, 1, Cc), P, (*sc, Tk, 1), B, H, Tq, Tk, hd, alpha=scale)       # S = scale Q K^T
+            bmm(dO, (*row_q, Cc, 1), v, (*row_k, 1, Cc), dS, (*sc, Tk, 1), B, H, Tq, Tk, hd)                  # dP = dO V^T
+            check(lib.vrd_attn_bwd_softmax(P.data_ptr(), dS.data_ptr(), _mask_ptr(ctx.kv_mask, B * Tk), B, Tq, Tk, H, _stream()),
+                  "vrd_attn_bwd_softmax")
+        else:
+            check(lib.vrd_attn_bwd_probs(q.data_ptr(), Cc, k.data_ptr(), v.data_ptr(), Cc, dO.data_ptr(), Cc,
+                                         _mask_ptr(ctx.kv_mask, B * Tk), B, Tq, Tk, H, hd, P.data_ptr(), dS.data_ptr(), _stream()),
+                  "vrd_attn_bwd_probs")
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         # dq[b, i, h, :] = scale * sum_j dS[b,h,i,j] k[b,j,h,:]
         bmm(dS, (*sc, Tk, 1), k, (*row_k, Cc, 1), dq, (*row_q, Cc, 1), B, H, Tq, hd, Tk, alpha=scale)
         # dk[b, j, h, :] = scale * sum_i dS[b,h,i,j] q[b,i,h,:]

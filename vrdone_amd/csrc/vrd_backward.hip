@@ -22,6 +22,7 @@
 //  vrd_bmm             strided batched matmul (dq = dS K, dk = dS^T Q, dv = P^T dO; mask head)
 //  vrd_maxpool_bwd     MaxPool1d(3,2,1) * mask
 #include "vrd_common.h"
+#include <cstdlib>
 #include <cmath>
 
 namespace {
@@ -651,6 +652,161 @@ __global__ __launch_bounds__(256) void bmm_kernel(BmmArgs p) {
     *c = p.accumulate ? *c + p.alpha * s : p.alpha * s;
 }
 
+// The same product on the matrix cores, exact f32 (v_mfma_f32_32x32x2_f32: an fmaf chain per output, k ascending) -- round 3:
+// at vidor.yaml's training sizes (48 pairs x 512 frames x 8 heads) the three products of the attention backward were
+// 40 ms of a 150 ms step on the kernel above (one thread per output, every operand element re-read per thread).
+// Workgroup = 4 waves = a 64 x 64 tile of C, one 32 x 32 accumulator per wave; K steps of 16 through k-major LDS tiles
+// (a lane's operand of one MFMA is A[k][row] / B[k][col]: 32 consecutive floats per half-wave, conflict free).  An operand is
+// read along whichever of its two indices has stride 1 (four elements per thread and K step, 16-byte loads when the launch's
+// pointers and strides allow); anything goes through the scalar gather.  The next K step's elements are in registers while
+// the current one multiplies.
+typedef __attribute__((ext_vector_type(16))) float bmm_f32x16;
+constexpr int BM_T = 64, BM_K = 16, BM_LD = BM_T + 4;
+template <bool VEC>
+__global__ __launch_bounds__(256) void bmm_mfma_kernel(BmmArgs p) {
+    __shared__ float As[BM_K][BM_LD], Bs[BM_K][BM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int z = blockIdx.z, z0 = z / p.Z1, z1 = z - z0 * p.Z1;
+    const int i0 = blockIdx.y * BM_T, n0 = blockIdx.x * BM_T;
+    const float* A = p.A + z0 * p.a0 + z1 * p.a1;
+    const float* Bm = p.B + z0 * p.b0 + z1 * p.b1;
+    // staging roles: "along k" = thread (row t / 4, four consecutive k), "along the row" = thread (k t / 16, four consecutive rows)
+    const bool a_k = p.ak == 1, b_n = p.bn == 1;
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        if (a_k) {                    // A[i][k], k contiguous
+            const int r = tid >> 2, kq = (tid & 3) * 4;
+            const float* src = A + (int64_t)(i0 + r) * p.ai + (k0 + kq);
+            if (VEC && i0 + r < p.M && k0 + kq + 3 < p.K) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                ra[0] = t.x, ra[1] = t.y, ra[2] = t.z, ra[3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ra[u] = (i0 + r < p.M && k0 + kq + u < p.K) ? src[u] : 0.f;
+            }
+        } else {                      // rows contiguous (or a general stride): thread (k, four rows)
+            const int k = tid >> 4, rq = (tid & 15) * 4;
+            const float* src = A + (int64_t)(k0 + k) * p.ak + (int64_t)(i0 + rq) * p.ai;
+            if (VEC && p.ai == 1 && k0 + k < p.K && i0 + rq + 3 < p.M) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                ra[0] = t.x, ra[1] = t.y, ra[2] = t.z, ra[3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ra[u] = (k0 + k < p.K && i0 + rq + u < p.M) ? src[u * p.ai] : 0.f;
+            }
+        }
+        if (b_n) {                    // B[k][n], n contiguous: thread (k, four columns)
+            const int k = tid >> 4, cq = (tid & 15) * 4;
+            const float* src = Bm + (int64_t)(k0 + k) * p.bk + (n0 + cq);
+            if (VEC && k0 + k < p.K && n0 + cq + 3 < p.N) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                rb[0] = t.x, rb[1] = t.y, rb[2] = t.z, rb[3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rb[u] = (k0 + k < p.K && n0 + cq + u < p.N) ? src[u] : 0.f;
+            }
+        } else {                      // k contiguous (B given transposed) or general: thread (column, four k)
+            const int c = tid >> 2, kq = (tid & 3) * 4;
+            const float* src = Bm + (int64_t)(n0 + c) * p.bn + (int64_t)(k0 + kq) * p.bk;
+            if (VEC && p.bk == 1 && n0 + c < p.N && k0 + kq + 3 < p.K) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                rb[0] = t.x, rb[1] = t.y, rb[2] = t.z, rb[3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rb[u] = (n0 + c < p.N && k0 + kq + u < p.K) ? src[u * p.bk] : 0.f;
+            }
+        }
+    };
+    auto stage = [&]() {
+        if (a_k) {
+            const int r = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) As[kq + u][r] = ra[u];
+        } else {
+            const int k = tid >> 4, rq = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(&As[k][rq]) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+        }
+        if (b_n) {
+            const int k = tid >> 4, cq = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(&Bs[k][cq]) = make_float4(rb[0], rb[1], rb[2], rb[3]);
+        } else {
+            const int c = tid >> 2, kq = (tid & 3) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Bs[kq + u][c] = rb[u];
+        }
+    };
+    bmm_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    fetch(0);
+    for (int k0 = 0; k0 < p.K; k0 += BM_K) {
+        __syncthreads();                              // everybody is done reading the previous tiles
+        stage();
+        __syncthreads();
+        if (k0 + BM_K < p.K) fetch(k0 + BM_K);
+#pragma unroll
+        for (int kk = 0; kk < BM_K / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * kk + lh][wm * 32 + li], Bs[2 * kk + lh][wn * 32 + li], acc, 0, 0, 0);
+    }
+    // accumulator register e of lane (li, lh): row (e & 3) + 8 * (e >> 2) + 4 * lh, column li
+    float* C = p.C + z0 * p.c0 + z1 * p.c1;
+    const int n = n0 + wn * 32 + li;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int i = i0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (i < p.M && n < p.N) {
+            float* c = C + (int64_t)i * p.ci + (int64_t)n * p.cn;
+            *c = p.accumulate ? *c + p.alpha * acc[e] : p.alpha * acc[e];
+        }
+    }
+}
+
+// Global attention backward on matrices (round 3): S = scale * Q K^T and dP = dO V^T come from two vrd_bmm products; this
+// kernel turns a row of each into P = softmax_j(S | kv_mask (masked: 0)) and dS = P * (dP - sum_j P dP), in place.
+// One wave per (b, h, tq) row, lanes over the keys (Tk <= 1024: 16 per lane in registers).
+__global__ __launch_bounds__(256) void attn_bwd_softmax_kernel(float* __restrict__ P, float* __restrict__ dS, const uint8_t* __restrict__ kv_mask,
+                                                               int64_t rows, int Tq, int Tk, int H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= rows) return;
+    const int b = (int)(w / ((int64_t)Tq * H));
+    constexpr int NJ = AB_TK_MAX / 64;
+    float s[NJ], dp[NJ];
+    float* const Pr = P + w * Tk;
+    float* const dSr = dS + w * Tk;
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int j = lane + 64 * i;
+        s[i] = -INFINITY;
+        dp[i] = 0.f;
+        if (j >= Tk || (kv_mask && !kv_mask[(int64_t)b * Tk + j])) continue;
+        s[i] = Pr[j];
+        dp[i] = dSr[j];
+        m = fmaxf(m, s[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        s[i] = (m == -INFINITY || s[i] == -INFINITY) ? 0.f : __expf(s[i] - m);
+        den += s[i];
+    }
+    den = vrd::wave_sum(den);
+    const float inv = den > 0.f ? 1.0f / den : 0.f;
+    float dsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) { s[i] *= inv; dsum = fmaf(s[i], dp[i], dsum); }
+    dsum = vrd::wave_sum(dsum);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        const int j = lane + 64 * i;
+        if (j < Tk) { Pr[j] = s[i]; dSr[j] = s[i] * (dp[i] - dsum); }
+    }
+}
+
 // MaxPool1d(3, 2, 1)(x) * mask[::2] backward: dx[b, ti, c] = sum over the (1 or 2) windows holding ti in which ti is the
 // FIRST maximum (ATen's tie rule) of mask[2 to] * dy[b, to, c]
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
@@ -840,7 +996,32 @@ int vrd_bmm(const vrd_bmm_args* a, void* stream) {
     p.Z0 = a->Z0, p.Z1 = a->Z1, p.M = a->M, p.N = a->N, p.K = a->K, p.alpha = a->alpha, p.accumulate = a->accumulate;
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * a->Z0 * a->Z1 * (double)a->M * a->N * a->K, 0.0);
-    hipLaunchKernelGGL(bmm_kernel, dim3((a->N + 63) / 64, (a->M + 3) / 4, a->Z0 * a->Z1), dim3(256), 0, s, p);
+    // matrix-core tiles once a 64 x 64 tile is at least a quarter full and K fills an LDS step (the predictor's 9-query
+    // attention and the mask head's Q-row products stay on the one-thread-per-output kernel: a tile would be mostly padding)
+    static const int mfma_env = [] { const char* e = getenv("VRD_BMM_MFMA"); return e ? atoi(e) : 1; }();
+    if (mfma_env && a->M >= 32 && a->N >= 32 && a->K >= 16 && (a->M + 63) / 64 <= 65535) {
+        auto al = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; };
+        auto m4 = [](int64_t v) { return v % 4 == 0; };
+        // 16-byte loads: bases aligned and every stride that is not the unit one a multiple of 4 floats
+        const bool vec = al(a->A) && al(a->B) && m4(a->a_z0) && m4(a->a_z1) && m4(a->b_z0) && m4(a->b_z1) &&
+                         (a->a_col == 1 ? m4(a->a_row) : a->a_row == 1 && m4(a->a_col)) &&
+                         (a->b_col == 1 ? m4(a->b_row) : a->b_row == 1 && m4(a->b_col));
+        const dim3 grid((a->N + 63) / 64, (a->M + 63) / 64, a->Z0 * a->Z1);
+        if (vec) hipLaunchKernelGGL(bmm_mfma_kernel<true>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(bmm_mfma_kernel<false>, grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(bmm_kernel, dim3((a->N + 63) / 64, (a->M + 3) / 4, a->Z0 * a->Z1), dim3(256), 0, s, p);
+    }
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_attn_bwd_softmax(float* P, float* dS, const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, void* stream) {
+    VRD_CHECK_ARG(P && dS && B > 0 && Tq > 0 && Tk > 0 && Tk <= AB_TK_MAX && n_head > 0, "vrd_attn_bwd_softmax: bad arguments (Tk <= %d)", AB_TK_MAX);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)B * n_head * Tq;
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 16.0 * (double)n * Tk);
+    hipLaunchKernelGGL(attn_bwd_softmax_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, P, dS, kv_mask, n, Tq, Tk, n_head);
     VRD_LAUNCH_CHECK();
     return 0;
 }
