@@ -9,7 +9,7 @@
 #   kernel_src_sha.txt               hash of the kernel sources these were collected on (bench.kernel_source_sha)
 # rocprofv3 is always followed directly by `python3 bench.py ...` (no wrapper after `--`), counters in their own passes.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 MODES=${2:-both}
 SQ=${3:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -18,7 +18,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha())" > $OUT/kernel_src_sha.txt || exit 1
 echo "[collect] bench line" && timeout -k 10 500 python3 $R/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err || exit 1
-LEAN="--no-cpu-baseline --no-alt --no-ragged --no-forward-test --no-train-step"
+LEAN="--no-cpu-baseline --no-alt --no-ragged --no-forward-test --no-train-step --no-shard-projection"
 for MODE in bf16x3 f32; do
   if [ "$MODES" != both ] && [ "$MODES" != $MODE ]; then continue; fi
   SUF=""; [ $MODE = f32 ] && SUF="_f32"
