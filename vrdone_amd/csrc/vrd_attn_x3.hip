@@ -308,7 +308,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
 //     instead of three, and the two blocks' accumulation chains are independent;
 //   * software pipeline across key tiles: the S^T MFMAs of tile t+1 are issued between the softmax instructions of tile t
 //     (a wave issues in order: vector instructions only overlap ITS OWN MFMAs if they sit between them in program order,
-//     ~5 per 32-cycle MFMA), then the O^T MFMAs of tile t between the second half of the softmax and the next requests;
+//     ~19 cycles of them per 32-cycle MFMA: scripts/lab/mfma_gap.hip), then the O^T MFMAs of tile t between the second half
+//     of the softmax and the next requests; every softmax piece is one volatile asm statement, so it stays in its gap;
 //   * register file by hand: the Q^T fragments (a[0:127] at head_dim 128) and the O^T accumulators (a[128:255]) live in the
 //     accumulator half (an MFMA takes A / B / C / D from either half), scores, probabilities and K / V fragments in the
 //     architectural half.  The compiler cannot be talked into that split -- with "a" operand constraints it keeps the values
@@ -336,10 +337,6 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 #ifndef VRD_W64_THR
 #define VRD_W64_THR 16.0f
 #endif
-// (VRD_PIN(x): an empty volatile asm through which x passes.  Volatile asm statements keep their order, so nothing computed
-//  from x is placed above the MFMA statement in front of it: that is what holds a piece in its gap -- `sched_barrier`
-//  alone does not, pure arithmetic is hoisted across it before instruction scheduling runs.)
-#define VRD_PIN(x) asm volatile("" : "+v"(x))
 
 template <int I>
 using ic = std::integral_constant<int, I>;
@@ -358,11 +355,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 // The s_nop 1 in front: a vector write of the register needs two wait states before a permlane reads it.
 __device__ __forceinline__ void swap32(float& a, float& b) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ float xchg32_max(float v) {
-    float a = v, b = v;
-    swap32(a, b);               // a = lower half-row's value in both halves, b = the upper's
-    return fmaxf(a, b);
 }
 __device__ __forceinline__ float xchg32_sum(float v) {
     float a = v, b = v;
@@ -392,7 +384,8 @@ __device__ __forceinline__ void agpr_scale(float alpha) {
 // softmax state of one 32-query block while a tile is in the pipeline
 struct SmBlock {
     float x[16];                // scaled scores, then probabilities
-    float mx, mu, alpha, sum, pend;
+    float mx, mu, ae, alpha, sum;
+    float mr, lp;               // reference point of the exponentials so far (log2 units), running sum
     u32x4 ph[2], pl[2];         // P^T fragments: k16 step s -> hi / lo (bf16x8 as four dwords)
 };
 
@@ -412,6 +405,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     constexpr int NG_S = 6 * KS;                  // MFMAs (= gaps) of the S^T phase
     constexpr int NG_O = 12 * DT;                 // MFMAs of the O^T phase
     constexpr int HPG_S = 48 / NG_S, HPG_O = 48 / NG_O;       // softmax half-pieces per gap (1 or 2)
+    constexpr int LEAD = 4;                       // pieces of the S^T phase that run in front of its first MFMA
     // accumulator-half map: Q^T fragment (block qb, k16 step s): hi a[AQ .. AQ+3], lo a[AQ+4 .. AQ+7]; O^T accumulator
     // (block qb, d tile d): a[AO .. AO+15]
 #define VRD_AQ(qb, s) (8 * ((qb) * KS + (s)))
@@ -537,7 +531,8 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
         kbias[key] = ok ? 0.f : -INFINITY;
         const unsigned long long bal = __ballot(ok);
-        if ((lane & 31) == 0) tile_on[key >> 5] = ((bal >> (lane & 32)) & 0xffffffffull) != 0ull;
+        const unsigned bits = (unsigned)((bal >> (lane & 32)) & 0xffffffffull);
+        if ((lane & 31) == 0) tile_on[key >> 5] = bits == 0u ? 0 : (bits == 0xffffffffu ? 2 : 1);      // keys of the tile: none / some / all valid
     }
     __syncthreads();
     unsigned long long act = ~0ull;                      // rows of more than 64 tiles: every tile is visited
@@ -549,6 +544,8 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         return m ? (int)__builtin_ctzll(m) : nkt;
     };
     const int n_act = nkt <= 64 ? (int)__builtin_popcountll(act) : nkt;      // tiles that are visited
+    unsigned long long cln = 0ull;                       // tiles whose 32 keys are all valid (no key bias needed)
+    if (nkt <= 64) cln = __ballot(lane < nkt && tile_on[lane < nkt ? lane : 0] == 2);
 #if defined(VRD_W64_DBG) && (VRD_W64_DBG & 16)
     float* const stamps = reinterpret_cast<float*>(lds + NS * G::STAGE + 8192);      // LDS: no effect on the vmcnt counting
     int n_stamp = 0;
@@ -558,7 +555,6 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
 #define VRD_STAMP() do {} while (0)
 #endif
 
-    float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
 
     const int krow = li * G::ROWB;
     const int vq = (lane >> 2) & 3, vp = lane & 3;
@@ -594,87 +590,125 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         return f;
     };
 
-    // ---- the softmax of one tile as 2 x 48 half-pieces, run in the gaps between MFMAs (one per gap at head_dim 128, two at 64).
-    // S^T phase of the NEXT tile:   0..15 scale + bias + running maximum of score e; 16/17 exchange with the other half-row;
-    //                               18/19 new maximum and alpha; 20..35 exponentials of scores 0..7 (k16 step 0 of P^T);
-    //                               36..43 their hi / lo split.
-    // first half of the O^T phase:  0..15 exponentials of scores 8..15; 16..23 their split (k16 step 1, used by the second
-    //                               half of the phase); 24 the running sums.
-    float bias[16];
+    // ---- the softmax of one tile as 73 pieces, run in the gaps between the MFMAs (one per gap at head_dim 128, two at 64).
+    // What fits in a gap was measured (scripts/lab/mfma_gap.hip, one wave per SIMD, cycles per MFMA + k instructions):
+    //   independent v_fma_f32: 33 up to k = 3, 36 at 4, 38-47 at 5, then +5..8 each -- an MFMA costs its wave ~13 cycles of
+    //   issue, which leaves ~19 per 32-cycle MFMA;  a DEPENDENT chain costs 8 per instruction beyond three;  v_exp_f32
+    //   12 cycles, v_cvt_pk_bf16_f32 8, v_max3_f32 4;  v_pk_fma_f32 and v_dot2_f32_bf16 stall the MFMA pipe (51 / 54 cycles
+    //   with ONE of them in the gap): no packed f32 arithmetic here;  a ds_read next to an MFMA ~6.
+    // So a tile's softmax (~1.8 k cycles of vector issue for 32 scores per lane) fits under its 96 MFMAs only if every gap
+    // carries <= ~19 cycles of independent instructions.  Each piece is ONE volatile asm statement (volatile statements keep
+    // their order: as plain C++ the compiler moved the tails of pieces into lumps of 10-20 instructions and left other gaps
+    // empty), and the two blocks A / B alternate inside a piece so that no instruction reads its predecessor's result.
+    //   S^T phase (pieces 0..47):  0-2 row maxima of the RAW scores (v_max3);  3 exchange with the other half-row;  4-7
+    //     new reference mu, alpha;  8-23 elements 0..7 of A, B: y = s * scale - mu (one FMA: the key bias of a tile with
+    //     masked keys is added to its raw scores before the step), exp2, running sum, software-pipelined one element apart;
+    //     24-39 hi / lo split of P^T's k16 step 0 (four pieces per pair);  40-47 elements 8..11.
+    //   O^T phase (pieces 48..):   48-55 elements 12..15;  56-71 split of k16 step 1 (needed from the phase's second half);
+    //     72 the running sums.
+    // Hazards the compiler cannot see inside: a transcendental's result needs one wait state before a vector instruction
+    // reads it (read a piece later at the earliest), a vector write two before a permlane reads it.
     SmBlock A, B;
-    auto half_s = [&](auto hp_c, const f32x16& sa, const f32x16& sb) __attribute__((always_inline)) {
-        constexpr int hp = decltype(hp_c)::value;
-        if constexpr (hp < 16) {
-            constexpr int e = hp;
-            float a = sa[e], bq = sb[e];
-            VRD_PIN(a);
-            VRD_PIN(bq);
-            A.x[e] = fmaf(a, scale_log2e, bias[e]);
-            B.x[e] = fmaf(bq, scale_log2e, bias[e]);
-            A.mx = e ? fmaxf(A.mx, A.x[e]) : A.x[e];
-            B.mx = e ? fmaxf(B.mx, B.x[e]) : B.x[e];
-        } else if constexpr (hp == 16) {
-            VRD_PIN(A.mx);
-            A.mx = xchg32_max(A.mx);
-            A.sum = A.pend = 0.f;
-        } else if constexpr (hp == 17) {
-            VRD_PIN(B.mx);
-            B.mx = xchg32_max(B.mx);
-            B.sum = B.pend = 0.f;
-        } else if constexpr (hp == 18 || hp == 19) {
+    A.mr = B.mr = -INFINITY;
+    A.lp = B.lp = 0.f;
+    float tsp[4];                                // temporaries of the split in flight
+    unsigned long long cmask[2] = {0ull, 0ull};
+    const float thr = VRD_W64_THR;
+    auto fea_piece = [&](SmBlock& X, const f32x16& sx, auto e_c) __attribute__((always_inline)) {
+        constexpr int e = decltype(e_c)::value;  // exp of element e, FMA of element e+1, element e-1 joins the sum
+        if constexpr (e == 0) {
+            asm volatile("v_fma_f32 %0, %2, %3, -%4\n\tv_exp_f32 %1, %1"
+                         : "=&v"(X.x[1]), "+v"(X.x[0]) : "v"(sx[1]), "s"(scale_log2e), "v"(X.mu));
+        } else if constexpr (e == 1) {           // sum = x[0]: the first term
+            asm volatile("v_fma_f32 %0, %3, %4, -%5\n\tv_exp_f32 %1, %1\n\tv_mov_b32 %2, %6"
+                         : "=&v"(X.x[2]), "+v"(X.x[1]), "=&v"(X.sum) : "v"(sx[2]), "s"(scale_log2e), "v"(X.mu), "v"(X.x[0]));
+        } else if constexpr (e < 15) {
+            asm volatile("v_fma_f32 %0, %3, %4, -%5\n\tv_exp_f32 %1, %1\n\tv_add_f32 %2, %2, %6"
+                         : "=&v"(X.x[e + 1]), "+v"(X.x[e]), "+v"(X.sum) : "v"(sx[e + 1]), "s"(scale_log2e), "v"(X.mu), "v"(X.x[e - 1]));
+        } else {
+            asm volatile("v_exp_f32 %0, %0\n\tv_add_f32 %1, %1, %2" : "+v"(X.x[15]), "+v"(X.sum) : "v"(X.x[14]));
+        }
+    };
+    auto split_piece = [&](auto s_c, auto q_c) __attribute__((always_inline)) {
+        constexpr int s = decltype(s_c)::value, q = decltype(q_c)::value, j = q >> 2, sub = q & 3, e0 = 8 * s + 2 * j;
+        if constexpr (sub == 0) {
+            asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5"
+                         : "=&v"(A.ph[s][j]), "=&v"(B.ph[s][j]) : "v"(A.x[e0]), "v"(A.x[e0 + 1]), "v"(B.x[e0]), "v"(B.x[e0 + 1]));
+        } else if constexpr (sub == 1) {
+            asm volatile("v_lshlrev_b32 %0, 16, %4\n\tv_lshlrev_b32 %2, 16, %5\n\tv_and_b32 %1, 0xffff0000, %4\n\tv_and_b32 %3, 0xffff0000, %5"
+                         : "=&v"(tsp[0]), "=&v"(tsp[1]), "=&v"(tsp[2]), "=&v"(tsp[3]) : "v"(A.ph[s][j]), "v"(B.ph[s][j]));
+        } else if constexpr (sub == 2) {
+            asm volatile("v_sub_f32 %0, %4, %0\n\tv_sub_f32 %2, %6, %2\n\tv_sub_f32 %1, %5, %1\n\tv_sub_f32 %3, %7, %3"
+                         : "+v"(tsp[0]), "+v"(tsp[1]), "+v"(tsp[2]), "+v"(tsp[3])
+                         : "v"(A.x[e0]), "v"(A.x[e0 + 1]), "v"(B.x[e0]), "v"(B.x[e0 + 1]));
+        } else {
+            asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5"
+                         : "=&v"(A.pl[s][j]), "=&v"(B.pl[s][j]) : "v"(tsp[0]), "v"(tsp[1]), "v"(tsp[2]), "v"(tsp[3]));
+        }
+    };
+    auto sm_piece = [&](auto i_c, const f32x16& sa, const f32x16& sb) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_c)::value;
+        if constexpr (i == 0) {
+            asm volatile("v_max_f32 %0, %2, %3\n\tv_max_f32 %1, %4, %5\n\tv_max3_f32 %0, %6, %7, %0\n\tv_max3_f32 %1, %8, %9, %1\n\t"
+                         "v_max3_f32 %0, %10, %11, %0\n\tv_max3_f32 %1, %12, %13, %1"
+                         : "=&v"(A.mx), "=&v"(B.mx)
+                         : "v"(sa[0]), "v"(sa[1]), "v"(sb[0]), "v"(sb[1]), "v"(sa[2]), "v"(sa[3]), "v"(sb[2]), "v"(sb[3]),
+                           "v"(sa[4]), "v"(sa[5]), "v"(sb[4]), "v"(sb[5]));
+        } else if constexpr (i == 1) {
+            asm volatile("v_max3_f32 %0, %2, %3, %0\n\tv_max3_f32 %1, %4, %5, %1\n\tv_max3_f32 %0, %6, %7, %0\n\tv_max3_f32 %1, %8, %9, %1\n\t"
+                         "v_max3_f32 %0, %10, %11, %0\n\tv_max3_f32 %1, %12, %13, %1"
+                         : "+v"(A.mx), "+v"(B.mx)
+                         : "v"(sa[6]), "v"(sa[7]), "v"(sb[6]), "v"(sb[7]), "v"(sa[8]), "v"(sa[9]), "v"(sb[8]), "v"(sb[9]),
+                           "v"(sa[10]), "v"(sa[11]), "v"(sb[10]), "v"(sb[11]));
+        } else if constexpr (i == 2) {
+            asm volatile("v_max3_f32 %0, %2, %3, %0\n\tv_max3_f32 %1, %4, %5, %1\n\tv_max3_f32 %0, %6, %7, %0\n\tv_max3_f32 %1, %8, %9, %1"
+                         : "+v"(A.mx), "+v"(B.mx)
+                         : "v"(sa[12]), "v"(sa[13]), "v"(sb[12]), "v"(sb[13]), "v"(sa[14]), "v"(sa[15]), "v"(sb[14]), "v"(sb[15]));
+        } else if constexpr (i == 3) {           // the other half-row's maximum
+            float ta, tb;
+            asm volatile("v_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 0\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                         "v_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3"
+                         : "+v"(A.mx), "+v"(B.mx), "=&v"(ta), "=&v"(tb));
+        } else if constexpr (i == 4) {
             // The reference point of the exponentials moves only when the row maximum has grown by more than VRD_W64_THR
             // (log2 units) since it was set: probabilities then reach 2^THR instead of 1, which costs nothing here (they are
             // split into hi + lo relative to their own magnitude and accumulated in f32), and the running output -- 64
             // accumulator-half registers per block, three instructions each -- is rescaled in the first tile or two only
             // instead of in nearly every tile (some query of the 32 almost always finds a slightly larger score).
-            SmBlock& X = (hp & 1) ? B : A;
-            VRD_PIN(X.mx);
-            const float m_old = m_run[hp & 1];
-            const float mn = (X.mx - m_old > VRD_W64_THR) ? X.mx : m_old;       // (m_old = -inf: always; mx = -inf cannot happen in a visited tile)
-            X.mu = (mn == -INFINITY) ? 0.f : mn;
-            X.alpha = __builtin_amdgcn_exp2f(m_old - X.mu);                     // exactly 1 where the reference stays
-            m_run[hp & 1] = mn;
-        } else if constexpr (hp < 36) {
-            constexpr int e = (hp - 20) >> 1;
-            SmBlock& X = (hp & 1) ? B : A;
-            VRD_PIN(X.x[e]);
-            X.sum += X.pend;                     // the previous exponential (not the one just issued: no dependent stall)
-            X.x[e] = __builtin_amdgcn_exp2f(X.x[e] - X.mu);
-            X.pend = X.x[e];
-        } else if constexpr (hp < 44) {
-            constexpr int j = (hp - 36) >> 1;
-            SmBlock& X = (hp & 1) ? B : A;
-            VRD_PIN(X.x[2 * j]);
-            VRD_PIN(X.x[2 * j + 1]);
-            unsigned hi, lo;
-            split_pair(X.x[2 * j], X.x[2 * j + 1], hi, lo);
-            X.ph[0][j] = hi;
-            X.pl[0][j] = lo;
-        }
-    };
-    auto half_o = [&](auto hp_c) __attribute__((always_inline)) {
-        constexpr int hp = decltype(hp_c)::value;
-        if constexpr (hp < 16) {
-            constexpr int e = 8 + (hp >> 1);
-            SmBlock& X = (hp & 1) ? B : A;
-            VRD_PIN(X.x[e]);
-            X.sum += X.pend;
-            X.x[e] = __builtin_amdgcn_exp2f(X.x[e] - X.mu);
-            X.pend = X.x[e];
-        } else if constexpr (hp < 24) {
-            constexpr int j = (hp - 16) >> 1;
-            SmBlock& X = (hp & 1) ? B : A;
-            VRD_PIN(X.x[8 + 2 * j]);
-            VRD_PIN(X.x[8 + 2 * j + 1]);
-            unsigned hi, lo;
-            split_pair(X.x[8 + 2 * j], X.x[8 + 2 * j + 1], hi, lo);
-            X.ph[1][j] = hi;
-            X.pl[1][j] = lo;
-        } else if constexpr (hp == 24) {
-            VRD_PIN(A.sum);
-            VRD_PIN(B.sum);
-            l_part[0] = l_part[0] * A.alpha + (A.sum + A.pend);
-            l_part[1] = l_part[1] * B.alpha + (B.sum + B.pend);
+            // mx (log2 units) = raw maximum * scale (scale > 0: the same value as the maximum of the scaled scores);
+            // ae = mx - m_old for now
+            asm volatile("v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_sub_f32 %2, %0, %5\n\tv_sub_f32 %3, %1, %6"
+                         : "+v"(A.mx), "+v"(B.mx), "=&v"(A.ae), "=&v"(B.ae) : "s"(scale_log2e), "v"(A.mr), "v"(B.mr));
+        } else if constexpr (i == 5) {           // moved = mx - m_old > THR (m_old = -inf: always);  mu = moved ? mx : m_old
+            asm volatile("v_cmp_lt_f32 %0, %4, %5\n\tv_cmp_lt_f32 %1, %4, %6\n\tv_cndmask_b32 %2, %7, %9, %0\n\tv_cndmask_b32 %3, %8, %10, %1"
+                         : "=&s"(cmask[0]), "=&s"(cmask[1]), "=&v"(A.mu), "=&v"(B.mu)
+                         : "v"(thr), "v"(A.ae), "v"(B.ae), "v"(A.mr), "v"(B.mr), "v"(A.mx), "v"(B.mx));
+        } else if constexpr (i == 6) {
+            // exponent of alpha = moved ? m_old - mx : 0 (alpha exactly 1 where the reference stays);  mu >= -FLT_MAX: a row
+            // that has seen masked keys only so far (rows of more than 64 tiles visit every tile) keeps exp2(-inf - mu) = 0
+            asm volatile("v_cndmask_b32 %0, 0, -%0, %4\n\tv_cndmask_b32 %1, 0, -%1, %5\n\tv_max_f32 %2, 0xff7fffff, %2\n\tv_max_f32 %3, 0xff7fffff, %3"
+                         : "+v"(A.ae), "+v"(B.ae), "+v"(A.mu), "+v"(B.mu) : "s"(cmask[0]), "s"(cmask[1]));
+            A.mr = A.mu;
+            B.mr = B.mu;
+        } else if constexpr (i == 7) {
+            asm volatile("v_fma_f32 %0, %2, %4, -%5\n\tv_fma_f32 %1, %3, %4, -%6"
+                         : "=&v"(A.x[0]), "=&v"(B.x[0]) : "v"(sa[0]), "v"(sb[0]), "s"(scale_log2e), "v"(A.mu), "v"(B.mu));
+        } else if constexpr (i < 24) {
+            if constexpr (i & 1) fea_piece(B, sb, ic<(i - 8) / 2>{});
+            else fea_piece(A, sa, ic<(i - 8) / 2>{});
+        } else if constexpr (i < 40) {
+            split_piece(ic<0>{}, ic<i - 24>{});
+        } else if constexpr (i < 56) {
+            if constexpr (i & 1) fea_piece(B, sb, ic<8 + (i - 40) / 2>{});
+            else fea_piece(A, sa, ic<8 + (i - 40) / 2>{});
+        } else if constexpr (i < 72) {
+            split_piece(ic<1>{}, ic<i - 56>{});
+        } else if constexpr (i == 72) {          // alpha = exp2(ae);  l = l * alpha + (sum + the last exponential)
+            float ta, tb;
+            asm volatile("v_exp_f32 %2, %6\n\tv_exp_f32 %3, %7\n\tv_add_f32 %4, %8, %10\n\tv_add_f32 %5, %9, %11\n\t"
+                         "v_fma_f32 %0, %0, %2, %4\n\tv_fma_f32 %1, %1, %3, %5"
+                         : "+v"(A.lp), "+v"(B.lp), "=&v"(A.alpha), "=&v"(B.alpha), "=&v"(ta), "=&v"(tb)
+                         : "v"(A.ae), "v"(B.ae), "v"(A.sum), "v"(B.sum), "v"(A.x[15]), "v"(B.x[15]));
         }
     };
 
@@ -716,19 +750,28 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     // One pipeline step.  In: the raw scores of tile `it` (sa_c, sb_c; stage st), out: the raw scores of tile it+1 (WITH_S;
     // stage st1) and tile it's contribution to the outputs.  do_req: the pieces of tile kt_req are requested into stage
     // buf_req during the second half of the O^T phase.
-    auto tile = [&](auto with_s_c, const f32x16& sa_c, const f32x16& sb_c, f32x16& sa_n, f32x16& sb_n, const char* st,
-                    const char* st1, const float* kbs, bool do_req, const Req& req, int buf_req, bool first) __attribute__((always_inline)) {
+    auto tile = [&](auto with_s_c, f32x16& sa_c, f32x16& sb_c, f32x16& sa_n, f32x16& sb_n, const char* st,
+                    const char* st1, const float* kbs, bool dirty, bool do_req, const Req& req, int buf_req, bool first) __attribute__((always_inline)) {
         constexpr bool WITH_S = decltype(with_s_c)::value;
+        if (dirty) {                                 // masked keys in this tile: their raw scores become -inf
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bv = *reinterpret_cast<const float4*>(kbs + 8 * g + 4 * lh);
-            bias[4 * g + 0] = bv.x;
-            bias[4 * g + 1] = bv.y;
-            bias[4 * g + 2] = bv.z;
-            bias[4 * g + 3] = bv.w;
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(kbs + 8 * g + 4 * lh);
+                sa_c[4 * g + 0] += bv.x;
+                sa_c[4 * g + 1] += bv.y;
+                sa_c[4 * g + 2] += bv.z;
+                sa_c[4 * g + 3] += bv.w;
+                sb_c[4 * g + 0] += bv.x;
+                sb_c[4 * g + 1] += bv.y;
+                sb_c[4 * g + 2] += bv.z;
+                sb_c[4 * g + 3] += bv.w;
+            }
         }
         KF kf{}, kn{}, vf{}, vn{};
         if (WITH_S) kf = load_k(st1, 0);
+        VRD_SB();
+        // the first K fragment is on its way (it could not be asked for before the barrier): the row maxima run meanwhile
+        if constexpr (!(VRD_W64_ABL & 4)) static_for<LEAD>([&](auto u_c) { sm_piece(u_c, sa_c, sb_c); });
         VRD_SB();
         static_for<KS>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
@@ -737,7 +780,10 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
                 if constexpr (WITH_S && !(VRD_W64_ABL & 1)) mfma_s(s_c, j_c, kf, sa_n, sb_n);
                 if constexpr (j == 0 && WITH_S && s + 1 < KS) kn = load_k(st1, s + 1);
                 if constexpr (gap == NG_S - 4) vf = load_v(st, 0, 0);
-                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_S>([&](auto u_c) { half_s(ic<gap * HPG_S + decltype(u_c)::value>{}, sa_c, sb_c); });
+                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_S>([&](auto u_c) {
+                    constexpr int piece = LEAD + gap * HPG_S + decltype(u_c)::value;
+                    if constexpr (piece < 48) sm_piece(ic<piece>{}, sa_c, sb_c);
+                });
 #if defined(VRD_W64_DBG) && (VRD_W64_DBG & 4)
                 asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #endif
@@ -748,12 +794,12 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         VRD_STAMP();                                     // 4 + 5 it: S^T phase done
 #if defined(VRD_W64_DBG) && (VRD_W64_DBG & 2)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        rescale(ic<0>{}, A.alpha);
-        rescale(ic<1>{}, B.alpha);
+        rescale(ic<0>{}, __builtin_amdgcn_exp2f(A.ae));
+        rescale(ic<1>{}, __builtin_amdgcn_exp2f(B.ae));
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #else
-        if (!first && __any(A.alpha != 1.0f)) rescale(ic<0>{}, A.alpha);
-        if (!first && __any(B.alpha != 1.0f)) rescale(ic<1>{}, B.alpha);
+        if (!first && cmask[0] != 0ull) rescale(ic<0>{}, __builtin_amdgcn_exp2f(A.ae));
+        if (!first && cmask[1] != 0ull) rescale(ic<1>{}, __builtin_amdgcn_exp2f(B.ae));
 #endif
         VRD_SB();
         VRD_STAMP();                                     // 5 + 5 it: rescale done
@@ -764,7 +810,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
                 constexpr int j = decltype(j_c)::value, gap = 6 * g + j;
                 if constexpr (!(VRD_W64_ABL & 2)) mfma_o(g_c, j_c, vf);
                 if constexpr (j == 0 && g + 1 < 2 * DT) vn = load_v(st, (g + 1) / DT, (g + 1) % DT);
-                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_O>([&](auto u_c) { half_o(ic<gap * HPG_O + decltype(u_c)::value>{}); });
+                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_O>([&](auto u_c) { sm_piece(ic<48 + gap * HPG_O + decltype(u_c)::value>{}, sa_c, sb_c); });
                 constexpr int rq = gap - NG_O / 2 - 1;
                 if constexpr (rq >= 0 && rq % 3 == 0 && rq / 3 < PER_WAVE) {
                     if (do_req && !(VRD_W64_ABL & 8)) issue1(req, buf_req, ic<rq / 3>{});
@@ -865,8 +911,9 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         const float* kbs = kbias + kt_cur * 32;
         const int buf_req = (it + NS - 1) & (NS - 1);
         if (q_live) {
-            if (has_next) tile(std::true_type{}, ca, cb, na, nb, st, st1, kbs, do_req, req, buf_req, it == 0);
-            else tile(std::false_type{}, ca, cb, na, nb, st, st1, kbs, do_req, req, buf_req, it == 0);
+            const bool dirty = nkt <= 64 ? ((cln >> kt_cur) & 1ull) == 0ull : __builtin_amdgcn_readfirstlane(tile_on[kt_cur]) != 2;
+            if (has_next) tile(std::true_type{}, ca, cb, na, nb, st, st1, kbs, dirty, do_req, req, buf_req, it == 0);
+            else tile(std::false_type{}, ca, cb, na, nb, st, st1, kbs, dirty, do_req, req, buf_req, it == 0);
         } else if (do_req) {
             static_for<PER_WAVE>([&](auto i_c) { issue1(req, buf_req, i_c); });
         }
@@ -892,7 +939,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     char* const slab = lds + wave * (64 * HD * 4);
     static_for<2>([&](auto qb_c) {
         constexpr int qb = decltype(qb_c)::value;
-        const float l_tot = xchg32_sum(l_part[qb]);
+        const float l_tot = xchg32_sum(qb ? B.lp : A.lp);
         const float inv = (qb ? live1 : live0) ? 1.0f / l_tot : 0.f;
         static_for<DT>([&](auto d_c) {
             constexpr int d = decltype(d_c)::value;
