@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 20
+#define VRD_ABI_VERSION 22
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -308,12 +308,26 @@ int vrd_postprocess(const float* logits, const float* masks, const int32_t* vali
 int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
                    int taps, int T, float* dW, void* stream);
 
+/* The same gradient in the split precision of the forward path (bf16x3 mode): every product as g_lo x_hi + g_hi x_lo + g_hi x_hi
+ * on v_mfma_f32_32x32x16_bf16, f32 accumulate (~2^-17 relative product error, ~5x the rate of the exact-f32 MFMA).  Same
+ * arguments and accumulation rules as vrd_gemm_wgrad; dbias (nullable, N floats) additionally receives the bias gradient
+ * dbias[n] += sum_r G[r, n] * row_mask[r] in the same pass (exact f32 sums). */
+int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
+                      int taps, int T, float* dW, float* dbias, void* stream);
+
 /* out[c] += sum_r a[r, c] * (b ? b[brow(r), c * b_cstride + b_coffset] : 1) * (row_mask ? row_mask[r] : 1) * (row_scale ?
  * row_scale[r] : 1), brow(r = s*T + t) = s * (b_rstride*T) + b_rstride*t + shift when that stays inside the sequence
  * (else the row contributes 0).  Bias gradients (b = NULL), AffineDropPath scale gradients (b = the branch value),
  * depthwise-conv weight gradients (b = conv input, shift = k - ksize/2, b_rstride = stride, b_cstride = inputs per group). */
 int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_cstride, int b_coffset, int b_rstride, int shift,
                int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, void* stream);
+
+/* Weight and bias gradient of a depthwise MaskedConv1D (models/blocks.py:91-113 under autograd; k = 1 / 3, `stride`, group_in
+ * = 1 or 2 inputs per group) in one pass over dD (rows x C, rows = B * T output rows):
+ *   dw[(g * ksize + kk) * C + c] += sum_r dD[r, c] * row_mask[r] * x[in_row(r, kk), c * group_in + g],  dbias[c] += sum_r dD[r, c] * row_mask[r]
+ * in_row(r = s*T + t, kk) = s * stride*T + stride*t + kk - ksize/2 where that stays inside sequence s; dbias may be NULL. */
+int vrd_dwconv_wgrad(const float* dD, int64_t lddd, const float* x, int64_t ldx, int ksize, int stride, int group_in, int T,
+                     const uint8_t* row_mask, int64_t rows, int C, float* dw, float* dbias, void* stream);
 
 /* out[r,c] = v[r,c] * col_scale[c] * row_scale[r] * row_mask[r] + res[r,c] * (res_masked ? row_mask[r] : 1) + res2[r,c]
  * (every factor / term optional).  Training form of the affine drop-path residual: models/blocks.py:1074-1076 with

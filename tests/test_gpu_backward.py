@@ -85,6 +85,29 @@ def test_linear_backward(k, Cin, N, precision):
     rel_close(bd.grad, br.grad, tol(precision), "db")
 
 
+@pytest.mark.parametrize("k,Cin,N,B,T", [(3, 96, 160, 7, 100), (1, 64, 64, 40, 90)])
+def test_linear_weight_gradient_over_many_row_chunks(k, Cin, N, B, T, precision):
+    """dW when the rows span several waves and blocks (row chunks end inside sequences; T is not a multiple of the 16 rows of a
+    step; masked tails), both wgrad kernels (exact f32 / split precision) by mode."""
+    from vrdone_amd import ops
+    g = torch.Generator().manual_seed(B * T + k)
+    lens = torch.randint(1, T + 1, (B,), generator=g).tolist()
+    lens[0] = T
+    m = mask_for(B, T, lens)
+    x = torch.randn(B, Cin, T, generator=g) * m[:, None]
+    w = torch.randn(N, Cin, k, generator=g) / (Cin * k) ** 0.5
+    dy = torch.randn(B, N, T, generator=g)
+    xr, wr = ref64(x), ref64(w)
+    yr, _ = O.masked_conv1d(xr, m[:, None], wr, None)
+    yr.backward(dy.double())
+    xd, wd = leaf(cl(x)), leaf(w)
+    with torch.enable_grad():
+        y = ops.conv_gemm(xd, wd, None, row_mask=m.to(DEV))
+    y.backward(cl(dy).to(DEV))
+    rel_close(wd.grad, wr.grad, tol(precision), "dW")
+    rel_close(xd.grad, cl(xr.grad), tol(precision), "dx")
+
+
 def test_conv_gemm_epilogue_backward(precision):
     """GELU + mask + AffineDropPath scale + per-sample keep factors + masked residual + second residual."""
     from vrdone_amd import ops

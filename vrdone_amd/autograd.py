@@ -160,14 +160,23 @@ class Linear(Function):
                     dx = ops.conv_gemm(g, weight.detach(), None, _dgrad=True)
                 else:
                     dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             packed = _zeros(N, k * Cin, device=dy.device)
             px, _, _, ldx = _rows(x)
-            check(lib.vrd_gemm_wgrad(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(), _stream()),
-                  "vrd_gemm_wgrad")
+            if ops.get_precision() == "bf16x3":
+                # split-precision products like the forward GEMMs; the bias gradient (exact f32 column sums) in the same pass
+                if want_db:
+                    db = _zeros(N, device=dy.device)
+                check(lib.vrd_gemm_wgrad_x3(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(),
+                                            db.data_ptr() if want_db else None, _stream()), "vrd_gemm_wgrad_x3")
+                want_db = False
+            else:            # exact f32 products
+                check(lib.vrd_gemm_wgrad(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(), _stream()),
+                      "vrd_gemm_wgrad")
             # tap-major -> the Conv1d layout (N, Cin, k), with the parameter's own strides (DDP's bucket views expect them)
             dw = packed.view(N, Cin, 1) if k == 1 else packed.view(N, k, Cin).permute(0, 2, 1).contiguous()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db:
             db = colsum(dy, _zeros(N, device=dy.device), row_mask=mask)
         return dx, dw, db, None
 
@@ -284,17 +293,18 @@ class DepthwiseConv(Function):
         # the conv's input, for the weight gradients: x + nearest-x2-upsampled x_up (the copy is torch's, the add a kernel)
         xin = x if x_up is None else rowcol_scale(x, res2=x_up.repeat_interleave(2, dim=1))
         grads = []
+        pxin, _, _, ldxin = _rows(xin)
         for i in range(n):
+            # all taps, both inputs of a group and the bias in one pass over dD (vrd_dwconv_wgrad)
             gw = _zeros(gin, k, Cout, device=dev)
-            for g in range(gin):
-                for kk in range(k):
-                    colsum(dDs[i], gw[g, kk], b=xin, b_cstride=gin, b_coffset=g, b_rstride=s, shift=kk - k // 2, T=Tout,
-                           row_mask=ctx.mask_out)
+            gb = _zeros(Cout, device=dev) if ctx.has_bias[i] else None
+            pd, rows_out, _, ldd = _rows(dDs[i])
+            check(lib.vrd_dwconv_wgrad(pd, ldd, pxin, ldxin, k, s, gin, Tout, _mask_ptr(ctx.mask_out, rows_out), rows_out, Cout,
+                                       gw.data_ptr(), gb.data_ptr() if gb is not None else None, _stream()), "vrd_dwconv_wgrad")
             # (C, gin, k) with the parameter's own strides: for gin = k = 1 `.contiguous()` is a no-op that keeps (1, C, C),
             # which DDP's bucket views flag as a layout mismatch
             grads.append(torch.empty(Cout, gin, k, device=dev, dtype=torch.float32).copy_(gw.permute(2, 0, 1)))
-            grads.append(colsum(dDs[i], _zeros(Cout, device=dev), row_mask=ctx.mask_out)
-                         if ctx.has_bias[i] else None)
+            grads.append(gb)
         return (dx, dx_up, None, None, *grads)
 
 

@@ -160,19 +160,330 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same contraction in the forward path's split precision (bf16x3): every product as g_lo x_hi + g_hi x_lo + g_hi x_hi on
+// v_mfma_f32_32x32x16_bf16 (16 rows per MFMA instead of 2, at 8x the f32 MFMA rate: ~5x for three products), f32
+// accumulate.  Same decomposition: a wave owns a 64 x 64 tile of dW for a chunk of rows and takes its operands straight
+// from global memory in MFMA layout -- lane (m = lane & 31, half = lane >> 5) holds rows r0 + 8 half .. + 7 of column m:
+// eight dword loads, each a 128-byte row segment per half-wave -- splits them into bf16 hi / lo in registers (24 vector
+// instructions per eight values; four fragments feed twelve MFMAs) and accumulates.  The four waves of a block reduce in
+// LDS as above.  Used in the bf16x3 mode only (vrd_gemm_wgrad_x3); gradients then carry ~2^-17 relative product error like
+// the forward pass, the f32 mode keeps exact products.
+// ------------------------------------------------------------------------------------------------------------------
+using bf16x8 = vrd::bf16x8_t;
+struct WFrag { bf16x8 h, l; };
+__device__ __forceinline__ WFrag wsplit8(const float (&v)[8]) {
+    WFrag f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        f.h[i] = h;
+        f.l[i] = (__bf16)(v[i] - (float)h);
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
+                                                       int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M, int N,
+                                                       int Cin, int taps, int T, int tiles_k, int chunk, float* __restrict__ dW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int K = Cin * taps;
+    const int tile = blockIdx.x;
+    const int n0 = (tile / tiles_k) * 64, j0 = (tile % tiles_k) * 64;
+    const int li = lane & 31, lh = lane >> 5;
+    int shift[2];
+    const float* xp[2];
+    const float* gp[2];
+    bool a_col[2], b_col[2];
+    const int64_t r_begin = ((int64_t)blockIdx.y * 4 + wave) * chunk;
+    const int64_t r_end = r_begin + chunk < M ? r_begin + chunk : M;              // (empty for a wave beyond the last row)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = n0 + 32 * h + li, j = j0 + 32 * h + li;
+        const int tap = j < K ? j / Cin : 0;
+        const int ci = j < K ? j - tap * Cin : 0;
+        shift[h] = tap - taps / 2;
+        a_col[h] = n < N, b_col[h] = j < K;
+        gp[h] = G + (r_begin + 8 * lh) * ldg + n;
+        xp[h] = X + (r_begin + 8 * lh + shift[h]) * ldx + ci;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int hj = 0; hj < 2; ++hj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[hn][hj][e] = 0.f;
+    int t = taps == 3 ? (int)((r_begin + 8 * lh) % T) : 0;      // position of this lane's first row in its sequence
+    const uint8_t* mp = row_mask ? row_mask + r_begin + 8 * lh : nullptr;
+    // sixteen rows per step; the 32 loads of step i + 1 are requested before the MFMAs of step i
+    auto fetch = [&](int64_t r0, float (&a)[2][8], float (&b)[2][8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool in = r0 + 8 * lh + i < r_end;
+            const bool live = in && (!mp || mp[i]);
+            int tt = 0;
+            if (taps == 3) {
+                tt = t + i;
+                while (tt >= T) tt -= T;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                a[h][i] = live && a_col[h] ? gp[h][(int64_t)i * ldg] : 0.f;
+                const bool ok = in && b_col[h] && (taps == 1 || (tt + shift[h] >= 0 && tt + shift[h] < T));
+                b[h][i] = ok ? xp[h][(int64_t)i * ldx] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) gp[h] += 16 * ldg, xp[h] += 16 * ldx;
+        if (mp) mp += 16;
+        if (taps == 3) {
+            t += 16;
+            while (t >= T) t -= T;
+        }
+    };
+    auto mac = [&](const float (&a)[2][8], const float (&b)[2][8]) {
+        const WFrag fa0 = wsplit8(a[0]), fa1 = wsplit8(a[1]), fb0 = wsplit8(b[0]), fb1 = wsplit8(b[1]);
+#pragma unroll
+        for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+            for (int hj = 0; hj < 2; ++hj) {
+                const WFrag& fa = hn ? fa1 : fa0;
+                const WFrag& fb = hj ? fb1 : fb0;
+                acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.l, fb.h, acc[hn][hj], 0, 0, 0);
+                acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.l, acc[hn][hj], 0, 0, 0);
+                acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.h, acc[hn][hj], 0, 0, 0);
+            }
+    };
+    float a0[2][8], b0[2][8], a1[2][8], b1[2][8];
+    if (r_begin < r_end) fetch(r_begin, a0, b0);
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 32) {
+        fetch(r0 + 16, a1, b1);                                 // (past r_end: zeros, no loads)
+        mac(a0, b0);
+        fetch(r0 + 32, a0, b0);
+        mac(a1, b1);
+    }
+    __shared__ f32x16 red[3][4][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave - 1][q][lane] = acc[q >> 1][q & 1];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x16 v = acc[q >> 1][q & 1];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const f32x16 part = red[o][q][lane];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += part[e];
+        }
+        const int j = j0 + 32 * (q & 1) + li;
+        if (j >= K) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int nn = n0 + 32 * (q >> 1) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (nn < N) {
+                if (single) dW[(int64_t)nn * K + j] += v[e];
+                else atomicAdd(dW + (int64_t)nn * K + j, v[e]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The split-precision weight gradient with operand reuse: the wave-per-tile kernel above moves 8 KiB from L2 per twelve
+// MFMAs (16 FLOP per byte: measured 150 TFLOP/s, the rate of its L2 traffic).  Here a block owns a 128 x 128 tile of dW for a
+// chunk of rows; per step of 32 rows its 256 threads load the 32 x 128 slabs of G and X once (four float4 each), split them
+// into bf16 hi / lo and write four row-major planes into LDS (two stages, one barrier per step); each wave then forms its
+// 64 x 64 sub-tile, taking the transposed fragments the MFMA wants -- eight consecutive ROWS of one column per lane --
+// with ds_read_b64_tr_b16 (the read the attention kernels use for V^T; 16-byte chunks swizzled by row & 3).  64 FLOP per
+// byte of L2 traffic.  Needs N, Cin, ldg, ldx multiples of 4 and 16-byte aligned operands (float4 loads that never straddle a
+// tap); the wave kernel above takes the rest.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WL_ROWS = 32;                 // rows per step
+constexpr int WL_ROWB = 256;                // bytes per plane row: 128 bf16
+constexpr int WL_PLANE = WL_ROWS * WL_ROWB; // 8 KiB
+constexpr int WL_STAGE = 4 * WL_PLANE;      // g_hi | g_lo | x_hi | x_lo
+
+typedef __attribute__((ext_vector_type(4))) short wl_s16x4;
+typedef __attribute__((address_space(3))) wl_s16x4* wl_lds_s16x4_ptr;
+typedef __attribute__((ext_vector_type(8))) short wl_s16x8;
+
+__global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
+                                                              int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M, int N,
+                                                              int Cin, int taps, int T, int tiles_k, int chunk,
+                                                              float* __restrict__ dW, float* __restrict__ dbias) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * WL_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = Cin * taps;
+    const int n0 = ((int)blockIdx.x / tiles_k) * 128, j0 = ((int)blockIdx.x % tiles_k) * 128;
+    const int64_t r_begin = (int64_t)blockIdx.y * chunk;
+    const int64_t r_end = r_begin + chunk < M ? r_begin + chunk : M;
+    // ---- loader: thread -> column group cg (4 columns) of both slabs, rows lr, lr + 8, lr + 16, lr + 24 of the step
+    const int cg = tid & 31, lr = tid >> 5;
+    const int gn = n0 + 4 * cg, xj = j0 + 4 * cg;
+    const bool g_ok = gn < N, x_ok = xj < K;
+    const int tap = x_ok ? xj / Cin : 0;
+    const int ci = x_ok ? xj - tap * Cin : 0;
+    const int shift = tap - taps / 2;
+    const float* gptr = G + (r_begin + lr) * ldg + (g_ok ? gn : 0);
+    const float* xptr = X + (r_begin + lr + shift) * ldx + ci;
+    const uint8_t* mp = row_mask ? row_mask + r_begin + lr : nullptr;
+    int tt[4] = {0, 0, 0, 0};                    // positions of the thread's four rows in their sequences (k = 3)
+    if (taps == 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tt[i] = (int)((r_begin + lr + 8 * i) % T);
+    }
+    float4 g4[4], x4[4];
+    // bias gradient on the way (the blocks of the first tile column only): column sums of the masked G slab this thread loads
+    const bool do_bias = dbias != nullptr && (int)blockIdx.x % tiles_k == 0;          // (block-uniform)
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int64_t r0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool in = r0 + lr + 8 * i < r_end;
+            const bool live = in && g_ok && (!mp || mp[8 * i]);
+            const bool ok = in && x_ok && (taps == 1 || (tt[i] + shift >= 0 && tt[i] + shift < T));
+            g4[i] = live ? ld4(gptr + (int64_t)(8 * i) * ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            x4[i] = ok ? ld4(xptr + (int64_t)(8 * i) * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        gptr += (int64_t)WL_ROWS * ldg;
+        xptr += (int64_t)WL_ROWS * ldx;
+        if (mp) mp += WL_ROWS;
+        if (taps == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tt[i] += WL_ROWS;
+                while (tt[i] >= T) tt[i] -= T;
+            }
+        }
+    };
+    auto put = [&](char* plane_hi, int row, const float4& v) {
+        const vrd::bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        const vrd::bf16x4_t l = {(__bf16)(v.x - (float)h[0]), (__bf16)(v.y - (float)h[1]), (__bf16)(v.z - (float)h[2]), (__bf16)(v.w - (float)h[3])};
+        const int off = row * WL_ROWB + (((cg >> 1) ^ ((row & 3) << 2)) * 16) + (cg & 1) * 8;
+        *reinterpret_cast<vrd::bf16x4_t*>(plane_hi + off) = h;
+        *reinterpret_cast<vrd::bf16x4_t*>(plane_hi + WL_PLANE + off) = l;
+    };
+    auto store = [&](char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            put(st, lr + 8 * i, g4[i]);
+            put(st + 2 * WL_PLANE, lr + 8 * i, x4[i]);
+            if (do_bias) bsum.x += g4[i].x, bsum.y += g4[i].y, bsum.z += g4[i].z, bsum.w += g4[i].w;
+        }
+    };
+    // ---- compute: wave (wn, wj) owns the 64 x 64 sub-tile at (64 wn, 64 wj) as 2 x 2 accumulators
+    const int wn = wave >> 1, wj = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int vq = (lane >> 2) & 3, vp = lane & 3, vcol0 = 16 * ((lane >> 4) & 1) + 4 * vp;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+        for (int hj = 0; hj < 2; ++hj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[hn][hj][e] = 0.f;
+    // fragment (k16 step s, 32 columns from colbase) of the plane pair at `pl`: lane (column lane & 31, half) <- rows 16 s + 8 half .. + 7
+    auto frag = [&](const char* pl, int s, int colbase) {
+        WFrag f;
+        wl_s16x8 rh, rl;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int row = 16 * s + 8 * part + 4 * lh + vq;
+            const int col = colbase + vcol0;
+            const int off = row * WL_ROWB + ((((col * 2) >> 4) ^ ((row & 3) << 2)) * 16) + ((col * 2) & 15);
+            const wl_s16x4 th = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wl_lds_s16x4_ptr)(pl + off));
+            const wl_s16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wl_lds_s16x4_ptr)(pl + WL_PLANE + off));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rh[4 * part + q] = th[q];
+                rl[4 * part + q] = tl[q];
+            }
+        }
+        f.h = __builtin_bit_cast(bf16x8, rh);
+        f.l = __builtin_bit_cast(bf16x8, rl);
+        return f;
+    };
+    auto compute = [&](const char* st) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const WFrag fa0 = frag(st, s, 64 * wn), fa1 = frag(st, s, 64 * wn + 32);
+            const WFrag fb0 = frag(st + 2 * WL_PLANE, s, 64 * wj), fb1 = frag(st + 2 * WL_PLANE, s, 64 * wj + 32);
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn)
+#pragma unroll
+                for (int hj = 0; hj < 2; ++hj) {
+                    const WFrag& fa = hn ? fa1 : fa0;
+                    const WFrag& fb = hj ? fb1 : fb0;
+                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.l, fb.h, acc[hn][hj], 0, 0, 0);
+                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.l, acc[hn][hj], 0, 0, 0);
+                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.h, acc[hn][hj], 0, 0, 0);
+                }
+        }
+    };
+    // ---- rows: the loads of step i + 1 are in flight under the MFMAs of step i; one barrier per step (a stage is rewritten only
+    // after every wave has passed the barrier behind its last read)
+    fetch(r_begin);
+    store(lds);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += WL_ROWS) {
+        const bool more = r0 + WL_ROWS < r_end;
+        if (more) fetch(r0 + WL_ROWS);
+        compute(lds + cur * WL_STAGE);
+        if (more) store(lds + (cur ^ 1) * WL_STAGE);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (do_bias) {       // the eight row threads of a column add up in LDS (free behind the loop's last barrier): one atomic per
+                         // column and block -- same-address atomics queue up one behind the other in L2
+        float* red = reinterpret_cast<float*>(lds);
+        *reinterpret_cast<float4*>(red + lr * 128 + 4 * cg) = bsum;
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t += red[q * 128 + tid];
+            atomicAdd(dbias + n0 + tid, t);
+        }
+    }
+    const bool single = gridDim.y == 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + 64 * wj + 32 * (q & 1) + li;
+        if (j >= K) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int nn = n0 + 64 * wn + 32 * (q >> 1) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (nn < N) {
+                if (single) dW[(int64_t)nn * K + j] += acc[q >> 1][q & 1][e];
+                else atomicAdd(dW + (int64_t)nn * K + j, acc[q >> 1][q & 1][e]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // out[c] += sum_r a[r, c] * (b ? b[brow(r), c * bc + bo] : 1) * (mask ? mask[r] : 1) * (rscale ? rscale[r] : 1)
 // brow(r): r = s * T + t  ->  s * (bs * T) + bs * t + shift, contributing only if 0 <= bs * t + shift < bs * T.
-// thread = one column; block = 64 rows x 256 columns; one atomic per thread.
+// block = rpb rows x 64 columns, a quarter of the rows per wave, one atomic per column and block: atomics on one address queue up
+// behind each other in L2 (~50 ns each), and with 32 rows per atomic a 49 k-row input put 1,536 of them on every output element.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int CS_ROWS = 32;
+constexpr int CS_ROWS = 32;      // smallest rows-per-block
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
                                                      int64_t ldb, int bc, int bo, int bs, int shift, int T,
                                                      const uint8_t* __restrict__ mask, const float* __restrict__ rscale,
-                                                     int64_t rows, int C, float* __restrict__ out) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS;
-    const int64_t r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
+                                                     int64_t rows, int C, int rpb, float* __restrict__ out) {
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool col_ok = c < C;
+    const int wrows = rpb / 4;                   // (rpb is a multiple of 32)
+    const int64_t r0 = (int64_t)blockIdx.x * rpb + (int64_t)wave * wrows;
+    const int64_t r1 = r0 + wrows < rows ? r0 + wrows : rows;
     // eight rows per iteration with their loads requested together (one row per iteration ran at the latency of its loads);
     // the row's (sequence, position) pair is carried along instead of a 64-bit division per row
     int64_t seq = b ? r0 / T : 0;
@@ -183,7 +494,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t r = rb + u;
-            bool live = r < r1 && (!mask || mask[r]);
+            bool live = col_ok && r < r1 && (!mask || mask[r]);
             av[u] = 0.f, bv[u] = 1.f, fv[u] = 1.f;
             if (b) {
                 int tq = tpos + u;
@@ -205,7 +516,81 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
             while (tpos >= T) tpos -= T, ++seq;
         }
     }
-    atomicAdd(out + c, s);
+    // the four waves (four row ranges of the same 64 columns) add up in LDS: one atomic per column and block
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col_ok) atomicAdd(out + c, s + red[0][lane] + red[1][lane] + red[2][lane]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight and bias gradient of a depthwise conv (k = 1 / 3, stride bs, gin inputs per group) in ONE pass over dD:
+//   dw[g, kk, c] += sum_r dD[r, c] * m[r] * x[brow(r, kk), c * gin + g],   dbias[c] += sum_r dD[r, c] * m[r]
+// (vrd_colsum computes one (g, kk) per launch: twelve launches and twelve passes over dD per q / k / v convolution triple).
+// block = rpb rows x 64 columns, a quarter of the rows per wave (as vrd_colsum); one atomic per column, output and block.
+// ------------------------------------------------------------------------------------------------------------------
+template <int KS, int GIN>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x,
+                                                           int64_t ldx, int bs, int T, const uint8_t* __restrict__ mask,
+                                                           int64_t rows, int C, int rpb, float* __restrict__ dw,
+                                                           float* __restrict__ dbias) {
+    __shared__ float red[3][GIN * KS + 1][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    const bool col_ok = c < C;
+    const int wrows = rpb / 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb + (int64_t)wave * wrows;
+    const int64_t r1 = r0 + wrows < rows ? r0 + wrows : rows;
+    int64_t seq = r0 / T;
+    int tpos = (int)(r0 - seq * T);
+    float sw[GIN][KS], sb = 0.f;
+#pragma unroll
+    for (int g = 0; g < GIN; ++g)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) sw[g][kk] = 0.f;
+    for (int64_t rb = r0; rb < r1; rb += 4) {
+        float av[4], xv[4][GIN][KS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + u;
+            const bool live = col_ok && r < r1 && (!mask || mask[r]);
+            int tq = tpos + u;
+            int64_t sq = seq;
+            while (tq >= T) tq -= T, ++sq;
+            av[u] = live ? a[r * lda + c] : 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int tb = bs * tq + kk - KS / 2;
+                const bool ok = live && tb >= 0 && tb < bs * T;
+#pragma unroll
+                for (int g = 0; g < GIN; ++g) xv[u][g][kk] = ok ? x[(sq * (int64_t)bs * T + tb) * ldx + (int64_t)c * GIN + g] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sb += av[u];
+#pragma unroll
+            for (int g = 0; g < GIN; ++g)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) sw[g][kk] = fmaf(av[u], xv[u][g][kk], sw[g][kk]);
+        }
+        tpos += 4;
+        while (tpos >= T) tpos -= T, ++seq;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int g = 0; g < GIN; ++g)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) red[wave - 1][g * KS + kk][lane] = sw[g][kk];
+        red[wave - 1][GIN * KS][lane] = sb;
+    }
+    __syncthreads();
+    if (wave > 0 || !col_ok) return;
+#pragma unroll
+    for (int g = 0; g < GIN; ++g)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+            atomicAdd(dw + (int64_t)(g * KS + kk) * C + c, sw[g][kk] + red[0][g * KS + kk][lane] + red[1][g * KS + kk][lane] + red[2][g * KS + kk][lane]);
+    if (dbias) atomicAdd(dbias + c, sb + red[0][GIN * KS][lane] + red[1][GIN * KS][lane] + red[2][GIN * KS][lane]);
 }
 
 // out[r,c] = v[r,c] * cs[c] * rs[r] * m[r] + res[r,c] * (res_masked ? m[r] : 1) + res2[r,c]
@@ -266,16 +651,18 @@ __global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ x, i
 //   g = dy * (relu ? y > 0 : 1) * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
 //   dgamma += sum_r dy' * xhat,  dbeta += sum_r dy'     (per-lane partial sums, one atomic per channel and wave)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int LNB_ROWS = 8;        // rows per wave
+constexpr int LNB_ROWS = 8;        // rows per wave at least (the host asks for more on long inputs: every block ends in 2 C
+                                   // atomics on the same 2 C addresses, and atomics on one address queue up in L2)
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                             int64_t lddy, int64_t rows, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu, float* __restrict__ dx,
-                                                            int64_t lddx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                            int64_t lddx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int rpw) {
     constexpr float inv_c = 1.0f / (256.0f * NV);
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t r0 = w * LNB_ROWS;        // (a wave beyond the last row adds zeros)
+    const int64_t r0 = w * rpw;             // (a wave beyond the last row adds zeros)
     float4 g4[NV], b4[NV], dg[NV], db[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -285,7 +672,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     // the rows of this wave in groups of four, a group's loads requested together (one row at a time ran at the latency of
     // its loads)
-    for (int h = 0; h < LNB_ROWS / 4; ++h) {
+    for (int h = 0; h < rpw / 4; ++h) {
     const int64_t rh = r0 + 4 * h;
     if (rh >= rows) break;
     float4 vr[4][NV], dr[4][NV];
@@ -837,6 +1224,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 
 }  // namespace
 
+// rows per block of the column-sum kernels: ~1024 blocks on long inputs, a multiple of 32 (a quarter per wave, eight rows per
+// iteration), 32 .. 2048
+static int64_t colsum_rows_per_block(int64_t rows, int col_blocks) {
+    int64_t rpb = rows * col_blocks / 1024;
+    rpb = (rpb + 31) / 32 * 32;
+    if (rpb < CS_ROWS) rpb = CS_ROWS;
+    if (rpb > 2048) rpb = 2048;
+    return rpb;
+}
+
 extern "C" {
 
 int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
@@ -857,6 +1254,81 @@ int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, con
     return 0;
 }
 
+int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
+                      int taps, int T, float* dW, float* dbias, void* stream) {
+    VRD_CHECK_ARG(G && X && dW, "vrd_gemm_wgrad_x3: null pointer");
+    VRD_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && (taps == 1 || taps == 3), "vrd_gemm_wgrad_x3: bad sizes M=%lld N=%d Cin=%d taps=%d", (long long)M, N, Cin, taps);
+    VRD_CHECK_ARG(ldg >= N && ldx >= Cin, "vrd_gemm_wgrad_x3: leading dimension too small");
+    VRD_CHECK_ARG(T > 0 && M % T == 0, "vrd_gemm_wgrad_x3: M (%lld) must be a multiple of T (%d)", (long long)M, T);
+    const int K = Cin * taps;
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * (double)M * N * K, 4.0 * ((double)M * (N + Cin) + (double)N * K));
+    static const bool use_lds = [] { const char* e = getenv("VRD_WGRAD_LDS"); return !(e && e[0] == '0'); }();
+    if (use_lds && N % 4 == 0 && Cin % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(G) && aligned16(X) && M >= 256) {
+        // 128 x 128 tiles; as few row chunks as still give ~2 blocks per CU (every block ends in 16 k atomics)
+        const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
+        const int64_t tiles = (int64_t)tiles_n * tiles_k;
+        int64_t want = (2 * (int64_t)n_cu + tiles - 1) / tiles;
+        if (want < 1) want = 1;
+        int64_t chunk = (M + want - 1) / want;
+        chunk = (chunk + WL_ROWS - 1) / WL_ROWS * WL_ROWS;
+        if (chunk < 4 * WL_ROWS) chunk = 4 * WL_ROWS;
+        const int64_t chunks = (M + chunk - 1) / chunk;
+        VRD_CHECK_ARG(chunks <= 65535 && chunk < (1ll << 30), "vrd_gemm_wgrad_x3: too many rows (%lld)", (long long)M);
+        hipLaunchKernelGGL(wgrad_x3_lds_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin,
+                           taps, T, tiles_k, (int)chunk, dW, dbias);
+        VRD_LAUNCH_CHECK();
+        return 0;
+    }
+    if (dbias) {                                 // the wave kernel has no bias path: a column-sum launch of its own
+        const int col_blocks = (N + 63) / 64;
+        const int64_t rpb = colsum_rows_per_block(M, col_blocks);
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((M + rpb - 1) / rpb), col_blocks), dim3(256), 0, s, G, ldg, (const float*)nullptr,
+                           (int64_t)0, 1, 0, 1, 0, 1, row_mask, (const float*)nullptr, M, N, (int)rpb, dbias);
+        VRD_LAUNCH_CHECK();
+    }
+    const int tiles_n = (N + 63) / 64, tiles_k = (K + 63) / 64;
+    // rows per wave: as few row chunks as still fill the chip (every block ends in 4096 atomics), multiples of 32 rows
+    const int64_t tiles = (int64_t)tiles_n * tiles_k;
+    int64_t want_blocks = (2 * (int64_t)n_cu + tiles - 1) / tiles;                  // row chunks for ~2 blocks per CU
+    if (want_blocks < 1) want_blocks = 1;
+    int64_t chunk = (M + 4 * want_blocks - 1) / (4 * want_blocks);
+    chunk = (chunk + 31) / 32 * 32;
+    if (chunk < 64) chunk = 64;
+    if (chunk > 1024) chunk = 1024;
+    const int64_t chunks = (M + 4 * chunk - 1) / (4 * chunk);
+    VRD_CHECK_ARG(chunks <= 65535, "vrd_gemm_wgrad_x3: too many rows (%lld)", (long long)M);
+    hipLaunchKernelGGL(wgrad_x3_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin, taps, T,
+                       tiles_k, (int)chunk, dW);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_dwconv_wgrad(const float* dD, int64_t lddd, const float* x, int64_t ldx, int ksize, int stride, int group_in, int T,
+                     const uint8_t* row_mask, int64_t rows, int C, float* dw, float* dbias, void* stream) {
+    VRD_CHECK_ARG(dD && x && dw && rows > 0 && C > 0 && lddd >= C, "vrd_dwconv_wgrad: bad arguments");
+    VRD_CHECK_ARG((ksize == 1 || ksize == 3) && (group_in == 1 || group_in == 2) && stride >= 1 && T > 0 && rows % T == 0,
+                  "vrd_dwconv_wgrad: unsupported k=%d group_in=%d stride=%d T=%d rows=%lld", ksize, group_in, stride, T, (long long)rows);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * (1 + group_in * stride));
+    const int col_blocks = (C + 63) / 64;
+    const int64_t rpb = colsum_rows_per_block(rows, col_blocks);
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), col_blocks);
+#define VRD_DWW(KS, GIN) hipLaunchKernelGGL((dwconv_wgrad_kernel<KS, GIN>), grid, dim3(256), 0, s, dD, lddd, x, ldx, stride, T, row_mask, rows, C, (int)rpb, dw, dbias)
+    if (ksize == 3 && group_in == 1) VRD_DWW(3, 1);
+    else if (ksize == 3) VRD_DWW(3, 2);
+    else if (group_in == 1) VRD_DWW(1, 1);
+    else VRD_DWW(1, 2);
+#undef VRD_DWW
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
 int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_cstride, int b_coffset, int b_rstride, int shift,
                int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, void* stream) {
     VRD_CHECK_ARG(a && out && rows > 0 && C > 0 && lda >= C, "vrd_colsum: bad arguments");
@@ -864,8 +1336,10 @@ int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_c
                   "vrd_colsum: bad second operand (T=%d rows=%lld)", T, (long long)rows);
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * (b ? 2 : 1));
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + CS_ROWS - 1) / CS_ROWS), (C + 255) / 256), dim3(256), 0, s, a, lda, b, ldb,
-                       b ? b_cstride : 1, b ? b_coffset : 0, b ? b_rstride : 1, shift, b ? T : 1, row_mask, row_scale, rows, C, out);
+    const int col_blocks = (C + 63) / 64;
+    const int64_t rpb = colsum_rows_per_block(rows, col_blocks);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), col_blocks), dim3(256), 0, s, a, lda, b, ldb,
+                       b ? b_cstride : 1, b ? b_coffset : 0, b ? b_rstride : 1, shift, b ? T : 1, row_mask, row_scale, rows, C, (int)rpb, out);
     VRD_LAUNCH_CHECK();
     return 0;
 }
@@ -911,9 +1385,12 @@ int vrd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy
     if (rows <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 12.0 * (double)rows * C);
-    dim3 grid((unsigned)((rows + 4 * LNB_ROWS - 1) / (4 * LNB_ROWS)));
-    if (C == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta);
+    int64_t rpw = (rows / (4 * 512) + 3) / 4 * 4;            // ~512 blocks on long inputs; a multiple of 4 rows, 8 .. 64
+    if (rpw < LNB_ROWS) rpw = LNB_ROWS;
+    if (rpw > 64) rpw = 64;
+    dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
+    if (C == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta, (int)rpw);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta, (int)rpw);
     VRD_LAUNCH_CHECK();
     return 0;
 }
