@@ -292,9 +292,10 @@ def main():
         lens[0] = args.frames
         del x, m
         batch["x"], batch["m"] = synth.synth_pairs(hi - lo, c_in, t_pad, lens.tolist(), seed=1234 + rank, device=dev)
-        r_elapsed, _ = run(main_mode, 1, args.steps)
+        r_elapsed, r_prof = run(main_mode, 1, args.steps)
         ragged = {"lengths": f"U[2, {args.frames}] (seed 1235), mean {float(lens.float().mean()):.1f}, T_pad {t_pad}",
-                  "value": args.pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps}
+                  "value": args.pairs * args.steps / r_elapsed, "unit": "pairs/s", "ms_per_step": 1e3 * r_elapsed / args.steps,
+                  "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in r_prof.items() if v["launches"]}}
 
     # What a rank of an N-GPU run computes per step, timed here on ONE GPU: the first pairs/N pairs of the batch for
     # N = 2, 4, 8 (strong scaling: the global batch is fixed).  A projection of the scaling curve, not a measurement of

@@ -299,8 +299,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
 // into bf16 hi / lo and write four row-major planes into LDS (two stages, one barrier per step); each wave then forms its
 // 64 x 64 sub-tile, taking the transposed fragments the MFMA wants -- eight consecutive ROWS of one column per lane --
 // with ds_read_b64_tr_b16 (the read the attention kernels use for V^T; 16-byte chunks swizzled by row & 3).  64 FLOP per
-// byte of L2 traffic.  Needs N, Cin, ldg, ldx multiples of 4 and 16-byte aligned operands (float4 loads that never straddle a
-// tap); the wave kernel above takes the rest.
+// byte of L2 traffic.  float4 loads when N, Cin, ldg, ldx are multiples of 4 and the operands 16-byte aligned (a group of four
+// columns then never straddles a tap), guarded scalar loads otherwise; the wave kernel above serves inputs of fewer than 256 rows.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int WL_ROWS = 32;                 // rows per step
 constexpr int WL_ROWB = 256;                // bytes per plane row: 128 bf16
@@ -311,6 +311,7 @@ typedef __attribute__((ext_vector_type(4))) short wl_s16x4;
 typedef __attribute__((address_space(3))) wl_s16x4* wl_lds_s16x4_ptr;
 typedef __attribute__((ext_vector_type(8))) short wl_s16x8;
 
+template <bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
                                                               int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M, int N,
                                                               int Cin, int taps, int T, int tiles_k, int chunk,
@@ -321,15 +322,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __res
     const int n0 = ((int)blockIdx.x / tiles_k) * 128, j0 = ((int)blockIdx.x % tiles_k) * 128;
     const int64_t r_begin = (int64_t)blockIdx.y * chunk;
     const int64_t r_end = r_begin + chunk < M ? r_begin + chunk : M;
-    // ---- loader: thread -> column group cg (4 columns) of both slabs, rows lr, lr + 8, lr + 16, lr + 24 of the step
+    // ---- loader: thread -> column group cg (4 columns) of both slabs, rows lr, lr + 8, lr + 16, lr + 24 of the step.
+    // VEC: float4 loads (N, Cin, both leading dimensions multiples of 4, 16-byte aligned bases: a group never straddles a tap
+    // or the matrix edge); otherwise four guarded scalar loads per group, each column with its own tap.
     const int cg = tid & 31, lr = tid >> 5;
     const int gn = n0 + 4 * cg, xj = j0 + 4 * cg;
-    const bool g_ok = gn < N, x_ok = xj < K;
-    const int tap = x_ok ? xj / Cin : 0;
-    const int ci = x_ok ? xj - tap * Cin : 0;
-    const int shift = tap - taps / 2;
-    const float* gptr = G + (r_begin + lr) * ldg + (g_ok ? gn : 0);
-    const float* xptr = X + (r_begin + lr + shift) * ldx + ci;
+    bool g_ok[4], x_ok[4];
+    int shift[4];
+    int64_t xoff[4];                             // element offset of column e's source inside row r of X: shift * ldx + ci
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        g_ok[e] = gn + e < N;
+        x_ok[e] = xj + e < K;
+        const int tap = x_ok[e] ? (xj + e) / Cin : 0;
+        const int ci = x_ok[e] ? (xj + e) - tap * Cin : 0;
+        shift[e] = tap - taps / 2;
+        xoff[e] = (int64_t)shift[e] * ldx + ci;
+    }
+    const float* gptr = G + (r_begin + lr) * ldg + (g_ok[0] ? gn : 0);
+    const float* xptr = X + (r_begin + lr) * ldx;
     const uint8_t* mp = row_mask ? row_mask + r_begin + lr : nullptr;
     int tt[4] = {0, 0, 0, 0};                    // positions of the thread's four rows in their sequences (k = 3)
     if (taps == 3) {
@@ -344,10 +355,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool in = r0 + lr + 8 * i < r_end;
-            const bool live = in && g_ok && (!mp || mp[8 * i]);
-            const bool ok = in && x_ok && (taps == 1 || (tt[i] + shift >= 0 && tt[i] + shift < T));
-            g4[i] = live ? ld4(gptr + (int64_t)(8 * i) * ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
-            x4[i] = ok ? ld4(xptr + (int64_t)(8 * i) * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool live = in && (!mp || mp[8 * i]);
+            auto seq_ok = [&](int e) { return taps == 1 || (tt[i] + shift[e] >= 0 && tt[i] + shift[e] < T); };
+            if (VEC) {
+                g4[i] = live && g_ok[0] ? ld4(gptr + (int64_t)(8 * i) * ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x4[i] = in && x_ok[0] && seq_ok(0) ? ld4(xptr + (int64_t)(8 * i) * ldx + xoff[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float* gr = gptr + (int64_t)(8 * i) * ldg;
+                const float* xr = xptr + (int64_t)(8 * i) * ldx;
+                g4[i].x = live && g_ok[0] ? gr[0] : 0.f;
+                g4[i].y = live && g_ok[1] ? gr[1] : 0.f;
+                g4[i].z = live && g_ok[2] ? gr[2] : 0.f;
+                g4[i].w = live && g_ok[3] ? gr[3] : 0.f;
+                x4[i].x = in && x_ok[0] && seq_ok(0) ? xr[xoff[0]] : 0.f;
+                x4[i].y = in && x_ok[1] && seq_ok(1) ? xr[xoff[1]] : 0.f;
+                x4[i].z = in && x_ok[2] && seq_ok(2) ? xr[xoff[2]] : 0.f;
+                x4[i].w = in && x_ok[3] && seq_ok(3) ? xr[xoff[3]] : 0.f;
+            }
         }
         gptr += (int64_t)WL_ROWS * ldg;
         xptr += (int64_t)WL_ROWS * ldx;
@@ -443,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __res
         float* red = reinterpret_cast<float*>(lds);
         *reinterpret_cast<float4*>(red + lr * 128 + 4 * cg) = bsum;
         __syncthreads();
-        if (tid < 128 && n0 + tid < N) {
+        if (tid < 128 && n0 + tid < N) {     // (columns beyond N carry zeros)
             float t = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) t += red[q * 128 + tid];
@@ -1269,7 +1293,7 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * (double)M * N * K, 4.0 * ((double)M * (N + Cin) + (double)N * K));
     static const bool use_lds = [] { const char* e = getenv("VRD_WGRAD_LDS"); return !(e && e[0] == '0'); }();
-    if (use_lds && N % 4 == 0 && Cin % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(G) && aligned16(X) && M >= 256) {
+    if (use_lds && M >= 256) {
         // 128 x 128 tiles; as few row chunks as still give ~2 blocks per CU (every block ends in 16 k atomics)
         const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
         const int64_t tiles = (int64_t)tiles_n * tiles_k;
@@ -1280,8 +1304,10 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
         if (chunk < 4 * WL_ROWS) chunk = 4 * WL_ROWS;
         const int64_t chunks = (M + chunk - 1) / chunk;
         VRD_CHECK_ARG(chunks <= 65535 && chunk < (1ll << 30), "vrd_gemm_wgrad_x3: too many rows (%lld)", (long long)M);
-        hipLaunchKernelGGL(wgrad_x3_lds_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin,
-                           taps, T, tiles_k, (int)chunk, dW, dbias);
+        const bool vec = N % 4 == 0 && Cin % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(G) && aligned16(X);
+        const dim3 grid((unsigned)tiles, (unsigned)chunks);
+        if (vec) hipLaunchKernelGGL(wgrad_x3_lds_kernel<true>, grid, dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, tiles_k, (int)chunk, dW, dbias);
+        else hipLaunchKernelGGL(wgrad_x3_lds_kernel<false>, grid, dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, tiles_k, (int)chunk, dW, dbias);
         VRD_LAUNCH_CHECK();
         return 0;
     }
