@@ -5,7 +5,7 @@
 #   bench.json                       the bench line (events on, CPU baseline on), default mode, alt mode included
 #   kernel_stats[_f32].csv           rocprofv3 --kernel-trace --stats of the same command in one precision mode
 #   pmc_FETCH_SIZE[_f32].csv / pmc_WRITE_SIZE[_f32].csv   per dispatch, separate passes (TCC slots)
-#   pmc_SQ.csv                       (with `sq`) one SQ pass: MFMA busy / wave cycles / waits / MFMA ops, every dispatch
+#   pmc_SQ[_f32].csv                 (with `sq`) one SQ pass per mode: MFMA busy / wave cycles / waits / MFMA ops, every dispatch
 #   kernel_src_sha.txt               hash of the kernel sources these were collected on (bench.kernel_source_sha)
 # rocprofv3 is always followed directly by `python3 bench.py ...` (no wrapper after `--`), counters in their own passes.
 set -o pipefail
@@ -33,10 +33,14 @@ for MODE in bf16x3 f32; do
   rm -rf $OUT/trace$SUF $OUT/pmc_FETCH_SIZE$SUF $OUT/pmc_WRITE_SIZE$SUF
 done
 if [ "$SQ" = sq ]; then
-  echo "[collect] SQ pass"
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-    --output-format csv -d $OUT/pmc_SQ -- python3 $R/bench.py --steps 1 --warmup 1 --precision bf16x3 $LEAN --no-prof > /dev/null 2> $OUT/pmc_SQ.err || exit 1
-  cp $OUT/pmc_SQ/*/*counter_collection.csv $OUT/pmc_SQ.csv
-  rm -rf $OUT/pmc_SQ
+  for MODE in bf16x3 f32; do
+    if [ "$MODES" != both ] && [ "$MODES" != $MODE ]; then continue; fi
+    SUF=""; [ $MODE = f32 ] && SUF="_f32"
+    echo "[collect] SQ pass $MODE"
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+      --output-format csv -d $OUT/pmc_SQ$SUF -- python3 $R/bench.py --steps 1 --warmup 1 --precision $MODE $LEAN --no-prof > /dev/null 2> $OUT/pmc_SQ$SUF.err || exit 1
+    cp $OUT/pmc_SQ$SUF/*/*counter_collection.csv $OUT/pmc_SQ$SUF.csv
+    rm -rf $OUT/pmc_SQ$SUF
+  done
 fi
 ls -la $OUT

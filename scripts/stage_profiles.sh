@@ -7,6 +7,7 @@ S=gpurun_out/profiles_$TAG
 python scripts/summarize_traffic.py $S profiles/${TAG}_hbm_traffic.json > /dev/null
 python scripts/summarize_traffic.py $S profiles/${TAG}_hbm_traffic_f32.json _f32 > /dev/null
 python scripts/summarize_sq.py $S profiles/${TAG}_sq_counters.json | head -3
+[ -f $S/pmc_SQ_f32.csv ] && python scripts/summarize_sq.py $S profiles/${TAG}_sq_counters_f32.json _f32 | head -2
 cp $S/kernel_stats.csv profiles/${TAG}_kernel_stats_bench_n1.csv
 cp $S/kernel_stats_f32.csv profiles/${TAG}_kernel_stats_bench_n1_f32.csv
 cp $S/bench.json profiles/${TAG}_bench_n1.json

@@ -26,10 +26,10 @@ sys.path.insert(0, REPO)
 N_CU, N_SIMD = 256, 4
 
 
-def main(src, dst):
+def main(src, dst, suffix=""):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     seen = collections.defaultdict(set)
-    with open(f"{src}/pmc_SQ.csv") as f:
+    with open(f"{src}/pmc_SQ{suffix}.csv") as f:
         for r in csv.DictReader(f):
             m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
             if not m:
@@ -44,7 +44,7 @@ def main(src, dst):
     sha_file = os.path.join(src, "kernel_src_sha.txt")
     out = {"source": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
                      "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE "
-                     "-- python3 bench.py --steps 1 --warmup 1 --precision bf16x3 (all dispatches of the process: warm-up + 1 step)",
+                     "-- python3 bench.py --steps 1 --warmup 1 --precision " + ("f32" if suffix == "_f32" else "bf16x3") + " (all dispatches of the process: warm-up + 1 step)",
            "kernel_src_sha": open(sha_file).read().strip() if os.path.exists(sha_file) else bench.kernel_source_sha(),
            "units": "SQ_VALU_MFMA_BUSY_CYCLES in cycles (summed over SIMDs); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in "
                     "quad-cycles summed over waves; clock = GRBM_GUI_ACTIVE / 8 / duration",
@@ -71,4 +71,4 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")

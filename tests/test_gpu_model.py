@@ -135,17 +135,9 @@ def test_forward_test_matches_reference_golden(precision):
     dev_data = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in data.items()}
     res = model(dev_data)
     assert len(res["triplets"]) == len(ref["triplets"]) == ic["n_max_pair"]
-    np.testing.assert_allclose(res["triple_scores_avg"], ref["triple_scores_avg"], atol=5e-5, rtol=0)
-    # the ranking can only differ where two scores are closer than the arithmetic noise
-    same = [a == b for a, b in zip(res["triplets"], ref["triplets"])]
-    assert sum(same) >= len(same) - 4
-    key = lambda r, i: (tuple(r["triplets"][i]), tuple(r["so_tids"][i]), tuple(r["pred_durations"][i]))   # noqa: E731
-    got = {key(res, i) for i in range(len(same))}
-    want = {key(ref, i) for i in range(len(same))}
-    assert len(got & want) >= len(want) - 4
-    dig = {(len(t[0]), round(float(np.sum(np.asarray(t, dtype=np.float64))), 3)) for t in res["so_trajs"]}
-    wdig = {(int(a), round(b, 3)) for a, b in ref["so_trajs_digest"]}
-    assert len(dig & wdig) >= len(wdig) - 4
+    # identical ranking, records and box tracks in both precision modes; scores within 5e-6 (measured: 1e-7 / 7e-7)
+    from golden_cases import compare_forward_test
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0)
 
 
 def _on_device(data):
@@ -162,7 +154,7 @@ def test_forward_test_many_slices_matches_reference_golden(precision):
     data = synth_proposal(c_in=c_in(mc), **SLICES)
     assert len(data["sids"]) == ref["n_pairs"] > 2 * mc["max_so_pair"]
     res = model(_on_device(data))
-    compare_forward_test(res, ref, ic["n_max_pair"], 5e-5, slack=4)
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0)
 
 
 def test_forward_test_vidor_x_matches_reference_golden(precision):
@@ -175,7 +167,7 @@ def test_forward_test_vidor_x_matches_reference_golden(precision):
     data = synth_proposal(c_in=c_in(mc), **VIDOR_X)
     assert data["so_offset"].tolist() == ref["so_offset"]
     res = model(_on_device(data))
-    compare_forward_test(res, ref, ic["n_max_pair"], 5e-5, slack=4)
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0)
 
 
 def test_mask_vrd_b256_matches_reference_golden(precision):

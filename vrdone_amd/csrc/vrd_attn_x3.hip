@@ -985,7 +985,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const int r = (t0 + u) * ROWS_PI + rr;
-                if (all_rows || q0 + r < Tq) {
+                if ((all_rows || q0 + r < Tq) && !(VRD_W64_ABL & 256)) {
                     uint4 hi, lo;
                     split_pair(va[u].x, va[u].y, hi.x, lo.x);
                     split_pair(va[u].z, va[u].w, hi.y, lo.y);
