@@ -580,6 +580,31 @@ def test_flash_attention_one_wave_per_simd_kernel(H, hd, Tq, Tk, precision, monk
     close(out["1"], out["0"], 5e-5)
 
 
+@pytest.mark.parametrize("Tk", [288, 2304])
+def test_flash_attention_key_masks_with_holes(Tk, precision, monkeypatch):
+    """Key masks that are not prefixes: leading tiles with no valid key (a row's reference point stays at its floor until the
+    first valid key), a hole of whole tiles and partial tiles in the middle; at 2304 keys (more than 64 key tiles) the
+    one-wave-per-SIMD kernel visits every tile, the fully masked ones included.  Both flash kernels against the oracle."""
+    if precision != "bf16x3":
+        pytest.skip("pair rows exist in bf16x3 mode only")
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(Tk)
+    B, H, hd, Tq = 2, 2, 128, 256
+    C = H * hd
+    q = torch.randn(B, Tq, C, generator=gen) * 2.0
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    mask = torch.ones(B, Tk, dtype=torch.bool)
+    mask[0, :70] = False                       # two leading tiles without a valid key, then a partial one
+    mask[0, 130:197] = False                   # a hole: partial, whole, partial tile
+    mask[1, 5:Tk - 3] = False                  # almost everything masked
+    want = O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H).transpose(1, 2)
+    qp, kp, vp = (_to_pair(t.to(DEV)) for t in (q, k, v))
+    for flag in ("0", "1"):
+        monkeypatch.setenv("VRD_FLASH_W64", flag)
+        close(ops.attention(qp, kp, vp, mask.to(DEV), H), want, 2e-4)
+
+
 def test_row_blocks_padding_map():
     """vrd_row_blocks: the 32-row blocks dealt into segments (about eight, whole 256-row tiles, the last one shorter);
     inside a segment the blocks holding a valid row first (ascending), the fully padded ones after (ascending); every
