@@ -76,20 +76,16 @@ __device__ __forceinline__ void load_w(const vrd_gemm_args& p, int n, int k, int
     }
 }
 
+// workgroups per CU the register budget is set for (3 x 168 registers; at the compiler's own choice of 208 two fit and the
+// MFMA pipes idle whenever both are outside their K loops: 0.71 -> 0.75 of the f32 MFMA peak with three)
+#ifndef VRD_F32_WAVES
+#define VRD_F32_WAVES 3
+#endif
 template <bool VEC, int TAPS, int BK, bool STAGED>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float (*lds_a)[BK][LDM] = reinterpret_cast<float (*)[BK][LDM]>(smem);
     float (*lds_b)[BK][LDM] = reinterpret_cast<float (*)[BK][LDM]>(smem + 2 * BK * LDM);
-
-    // XCD-aware (bijective) renumbering of the workgroup id
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int64_t m0 = (int64_t)tm * BM;
-    const int n0 = tn * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -97,6 +93,15 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(vrd_gemm_args p, int
     const int li = lane & 31, lh = lane >> 5;
     const int K = p.Cin * TAPS;
     const int nkt = (K + BK - 1) / BK;
+    // XCD-aware (bijective) renumbering of the workgroup id.  (Persistent workgroups -- a grid of CUs x 3 walking the tiles --
+    // were measured: 414 against 397 ms per step in the f32 mode; not kept.)
+    const int nwg = tiles_m * tiles_n;
+    const int vb = blockIdx.x;
+    const int xcd = vb & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (vb >> 3);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
 
     // staging assignment: NP (row, 4-wide k chunk) pieces of each operand per thread
     constexpr int NP = BK / 8, KQ = BK / 4;
