@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const float* __restrict
 // sums are order-dependent only in the last bits.
 // ------------------------------------------------------------------------------------------
 template <int HD, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_flash_kernel(const float* __restrict__ q, int64_t ldq,
+__global__ __launch_bounds__(NW * 64, 2) void attn_flash_kernel(const float* __restrict__ q, int64_t ldq,
                                                              const float* __restrict__ k, const float* __restrict__ v,
                                                              int64_t ldkv, const uint8_t* __restrict__ kv_mask, int Tq,
                                                              int Tk, float scale, float* __restrict__ out, int64_t ldo,
