@@ -324,7 +324,8 @@ int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_c
 
 /* Weight and bias gradient of a depthwise MaskedConv1D (models/blocks.py:91-113 under autograd; k = 1 / 3, `stride`, group_in
  * = 1 or 2 inputs per group) in one pass over dD (rows x C, rows = B * T output rows):
- *   dw[(g * ksize + kk) * C + c] += sum_r dD[r, c] * row_mask[r] * x[in_row(r, kk), c * group_in + g],  dbias[c] += sum_r dD[r, c] * row_mask[r]
+ *   dw[(c * group_in + g) * ksize + kk] += sum_r dD[r, c] * row_mask[r] * x[in_row(r, kk), c * group_in + g]   (the Conv1d weight's own
+ *   (C, group_in, ksize) layout),  dbias[c] += sum_r dD[r, c] * row_mask[r]
  * in_row(r = s*T + t, kk) = s * stride*T + stride*t + kk - ksize/2 where that stays inside sequence s; dbias may be NULL. */
 int vrd_dwconv_wgrad(const float* dD, int64_t lddd, const float* x, int64_t ldx, int ksize, int stride, int group_in, int T,
                      const uint8_t* row_mask, int64_t rows, int C, float* dw, float* dbias, void* stream);

@@ -296,14 +296,12 @@ class DepthwiseConv(Function):
         pxin, _, _, ldxin = _rows(xin)
         for i in range(n):
             # all taps, both inputs of a group and the bias in one pass over dD (vrd_dwconv_wgrad)
-            gw = _zeros(gin, k, Cout, device=dev)
+            gw = _zeros(Cout, gin, k, device=dev)          # the parameter's own layout and strides (DDP's bucket views expect them)
             gb = _zeros(Cout, device=dev) if ctx.has_bias[i] else None
             pd, rows_out, _, ldd = _rows(dDs[i])
             check(lib.vrd_dwconv_wgrad(pd, ldd, pxin, ldxin, k, s, gin, Tout, _mask_ptr(ctx.mask_out, rows_out), rows_out, Cout,
                                        gw.data_ptr(), gb.data_ptr() if gb is not None else None, _stream()), "vrd_dwconv_wgrad")
-            # (C, gin, k) with the parameter's own strides: for gin = k = 1 `.contiguous()` is a no-op that keeps (1, C, C),
-            # which DDP's bucket views flag as a layout mismatch
-            grads.append(torch.empty(Cout, gin, k, device=dev, dtype=torch.float32).copy_(gw.permute(2, 0, 1)))
+            grads.append(gw)
             grads.append(gb)
         return (dx, dx_up, None, None, *grads)
 

@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 
 // ------------------------------------------------------------------------------------------------------------------
 // Weight and bias gradient of a depthwise conv (k = 1 / 3, stride bs, gin inputs per group) in ONE pass over dD:
-//   dw[g, kk, c] += sum_r dD[r, c] * m[r] * x[brow(r, kk), c * gin + g],   dbias[c] += sum_r dD[r, c] * m[r]
+//   dw[c, g, kk] += sum_r dD[r, c] * m[r] * x[brow(r, kk), c * gin + g],   dbias[c] += sum_r dD[r, c] * m[r]
+// (dw in the parameter's own (C, gin, k) layout)
 // (vrd_colsum computes one (g, kk) per launch: twelve launches and twelve passes over dD per q / k / v convolution triple).
 // block = rpb rows x 64 columns, a quarter of the rows per wave (as vrd_colsum); one atomic per column, output and block.
 // ------------------------------------------------------------------------------------------------------------------
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
     for (int g = 0; g < GIN; ++g)
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk)
-            atomicAdd(dw + (int64_t)(g * KS + kk) * C + c, sw[g][kk] + red[0][g * KS + kk][lane] + red[1][g * KS + kk][lane] + red[2][g * KS + kk][lane]);
+            atomicAdd(dw + (int64_t)c * (GIN * KS) + g * KS + kk, sw[g][kk] + red[0][g * KS + kk][lane] + red[1][g * KS + kk][lane] + red[2][g * KS + kk][lane]);
     if (dbias) atomicAdd(dbias + c, sb + red[0][GIN * KS][lane] + red[1][GIN * KS][lane] + red[2][GIN * KS][lane]);
 }
 
