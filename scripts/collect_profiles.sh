@@ -2,7 +2,8 @@
 # Run on the GPU box (through gpurun) from the repo root:  bash scripts/collect_profiles.sh r02 [bf16x3|f32|both] [sq]
 # Produces, under gpurun_out/profiles_<tag>/ (copy the summaries you want judged into profiles/ with
 # scripts/summarize_traffic.py / scripts/summarize_sq.py):
-#   bench.json                       the bench line (events on, CPU baseline on), default mode, alt mode included
+#   bench.json                       the bench line (events on, CPU baseline on), default mode, alt mode included; run LAST,
+#                                    after the traffic summaries of this run were written into profiles/ on the box
 #   kernel_stats[_f32].csv           rocprofv3 --kernel-trace --stats of the same command in one precision mode
 #   pmc_FETCH_SIZE[_f32].csv / pmc_WRITE_SIZE[_f32].csv   per dispatch, separate passes (TCC slots)
 #   pmc_SQ[_f32].csv                 (with `sq`) one SQ pass per mode: MFMA busy / wave cycles / waits / MFMA ops, every dispatch
@@ -17,7 +18,6 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_sha())" > $OUT/kernel_src_sha.txt || exit 1
-echo "[collect] bench line" && timeout -k 10 500 python3 $R/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 LEAN="--no-cpu-baseline --no-alt --no-ragged --no-forward-test --no-train-step --no-shard-projection"
 for MODE in bf16x3 f32; do
   if [ "$MODES" != both ] && [ "$MODES" != $MODE ]; then continue; fi
@@ -43,4 +43,10 @@ if [ "$SQ" = sq ]; then
     rm -rf $OUT/pmc_SQ$SUF
   done
 fi
+# the bench line last, with this run's traffic summaries in place on the box (bench.py reads roofline.traffic from the newest
+# profiles/*_hbm_traffic[_f32].json whose source stamp matches the tree; stage_profiles.sh writes the same files at home)
+for SUF in "" _f32; do
+  [ -f $OUT/pmc_FETCH_SIZE$SUF.csv ] && (cd $R && python3 scripts/summarize_traffic.py $OUT profiles/${TAG}_hbm_traffic$SUF.json $SUF > /dev/null)
+done
+echo "[collect] bench line" && timeout -k 10 500 python3 $R/bench.py --steps 5 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 ls -la $OUT
