@@ -32,6 +32,10 @@ from oracle.synth import synth_relations                    # noqa: E402
 
 B, T, SEED_LEN, SEED_X, SEED_GT = 24, 96, 2024, 3, 2025
 SAMPLE = 499         # stride of the stored sample of a large gradient
+# second golden (round 3): configs/vidor.yaml -- 8 heads of 64 channels, window 9, 50 classes, T = max_seq_len = 512 -- on 6 pairs
+# with ragged lengths, stochastic depth off: the backward kernels at the other shipped training shape (the attention
+# backward as matrix-core products, the weight-gradient tiles with row chunks that end inside sequences)
+VIDOR = dict(config="vidor", B=6, T=512, seed_len=3024, seed_x=5, seed_gt=3025)
 
 
 def keep_vector(name, n, keep_prob):
@@ -40,10 +44,10 @@ def keep_vector(name, n, keep_prob):
     return torch.floor(keep_prob + torch.rand(n, generator=g))
 
 
-def batch(mc):
-    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(SEED_LEN)).tolist()
-    x, _ = O.synth_pairs(B, c_in(mc), T, lens, seed=SEED_X)
-    gp, gm, gs = synth_relations(lens, T, mc["num_classes"], max_rel=4, seed=SEED_GT)
+def batch(mc, B=B, T=T, seed_len=SEED_LEN, seed_x=SEED_X, seed_gt=SEED_GT):
+    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(seed_len)).tolist()
+    x, _ = O.synth_pairs(B, c_in(mc), T, lens, seed=seed_x)
+    gp, gm, gs = synth_relations(lens, T, mc["num_classes"], max_rel=4, seed=seed_gt)
     return lens, {"so_features_list": [x[i, :, :n].contiguous() for i, n in enumerate(lens)],
                   "preds_list": gp, "masks_list": gm, "segs_list": gs}
 
@@ -57,16 +61,17 @@ def run(model, data):
     return loss
 
 
-def main():
-    cfg, mc = load_cfg("vidvrd.yaml")
+def main(config="vidvrd", cases=("nodrop", "pinned"), spec=None):
+    cfg, mc = load_cfg(config + ".yaml")
     model, _, _ = build(mc)
     for p in model.parameters():
         p.requires_grad_(True)
-    lens, data = batch(mc)
-    arrs, meta = {}, {"B": B, "T": T, "lengths": lens, "sample_stride": SAMPLE, "cases": {}}
+    spec = spec or dict(B=B, T=T, seed_len=SEED_LEN, seed_x=SEED_X, seed_gt=SEED_GT)
+    lens, data = batch(mc, **spec)
+    arrs, meta = {}, {"B": spec["B"], "T": spec["T"], "lengths": lens, "sample_stride": SAMPLE, "cases": {}}
 
     orig_drop = ref_blocks.drop_path
-    for case in ("nodrop", "pinned"):
+    for case in cases:
         restore = []
         if case == "nodrop":
             ref_blocks.drop_path = lambda x, drop_prob=0.0, training=False: x
@@ -75,7 +80,7 @@ def main():
             keeps = {}
             for name, mod in model.named_modules():
                 if isinstance(mod, ref_blocks.AffineDropPath) and mod.drop_prob > 0:
-                    keeps[name] = keep_vector(name, 2 * B, 1.0 - mod.drop_prob)
+                    keeps[name] = keep_vector(name, 2 * spec["B"], 1.0 - mod.drop_prob)
                     state = {"calls": 0}
 
                     def fwd(x, mod=mod, name=name, state=state):
@@ -113,11 +118,15 @@ def main():
         print(case, "total_loss", float(loss["total_loss"]), "params with grads", len(stats),
               "max |grad|", max(float(p.grad.abs().max()) for p in model.parameters()))
     ref_blocks.drop_path = orig_drop
-    np.savez_compressed(os.path.join(OUT, "train_step_vidvrd.npz"), **arrs)
-    with open(os.path.join(OUT, "train_step_vidvrd.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT, f"train_step_{config}.npz"), **arrs)
+    with open(os.path.join(OUT, f"train_step_{config}.json"), "w") as f:
         json.dump(meta, f)
 
 
 if __name__ == "__main__":
     torch.set_grad_enabled(True)
-    main()
+    if "--vidor" in sys.argv:
+        v = dict(VIDOR)
+        main(v.pop("config"), cases=("nodrop",), spec=v)
+    else:
+        main()

@@ -43,17 +43,19 @@ def compare_forward_test(res, ref, n_max_pair, score_tol, slack):
 
 # ---- training step (scripts/make_golden_train.py)
 TRAIN = dict(B=24, T=96, seed_len=2024, seed_x=3, seed_gt=2025)
+TRAIN_VIDOR = dict(B=6, T=512, seed_len=3024, seed_x=5, seed_gt=3025)      # scripts/make_golden_train.py --vidor
 
 
-def train_batch(mc, c_in, device="cpu"):
-    """The 24-pair training batch of the train_step golden, in the dataloader's training format
-    (dataloaders/vidvrd.py:451-457): so_features_list (C_in, L_i), preds_list, masks_list (N_i, max_seq_len), segs_list."""
+def train_batch(mc, c_in, device="cpu", spec=TRAIN):
+    """The training batch of a train_step golden (24 pairs x 96 frames for vidvrd.yaml, 6 x 512 for vidor.yaml), in the
+    dataloader's training format (dataloaders/vidvrd.py:451-457): so_features_list (C_in, L_i), preds_list, masks_list
+    (N_i, max_seq_len), segs_list."""
     from oracle import vrd_oracle as O
     from oracle.synth import synth_relations
-    B, T = TRAIN["B"], TRAIN["T"]
-    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(TRAIN["seed_len"])).tolist()
-    x, m = O.synth_pairs(B, c_in, T, lens, seed=TRAIN["seed_x"])
-    gp, gm, gs = synth_relations(lens, T, mc["num_classes"], max_rel=4, seed=TRAIN["seed_gt"])
+    B, T = spec["B"], spec["T"]
+    lens = torch.randint(2, T + 1, (B,), generator=torch.Generator().manual_seed(spec["seed_len"])).tolist()
+    x, m = O.synth_pairs(B, c_in, T, lens, seed=spec["seed_x"])
+    gp, gm, gs = synth_relations(lens, T, mc["num_classes"], max_rel=4, seed=spec["seed_gt"])
     to = lambda ts: [t.to(device) for t in ts]      # noqa: E731
     data = {"so_features_list": to([x[i, :, :n].contiguous() for i, n in enumerate(lens)]),
             "preds_list": to(gp), "masks_list": to(gm), "segs_list": to(gs)}

@@ -186,6 +186,38 @@ def test_training_step_matches_reference_gradients(case, precision):
     print(f"[{case}/{precision}] relative gradient error: worst {worst:.2e}, median {median:.2e}")
 
 
+def test_training_step_vidor_matches_reference_gradients(precision):
+    """The other shipped training shape -- configs/vidor.yaml: 8 heads of 64 channels, window 9, 50 classes, T = 512 -- on 6
+    ragged pairs, stochastic depth off, against the reference's own step (tests/golden/train_step_vidor.*, scripts/
+    make_golden_train.py --vidor): the attention backward as matrix-core products (512 x 512 scores), the weight-gradient tiles
+    on 6,144 rows, the 64-channel-head forward kernels under autograd."""
+    from golden_cases import TRAIN_VIDOR
+    from vrdone_amd.models.blocks import AffineDropPath
+    model, mc, _ = build("vidor")
+    with open(os.path.join(GOLDEN, "train_step_vidor.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "train_step_vidor.npz"))
+    lens, _, _, data = train_batch(mc, c_in(mc), device=DEV, spec=TRAIN_VIDOR)
+    assert lens == meta["lengths"] and meta["T"] == 512
+    model.train()
+    for mod in model.modules():
+        if isinstance(mod, AffineDropPath):
+            mod.drop_prob = 0.0
+    differing = replay_matching(model, meta["cases"]["nodrop"]["indices"])
+    with torch.enable_grad():
+        loss = model(data)
+        loss["total_loss"].backward()
+    want = meta["cases"]["nodrop"]["losses"]
+    assert set(loss) == set(want)
+    for k, v in want.items():
+        assert abs(float(loss[k].detach()) - v) <= (1e-5 if precision == "f32" else 2e-4) * max(1.0, abs(v)), (k, float(loss[k]), v)
+    assert all(len(call) <= 2 for call in differing), differing
+    worst, median = compare_grads(((n, p.grad) for n, p in model.named_parameters()), g, meta, "nodrop",
+                                  rtol=3e-2, atol_frac=1e-4, median_tol=2e-5 if precision == "f32" else 5e-4, outlier_tol=1e-3,
+                                  max_outliers=3)
+    print(f"[vidor/{precision}] relative gradient error: worst {worst:.2e}, median {median:.2e}")
+
+
 def test_drop_path_sampling_statistics():
     """AffineDropPath in training mode: per-sample factors are 0 or 1/keep_prob, E[factor] = 1, one decision per sample
     repeated over its rows; nothing is sampled in eval or under no_grad."""

@@ -233,6 +233,32 @@ def test_training_step_gradients_match_reference(weights):
     compare_grads([(n, leaves[n].grad) for n in names], g, meta, "nodrop", rtol=1e-3, median_tol=2e-5)
 
 
+def test_training_step_gradients_vidor_match_reference(weights):
+    """The same for configs/vidor.yaml (8 heads of 64 channels, T = 512, 6 ragged pairs; tests/golden/train_step_vidor.*)."""
+    from golden_cases import TRAIN_VIDOR, compare_grads, replay_matching, train_batch
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, _, sd = weights("vidor")
+    with open(os.path.join(GOLDEN, "train_step_vidor.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "train_step_vidor.npz"))
+    lens, x, m, data = train_batch(mc, c_in(mc), spec=TRAIN_VIDOR)
+    assert lens == meta["lengths"]
+    model = MaskVRD(mc, device="cpu").train()
+    differing = replay_matching(model, meta["cases"]["nodrop"]["indices"])
+    names = [n for n, _ in model.named_parameters()]
+    leaves = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        pred = O.mask_vrd(leaves, mc, x, m, with_aux=True)
+        loss = model.criterion(pred, data)
+        loss["total_loss"].backward()
+    want = meta["cases"]["nodrop"]["losses"]
+    assert set(loss) == set(want)
+    for k, v in want.items():
+        assert abs(float(loss[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
+    assert len(differing) == 4 and all(len(call) <= 2 for call in differing), differing
+    compare_grads([(n, leaves[n].grad) for n in names], g, meta, "nodrop", rtol=1e-3, median_tol=2e-5)
+
+
 def test_preprocess_eval_shapes():
     mc, _, _ = load_case("vidvrd")
     assert O.max_div_factor(mc) == 48
