@@ -36,6 +36,8 @@ SAMPLE = 499         # stride of the stored sample of a large gradient
 # with ragged lengths, stochastic depth off: the backward kernels at the other shipped training shape (the attention
 # backward as matrix-core products, the weight-gradient tiles with row chunks that end inside sequences)
 VIDOR = dict(config="vidor", B=6, T=512, seed_len=3024, seed_x=5, seed_gt=3025)
+VARIANTS = {"vidor_x": dict(B=4, T=512, seed_len=4024, seed_x=11, seed_gt=4025),
+            "vidor_local": dict(B=4, T=512, seed_len=5024, seed_x=9, seed_gt=5025)}
 
 
 def keep_vector(name, n, keep_prob):
@@ -128,5 +130,8 @@ if __name__ == "__main__":
     if "--vidor" in sys.argv:
         v = dict(VIDOR)
         main(v.pop("config"), cases=("nodrop",), spec=v)
+    elif "--vidor-variants" in sys.argv:     # the CLIP backbone (vidor_x.yaml) and the banded SOS attention (vidor_local.yaml)
+        for name, spec in VARIANTS.items():
+            main(name, cases=("nodrop",), spec=dict(spec))
     else:
         main()

@@ -44,6 +44,9 @@ def compare_forward_test(res, ref, n_max_pair, score_tol, slack):
 # ---- training step (scripts/make_golden_train.py)
 TRAIN = dict(B=24, T=96, seed_len=2024, seed_x=3, seed_gt=2025)
 TRAIN_VIDOR = dict(B=6, T=512, seed_len=3024, seed_x=5, seed_gt=3025)      # scripts/make_golden_train.py --vidor
+# scripts/make_golden_train.py --vidor-variants: the CLIP backbone (vidor_x.yaml), the banded SOS attention (vidor_local.yaml)
+TRAIN_SPECS = {"vidor": TRAIN_VIDOR, "vidor_x": dict(B=4, T=512, seed_len=4024, seed_x=11, seed_gt=4025),
+               "vidor_local": dict(B=4, T=512, seed_len=5024, seed_x=9, seed_gt=5025)}
 
 
 def train_batch(mc, c_in, device="cpu", spec=TRAIN):

@@ -233,15 +233,17 @@ def test_training_step_gradients_match_reference(weights):
     compare_grads([(n, leaves[n].grad) for n in names], g, meta, "nodrop", rtol=1e-3, median_tol=2e-5)
 
 
-def test_training_step_gradients_vidor_match_reference(weights):
-    """The same for configs/vidor.yaml (8 heads of 64 channels, T = 512, 6 ragged pairs; tests/golden/train_step_vidor.*)."""
-    from golden_cases import TRAIN_VIDOR, compare_grads, replay_matching, train_batch
+@pytest.mark.parametrize("name", ["vidor", "vidor_x", "vidor_local"])
+def test_training_step_gradients_vidor_match_reference(weights, name):
+    """The same for the T = 512 configs: vidor.yaml (8 heads of 64 channels, 6 ragged pairs), vidor_x.yaml (CLIP backbone),
+    vidor_local.yaml (banded SOS attention); tests/golden/train_step_<name>.*."""
+    from golden_cases import TRAIN_SPECS, compare_grads, replay_matching, train_batch
     from vrdone_amd.models.maskvrd import MaskVRD
-    mc, _, sd = weights("vidor")
-    with open(os.path.join(GOLDEN, "train_step_vidor.json")) as f:
+    mc, _, sd = weights(name)
+    with open(os.path.join(GOLDEN, f"train_step_{name}.json")) as f:
         meta = json.load(f)
-    g = np.load(os.path.join(GOLDEN, "train_step_vidor.npz"))
-    lens, x, m, data = train_batch(mc, c_in(mc), spec=TRAIN_VIDOR)
+    g = np.load(os.path.join(GOLDEN, f"train_step_{name}.npz"))
+    lens, x, m, data = train_batch(mc, c_in(mc), spec=TRAIN_SPECS[name])
     assert lens == meta["lengths"]
     model = MaskVRD(mc, device="cpu").train()
     differing = replay_matching(model, meta["cases"]["nodrop"]["indices"])
@@ -256,7 +258,8 @@ def test_training_step_gradients_vidor_match_reference(weights):
     for k, v in want.items():
         assert abs(float(loss[k]) - v) <= 1e-4 * max(1.0, abs(v)), k
     assert len(differing) == 4 and all(len(call) <= 2 for call in differing), differing
-    compare_grads([(n, leaves[n].grad) for n in names], g, meta, "nodrop", rtol=1e-3, median_tol=2e-5)
+    # (atol_frac: a key projection's bias shifts every score of a query equally, its gradient is rounding noise on both sides)
+    compare_grads([(n, leaves[n].grad) for n in names], g, meta, "nodrop", rtol=1e-3, atol_frac=1e-5, median_tol=2e-5)
 
 
 def test_preprocess_eval_shapes():
