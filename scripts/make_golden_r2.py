@@ -30,6 +30,8 @@ torch.set_grad_enabled(False)
 # shared with the tests (tests/golden_cases.py imports nothing from here: the numbers are repeated there)
 SLICES = dict(n_tracklets=23, min_len=30, max_len=250, seed=2718, sort_by_length=True)
 VIDOR_X = dict(n_tracklets=5, min_len=150, max_len=800, seed=1618, feat_stride=4, random_offset=True)
+FORWARD_TEST_VARIANTS = {"vidor": dict(n_tracklets=5, min_len=150, max_len=800, seed=2618, feat_stride=4, random_offset=True),
+                         "vidor_local": dict(n_tracklets=5, min_len=150, max_len=700, seed=3618, feat_stride=4, random_offset=True)}
 B256 = dict(B=256, T=288, seed=31415, every=16)
 CFG2 = dict(B=1024, T=144, frames=128, seed=27182, every=64)       # BASELINE config 2 at its size: 1024 pairs x 128 frames -> T_pad 144
 
@@ -346,5 +348,24 @@ def vidor_x_case():
     print("  triplets", len(res["triplets"]), f"{time.time() - t0:.0f} s")
 
 
+def forward_test_variants():
+    """forward_test under vidor.yaml (plain backbone, 8 heads) and vidor_local.yaml (banded SOS attention): the same kind of
+    synthetic video as the vidor_x case (feat_stride 4, so_offset in 0..3, pairs longer than max_seq_len), other seeds."""
+    for name, spec in FORWARD_TEST_VARIANTS.items():
+        t0 = time.time()
+        cfg, mc = load_cfg(name + ".yaml")
+        model, _, _ = build(mc)
+        model._config_eval(cfg["inference_config"])
+        data = synth_proposal(c_in=c_in(mc), **spec)
+        print(name, "forward_test case: pairs", len(data["sids"]), "lengths", sorted(int(f.shape[1]) for f in data["so_features_list"]))
+        res = digest(model(data), data)
+        with open(os.path.join(OUT, f"forward_test_{name}.json"), "w") as f:
+            json.dump(res, f)
+        print("  triplets", len(res["triplets"]), f"{time.time() - t0:.0f} s")
+
+
 if __name__ == "__main__":
-    main()
+    if "--only-forward-test-variants" in sys.argv:
+        forward_test_variants()
+    else:
+        main()

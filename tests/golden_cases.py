@@ -4,6 +4,9 @@ import torch
 
 SLICES = dict(n_tracklets=23, min_len=30, max_len=250, seed=2718, sort_by_length=True)
 VIDOR_X = dict(n_tracklets=5, min_len=150, max_len=800, seed=1618, feat_stride=4, random_offset=True)
+# scripts/make_golden_r2.py --only-forward-test-variants
+FORWARD_TEST_VARIANTS = {"vidor": dict(n_tracklets=5, min_len=150, max_len=800, seed=2618, feat_stride=4, random_offset=True),
+                         "vidor_local": dict(n_tracklets=5, min_len=150, max_len=700, seed=3618, feat_stride=4, random_offset=True)}
 B256 = dict(B=256, T=288, seed=31415, every=16)
 CFG2 = dict(B=1024, T=144, frames=128, seed=27182, every=64)       # scripts/make_golden_r2.py --only-cfg2
 
@@ -22,18 +25,27 @@ def b256_lengths():
     return lens.tolist()
 
 
-def compare_forward_test(res, ref, n_max_pair, score_tol, slack):
+def compare_forward_test(res, ref, n_max_pair, score_tol, slack, tie_tol=0.0):
     """A forward_test result against a stored reference result: same number of triplets, sorted scores within
     score_tol, and the same (triplet, tracklets, duration) records and box-track digests up to `slack` entries (the
     ranking can only differ where two scores are closer than the arithmetic noise; slack = 0 demands identity -- which
-    holds for all three goldens in both precision modes, measured score error 1e-7 (f32) / 1e-6 (bf16x3))."""
+    holds for the goldens in both precision modes, measured score error 1e-7 (f32) / 1e-6 (bf16x3)).  tie_tol: ranks inside a tie
+    of the reference's own scores may be permuted (vidor_local returns ALL 180 candidates, the last of them with scores that
+    differ by less than the arithmetic noise)."""
     import numpy as np
-    assert len(res["triplets"]) == len(ref["triplets"]) == n_max_pair
+    assert len(res["triplets"]) == len(ref["triplets"]) <= n_max_pair          # (fewer candidates than n_max_pair: all of them)
     np.testing.assert_allclose(res["triple_scores_avg"], ref["triple_scores_avg"], atol=score_tol, rtol=0)
     n = len(ref["triplets"])
-    same = sum(a == b for a, b in zip(res["triplets"], ref["triplets"]))
-    assert same >= n - slack, f"{n - same} ranks differ"
     key = lambda r, i: (tuple(r["triplets"][i]), tuple(r["so_tids"][i]), tuple(r["pred_durations"][i]))   # noqa: E731
+    # a rank may differ only inside a tie: the record found at rank i stands, in the reference, at a rank whose score is
+    # within tie_tol of rank i's (tie_tol = 0: no rank may differ beyond `slack`)
+    sc = ref["triple_scores_avg"]
+    where = {}
+    for j in range(n):
+        where.setdefault(key(ref, j), []).append(j)
+    off = [i for i in range(n) if key(res, i) != key(ref, i)]
+    untied = [i for i in off if not any(abs(sc[j] - sc[i]) <= tie_tol for j in where.get(key(res, i), []))] if tie_tol > 0 else off
+    assert len(untied) <= slack, f"{len(untied)} ranks differ outside ties: {untied[:8]}"
     got, want = {key(res, i) for i in range(n)}, {key(ref, i) for i in range(n)}
     assert len(got & want) >= len(want) - slack
     dig = {(len(t[0]), round(float(np.sum(np.asarray(t, dtype=np.float64))), 3)) for t in res["so_trajs"]}

@@ -170,6 +170,19 @@ def test_forward_test_vidor_x_matches_reference_golden(precision):
     compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0)
 
 
+@pytest.mark.parametrize("name", ["vidor", "vidor_local"])
+def test_forward_test_vidor_variants_match_reference_golden(name, precision):
+    """forward_test under vidor.yaml and vidor_local.yaml against the REFERENCE's results (identity of ranking, records
+    and tracks; vidor_local: 180 candidates, fewer than n_max_pair)."""
+    from golden_cases import FORWARD_TEST_VARIANTS, compare_forward_test
+    model, mc, ic, _ = get_model(name)
+    with open(os.path.join(GOLDEN, f"forward_test_{name}.json")) as f:
+        ref = json.load(f)
+    data = synth_proposal(c_in=c_in(mc), **FORWARD_TEST_VARIANTS[name])
+    res = model(_on_device(data))
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0, tie_tol=2e-6)
+
+
 def test_mask_vrd_b256_matches_reference_golden(precision):
     """256 pairs x T_pad 288 with ragged lengths: the batch size at which the model selects the 256 x 256 LDS-DMA GEMM
     kernel, the padding maps and vrd_gemm_batch (ops.SKIP_MIN_ROWS rows), compared with the REFERENCE's outputs for

@@ -160,6 +160,19 @@ def test_forward_test_many_slices_matches_reference(weights):
     compare_forward_test(res, ref, ic["n_max_pair"], 1e-5, slack=0)
 
 
+@pytest.mark.parametrize("name", ["vidor", "vidor_local"])
+def test_forward_test_vidor_variants_match_reference(weights, name):
+    """forward_test under vidor.yaml (plain backbone, 8 heads of 64 channels) and vidor_local.yaml (banded SOS attention;
+    20 pairs x 9 queries = 180 candidates, fewer than n_max_pair): feat_stride 4, so_offset in 0..3."""
+    from golden_cases import FORWARD_TEST_VARIANTS, compare_forward_test
+    mc, ic, sd = weights(name)
+    with open(os.path.join(GOLDEN, f"forward_test_{name}.json")) as f:
+        ref = json.load(f)
+    data = synth_proposal(c_in=c_in(mc), **FORWARD_TEST_VARIANTS[name])
+    res = O.forward_test(sd, mc, ic, data)
+    compare_forward_test(res, ref, ic["n_max_pair"], 1e-5, slack=0)
+
+
 def test_forward_test_vidor_x_with_offsets_matches_reference(weights):
     """vidor_x.yaml (Q = 10, topk 6, feat_stride 4, pred_min_frames 5) with so_offset in {0..3}
     (models/maskvrd.py:283-299: start = first * feat_stride + offset)."""
