@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 22
+#define VRD_ABI_VERSION 23
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -461,6 +461,18 @@ int vrd_criterion_backward(const vrd_criterion_args* a, const int32_t* query_of,
  * sq = Cin*k.  In a training step every weight changes every step, so both are rebuilt per step: as tensor expressions that
  * was ~11 elementwise launches per weight. */
 int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, void* stream);
+
+/* The same for many weights in ONE launch (a training step re-splits every conv weight, forward and input-gradient form, after
+ * each optimiser update).  jobs: DEVICE array; chunk c of the launch is one 32 x 32 tile of job chunk_job[c]: with KB = taps*Q/32
+ * blocks per row, rows 32 * (chunk_index[c] / KB) .. + 31 and K block chunk_index[c] % KB (both device int32 arrays of n_chunks
+ * entries; a job is covered by ceil(R / 32) * KB chunks). */
+typedef struct {
+    const float* src;      /* element (r, tap, q) at src[r*sr + tap*st + q*sq] */
+    uint16_t* out;         /* (R, taps*Q/32, 2, 32) bf16 */
+    int32_t R, Q, taps, reserved;
+    int64_t sr, st, sq;
+} vrd_split_job;
+int vrd_split_weights(const vrd_split_job* jobs, const int32_t* chunk_job, const int32_t* chunk_index, int n_chunks, void* stream);
 
 #ifdef __cplusplus
 }

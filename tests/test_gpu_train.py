@@ -228,6 +228,48 @@ def test_training_step_vidor_matches_reference_gradients(name, precision):
     print(f"[{name}/{precision}] relative gradient error: worst {worst:.2e}, median {median:.2e}; downstream of the pools: {w2:.2e}, {m2:.2e}")
 
 
+def test_presplit_weights_equal_the_per_weight_launches():
+    """ops.presplit_weights (one vrd_split_weights launch for all dense conv weights of a training step) leaves, in every
+    weight's operand caches, exactly what split_conv_weight / split_conv_weight_dgrad build one launch at a time; a later
+    in-place update of a weight invalidates its entries."""
+    from vrdone_amd import ops
+    old = ops.get_precision()
+    ops.set_precision("bf16x3")
+    try:
+        model, _, _ = build()
+        ws = model._dense_conv_weights()
+        assert len(ws) > 100
+        want = {}
+        for w in ws:
+            N, Cin, k = w.shape
+            if (Cin * k) % 32 == 0:
+                want[(id(w), "_vrd_split")] = ops.split_conv_weight(w).clone()
+            if (N * k) % 32 == 0:
+                want[(id(w), "_vrd_split_t")] = ops.split_conv_weight_dgrad(w).clone()
+            for slot in ("_vrd_split", "_vrd_split_t"):
+                if hasattr(w, slot):
+                    delattr(w, slot)
+        plans = {}
+        ops.presplit_weights(ws, plans)
+        assert len(plans) == 1 and len(want) > 200
+        for w in ws:
+            for slot in ("_vrd_split", "_vrd_split_t"):
+                if (id(w), slot) in want:
+                    key, val = getattr(w, slot)[:2]
+                    assert key == (w.data_ptr(), w._version)
+                    assert torch.equal(val.view(torch.int16), want[(id(w), slot)].view(torch.int16)), slot
+        w0 = ws[0]
+        assert ops.split_conv_weight(w0) is getattr(w0, "_vrd_split")[1]          # served from the cache
+        with torch.no_grad():
+            w0.mul_(1.5)
+        fresh = ops.split_conv_weight(w0)                                          # stale entry: rebuilt for the new version
+        assert not torch.equal(fresh.view(torch.int16), want[(id(w0), "_vrd_split")].view(torch.int16))
+        ops.presplit_weights(ws, plans)                                            # the next step: same plan, new values
+        assert len(plans) == 1 and torch.equal(getattr(w0, "_vrd_split")[1].view(torch.int16), fresh.view(torch.int16))
+    finally:
+        ops.set_precision(old)
+
+
 def test_drop_path_sampling_statistics():
     """AffineDropPath in training mode: per-sample factors are 0 or 1/keep_prob, E[factor] = 1, one decision per sample
     repeated over its rows; nothing is sampled in eval or under no_grad."""

@@ -79,6 +79,11 @@ class BmmArgs(C.Structure):
                 ("alpha", C.c_float), ("accumulate", C.c_int32)]
 
 
+class SplitJob(C.Structure):
+    _fields_ = [("src", c_f32p), ("out", C.c_void_p), ("R", C.c_int32), ("Q", C.c_int32), ("taps", C.c_int32), ("reserved", C.c_int32),
+                ("sr", C.c_int64), ("st", C.c_int64), ("sq", C.c_int64)]
+
+
 class GatherArgs(C.Structure):
     _fields_ = [("vis", c_f32p), ("clip", c_f32p), ("boxes", c_f32p), ("s_row", C.c_void_p), ("o_row", C.c_void_p),
                 ("lens", C.c_void_p), ("P", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("Cc", C.c_int32),
@@ -108,6 +113,7 @@ _SIGNATURES = {
     "vrd_gather_pairs": (C.c_int, [C.POINTER(GatherArgs), C.c_void_p]),
     "vrd_assemble_pairs": (C.c_int, [C.POINTER(AssembleArgs), C.c_void_p]),
     "vrd_split_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "vrd_split_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_gemm_batch": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "vrd_row_blocks": (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -156,7 +162,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class HipLibraryError(RuntimeError):

@@ -147,17 +147,20 @@ class Linear(Function):
             # split-precision mode: the transposed (k = 3: tap-flipped) operand comes straight from the parameter in one
             # launch (ops.split_conv_weight_dgrad); as tensor expressions -- transpose, then the hi / lo split of a tensor
             # that is new every step -- it was seven launches per weight and step
+            # (the parameter object itself while autograd is not recording -- the usual case in a backward pass: its operand
+            # caches, which ops.presplit_weights fills for the whole step, hang on the object; a detached view has none)
+            wd = weight if not torch.is_grad_enabled() else weight.detach()
             fused = (ops.get_precision() == "bf16x3" and (N * k) % 32 == 0 and N % 4 == 0 and dy.stride(-2) % 4 == 0 and
                      dy.data_ptr() % 16 == 0 and weight.is_contiguous())
             if k == 1:       # masking the rows of dy = masking the rows of dx
                 if fused:
-                    dx = ops.conv_gemm(dy, weight.detach(), None, row_mask=mask, _dgrad=True)
+                    dx = ops.conv_gemm(dy, wd, None, row_mask=mask, _dgrad=True)
                 else:
                     dx = ops.conv_gemm(dy, weight.detach().permute(1, 0, 2).contiguous(), None, row_mask=mask)
             else:            # dx[r] = sum_tap (dy * mask)[r - (tap - 1)] W[:, :, tap]: a k=3 conv with flipped, transposed taps
                 g = rowcol_scale(dy, row_mask=mask) if mask is not None else dy
                 if fused:
-                    dx = ops.conv_gemm(g, weight.detach(), None, _dgrad=True)
+                    dx = ops.conv_gemm(g, wd, None, _dgrad=True)
                 else:
                     dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]

@@ -107,6 +107,10 @@ class MaskVRD(nn.Module):
             raise RuntimeError("MaskVRD._mask_vrd runs on the HIP device only; move the model and inputs to 'cuda'")
         B = batched_inputs.shape[0]
         masks2d = batched_masks.reshape(B, batched_masks.shape[-1]).contiguous()
+        if self.training and torch.is_grad_enabled():
+            # a training step: the split-precision operands of all dense conv weights (forward and input-gradient form) in one
+            # launch instead of one per weight and form (they are rebuilt after every optimiser update)
+            _ops().presplit_weights(self._dense_conv_weights(), self.__dict__.setdefault("_split_plans", {}))
         outs = []
         step = self._chunk_size(B)
         for b0 in range(0, B, step):
@@ -114,6 +118,14 @@ class MaskVRD(nn.Module):
             m = masks2d[b0:b0 + step]
             outs.append(self._heads(*self.backbone.cl(x, m), with_aux))
         return self._merge(outs)
+
+    def _dense_conv_weights(self):
+        """The Conv1d weights that reach vrd_gemm (groups == 1), in module order; looked up on every call: training graphs swap
+        the modules' parameters for aliases of the same storage while they record."""
+        convs = self.__dict__.get("_dense_convs")
+        if convs is None:
+            convs = self.__dict__["_dense_convs"] = [mod for mod in self.modules() if isinstance(mod, nn.Conv1d) and mod.groups == 1]
+        return [mod.weight for mod in convs if mod.weight.is_contiguous()]
 
     def _chunk_size(self, n):
         """Pairs per launch wave: one wave up to 1.25 x pair_chunk, otherwise equal waves (a 2070-pair video is one wave,

@@ -145,10 +145,14 @@ def _keep_for_capture(val):
 
 
 def _cached(w, slot, build):
-    if _capturing():
-        return _keep_for_capture(build())
     key = (w.data_ptr(), w._version)
     hit = getattr(w, slot, None)
+    if _capturing():
+        # inside a recording only what presplit_weights built inside the SAME recording scope counts (its launch is part of
+        # the graph; train_graph opens one scope around a recording's forward and backward graphs)
+        if hit is not None and hit[0] == key and len(hit) > 2 and hit[2] is not None and hit[2] is _presplit_scope:
+            return hit[1]
+        return _keep_for_capture(build())
     if hit is not None and hit[0] == key:
         return hit[1]
     val = build()
@@ -207,6 +211,81 @@ def split_conv_weight_dgrad(w):
     (transposed, taps flipped), straight from the parameter."""
     N, Cin, k = w.shape
     return _cached(w, "_vrd_split_t", lambda: _split_weight(w.detach(), k - 1, Cin, N, k, k, -1, Cin * k))
+
+
+# ---- all split operands of a training step in one launch
+_presplit_scope = None     # token of the recording scope that is open (train_graph), None outside
+_presplit_on = os.environ.get("VRDONE_PRESPLIT", "1") != "0"        # A/B switch
+
+
+class presplit_scope:
+    """`with ops.presplit_scope():` around the graph captures of one recording: operands that presplit_weights builds inside
+    are accepted by the captures of the same scope (the backward graph reads what the forward graph's launch wrote)."""
+
+    def __enter__(self):
+        global _presplit_scope
+        self.prev, _presplit_scope = _presplit_scope, object()
+        return self
+
+    def __exit__(self, *exc):
+        global _presplit_scope
+        _presplit_scope = self.prev
+        return False
+
+
+def presplit_weights(weights, plans):
+    """The split-precision operands of `weights` (Conv1d parameters (N, Cin, k)) -- the forward operand where Cin*k % 32 == 0
+    and the input-gradient operand where N*k % 32 == 0 -- built by ONE vrd_split_weights launch into persistent buffers and
+    left in the weights' operand caches (the attributes split_conv_weight / split_conv_weight_dgrad look at) for the current
+    version of each weight.  A training step otherwise
+    re-splits every weight with a launch of its own, twice (after every optimiser update): 242 launches on the 24-pair batch.
+    plans: a dict the caller owns (the model's): tuple of weight addresses -> (job table on the device, chunk tables, the
+    persistent operand buffers); it lives as long as the model and the graphs recorded for it, which read those buffers.
+    The job table is built (and uploaded) on the first call for a set of weights -- outside any graph capture: inside one,
+    without a table, nothing is done and the per-weight launches run as before."""
+    if _precision != "bf16x3" or not weights or not _presplit_on:
+        return
+    key = tuple(w.data_ptr() for w in weights)
+    plan = plans.get(key)
+    if plan is None:
+        if _capturing():
+            return
+        import ctypes as C
+        jobs, outs, chunk_job, chunk_index = [], [], [], []
+        for w in weights:
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 3
+            N, Cin, k = w.shape
+            forms = []
+            if (Cin * k) % 32 == 0:
+                forms.append(("_vrd_split", 0, N, Cin, k, Cin * k, 1, k))                       # = split_conv_weight
+            if (N * k) % 32 == 0:
+                forms.append(("_vrd_split_t", k - 1, Cin, N, k, k, -1, Cin * k))                 # = split_conv_weight_dgrad
+            for slot, offset, R, Q, taps, sr, st, sq in forms:
+                out = torch.empty(R, taps * Q // 32, 2, 32, device=w.device, dtype=torch.bfloat16)
+                jobs.append(_hip.SplitJob(src=w.data_ptr() + 4 * offset, out=out.data_ptr(), R=R, Q=Q, taps=taps, reserved=0, sr=sr, st=st, sq=sq))
+                n_tiles = -(-R // 32) * (taps * Q // 32)          # 32 x 32 tiles: row block x K block
+                chunk_job.extend([len(jobs) - 1] * n_tiles)
+                chunk_index.extend(range(n_tiles))
+                outs.append((w.data_ptr(), slot, out))
+        if not jobs:
+            return
+        raw = bytes((_hip.SplitJob * len(jobs))(*jobs))
+        dev = weights[0].device
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        plan = (table, torch.tensor(chunk_job, dtype=torch.int32, device=dev), torch.tensor(chunk_index, dtype=torch.int32, device=dev), outs)
+        plans[key] = plan
+    table, cj, ci, outs = plan
+    by_ptr = {w.data_ptr(): w for w in weights}
+    if not _capturing():        # nothing moved since the last call (an evaluation of the same weights, a second forward): keep the operands
+        def current(ptr, slot):
+            hit = getattr(by_ptr[ptr], slot, None)
+            return hit is not None and hit[0] == (ptr, by_ptr[ptr]._version) and hit[1] is not None
+        if all(current(ptr, slot) for ptr, slot, _ in outs):
+            return
+    _hip.check(lib.vrd_split_weights(table.data_ptr(), cj.data_ptr(), ci.data_ptr(), cj.numel(), _stream()), "vrd_split_weights")
+    for ptr, slot, out in outs:
+        w = by_ptr[ptr]
+        setattr(w, slot, ((ptr, w._version), out, _presplit_scope if _capturing() else None))
 
 
 def bct_to_btc(x, c0, count, out, pair=False):

@@ -86,12 +86,13 @@ class _Recording:
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
             self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.fwd, pool=pool):
-                out = network()
-            self.static_out, self.spec = pytree.tree_flatten(out)
-            self.static_gout = grad_outputs(self.static_out)
-            with torch.cuda.graph(self.bwd, pool=pool):
-                self.static_gin = backward(self.static_out, self.static_gout)
+            with ops.presplit_scope():          # the backward graph reads the operands the forward graph's one split launch writes
+                with torch.cuda.graph(self.fwd, pool=pool):
+                    out = network()
+                self.static_out, self.spec = pytree.tree_flatten(out)
+                self.static_gout = grad_outputs(self.static_out)
+                with torch.cuda.graph(self.bwd, pool=pool):
+                    self.static_gin = backward(self.static_out, self.static_gout)
         finally:
             for mod, name, p in slots:
                 mod._parameters[name] = p
