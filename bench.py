@@ -398,6 +398,8 @@ def main():
             times = []
             for it in range(n):
                 tmodel.zero_grad(set_to_none=True)
+                with torch.no_grad():      # an optimiser step moved the weights (values unchanged here): the timed step rebuilds its derived operands like a real one
+                    torch._foreach_mul_([p for p in tmodel.parameters() if p.requires_grad], 1.0)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 loss = tmodel(tdata)["total_loss"]
@@ -411,6 +413,9 @@ def main():
         try:
             from torch.profiler import profile, ProfilerActivity
             tmodel.zero_grad(set_to_none=True)
+            with torch.no_grad():
+                torch._foreach_mul_([p for p in tmodel.parameters() if p.requires_grad], 1.0)
+            torch.cuda.synchronize()
             with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as tp:
                 tmodel(tdata)["total_loss"].backward()
                 torch.cuda.synchronize()
@@ -428,7 +433,8 @@ def main():
                  "ms_forward_backward_hip_graphs": graph_ms,
                  "params_with_finite_grad": f"{n_grad}/{n_par}", "params_with_finite_grad_hip_graphs": f"{n_grad_g}/{n_par}",
                  "total_loss": float(loss.detach()), "launches_forward_backward": launches,
-                 "note": "model.train(): forward_training + total_loss.backward() on the HIP backward kernels, stochastic depth on; "
+                 "note": "model.train(): forward_training + total_loss.backward() on the HIP backward kernels, stochastic depth on, every "
+                         "weight touched in place before each timed step (as after an optimiser update: derived operands are rebuilt); "
                          "median after 2 warm-up steps; hip_graphs: MaskVRD.enable_training_graphs() (vrdone_amd/train_graph.py), "
                          "batching eager, criterion = vrd_criterion_* (costs, assignment, losses, gradients: 4 launches for all layers)"}
         del tmodel, tdata
