@@ -28,7 +28,11 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: bf16 MFMA, dense (not the 2:1-sparsity figure)
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: bf16 / f16 MFMA, dense (not the 2:1-sparsity figure; the f16 forms take the same cycles)
+SPLIT_MODES = ("f16x3", "bf16x3")
+DTYPE = {"f16x3": "f16x3: f32 products as 3 scaled-f16 MFMA products (~22-bit), f32 accumulate; reference-grade: distance to a float64 run "
+                  "of the reference <= 1.4 x the reference's own float32 error (tests/golden/mask_vrd_f64.npz)",
+         "bf16x3": "bf16x3 split (~17-bit products), f32 accumulate", "f32": "f32"}
 # closed-form algorithmic FLOPs per pair at T_pad (cross-checked with FlopCounterMode)
 FLOPS_PER_PAIR = {("vidvrd", 96): 6.386e9, ("vidvrd", 144): 9.650e9, ("vidvrd", 288): 19.897e9,
                   ("vidor_x", 512): 42.038e9}
@@ -44,8 +48,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--pair-chunk", type=int, default=0, help="pairs per launch wave inside _mask_vrd (0 = model default)")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--precision", default=None, choices=["bf16x3", "f32"], help="GEMM product mode (default: the library default)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second run in the other precision mode")
+    ap.add_argument("--precision", default=None, choices=["f16x3", "bf16x3", "f32"], help="GEMM product mode of the headline (default: the library default, f16x3)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra runs in the other precision modes")
     ap.add_argument("--no-ragged", action="store_true", help="skip the extra run on ragged pair lengths")
     ap.add_argument("--no-forward-test", action="store_true", help="skip the secondary metric (whole eval call on one synthetic video)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the training-step leg (BASELINE config 3: forward + backward on a 24-pair batch)")
@@ -114,7 +118,9 @@ def hbm_traffic(kernel, mode):
     cannot be read inside this process).  (None, reason) when there is none or when it was collected on other
     kernel sources than the ones running (its kernel_src_sha stamp differs)."""
     import glob
-    suffix = "_hbm_traffic.json" if mode == "bf16x3" else f"_hbm_traffic_{mode}.json"
+    suffix = f"_hbm_traffic_{mode}.json"
+    if mode == "bf16x3" and not glob.glob(os.path.join(REPO, "profiles", "*" + suffix)):
+        suffix = "_hbm_traffic.json"        # (rounds 1-3 named the bf16x3 summary without a mode)
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*" + suffix)))
     if not files:
         return None, "no PMC summary committed for this mode"
@@ -244,7 +250,7 @@ def main():
 
     def roofline(mode, prof):
         """Dominant kernel family of the mode: algorithmic FLOPs (2*M*N*K per launch) / HIP-event time."""
-        if mode == "bf16x3":       # the split-precision GEMM family that takes the most time (256x256 or 128x256 tile)
+        if mode in SPLIT_MODES:    # the split-precision GEMM family that takes the most time (256x256 or 128x256 tile)
             fam = max(("gemm_bf16x3_big", "gemm_bf16x3_dma"), key=lambda f: prof[f]["ms"])
         else:
             fam = "gemm_f32_mfma"
@@ -255,11 +261,12 @@ def main():
         # although the reference computes them (SURVEY 8d counts FLOPs at T_pad: that figure is `algorithmic_tflops`)
         executed = g["flops"] - g.get("flops_skipped", 0.0)
         achieved = executed / n / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        if mode == "bf16x3":
-            # three bf16 MFMA products per f32-equivalent product: peak in algorithmic FLOP/s = bf16 dense peak / 3
+        if mode in SPLIT_MODES:
+            # three 16-bit MFMA products per f32-equivalent product: peak in algorithmic FLOP/s = bf16 / f16 dense peak / 3
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             extra = {"mfma_tflops_executed": 3.0 * achieved, "mfma_peak": PEAK_BF16_MFMA_TFLOPS,
-                     "note": "peak = bf16 dense MFMA peak / 3 (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi per product)"}
+                     "note": "peak = 16-bit dense MFMA peak / 3 (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi per product); the kernel family is "
+                             "named for its first format: the f16x3 mode runs its F16 = true instantiations (v_mfma_f32_32x32x16_f16)"}
             kern = fam + "_kernel"
         else:
             peak, extra, kern = PEAK_F32_MFMA_TFLOPS, {}, "gemm_f32_mfma_kernel"
@@ -278,11 +285,12 @@ def main():
         # multi-GPU runs record the GEMM families only (what `roofline` needs); N = 1 records every family
         _hip.prof_select(["gemm_f32_mfma", "gemm_bf16x3_mfma", "gemm_bf16x3_dma", "gemm_bf16x3_big"])
     main_mode = args.precision or ops.get_precision()
-    alt_mode = "f32" if main_mode == "bf16x3" else "bf16x3"
     elapsed, prof = run(main_mode, args.warmup, args.steps)
-    alt = None
+    alts = {}
     if not args.no_alt:
-        alt = run(alt_mode, 1, args.steps)
+        for alt_mode in ("f16x3", "bf16x3", "f32"):
+            if alt_mode != main_mode:
+                alts[alt_mode] = run(alt_mode, 1, args.steps)
     ragged = None
     if not args.no_ragged:
         # SURVEY 8d's second input set, reported separately: same pairs, lengths ~ U[2, frames] (seed 1235), padded to
@@ -465,7 +473,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "bf16x3 split (~17-bit products), f32 accumulate" if main_mode == "bf16x3" else "f32",
+            "dtype": DTYPE[main_mode],
             "data": "synthetic",
             "config": {"workload": f"{args.config}.yaml MaskVRD._mask_vrd, {args.pairs} pairs x {args.frames} frames "
                                    f"(T_pad {t_pad}) x C_in {c_in}, embd 512, eval, last-layer heads",
@@ -489,12 +497,15 @@ def main():
             # algorithmic HBM bytes of each family / its time (how close each family runs to the ~6.3 TB/s roof)
             line["kernel_algorithmic_gbps"] = {k: round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
                                                for k, v in prof.items() if v["launches"] and v["ms"] > 0}
-        if alt is not None:
-            a_elapsed, a_prof = alt
-            line["alt_precision"] = {"gemm_precision": alt_mode, "value": args.pairs * args.steps / a_elapsed,
-                                     "ms_per_step": 1e3 * a_elapsed / args.steps}
-            if a_prof:
-                line["alt_precision"]["roofline"] = roofline(alt_mode, a_prof)
+        if alts:
+            line["alt_precision"] = []
+            for alt_mode, (a_elapsed, a_prof) in alts.items():
+                entry = {"gemm_precision": alt_mode, "dtype": DTYPE[alt_mode], "value": args.pairs * args.steps / a_elapsed,
+                         "ms_per_step": 1e3 * a_elapsed / args.steps}
+                if a_prof:
+                    entry["roofline"] = roofline(alt_mode, a_prof)
+                    entry["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in a_prof.items() if v["launches"]}
+                line["alt_precision"].append(entry)
         if ragged is not None:
             line["ragged_variant"] = ragged
         if projection is not None:

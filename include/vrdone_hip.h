@@ -11,11 +11,12 @@
  *  - every activation tensor is fp32, channels-last: a matrix of `rows` x `C` with an
  *    explicit leading dimension `ld*` (floats between consecutive rows); row r = b*T + t.
  *    Leading dimensions let producers write straight into concatenation buffers.
- *  - "pair" rows (bf16x3 mode only): a tensor whose only consumer is a GEMM (or the global attention) may be
+ *  - "pair" rows (split-precision modes only): a tensor whose only consumer is a GEMM (or the global attention) may be
  *    produced in the operand format of the split-precision MFMA: the 4*C bytes of a C-channel row (C % 32 == 0,
- *    row start 16-byte aligned) hold, per block of 32 channels, [32 x bf16 hi | 32 x bf16 lo], hi = bf16(x),
- *    lo = bf16(x - hi): one 128-byte line per 32 channels.  Same leading dimension as the f32 row; producers
- *    take an `out_pair` flag; vrd_gemm takes `a_pair_width` (> 0: A is pair rows; 0 for f32 input).
+ *    row start 16-byte aligned) hold, per block of 32 channels, [32 x 16-bit hi | 32 x 16-bit lo]: one 128-byte line
+ *    per 32 channels.  Same leading dimension as the f32 row.  Producers take an `out_pair` argument (enum
+ *    vrd_pair_format: 0 = plain f32 rows); vrd_gemm takes `a_pair_width` (> 0: A is pair rows in the format
+ *    `split_fmt`; 0 for f32 input).
  *  - masks are uint8 (0/1), one byte per row (the reference's (B,1,T) bool mask).
  *  - all pointers are device pointers owned by the caller; the library allocates no
  *    device memory and keeps no state besides the optional profiling event list.
@@ -32,9 +33,21 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 23
+#define VRD_ABI_VERSION 24
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
+
+/* Element format of pair rows and of the split weight operand (W_split).  Both replace an f32 product a*w by
+ * a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the 16-bit MFMA with f32 accumulation.
+ *   VRD_PAIR_BF16 ("bf16x3"): hi = bf16(x), lo = bf16(x - hi).  ~17 significand bits per product; the full f32 range.
+ *   VRD_PAIR_F16  ("f16x3"):  hi = f16(y), lo = f16(y - hi) of y = x * 2^e, round to nearest: ~22 significand bits per
+ *       product -- the reference-grade mode: end to end its distance to a float64 run of the reference is within
+ *       1.0-1.3x the distance of the reference's own float32 run (tests/golden/mask_vrd_f64.npz).  e is the fixed
+ *       VRD_F16_ACT_EXP for activations (|x| < 4094 representable; larger magnitudes come out as NaN, never as a
+ *       silently wrong number) and a per-tensor power of two for weights (vrd_split_weight: max |w| * 2^e in
+ *       [2^14, 2^15)); the GEMM epilogue multiplies the accumulator by the exact power of two that undoes both. */
+enum vrd_pair_format { VRD_PAIR_NONE = 0, VRD_PAIR_BF16 = 1, VRD_PAIR_F16 = 2 };
+#define VRD_F16_ACT_EXP 4
 
 /* kernel families, for vrd_prof_read() */
 enum vrd_kernel_id {
@@ -67,7 +80,7 @@ int vrd_prof_select(unsigned long long family_mask);
  * Replaces the channel slicing of models/backbones.py:161-166 / :329-341 and the
  * transposing copy of models/maskvrd.py:382-385. */
 int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count,
-                   float* dst, int64_t ld_dst, int out_pair, void* stream);
+                   float* dst, int64_t ld_dst, int out_pair /* enum vrd_pair_format */, void* stream);
 /* Eval batching (models/maskvrd.py:363-414 + backbones.py:161-166) without the (B, C_in, T) intermediate: pair p
  * is an (L_p, C_in) frame-major matrix src[p] (how dataloaders/vidvrd.py:693 builds it, before its permute view)
  * laid out [s_vis V | o_vis V | (s_clip Cc | o_clip Cc) | so_box S | s_box E | o_box E].  Writes the backbone's
@@ -84,7 +97,7 @@ typedef struct {
     float* clip;
     float* so_box;
     float* ent;
-    int32_t pair_wide;
+    int32_t pair_wide;      /* enum vrd_pair_format of vis / clip */
 } vrd_pack_args;
 int vrd_pack_pairs(const vrd_pack_args* a, void* stream);
 
@@ -109,7 +122,7 @@ typedef struct {
     float* out_clip;
     float* out_so_box;
     float* out_ent;
-    int32_t pair_wide;
+    int32_t pair_wide;      /* enum vrd_pair_format of out_vis / out_clip */
 } vrd_gather_args;
 int vrd_gather_pairs(const vrd_gather_args* a, void* stream);
 
@@ -157,9 +170,9 @@ int vrd_btc_to_bct(const float* src, int64_t ld_src, int B, int C, int T, float*
  * W is [N][K] row-major with K = taps*Cin, tap-major (the caller re-packs a (N,Cin,3)
  * Conv1d weight once).
  * Precision: with W_split == NULL every product is an exact f32 MFMA product.  With W_split set
- * (2*N*K bf16: bf16(W) followed by bf16(W - bf16(W))) and K % 32 == 0, 16-byte aligned operands, the
- * kernel splits the activations the same way on the fly and forms a*w ~= a_hi*w_hi + a_hi*w_lo +
- * a_lo*w_hi on the bf16 MFMA with f32 accumulation (~17 significand bits per product); shapes that do
+ * (vrd_split_weight's output in the format `split_fmt`) and K % 32 == 0, 16-byte aligned operands, the
+ * kernel splits f32 activations the same way on the fly (or takes pair rows) and forms a*w ~= a_hi*w_hi + a_hi*w_lo +
+ * a_lo*w_hi on the 16-bit MFMA with f32 accumulation (enum vrd_pair_format); shapes that do
  * not qualify silently use the f32 kernel. */
 typedef struct {
     const float* A;  int64_t lda;
@@ -172,10 +185,11 @@ typedef struct {
     const float* scale;
     const float* res;  int64_t ldres;  int32_t res_masked;
     const float* res2;  int64_t ldres2;
-    const uint16_t* W_split; /* optional bf16 split of W in pair-row blocks, (N, K/32, [32 hi | 32 lo]), K % 32 == 0:
-                                enables the split-bf16 MFMA path */
-    int32_t a_pair_width;   /* > 0: A rows are pair rows (needs W_split, Cin % 32 == 0, lda % 32 == 0) */
-    int32_t c_pair;         /* 1: write C as pair rows of width N (N % 32 == 0, ldc % 32 == 0) */
+    const uint16_t* W_split; /* optional 16-bit split of W in pair-row blocks, (N, K/32, [32 hi | 32 lo]), K % 32 == 0:
+                                enables the split-precision MFMA path */
+    int32_t a_pair_width;   /* > 0: A rows are pair rows in the format split_fmt (needs W_split, Cin % 32 == 0, lda % 32 == 0) */
+    int32_t c_pair;         /* enum vrd_pair_format: write C as pair rows of width N (N % 32 == 0, ldc % 32 == 0); a format
+                               other than VRD_PAIR_NONE must equal split_fmt */
     /* Optional padding skip (M % 32 == 0): row_blocks = a permutation of the M/32 indices of 32-row blocks in
      * segments of row_block_seg_len entries (a multiple of 8; the last segment may be shorter), each holding its
      * blocks with a valid frame first (vrd_row_blocks); row_blocks_active[segment] = how many those are (device
@@ -187,6 +201,10 @@ typedef struct {
     const int32_t* row_blocks;
     const int32_t* row_blocks_active;
     int32_t row_block_seg_len;
+    int32_t split_fmt;      /* format of W_split (and of pair-row A): VRD_PAIR_BF16 (also when 0) or VRD_PAIR_F16 */
+    const float* w_scale;   /* VRD_PAIR_F16 only: device pointer to the factor that turns the accumulator of the scaled
+                               operands back into the product, 2^-(e_w + VRD_F16_ACT_EXP) -- element 0 of vrd_split_weight's
+                               `scale` output for W_split */
 } vrd_gemm_args;
 int vrd_gemm(const vrd_gemm_args* a, void* stream);
 /* `count` (1..4) GEMMs of an array of argument structs.  Problems that differ only in A, W / W_split, bias and C and
@@ -210,7 +228,7 @@ int vrd_row_blocks(const uint8_t* mask, int64_t rows, int seg_len, int32_t* orde
  * models/local_transformer.py:809,820). */
 int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C,
                   const float* gamma, const float* beta, int relu,
-                  const float* post_add, int64_t ld_add, int add_period, int out_pair, void* stream);
+                  const float* post_add, int64_t ld_add, int add_period, int out_pair /* enum vrd_pair_format */, void* stream);
 
 /* ---- depthwise conv (+ nearest-upsample add) * mask -> LayerNorm, fused -----------------
  * for o in [0, n_out): y_o[b,t',:] = LN_o( mask_out[b,t'] * (bias_o + sum_k w_o[c,g,k] *
@@ -234,7 +252,7 @@ typedef struct {
     int32_t relu[3];
     float* y[3];
     int64_t ldy[3];
-    int32_t out_pair[3];
+    int32_t out_pair[3];        /* enum vrd_pair_format per set */
     const float* pre_gamma;     /* optional LayerNorm on the input rows (needs group_in == 1, no x_up) */
     const float* pre_beta;
     const float* packed[3];     /* optional per set: the set's parameters as the kernel keeps them on chip,
@@ -262,13 +280,14 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
                   const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim,
                   float* out, int64_t ldo, int algo, int out_pair, void* stream);
 
-/* Same attention for pair-row q, k, v (bf16x3 mode; rows of width n_head*head_dim written by the projection
- * GEMMs with c_pair): both contractions as split-bf16 MFMA products, f32 softmax.  head_dim in {64, 128}.
+/* Same attention for pair-row q, k, v (split-precision modes; rows of width n_head*head_dim written by the projection
+ * GEMMs with c_pair): both contractions as three 16-bit MFMA products, f32 softmax.  head_dim in {64, 128}.
+ * pair_fmt: the format of q, k, v (VRD_PAIR_BF16 / VRD_PAIR_F16); out_pair: 0 or the same format.
  * q_mask (optional, B*Tq bytes): query rows the caller zeroes afterwards anyway (the output projection's row mask,
  * local_transformer.py:183); tiles of 32 queries without a valid one are not computed and read 0. */
 int vrd_attention_pair(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                        const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq, int Tk, int n_head, int head_dim,
-                       float* out, int64_t ldo, int out_pair, void* stream);
+                       float* out, int64_t ldo, int out_pair, int pair_fmt, void* stream);
 
 /* ---- MaxPool1d(3,2,1) skip * mask (models/blocks.py:1040-1046,1074) and mask[::2] ------- */
 int vrd_maxpool_mask(const float* x, int64_t ldx, int B, int Tin, int C, const uint8_t* mask_in,
@@ -453,14 +472,19 @@ int vrd_criterion_losses(const vrd_criterion_args* a, const int32_t* query_of, c
 int vrd_criterion_backward(const vrd_criterion_args* a, const int32_t* query_of, const float* class_weight, float num_masks,
                            const float* fwd_out, const float* gout, const vrd_criterion_grads* grads, void* stream);
 
-/* The split-precision GEMMs' weight operand (vrd_gemm_args.W_split) from an f32 weight in ONE launch: logical matrix
+/* The split-precision GEMMs' weight operand (vrd_gemm_args.W_split) from an f32 weight: logical matrix
  * W'[r][tap*Q + q] = src[r*sr + tap*st + q*sq]  (R rows, K = taps*Q columns, K % 32 == 0; strides in floats, may be negative)
- * -> out (R, K/32, 2, 32) bf16: per block of 32 columns [32 x hi | 32 x lo], hi = bf16(w), lo = bf16(w - hi).
+ * -> out (R, K/32, 2, 32) 16-bit: per block of 32 columns [32 x hi | 32 x lo].
+ * fmt = VRD_PAIR_BF16: hi = bf16(w), lo = bf16(w - hi), one launch; scale unused (may be NULL).
+ * fmt = VRD_PAIR_F16: hi = f16(y), lo = f16(y - hi) of y = w * 2^e_w with e_w chosen on the device so that max |w| * 2^e_w lies in
+ *   [2^14, 2^15) (e_w in [-113, 100]; an all-zero weight: e_w = 0): three launches (clear, max, split), no host synchronisation.
+ *   scale: 4 device floats written: [0] = 2^-(e_w + VRD_F16_ACT_EXP) (vrd_gemm_args.w_scale), [1] = 2^e_w, [2] scratch, [3] unused.
  * Forward operand of a Conv1d weight (N, Cin, k): R = N, Q = Cin, sr = Cin*k, st = 1, sq = k.  Operand of its input-gradient
  * GEMM (autograd of models/blocks.py:91-113; k = 3: taps flipped): R = Cin, Q = N, src = w + (k - 1), sr = k, st = -1,
  * sq = Cin*k.  In a training step every weight changes every step, so both are rebuilt per step: as tensor expressions that
  * was ~11 elementwise launches per weight. */
-int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, void* stream);
+int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, int fmt, float* scale,
+                     void* stream);
 
 /* The same for many weights in ONE launch (a training step re-splits every conv weight, forward and input-gradient form, after
  * each optimiser update).  jobs: DEVICE array; chunk c of the launch is one 32 x 32 tile of job chunk_job[c]: with KB = taps*Q/32
@@ -468,11 +492,13 @@ int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64
  * entries; a job is covered by ceil(R / 32) * KB chunks). */
 typedef struct {
     const float* src;      /* element (r, tap, q) at src[r*sr + tap*st + q*sq] */
-    uint16_t* out;         /* (R, taps*Q/32, 2, 32) bf16 */
-    int32_t R, Q, taps, reserved;
+    uint16_t* out;         /* (R, taps*Q/32, 2, 32) 16-bit */
+    int32_t R, Q, taps, fmt;   /* fmt: enum vrd_pair_format; 0 is read as VRD_PAIR_BF16 */
     int64_t sr, st, sq;
+    float* scale;          /* VRD_PAIR_F16: the job's 4 scale floats (see vrd_split_weight); else unused */
 } vrd_split_job;
-int vrd_split_weights(const vrd_split_job* jobs, const int32_t* chunk_job, const int32_t* chunk_index, int n_chunks, void* stream);
+int vrd_split_weights(const vrd_split_job* jobs, int n_jobs, const int32_t* chunk_job, const int32_t* chunk_index, int n_chunks,
+                      void* stream);
 
 #ifdef __cplusplus
 }

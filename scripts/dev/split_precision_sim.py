@@ -144,5 +144,41 @@ def main():
               f"rms {dm.pow(2).mean().sqrt():.3e}")
 
 
+
+
+def goldens():
+    """python scripts/dev/split_precision_sim.py --goldens : the same comparison on the inputs of the committed goldens, as ratios
+    to the reference's own |ref32 - ref64| (tests/golden/mask_vrd_f64.npz)."""
+    import numpy as np
+    G = os.path.join(REPO, "tests", "golden")
+    f64 = np.load(os.path.join(G, "mask_vrd_f64.npz"))
+    cases = {"vidvrd": [(4, 96, [96, 95, 41, 2]), (3, 144, [144, 97, 130]), (2, 288, [288, 201])],
+             "vidor_x": [(2, 512, [512, 333])], "vidor_local": [(2, 512, [512, 77])], "vidor": [(2, 512, [512, 301])]}
+    for name, shapes in cases.items():
+        meta = json.load(open(os.path.join(G, f"state_keys_{name}.json")))
+        cfg = meta["model_config"]
+        sd = O.synth_state_dict([(k, tuple(s)) for k, s in meta["keys"]], eos_coef=cfg["loss_coeff_dict"]["eos_coef"])
+        V, E, S = cfg["visual_dim"], cfg["bbox_entity_dim"], cfg["bbox_so_dim"]
+        Cc = cfg["clip_dim"] if cfg.get("with_clip_feature", False) else 0
+        g32 = np.load(os.path.join(G, f"mask_vrd_{name}.npz"))
+        for B, T, lens in shapes:
+            x, m = O.synth_pairs(B, 2 * V + 2 * Cc + S + 2 * E, T, lens, seed=1234 + T)
+            row = [f"{name} T{T}"]
+            for key in ("pred_logits", "pred_masks"):
+                r64 = f64[f"{name}_T{T}_{key}"]
+                e32 = np.abs(g32[f"T{T}_{key}"] - r64)
+                row.append(f"{key[5:]} e32 max {e32.max():.2e} rms {np.sqrt((e32 ** 2).mean()):.2e}")
+            print(" | ".join(row), flush=True)
+            for tag, emu in [("oracle f32", None), ("f16x3 s4", Emu("f16", 3, 4)), ("f16x4 s4", Emu("f16", 4, 4))]:
+                o = run(sd, cfg, x, m, emu)
+                row = [f"    {tag:12s}"]
+                for key in ("pred_logits", "pred_masks"):
+                    r64 = f64[f"{name}_T{T}_{key}"]
+                    e32 = np.abs(g32[f"T{T}_{key}"] - r64)
+                    e = np.abs(o[key].double().numpy() - r64)
+                    row.append(f"{key[5:]} max x{e.max() / e32.max():.2f} rms x{np.sqrt((e ** 2).mean() / (e32 ** 2).mean()):.2f}")
+                print(" | ".join(row), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    goldens() if "--goldens" in sys.argv else main()

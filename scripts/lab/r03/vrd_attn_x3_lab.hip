@@ -1,10 +1,6 @@
 // Global masked attention (the SOS self / cross attention) in split precision: both contractions of flash
-// attention as three 16-bit MFMA products each (x = x_hi + x_lo, see vrd_gemm_x3.hip), f32 accumulate,
-// f32 softmax.  Inputs q, k, v are pair rows ([hi | lo] 16-bit planes) written by the projection GEMMs.
-// Both kernels exist per element format (template parameter F16, vrd_common.h): bf16 planes, or f16 planes of the values
-// times 2^VRD_F16_ACT_EXP -- then the scores come out times 2^(2 * VRD_F16_ACT_EXP), which the host folds into the softmax
-// scale, the probabilities are split as P * 2^VRD_F16_ACT_EXP as well (P <= 1, or <= 2^8 with the deferred rescaling of the
-// second kernel: far inside the f16 range), and the powers of two cancel in O / l up to one exact factor at the end.
+// attention as three bf16 MFMA products each (x = x_hi + x_lo, see vrd_gemm_x3.hip), f32 accumulate,
+// f32 softmax.  Inputs q, k, v are pair rows ([hi | lo] bf16 planes) written by the projection GEMMs.
 //
 // One workgroup = NW waves = NW*32 query rows of one (b, head); KV tiles of 32 keys.
 //   S^T = K . Q^T   A = K fragments from LDS (ds_read_b128), B = Q^T fragments held in registers for the whole
@@ -48,7 +44,15 @@ struct AG {
     __device__ static constexpr int vswz(int key) { return ((key & 3) << 2) % CPR ^ (CPR == 8 ? ((key >> 1) & 1) << 2 : 0); }
 };
 
-template <int HD, int NW, bool F16>
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (__bf16)x[j];
+        lo[j] = (__bf16)(x[j] - (float)hi[j]);
+    }
+}
+
+template <int HD, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* __restrict__ q, int64_t ldq,
                                                                 const float* __restrict__ k, const float* __restrict__ v,
                                                                 int64_t ldkv, const uint8_t* __restrict__ kv_mask,
@@ -56,7 +60,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                                                                 int Tk, int width, float scale, float* __restrict__ out,
                                                                 int64_t ldo, int pair_out, int q_blocks, int n_head_) {
     using G = AG<HD>;
-    typedef typename vrd::SplitFmt<F16>::x8 bf16x8;      // eight 16-bit elements of this instantiation's format (bf16 or f16)
     constexpr int KS = HD / 16;                   // k16 steps of the S^T contraction
     constexpr int DT = HD / 32;                   // 32-row d tiles of O^T
     constexpr int PER_WAVE = (G::N_DMA + NW - 1) / NW;
@@ -194,9 +197,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 nh = *reinterpret_cast<const bf16x8*>(st + off);
                 nl = *reinterpret_cast<const bf16x8*>(st + G::PLANE + off);
             }
-            sacc = vrd::mfma32(kl, qh[s], sacc);
-            sacc = vrd::mfma32(kh, ql[s], sacc);
-            sacc = vrd::mfma32(kh, qh[s], sacc);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[s], sacc, 0, 0, 0);
             kh = nh;
             kl = nl;
         }
@@ -236,10 +239,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = sacc[8 * s + j];
             bf16x8 ph, pl;
-            vrd::split_n<F16>(pf, ph, pl);          // (f16: P * 2^VRD_F16_ACT_EXP)
+            split8(pf, ph, pl);
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
                 bf16x8 vh, vl;
+#ifdef VRD_ATTN_NO_TR
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int key = 16 * s + 8 * (jj >> 2) + 4 * lh + (jj & 3);
+                    const int col = 32 * d + li;
+                    const int off = key * G::ROWB + ((((col * 2) >> 4) ^ G::vswz(key)) * 16) + ((col * 2) & 15);
+                    vh[jj] = *reinterpret_cast<const __bf16*>(st + 2 * G::PLANE + off);
+                    vl[jj] = *reinterpret_cast<const __bf16*>(st + 3 * G::PLANE + off);
+                }
+#else
                 s16x8 rh, rl;
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
@@ -256,17 +269,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 }
                 vh = __builtin_bit_cast(bf16x8, rh);
                 vl = __builtin_bit_cast(bf16x8, rl);
-                oacc[d] = vrd::mfma32(vl, ph, oacc[d]);
-                oacc[d] = vrd::mfma32(vh, pl, oacc[d]);
-                oacc[d] = vrd::mfma32(vh, ph, oacc[d]);
+#endif
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[d], 0, 0, 0);
             }
         }
         kt = kt_next;
     }
 
     const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
-    // f16: the accumulators hold sum (P 2^e)(V 2^e); l is the sum of the unscaled P
-    const float inv = q_live ? (F16 ? vrd::F16_ACT_INV * vrd::F16_ACT_INV : 1.0f) / l_tot : 0.f;
+    const float inv = q_live ? 1.0f / l_tot : 0.f;
     const int tq = q0 + li;
     if (tq < Tq) {
         float* orow = out + ((int64_t)b * Tq + tq) * ldo;
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 const int c = h * HD + 32 * d + 8 * g + 4 * lh;           // registers 4g..4g+3 are d = 32d + 8g + 4lh + 0..3
                 const float4 val = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv,
                                                oacc[d][4 * g + 3] * inv);
-                if (pair_out) vrd::store_pair4(orow, c, width, val, vrd::SplitFmt<F16>::fmt);
+                if (pair_out) vrd::store_pair4(orow, c, width, val);
                 else *reinterpret_cast<float4*>(orow + c) = val;
             }
     }
@@ -318,6 +331,12 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 #define VRD_ALL_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
 #define VRD_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef VRD_W64_ABL
+#define VRD_W64_ABL 0
+#endif
+#ifndef VRD_W64_THR
+#define VRD_W64_THR 16.0f
+#endif
 
 template <int I>
 using ic = std::integral_constant<int, I>;
@@ -342,31 +361,14 @@ __device__ __forceinline__ float xchg32_sum(float v) {
     swap32(a, b);
     return a + b;
 }
-// (p0, p1) -> packed hi pair and lo pair (lo = round(p - hi)) in bf16, or (F16) in f16 -- of the values as they are: the
-// caller has the f16 format's scale in them already
-template <bool F16>
+// (p0, p1) -> packed bf16 hi pair and lo pair (lo = bf16(p - hi))
 __device__ __forceinline__ void split_pair(float p0, float p1, unsigned& hi, unsigned& lo) {
-    if constexpr (F16) {
-        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-        const f16x2 h = {(_Float16)p0, (_Float16)p1};
-        hi = __builtin_bit_cast(unsigned, h);
-        const f16x2 l = {(_Float16)(p0 - (float)h[0]), (_Float16)(p1 - (float)h[1])};
-        lo = __builtin_bit_cast(unsigned, l);
-    } else {
-        const bf16x2 h = {(__bf16)p0, (__bf16)p1};
-        hi = __builtin_bit_cast(unsigned, h);
-        const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
-        const bf16x2 l = {(__bf16)(p0 - h0), (__bf16)(p1 - h1)};
-        lo = __builtin_bit_cast(unsigned, l);
-    }
+    const bf16x2 h = {(__bf16)p0, (__bf16)p1};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float h0 = __builtin_bit_cast(float, hi << 16), h1 = __builtin_bit_cast(float, hi & 0xffff0000u);
+    const bf16x2 l = {(__bf16)(p0 - h0), (__bf16)(p1 - h1)};
+    lo = __builtin_bit_cast(unsigned, l);
 }
-
-// one MFMA of the element format as an asm statement: VRD_MFMA(prefix, "operands", constraints...)
-#define VRD_MFMA(pre, ops, ...)                                                   \
-    do {                                                                          \
-        if constexpr (F16) asm volatile(pre "v_mfma_f32_32x32x16_f16 " ops __VA_ARGS__);  \
-        else asm volatile(pre "v_mfma_f32_32x32x16_bf16 " ops __VA_ARGS__);       \
-    } while (0)
 
 // a[R0 .. R0+N-1] *= alpha
 template <int R0, int N>
@@ -387,7 +389,7 @@ struct SmBlock {
     u32x4 ph[2], pl[2];         // P^T fragments: k16 step s -> hi / lo (bf16x8 as four dwords)
 };
 
-template <int HD, bool F16>
+template <int HD>
 __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* __restrict__ q, int64_t ldq,
                                                                   const float* __restrict__ k, const float* __restrict__ v,
                                                                   int64_t ldkv, const uint8_t* __restrict__ kv_mask,
@@ -458,6 +460,10 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const int off = vrd::pair_index(16 * s + 8 * lh) * 2;
+            if constexpr ((VRD_W64_ABL & 128) != 0) {
+                qtmp[qb][s][0] = qtmp[qb][s][1] = u32x4{(unsigned)off, 1u, 2u, 3u};
+                continue;
+            }
             qtmp[qb][s][0] = *reinterpret_cast<const u32x4*>(qr + off);
             qtmp[qb][s][1] = *reinterpret_cast<const u32x4*>(qr + off + 64);
         }
@@ -540,6 +546,16 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     const int n_act = nkt <= 64 ? (int)__builtin_popcountll(act) : nkt;      // tiles that are visited
     unsigned long long cln = 0ull;                       // tiles whose 32 keys are all valid (no key bias needed)
     if (nkt <= 64) cln = __ballot(lane < nkt && tile_on[lane < nkt ? lane : 0] == 2);
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 16)
+    float* const stamps = reinterpret_cast<float*>(lds + NS * G::STAGE + 8192);      // LDS: no effect on the vmcnt counting
+    int n_stamp = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#define VRD_STAMP() do { if (n_stamp < 64 && tid == 0) stamps[n_stamp] = (float)(long long)(__builtin_amdgcn_s_memtime() - t_start); ++n_stamp; } while (0)
+#else
+#define VRD_STAMP() do {} while (0)
+#endif
+
+
     const int krow = li * G::ROWB;
     const int vq = (lane >> 2) & 3, vp = lane & 3;
     const int vcol0 = 16 * ((lane >> 4) & 1) + 4 * vp;          // column inside a 32-wide d tile
@@ -597,9 +613,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     A.lp = B.lp = 0.f;
     float tsp[4];                                // temporaries of the split in flight
     unsigned long long cmask[2] = {0ull, 0ull};
-    // how far (log2 units) a row maximum may run ahead of the reference point of its exponentials before the running output
-    // is rescaled: probabilities reach 2^thr.  f16: P * 2^VRD_F16_ACT_EXP is what gets split, so 2^(8 + 4) at most
-    const float thr = F16 ? 8.0f : 16.0f;
+    const float thr = VRD_W64_THR;
     auto fea_piece = [&](SmBlock& X, const f32x16& sx, auto e_c) __attribute__((always_inline)) {
         constexpr int e = decltype(e_c)::value;  // exp of element e, FMA of element e+1, element e-1 joins the sum
         if constexpr (e == 0) {
@@ -618,32 +632,18 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     auto split_piece = [&](auto s_c, auto q_c) __attribute__((always_inline)) {
         constexpr int s = decltype(s_c)::value, q = decltype(q_c)::value, j = q >> 2, sub = q & 3, e0 = 8 * s + 2 * j;
         if constexpr (sub == 0) {
-            if constexpr (F16)
-                asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
-                             : "=&v"(A.ph[s][j]), "=&v"(B.ph[s][j]) : "v"(A.x[e0]), "v"(A.x[e0 + 1]), "v"(B.x[e0]), "v"(B.x[e0 + 1]));
-            else
-                asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5"
-                             : "=&v"(A.ph[s][j]), "=&v"(B.ph[s][j]) : "v"(A.x[e0]), "v"(A.x[e0 + 1]), "v"(B.x[e0]), "v"(B.x[e0 + 1]));
-        } else if constexpr (sub == 1) {        // the hi halves back as f32 (bf16: bit moves; f16: conversions, the upper half by SDWA select)
-            if constexpr (F16)
-                asm volatile("v_cvt_f32_f16 %0, %4\n\tv_cvt_f32_f16 %2, %5\n\t"
-                             "v_cvt_f32_f16_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-                             "v_cvt_f32_f16_sdwa %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
-                             : "=&v"(tsp[0]), "=&v"(tsp[1]), "=&v"(tsp[2]), "=&v"(tsp[3]) : "v"(A.ph[s][j]), "v"(B.ph[s][j]));
-            else
-                asm volatile("v_lshlrev_b32 %0, 16, %4\n\tv_lshlrev_b32 %2, 16, %5\n\tv_and_b32 %1, 0xffff0000, %4\n\tv_and_b32 %3, 0xffff0000, %5"
-                             : "=&v"(tsp[0]), "=&v"(tsp[1]), "=&v"(tsp[2]), "=&v"(tsp[3]) : "v"(A.ph[s][j]), "v"(B.ph[s][j]));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5"
+                         : "=&v"(A.ph[s][j]), "=&v"(B.ph[s][j]) : "v"(A.x[e0]), "v"(A.x[e0 + 1]), "v"(B.x[e0]), "v"(B.x[e0 + 1]));
+        } else if constexpr (sub == 1) {
+            asm volatile("v_lshlrev_b32 %0, 16, %4\n\tv_lshlrev_b32 %2, 16, %5\n\tv_and_b32 %1, 0xffff0000, %4\n\tv_and_b32 %3, 0xffff0000, %5"
+                         : "=&v"(tsp[0]), "=&v"(tsp[1]), "=&v"(tsp[2]), "=&v"(tsp[3]) : "v"(A.ph[s][j]), "v"(B.ph[s][j]));
         } else if constexpr (sub == 2) {
             asm volatile("v_sub_f32 %0, %4, %0\n\tv_sub_f32 %2, %6, %2\n\tv_sub_f32 %1, %5, %1\n\tv_sub_f32 %3, %7, %3"
                          : "+v"(tsp[0]), "+v"(tsp[1]), "+v"(tsp[2]), "+v"(tsp[3])
                          : "v"(A.x[e0]), "v"(A.x[e0 + 1]), "v"(B.x[e0]), "v"(B.x[e0 + 1]));
         } else {
-            if constexpr (F16)
-                asm volatile("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5"
-                             : "=&v"(A.pl[s][j]), "=&v"(B.pl[s][j]) : "v"(tsp[0]), "v"(tsp[1]), "v"(tsp[2]), "v"(tsp[3]));
-            else
-                asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5"
-                             : "=&v"(A.pl[s][j]), "=&v"(B.pl[s][j]) : "v"(tsp[0]), "v"(tsp[1]), "v"(tsp[2]), "v"(tsp[3]));
+            asm volatile("v_cvt_pk_bf16_f32 %0, %2, %3\n\tv_cvt_pk_bf16_f32 %1, %4, %5"
+                         : "=&v"(A.pl[s][j]), "=&v"(B.pl[s][j]) : "v"(tsp[0]), "v"(tsp[1]), "v"(tsp[2]), "v"(tsp[3]));
         }
     };
     auto sm_piece = [&](auto i_c, const f32x16& sa, const f32x16& sb) __attribute__((always_inline)) {
@@ -670,23 +670,15 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
                          "v_max_f32 %0, %0, %2\n\tv_max_f32 %1, %1, %3"
                          : "+v"(A.mx), "+v"(B.mx), "=&v"(ta), "=&v"(tb));
         } else if constexpr (i == 4) {
-            // The reference point of the exponentials moves only when the row maximum has grown by more than `thr`
+            // The reference point of the exponentials moves only when the row maximum has grown by more than VRD_W64_THR
             // (log2 units) since it was set: probabilities then reach 2^THR instead of 1, which costs nothing here (they are
             // split into hi + lo relative to their own magnitude and accumulated in f32), and the running output -- 64
             // accumulator-half registers per block, three instructions each -- is rescaled in the first tile or two only
             // instead of in nearly every tile (some query of the 32 almost always finds a slightly larger score).
             // mx (log2 units) = raw maximum * scale (scale > 0: the same value as the maximum of the scaled scores);
             // ae = mx - m_old for now
-            // f16: the whole frame of reference sits VRD_F16_ACT_EXP (= 4) lower -- mx' = mx - 4, hence mu' and the stored
-            // reference too -- so that exp2(s * scale - mu') = P * 2^4, the value that is split; differences (ae, alpha) are
-            // what they were
-            static_assert(vrd::F16_ACT_EXP == 4, "the inline constant below");
-            if constexpr (F16)
-                asm volatile("v_fma_f32 %0, %0, %4, -4.0\n\tv_fma_f32 %1, %1, %4, -4.0\n\tv_sub_f32 %2, %0, %5\n\tv_sub_f32 %3, %1, %6"
-                             : "+v"(A.mx), "+v"(B.mx), "=&v"(A.ae), "=&v"(B.ae) : "s"(scale_log2e), "v"(A.mr), "v"(B.mr));
-            else
-                asm volatile("v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_sub_f32 %2, %0, %5\n\tv_sub_f32 %3, %1, %6"
-                             : "+v"(A.mx), "+v"(B.mx), "=&v"(A.ae), "=&v"(B.ae) : "s"(scale_log2e), "v"(A.mr), "v"(B.mr));
+            asm volatile("v_mul_f32 %0, %0, %4\n\tv_mul_f32 %1, %1, %4\n\tv_sub_f32 %2, %0, %5\n\tv_sub_f32 %3, %1, %6"
+                         : "+v"(A.mx), "+v"(B.mx), "=&v"(A.ae), "=&v"(B.ae) : "s"(scale_log2e), "v"(A.mr), "v"(B.mr));
         } else if constexpr (i == 5) {           // moved = mx - m_old > THR (m_old = -inf: always);  mu = moved ? mx : m_old
             asm volatile("v_cmp_lt_f32 %0, %4, %5\n\tv_cmp_lt_f32 %1, %4, %6\n\tv_cndmask_b32 %2, %7, %9, %0\n\tv_cndmask_b32 %3, %8, %10, %1"
                          : "=&s"(cmask[0]), "=&s"(cmask[1]), "=&v"(A.mu), "=&v"(B.mu)
@@ -727,11 +719,11 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         f32x16& acc = qb ? sb : sa;
         constexpr int aq = VRD_AQ(qb, s) + (j >= 2 && j < 4 ? 4 : 0);          // q_lo for the middle product
         if constexpr (s == 0 && j < 2) {
-            VRD_MFMA("", "%0, %1, a[%c2:%c3], 0", : "=&v"(acc) : "v"(kf.l), "n"(aq), "n"(aq + 3));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(acc) : "v"(kf.l), "n"(aq), "n"(aq + 3));
         } else if constexpr (j < 2) {
-            VRD_MFMA("", "%0, %1, a[%c2:%c3], %0", : "+v"(acc) : "v"(kf.l), "n"(aq), "n"(aq + 3));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(kf.l), "n"(aq), "n"(aq + 3));
         } else {
-            VRD_MFMA("", "%0, %1, a[%c2:%c3], %0", : "+v"(acc) : "v"(kf.h), "n"(aq), "n"(aq + 3));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(acc) : "v"(kf.h), "n"(aq), "n"(aq + 3));
         }
     };
     // O^T MFMA j (0..5) of group g = (k16 step s, d tile d): (v_lo p_hi), (v_hi p_lo), (v_hi p_hi) for both blocks
@@ -741,13 +733,13 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         const SmBlock& X = qb ? B : A;
         if constexpr (j < 2) {
             if constexpr (d == 0 && j == 0)      // the fragments of this k16 step were written by vector instructions just now
-                VRD_MFMA("s_nop 1\n\t", "a[%c2:%c3], %0, %1, a[%c2:%c3]", :: "v"(vf.l), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
+                asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.l), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
             else
-                VRD_MFMA("", "a[%c2:%c3], %0, %1, a[%c2:%c3]", :: "v"(vf.l), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
+                asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.l), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
         } else if constexpr (j < 4) {
-            VRD_MFMA("", "a[%c2:%c3], %0, %1, a[%c2:%c3]", :: "v"(vf.h), "v"(X.pl[s]), "n"(ao), "n"(ao + 15));
+            asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.h), "v"(X.pl[s]), "n"(ao), "n"(ao + 15));
         } else {
-            VRD_MFMA("", "a[%c2:%c3], %0, %1, a[%c2:%c3]", :: "v"(vf.h), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
+            asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(vf.h), "v"(X.ph[s]), "n"(ao), "n"(ao + 15));
         }
     };
     // running output of block qb *= alpha (rare: only when some query's maximum moved)
@@ -779,42 +771,58 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         if (WITH_S) kf = load_k(st1, 0);
         VRD_SB();
         // the first K fragment is on its way (it could not be asked for before the barrier): the row maxima run meanwhile
-        static_for<LEAD>([&](auto u_c) { sm_piece(u_c, sa_c, sb_c); });
+        if constexpr (!(VRD_W64_ABL & 4)) static_for<LEAD>([&](auto u_c) { sm_piece(u_c, sa_c, sb_c); });
         VRD_SB();
         static_for<KS>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
             static_for<6>([&](auto j_c) {
                 constexpr int j = decltype(j_c)::value, gap = 6 * s + j;
-                if constexpr (WITH_S) mfma_s(s_c, j_c, kf, sa_n, sb_n);
+                if constexpr (WITH_S && !(VRD_W64_ABL & 1)) mfma_s(s_c, j_c, kf, sa_n, sb_n);
                 if constexpr (j == 0 && WITH_S && s + 1 < KS) kn = load_k(st1, s + 1);
                 if constexpr (gap == NG_S - 4) vf = load_v(st, 0, 0);
-                static_for<HPG_S>([&](auto u_c) {
+                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_S>([&](auto u_c) {
                     constexpr int piece = LEAD + gap * HPG_S + decltype(u_c)::value;
                     if constexpr (piece < 48) sm_piece(ic<piece>{}, sa_c, sb_c);
                 });
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 4)
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
                 VRD_SB();
             });
             kf = kn;
         });
+        VRD_STAMP();                                     // 4 + 5 it: S^T phase done
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 2)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        rescale(ic<0>{}, __builtin_amdgcn_exp2f(A.ae));
+        rescale(ic<1>{}, __builtin_amdgcn_exp2f(B.ae));
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#else
         if (!first && cmask[0] != 0ull) rescale(ic<0>{}, __builtin_amdgcn_exp2f(A.ae));
         if (!first && cmask[1] != 0ull) rescale(ic<1>{}, __builtin_amdgcn_exp2f(B.ae));
+#endif
         VRD_SB();
+        VRD_STAMP();                                     // 5 + 5 it: rescale done
         // ---- O^T += V^T . P^T for both blocks: each V^T fragment pair feeds six MFMAs, fragments one group ahead
         static_for<2 * DT>([&](auto g_c) {
             constexpr int g = decltype(g_c)::value;
             static_for<6>([&](auto j_c) {
                 constexpr int j = decltype(j_c)::value, gap = 6 * g + j;
-                mfma_o(g_c, j_c, vf);
+                if constexpr (!(VRD_W64_ABL & 2)) mfma_o(g_c, j_c, vf);
                 if constexpr (j == 0 && g + 1 < 2 * DT) vn = load_v(st, (g + 1) / DT, (g + 1) % DT);
-                static_for<HPG_O>([&](auto u_c) { sm_piece(ic<48 + gap * HPG_O + decltype(u_c)::value>{}, sa_c, sb_c); });
+                if constexpr (!(VRD_W64_ABL & 4)) static_for<HPG_O>([&](auto u_c) { sm_piece(ic<48 + gap * HPG_O + decltype(u_c)::value>{}, sa_c, sb_c); });
                 constexpr int rq = gap - NG_O / 2 - 1;
                 if constexpr (rq >= 0 && rq % 3 == 0 && rq / 3 < PER_WAVE) {
-                    if (do_req) issue1(req, buf_req, ic<rq / 3>{});
+                    if (do_req && !(VRD_W64_ABL & 8)) issue1(req, buf_req, ic<rq / 3>{});
                 }
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 4)
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
                 VRD_SB();
             });
             vf = vn;
         });
+        VRD_STAMP();                                     // 6 + 5 it: O^T phase done
     };
 
     // ---- prologue: the first NS-1 visited tiles are requested, S^T of the first one is formed
@@ -847,6 +855,12 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     });
 #pragma unroll
     for (int jq = 1; jq < NS - 1; ++jq) request_next(jq);
+    if constexpr ((VRD_W64_ABL & 64) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    VRD_STAMP();                                         // 0: requests and Q moves done
     int kt_cur = next_on(0);                             // tile whose raw scores the next step consumes
     f32x16 s0a, s0b, s1a, s1b;
 #pragma unroll
@@ -868,6 +882,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             asm volatile("s_nop 15" : "+v"(s0a), "+v"(s0b));       // MFMA result -> vector read: wait states by hand
         }
     }
+    VRD_STAMP();                                         // 1: first S^T done
     // a step: wait for tile it+1, barrier, pipeline step (scores of tile `it` in (ca, cb), of tile it+1 into (na, nb))
     int it = 0;
     auto step = [&](f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) __attribute__((always_inline)) {
@@ -879,7 +894,12 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             if (it + 2 < issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        VRD_STAMP();                                     // 2 + 5 it: counted wait done
         __builtin_amdgcn_s_barrier();
+        VRD_STAMP();                                     // 3 + 5 it: barrier passed
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 1)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
         const bool do_req = issued < n_act;
         if (do_req) {
             kt_iss = next_on(kt_iss + 1);
@@ -914,13 +934,13 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     // c ^ (r % chunks) (conflict-free writes -- lanes are rows -- and reads -- lanes are chunks).
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    VRD_STAMP();                                         // after the last step: barrier passed
     constexpr int CH = HD / 4;                                       // 16-byte chunks per output row of this head
     char* const slab = lds + wave * (64 * HD * 4);
     static_for<2>([&](auto qb_c) {
         constexpr int qb = decltype(qb_c)::value;
         const float l_tot = xchg32_sum(qb ? B.lp : A.lp);
-        // f16: accumulators = sum (P 2^e)(V 2^e), l = sum P 2^e: acc / l is the output times 2^e -- what a pair row stores
-        const float inv = (qb ? live1 : live0) ? ((F16 && !pair_out) ? vrd::F16_ACT_INV : 1.0f) / l_tot : 0.f;
+        const float inv = (qb ? live1 : live0) ? 1.0f / l_tot : 0.f;
         static_for<DT>([&](auto d_c) {
             constexpr int d = decltype(d_c)::value;
             static_for<4>([&](auto g_c) {
@@ -938,6 +958,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             });
         });
     });
+    VRD_STAMP();                                         // outputs in LDS
     // (wave-private slab: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt wait)
     // Rows leave in batches of eight wave instructions: the reads of a batch together, then its stores; the row pointer
     // advances by a constant (no 64-bit multiply per row), and the rows-inside-the-sequence test is per wave unless the
@@ -964,12 +985,12 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
                 const int r = (t0 + u) * ROWS_PI + rr;
-                if (all_rows || q0 + r < Tq) {
+                if ((all_rows || q0 + r < Tq) && !(VRD_W64_ABL & 256)) {
                     uint4 hi, lo;
-                    split_pair<F16>(va[u].x, va[u].y, hi.x, lo.x);
-                    split_pair<F16>(va[u].z, va[u].w, hi.y, lo.y);
-                    split_pair<F16>(vb[u].x, vb[u].y, hi.z, lo.z);
-                    split_pair<F16>(vb[u].z, vb[u].w, hi.w, lo.w);
+                    split_pair(va[u].x, va[u].y, hi.x, lo.x);
+                    split_pair(va[u].z, va[u].w, hi.y, lo.y);
+                    split_pair(vb[u].x, vb[u].y, hi.z, lo.z);
+                    split_pair(vb[u].z, vb[u].w, hi.w, lo.w);
                     *reinterpret_cast<uint4*>(gp) = hi;
                     *reinterpret_cast<uint4*>(gp + 64) = lo;
                 }
@@ -998,17 +1019,25 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             }
         }
     }
+#if defined(VRD_W64_DBG) && (VRD_W64_DBG & 16)
+    VRD_STAMP();                                         // last: stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid == 0) {
+        float* dbg = out + ((int64_t)b * Tq + qblk * 256) * ldo + h * HD;          // row 0 of the block, this head's columns
+        for (int i = 0; i < 64 && i < HD; ++i) dbg[i] = i < n_stamp ? stamps[i] : -1.f;
+    }
+#endif
     }       // 256-query blocks
     }       // items
 #undef VRD_AQ
 #undef VRD_AO
-#undef VRD_MFMA
 }
 
-template <int HD, bool F16>
+template <int HD>
 int launch_w64(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, const uint8_t* q_mask, int B,
                int Tq, int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
-    auto kern = attn_flash_x3_w64_kernel<HD, F16>;
+    auto kern = attn_flash_x3_w64_kernel<HD>;
     constexpr size_t lds_max = 4 * AG<HD>::STAGE + (4096 + 128) * sizeof(float);       // key bias + tile flags for Tk <= 4096
     const size_t lds = 4 * AG<HD>::STAGE + (size_t)((Tk + 31) / 32) * 33 * sizeof(float);
     if (lds > lds_max) {
@@ -1017,7 +1046,11 @@ int launch_w64(const float* q, int64_t ldq, const float* k, const float* v, int6
     }
     if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds_max, "vrd_attention_pair(w64)")) return rc;
     const int q_blocks = (Tq + 255) / 256;
+#if defined(VRD_W64_DBG)
+    const size_t lds_launch = lds_max;          // the stamp buffer of the diagnostic build lives behind the key-bias row
+#else
     const size_t lds_launch = lds;
+#endif
     static const int n_cu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1025,14 +1058,14 @@ int launch_w64(const float* q, int64_t ldq, const float* k, const float* v, int6
     }();
     const int n_items = n_head * B;
     hipLaunchKernelGGL(kern, dim3((unsigned)(n_items < n_cu ? n_items : n_cu)), dim3(256), lds_launch, s, q, ldq, k, v, ldkv, kv_mask, q_mask,
-                       Tq, Tk, n_head * HD, scale * 1.44269504088896340736f, out, ldo, pair_out, q_blocks, n_head, B);      // (scale: see vrd_attention_pair)
+                       Tq, Tk, n_head * HD, scale * 1.44269504088896340736f, out, ldo, pair_out, q_blocks, n_head, B);
     return 0;
 }
 
-template <int HD, int NW, bool F16>
+template <int HD, int NW>
 int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq,
            int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
-    auto kern = attn_flash_x3_kernel<HD, NW, F16>;
+    auto kern = attn_flash_x3_kernel<HD, NW>;
     constexpr size_t lds_max = 2 * AG<HD>::STAGE + (4096 + 128) * sizeof(float);       // key bias + tile flags for Tk <= 4096
     const size_t lds = 2 * AG<HD>::STAGE + (size_t)((Tk + 31) / 32) * 33 * sizeof(float);
     if (lds > lds_max) {
@@ -1053,7 +1086,7 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 
 extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                                   const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq, int Tk, int n_head, int head_dim,
-                                  float* out, int64_t ldo, int out_pair, int pair_fmt, void* stream) {
+                                  float* out, int64_t ldo, int out_pair, void* stream) {
     VRD_CHECK_ARG(q && k && v && out, "vrd_attention_pair: null pointer");
     VRD_CHECK_ARG(head_dim == 64 || head_dim == 128, "vrd_attention_pair: head_dim must be 64 or 128 (got %d)", head_dim);
     VRD_CHECK_ARG(B > 0 && B <= 65535 && Tq > 0 && Tk > 0 && n_head > 0 && n_head <= 65535, "vrd_attention_pair: bad sizes");
@@ -1061,12 +1094,8 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     VRD_CHECK_ARG(ldq >= width && ldkv >= width && ldo >= width && ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 &&
                       aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out),
                   "vrd_attention_pair: rows must be 16-byte aligned pair rows of width n_head*head_dim");
-    VRD_CHECK_ARG(pair_fmt == VRD_PAIR_BF16 || pair_fmt == VRD_PAIR_F16, "vrd_attention_pair: pair_fmt must be VRD_PAIR_BF16 or VRD_PAIR_F16");
-    VRD_CHECK_ARG(out_pair == VRD_PAIR_NONE || out_pair == pair_fmt, "vrd_attention_pair: pair output comes in the operands' format");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool f16 = pair_fmt == VRD_PAIR_F16;
-    // f16 operands hold q and k times 2^VRD_F16_ACT_EXP each: the raw scores are 2^(2 e) too large, undone in the softmax scale
-    const float scale = (f16 ? vrd::F16_ACT_INV * vrd::F16_ACT_INV : 1.0f) / sqrtf((float)head_dim);
+    const float scale = 1.0f / sqrtf((float)head_dim);
     vrd::ProfScope prof(VRD_K_ATTN_FLASH, s, 4.0 * B * (double)n_head * Tq * Tk * head_dim,
                         4.0 * B * (double)width * (2.0 * Tq + 2.0 * Tk));
     // waves (32-query tiles) per workgroup: every workgroup streams the whole K / V row of its (b, h), and the kernel is
@@ -1087,14 +1116,12 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     // (its LDS-DMA offsets are 32-bit: a batch element's K / V slab has to stay below 2 GiB)
     const bool w64 = (w64_env >= 0 ? w64_env != 0 : (head_dim == 128 && Tq >= 224)) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31);
     int rc;
-#define VRD_ATTN_ARGS q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s
-    if (w64) rc = head_dim == 128 ? (f16 ? launch_w64<128, true>(VRD_ATTN_ARGS) : launch_w64<128, false>(VRD_ATTN_ARGS))
-                                  : (f16 ? launch_w64<64, true>(VRD_ATTN_ARGS) : launch_w64<64, false>(VRD_ATTN_ARGS));
-    else if (head_dim == 128) rc = nw == 3 ? (f16 ? launch<128, 3, true>(VRD_ATTN_ARGS) : launch<128, 3, false>(VRD_ATTN_ARGS))
-                                           : (f16 ? launch<128, 4, true>(VRD_ATTN_ARGS) : launch<128, 4, false>(VRD_ATTN_ARGS));
-    else rc = nw == 3 ? (f16 ? launch<64, 3, true>(VRD_ATTN_ARGS) : launch<64, 3, false>(VRD_ATTN_ARGS))
-                      : (f16 ? launch<64, 4, true>(VRD_ATTN_ARGS) : launch<64, 4, false>(VRD_ATTN_ARGS));
-#undef VRD_ATTN_ARGS
+    if (w64) rc = head_dim == 128 ? launch_w64<128>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
+                                  : launch_w64<64>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
+    else if (head_dim == 128) rc = nw == 3 ? launch<128, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
+                                      : launch<128, 4>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
+    else rc = nw == 3 ? launch<64, 3>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s)
+                      : launch<64, 4>(q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s);
     if (rc) return rc;
     VRD_LAUNCH_CHECK();
     return 0;

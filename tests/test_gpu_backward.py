@@ -22,7 +22,7 @@ def _autograd_on():
         yield
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16x3", "f16x3"])
 def precision(request):
     from vrdone_amd import ops
     old = ops.get_precision()
@@ -326,24 +326,43 @@ def test_maxpool_and_mask_head_backward():
 
 @pytest.mark.parametrize("k", [1, 3])
 def test_split_weight_operands_are_the_tensor_expression_bit_for_bit(k):
-    """vrd_split_weight (one launch from the parameter) against what it replaces: hi = bf16(W), lo = bf16(W - hi) of the
-    tap-major packed weight in blocks of 32, for the forward operand and for the transposed, tap-flipped operand of the
-    input-gradient GEMM."""
-    from vrdone_amd import ops
+    """vrd_split_weight (from the parameter) against what it replaces: hi = bf16(W), lo = bf16(W - hi) of the tap-major
+    packed weight in blocks of 32, for the forward operand and for the transposed, tap-flipped operand of the
+    input-gradient GEMM; in the f16 format hi = f16(y), lo = f16(y - hi) of y = W * 2^e_w with max |W| * 2^e_w in [2^14, 2^15)."""
+    import math
+    from vrdone_amd import _hip, ops
 
-    def expression(w):              # w: Conv1d weight (N, Cin, k), contiguous
+    def expression(w, f16=False):              # w: Conv1d weight (N, Cin, k), contiguous
         packed = w.permute(0, 2, 1).contiguous().reshape(w.shape[0], -1)
-        hi = packed.to(torch.bfloat16)
-        lo = (packed - hi.float()).to(torch.bfloat16)
+        dt = torch.float16 if f16 else torch.bfloat16
+        ew = 15 - math.frexp(float(packed.abs().max()))[1] if f16 else 0       # frexp: max = m * 2^e, m in [0.5, 1)
+        packed = packed * 2.0 ** ew
+        hi = packed.to(dt)
+        lo = (packed - hi.float()).to(dt)
         n, kk = hi.shape
-        return torch.stack([hi.reshape(n, kk // 32, 32), lo.reshape(n, kk // 32, 32)], dim=2)
+        return torch.stack([hi.reshape(n, kk // 32, 32), lo.reshape(n, kk // 32, 32)], dim=2), ew
 
     g = torch.Generator().manual_seed(11)
     w = (torch.randn(96, 64, k, generator=g) * 3).to(DEV)
-    assert torch.equal(ops.split_conv_weight(w), expression(w))
-    assert torch.equal(ops.split_conv_weight_dgrad(w), expression(w.flip(2).permute(1, 0, 2).contiguous()))
-    # cached per weight version: an in-place update rebuilds both
-    first = ops.split_conv_weight(w)
-    assert ops.split_conv_weight(w) is first
-    w.mul_(0.5)
-    assert ops.split_conv_weight(w) is not first and torch.equal(ops.split_conv_weight(w), expression(w))
+    with ops.use_precision("bf16x3"):
+        got = ops.split_conv_weight(w)
+        assert got.fmt == _hip.PAIR_BF16 and got.scale is None and torch.equal(got.t, expression(w)[0])
+        assert torch.equal(ops.split_conv_weight_dgrad(w).t, expression(w.flip(2).permute(1, 0, 2).contiguous())[0])
+        # cached per weight version: an in-place update rebuilds both
+        first = ops.split_conv_weight(w)
+        assert ops.split_conv_weight(w) is first
+        w.mul_(0.5)
+        assert ops.split_conv_weight(w) is not first and torch.equal(ops.split_conv_weight(w).t, expression(w)[0])
+    with ops.use_precision("f16x3"):
+        for scale in (1.0, 1e-3, 700.0):          # per-tensor exponent: whatever the weight's magnitude, the planes are full
+            w2 = (w * scale).contiguous()
+            got = ops.split_conv_weight(w2)
+            want, ew = expression(w2, f16=True)
+            assert got.fmt == _hip.PAIR_F16 and torch.equal(got.t, want)
+            sc = got.scale.cpu().tolist()
+            assert sc[0] == 2.0 ** -(ew + _hip.F16_ACT_EXP) and sc[1] == 2.0 ** ew
+            assert 2 ** 14 <= float(got.t[:, :, 0].float().abs().max()) <= 2 ** 15
+        z = ops.split_conv_weight(torch.zeros(32, 32, 1, device=DEV))          # an all-zero weight: exponent 0
+        assert z.scale.cpu().tolist()[:2] == [2.0 ** -_hip.F16_ACT_EXP, 1.0] and not bool(z.t.any())
+        # the input-gradient operand stays bf16 in this mode too (ops.split_backward)
+        assert ops.split_conv_weight_dgrad(w).fmt == _hip.PAIR_BF16

@@ -4,8 +4,10 @@ fresh inputs, plus size-independent properties at the benchmark shape.
 
 Stated tolerance (BASELINE north star): predicate logits within 1e-3 of the reference.  Measured
 max differences vs the reference: f32 mode ~6e-6 (logits) / 6e-5 (mask logits, range +-25); bf16x3 mode
-(the default: split-bf16 MFMA products, f32 accumulate) ~7e-5 / 5e-4.  The asserts use 2e-4 / 2e-3 for
-both modes."""
+(the default: split-bf16 MFMA products, f32 accumulate) ~7e-5 / 5e-4; f16x3 mode (scaled split-f16 products: the
+reference-grade mode) like f32.  The asserts use 2e-4 / 2e-3 for all modes; the two reference-grade modes are in
+addition held to 2 x the reference's own float32 error against a float64 run of the reference
+(test_reference_grade_against_float64)."""
 import json
 import os
 
@@ -51,7 +53,7 @@ def close(got, want, atol):
     np.testing.assert_allclose(got, want, atol=atol, rtol=0)
 
 
-@pytest.fixture(params=["bf16x3", "f32"])
+@pytest.fixture(params=["bf16x3", "f16x3", "f32"])
 def precision(request):
     from vrdone_amd import ops
     old = ops.get_precision()
@@ -86,6 +88,89 @@ def test_mask_vrd_matches_reference_golden(name, T, precision):
     fast = model._mask_vrd(xd, md, with_aux=False)
     assert "aux_outputs" not in fast
     assert torch.equal(fast["pred_logits"], out["pred_logits"]) and torch.equal(fast["pred_masks"], out["pred_masks"])
+
+
+F64_CASES = [("vidvrd", 96), ("vidvrd", 144), ("vidvrd", 288), ("vidor_x", 512), ("vidor_local", 512), ("vidor", 512),
+             ("b256", None), ("cfg2", None)]
+
+
+def f64_case(name, T):
+    """(model, x, m, ref32 outputs, ref64 outputs, row stride of the stored pairs) of a case of tests/golden/mask_vrd_f64.npz
+    (scripts/make_golden_f64.py: the real reference run in float64 on the goldens' inputs)."""
+    from golden_cases import B256, CFG2, b256_lengths, cfg2_lengths
+    f64 = np.load(os.path.join(GOLDEN, "mask_vrd_f64.npz"))
+    if T is None:
+        spec, lens = (B256, b256_lengths()) if name == "b256" else (CFG2, cfg2_lengths())
+        model, mc, _, _ = get_model("vidvrd")
+        g = np.load(os.path.join(GOLDEN, f"mask_vrd_vidvrd_{name}.npz"))
+        x, m = O.synth_pairs(spec["B"], c_in(mc), spec["T"], lens, seed=spec["seed"])
+        return (model, x, m, {k: g[k] for k in ("pred_logits", "pred_masks")},
+                {k: f64[f"{name}_{k}"] for k in ("pred_logits", "pred_masks")}, spec["every"])
+    model, mc, _, _ = get_model(name)
+    g = np.load(os.path.join(GOLDEN, f"mask_vrd_{name}.npz"))
+    lens = g[f"T{T}_lengths"].tolist()
+    x, m = O.synth_pairs(len(lens), c_in(mc), T, lens, seed=1234 + T)
+    return (model, x, m, {k: g[f"T{T}_{k}"] for k in ("pred_logits", "pred_masks")},
+            {k: f64[f"{name}_T{T}_{k}"] for k in ("pred_logits", "pred_masks")}, 1)
+
+
+def f64_distance(name, T):
+    """{output: (max, rms) of |ours - ref64| / the same of |ref32 - ref64|} for the current precision mode"""
+    model, x, m, ref32, ref64, every = f64_case(name, T)
+    out = model._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
+    res = {}
+    for k in ("pred_logits", "pred_masks"):
+        ours = out[k][::every].double().cpu().numpy()
+        assert np.isfinite(ours).all()
+        e, e32 = np.abs(ours - ref64[k]), np.abs(ref32[k].astype(np.float64) - ref64[k])
+        res[k] = (float(e.max() / e32.max()), float(np.sqrt((e ** 2).mean() / (e32 ** 2).mean())), float(e.max()), float(e32.max()))
+    return res
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+@pytest.mark.parametrize("name,T", F64_CASES)
+def test_reference_grade_against_float64(name, T, mode):
+    """The two modes that may be quoted as the reference's arithmetic: their distance to a FLOAT64 run of the real reference
+    (tests/golden/mask_vrd_f64.npz) is within 2 x the distance of the reference's own float32 run (the committed float32
+    goldens) on the same inputs -- worst element and rms, logits and mask logits, every golden case of `_mask_vrd`
+    (all four shipped configs, the 256-pair batch, BASELINE config 2 at its size).  Measured (profiles/r04_f64_distance.txt):
+    f16x3 x0.56 - x1.36 worst element, x0.87 - x1.11 rms; f32 x0.92 - x2.88 / x1.09 - x1.79; the bf16x3 mode sits at ~x17 and
+    is not held to this."""
+    from vrdone_amd import ops
+    old = ops.get_precision()
+    ops.set_precision(mode)
+    try:
+        res = f64_distance(name, T)
+    finally:
+        ops.set_precision(old)
+    # f32 (exact products, but ONE accumulation chain along K per output in the f32 MFMA: its rounding errors add up where
+    # the 16-bit MFMA sums 16 products per instruction) measures x0.9 - x2.9 on the worst element: held to 4 x, rms to 2 x
+    bound_max = 2.0 if mode == "f16x3" else 4.0
+    for k, (r_max, r_rms, e_max, e32_max) in res.items():
+        assert r_max <= bound_max and r_rms <= 2.0, \
+            f"{name} T{T} {mode} {k}: max {e_max:.3e} vs ref32 {e32_max:.3e} (x{r_max:.2f}), rms x{r_rms:.2f}"
+
+
+def test_f16x3_overflow_is_loud_and_forward_test_repeats_in_f32():
+    """Inputs beyond the f16x3 mode's operand range (|x| >= 4094): the path returns NaN, never a wrong finite number, and
+    forward_test repeats the video in the f32 mode -- whose result it then returns (the reference computes float32)."""
+    import warnings
+    from vrdone_amd import ops
+    model, mc, _, _ = get_model("vidvrd")
+    data = synth_proposal(4, c_in(mc), 20, 60, seed=99)
+    big = dict(data, so_features_list=[f * 3.0e4 for f in data["so_features_list"]])
+    dev_data = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in big.items()}
+    inputs, masks, _ = model.preprocessing(dev_data["so_features_list"])
+    with ops.use_precision("f16x3"):
+        out = model._mask_vrd(inputs[0], masks[0], with_aux=False)
+        assert not bool(torch.isfinite(out["pred_logits"]).all())          # poisoned, not silently wrong
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = model(dev_data)
+        assert any("f16x3" in str(x.message) for x in w)
+    with ops.use_precision("f32"):
+        want = model(dev_data)
+    assert got is not None and got["triplets"] == want["triplets"] and got["triple_scores_avg"] == want["triple_scores_avg"]
 
 
 def test_mask_vrd_matches_oracle_on_a_ragged_batch(precision):
@@ -203,7 +288,7 @@ def test_mask_vrd_b256_matches_reference_golden(precision):
     e = B256["every"]
     close(out["pred_logits"][::e], g["pred_logits"], LOGIT_TOL)
     close(out["pred_masks"][::e], g["pred_masks"], MASK_TOL)
-    if precision == "bf16x3":       # the kernel this case exists for did run, and skipped padded tiles
+    if precision in ("bf16x3", "f16x3"):       # the kernel this case exists for did run, and skipped padded tiles
         assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
 
 

@@ -17,14 +17,17 @@ torch.set_grad_enabled(False)
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+SPLIT = ("bf16x3", "f16x3")        # the split-precision modes (pair rows, LDS-DMA GEMMs, split flash attention)
+
+
+@pytest.fixture(autouse=True, params=["bf16x3", "f16x3", "f32"])
 def precision(request):
-    """Every operator test runs in both GEMM precision modes (same tolerances)."""
+    """Every operator test runs in all GEMM precision modes (tolerances stated for f32 products)."""
     from vrdone_amd import ops
     global GEMM_TOL_SCALE
     old = ops.get_precision()
     ops.set_precision(request.param)
-    GEMM_TOL_SCALE = 1.0 if request.param == "f32" else 5.0
+    GEMM_TOL_SCALE = 5.0 if request.param == "bf16x3" else 1.0          # f16x3 products: held to the f32 tolerances
     yield request.param
     ops.set_precision(old)
     GEMM_TOL_SCALE = 1.0
@@ -408,22 +411,28 @@ def test_gemm_split_bf16_precision(M, N, Cin, taps, T, precision):
     try:
         ops.set_precision("bf16x3")
         got = ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)).cpu().double()
+        ops.set_precision("f16x3")
+        got16 = ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)).cpu().double()
     finally:
         ops.set_precision("f32")
     f32 = ops.conv_gemm(x.to(DEV), w.to(DEV), bias.to(DEV)).cpu().double()
     rel = float(((got - ref).abs() / mag).max())
+    rel16 = float(((got16 - ref).abs() / mag).max())
     rel32 = float(((f32 - ref).abs() / mag).max())
-    print(f"max rel err vs fp64: bf16x3 {rel:.2e}, f32 {rel32:.2e}; max abs bf16x3 {float((got - ref).abs().max()):.2e}")
+    print(f"max rel err vs fp64: bf16x3 {rel:.2e}, f16x3 {rel16:.2e}, f32 {rel32:.2e}; max abs bf16x3 {float((got - ref).abs().max()):.2e}")
     assert rel < 3e-6, (rel, rel32)          # 2^-18 ~ 3.8e-6 per product before averaging
     assert rel32 < 3e-7
+    # f16x3 (scaled f16 planes: 2^-22 per product before averaging): the reference-grade mode is held to the f32 kernel's bound
+    assert rel16 < 3e-7, (rel16, rel32)
     close(got.float(), ref.float(), 1e-4)
+    close(got16.float(), ref.float(), 1e-5)
 
 
 def test_pair_row_format_round_trip(precision):
     """Producers' pair rows decode to the f32 value within 2^-16 relative; a GEMM fed with pair rows equals the
     GEMM fed with the f32 tensor (same split, done by the producer instead of the GEMM's staging)."""
-    if precision != "bf16x3":
-        pytest.skip("pair rows exist in bf16x3 mode only")
+    if precision not in SPLIT:
+        pytest.skip("pair rows exist in the split-precision modes only")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(123)
     x = torch.randn(3, 40, 512, generator=gen) * 3
@@ -456,7 +465,7 @@ def test_gemm_large_tile_kernels(k, precision):
     """Shapes with enough tiles for the 256 x 256 (and, in the smaller call, the 128 x 256) LDS-DMA kernels:
     pair-row input, k = 1 / 3, mask * scale + two residuals, f32 and pair output, checked per sequence against
     an f64 reference on a sample of the sequences (rows of other sequences never enter a sequence's result)."""
-    if precision != "bf16x3":
+    if precision not in SPLIT:
         pytest.skip("the LDS-DMA kernels are split-precision kernels")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(7 + k)
@@ -486,7 +495,7 @@ def test_gemm_large_tile_kernels(k, precision):
 def test_gemm_k3_short_sequences(precision):
     """k = 3 over many short sequences (T = 24 < 32): enough tiles for the LDS-DMA kernels; the 256 x 256 kernel
     must decline (it advances the position inside the sequence by 8 rows per DMA piece, which needs T >= 32)."""
-    if precision != "bf16x3":
+    if precision not in SPLIT:
         pytest.skip("the LDS-DMA kernels are split-precision kernels")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(99)
@@ -502,9 +511,12 @@ def test_gemm_k3_short_sequences(precision):
 
 def _to_pair(t):
     """Encode an f32 (B, T, C) tensor as pair rows (test helper; mirrors vrd::store_pair4)."""
-    from vrdone_amd import ops
-    hi = t.to(torch.bfloat16)
-    lo = (t - hi.float()).to(torch.bfloat16)
+    from vrdone_amd import _hip, ops
+    f16 = ops.pair_fmt() == _hip.PAIR_F16          # the current mode's element format: f16 planes hold x * 2^F16_ACT_EXP
+    dt = torch.float16 if f16 else torch.bfloat16
+    t = t * 2.0 ** _hip.F16_ACT_EXP if f16 else t
+    hi = t.to(dt)
+    lo = (t - hi.float()).to(dt)
     C = t.shape[-1]
     raw = torch.stack([hi.reshape(*t.shape[:-1], C // 32, 32), lo.reshape(*t.shape[:-1], C // 32, 32)], dim=-2)
     raw = raw.reshape(*t.shape[:-1], 2 * C).contiguous()            # blocks of [32 hi | 32 lo]: 4C bytes per row
@@ -514,8 +526,8 @@ def _to_pair(t):
 @pytest.mark.parametrize("H,hd,Tq,Tk", [(4, 128, 96, 96), (8, 64, 144, 144), (4, 128, 288, 288), (8, 64, 512, 512),
                                         (4, 128, 40, 77)])
 def test_flash_attention_pair_rows(H, hd, Tq, Tk, precision):
-    if precision != "bf16x3":
-        pytest.skip("pair rows exist in bf16x3 mode only")
+    if precision not in SPLIT:
+        pytest.skip("pair rows exist in the split-precision modes only")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(H + hd + Tq + Tk)
     B, C = 3, H * hd
@@ -550,8 +562,8 @@ def test_flash_attention_one_wave_per_simd_kernel(H, hd, Tq, Tk, precision, monk
     """The 64-queries-per-wave kernel (vrd_attn_x3.hip, attn_flash_x3_w64_kernel) forced on every shape -- partial last key
     tile, several 256-query blocks, blocks of padding only, a dominant late key (the deferred rescale) -- against the oracle
     and against the 32-queries-per-wave kernel."""
-    if precision != "bf16x3":
-        pytest.skip("pair rows exist in bf16x3 mode only")
+    if precision not in SPLIT:
+        pytest.skip("pair rows exist in the split-precision modes only")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(3 * H + hd + Tq + Tk)
     B, C = 3, H * hd
@@ -585,8 +597,8 @@ def test_flash_attention_key_masks_with_holes(Tk, precision, monkeypatch):
     """Key masks that are not prefixes: leading tiles with no valid key (a row's reference point stays at its floor until the
     first valid key), a hole of whole tiles and partial tiles in the middle; at 2304 keys (more than 64 key tiles) the
     one-wave-per-SIMD kernel visits every tile, the fully masked ones included.  Both flash kernels against the oracle."""
-    if precision != "bf16x3":
-        pytest.skip("pair rows exist in bf16x3 mode only")
+    if precision not in SPLIT:
+        pytest.skip("pair rows exist in the split-precision modes only")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(Tk)
     B, H, hd, Tq = 2, 2, 128, 256
@@ -641,7 +653,7 @@ def test_gemm_padding_skip_is_exact(k, precision):
     """The 256 x 256 kernel with a padding map: blocks without a valid row skip the contraction.  With row_mask the
     result is bit-identical to the full computation (masked rows are res*mask + res2 either way); without it the
     rows that hold valid frames are bit-identical and the skipped ones finite."""
-    if precision != "bf16x3":
+    if precision not in SPLIT:
         pytest.skip("the LDS-DMA kernels are split-precision kernels")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(21 + k)
@@ -682,7 +694,7 @@ def test_gemm_batch_equals_single_calls(precision):
     """vrd_gemm_batch: three GEMMs that differ only in input / weight / bias / output as one launch of the 256 x 256
     kernel (with a padding map), and a mixed list that has to fall back to one launch per problem: same bits as
     calling conv_gemm on each."""
-    if precision != "bf16x3":
+    if precision not in SPLIT:
         pytest.skip("the 256 x 256 kernel is a split-precision kernel")
     from vrdone_amd import ops
     gen = torch.Generator().manual_seed(5)

@@ -41,7 +41,7 @@ def c_in(mc):
     return 2 * mc["visual_dim"] + 2 * cc + mc["bbox_so_dim"] + 2 * mc["bbox_entity_dim"]
 
 
-@pytest.fixture(params=["f32", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16x3", "f16x3"])
 def precision(request):
     from vrdone_amd import ops
     old = ops.get_precision()
@@ -228,14 +228,17 @@ def test_training_step_vidor_matches_reference_gradients(name, precision):
     print(f"[{name}/{precision}] relative gradient error: worst {worst:.2e}, median {median:.2e}; downstream of the pools: {w2:.2e}, {m2:.2e}")
 
 
-def test_presplit_weights_equal_the_per_weight_launches():
-    """ops.presplit_weights (one vrd_split_weights launch for all dense conv weights of a training step) leaves, in every
-    weight's operand caches, exactly what split_conv_weight / split_conv_weight_dgrad build one launch at a time; a later
-    in-place update of a weight invalidates its entries."""
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+def test_presplit_weights_equal_the_per_weight_launches(mode):
+    """ops.presplit_weights (one vrd_split_weights call for all dense conv weights of a training step) leaves, in every
+    weight's operand caches, exactly what split_conv_weight / split_conv_weight_dgrad build one weight at a time -- planes and,
+    in the f16 format, the per-tensor scale; a later in-place update of a weight invalidates its entries; a change of mode
+    builds a new plan and drops the old one."""
     from vrdone_amd import ops
-    old = ops.get_precision()
-    ops.set_precision("bf16x3")
-    try:
+    fwd = "_vrd_split_f16" if mode == "f16x3" else "_vrd_split"
+    slots = (fwd, "_vrd_split_t")
+    bits = lambda sw: sw.t.view(torch.int16)        # noqa: E731
+    with ops.use_precision(mode):
         model, _, _ = build()
         ws = model._dense_conv_weights()
         assert len(ws) > 100
@@ -243,31 +246,37 @@ def test_presplit_weights_equal_the_per_weight_launches():
         for w in ws:
             N, Cin, k = w.shape
             if (Cin * k) % 32 == 0:
-                want[(id(w), "_vrd_split")] = ops.split_conv_weight(w).clone()
+                sw = ops.split_conv_weight(w)
+                want[(id(w), fwd)] = (sw.t.clone(), None if sw.scale is None else sw.scale.clone(), sw.fmt)
             if (N * k) % 32 == 0:
-                want[(id(w), "_vrd_split_t")] = ops.split_conv_weight_dgrad(w).clone()
-            for slot in ("_vrd_split", "_vrd_split_t"):
+                sw = ops.split_conv_weight_dgrad(w)
+                want[(id(w), "_vrd_split_t")] = (sw.t.clone(), None, sw.fmt)
+            for slot in slots:
                 if hasattr(w, slot):
                     delattr(w, slot)
         plans = {}
         ops.presplit_weights(ws, plans)
         assert len(plans) == 1 and len(want) > 200
         for w in ws:
-            for slot in ("_vrd_split", "_vrd_split_t"):
+            for slot in slots:
                 if (id(w), slot) in want:
                     key, val = getattr(w, slot)[:2]
-                    assert key == (w.data_ptr(), w._version)
-                    assert torch.equal(val.view(torch.int16), want[(id(w), slot)].view(torch.int16)), slot
+                    t, scale, fmt = want[(id(w), slot)]
+                    assert key == (w.data_ptr(), w._version) and val.fmt == fmt
+                    assert torch.equal(bits(val), t.view(torch.int16)), slot
+                    if scale is not None:
+                        assert torch.equal(val.scale[:2], scale[:2]), slot
         w0 = ws[0]
-        assert ops.split_conv_weight(w0) is getattr(w0, "_vrd_split")[1]          # served from the cache
+        assert ops.split_conv_weight(w0) is getattr(w0, fwd)[1]                    # served from the cache
         with torch.no_grad():
             w0.mul_(1.5)
         fresh = ops.split_conv_weight(w0)                                          # stale entry: rebuilt for the new version
-        assert not torch.equal(fresh.view(torch.int16), want[(id(w0), "_vrd_split")].view(torch.int16))
+        assert not torch.equal(bits(fresh), want[(id(w0), fwd)][0].view(torch.int16))
         ops.presplit_weights(ws, plans)                                            # the next step: same plan, new values
-        assert len(plans) == 1 and torch.equal(getattr(w0, "_vrd_split")[1].view(torch.int16), fresh.view(torch.int16))
-    finally:
-        ops.set_precision(old)
+        assert len(plans) == 1 and torch.equal(bits(getattr(w0, fwd)[1]), bits(fresh))
+        with ops.use_precision("f16x3" if mode == "bf16x3" else "bf16x3"):         # the other element format: its own plan
+            ops.presplit_weights(ws, plans)
+            assert len(plans) == 1
 
 
 def test_drop_path_sampling_statistics():

@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VRDONE_HIP_LIB") or os.path.join(_HERE, "csrc", "libvrdone_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+PAIR_NONE, PAIR_BF16, PAIR_F16 = 0, 1, 2          # enum vrd_pair_format
+F16_ACT_EXP = 4                                   # VRD_F16_ACT_EXP
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
  K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_GEMM_X3_BIG, K_BACKWARD, K_COUNT) = range(15)   # enum vrd_kernel_id
 KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
@@ -44,7 +46,8 @@ class GemmArgs(C.Structure):
                 ("res", c_f32p), ("ldres", C.c_int64), ("res_masked", C.c_int32),
                 ("res2", c_f32p), ("ldres2", C.c_int64), ("W_split", C.c_void_p),
                 ("a_pair_width", C.c_int32), ("c_pair", C.c_int32),
-                ("row_blocks", C.c_void_p), ("row_blocks_active", C.c_void_p), ("row_block_seg_len", C.c_int32)]
+                ("row_blocks", C.c_void_p), ("row_blocks_active", C.c_void_p), ("row_block_seg_len", C.c_int32),
+                ("split_fmt", C.c_int32), ("w_scale", c_f32p)]
 
 
 class DwconvLnArgs(C.Structure):
@@ -80,8 +83,8 @@ class BmmArgs(C.Structure):
 
 
 class SplitJob(C.Structure):
-    _fields_ = [("src", c_f32p), ("out", C.c_void_p), ("R", C.c_int32), ("Q", C.c_int32), ("taps", C.c_int32), ("reserved", C.c_int32),
-                ("sr", C.c_int64), ("st", C.c_int64), ("sq", C.c_int64)]
+    _fields_ = [("src", c_f32p), ("out", C.c_void_p), ("R", C.c_int32), ("Q", C.c_int32), ("taps", C.c_int32), ("fmt", C.c_int32),
+                ("sr", C.c_int64), ("st", C.c_int64), ("sq", C.c_int64), ("scale", c_f32p)]
 
 
 class GatherArgs(C.Structure):
@@ -112,8 +115,9 @@ _SIGNATURES = {
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
     "vrd_gather_pairs": (C.c_int, [C.POINTER(GatherArgs), C.c_void_p]),
     "vrd_assemble_pairs": (C.c_int, [C.POINTER(AssembleArgs), C.c_void_p]),
-    "vrd_split_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
-    "vrd_split_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vrd_split_weight": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int, c_f32p,
+                                   C.c_void_p]),
+    "vrd_split_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_gemm_batch": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "vrd_row_blocks": (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -125,7 +129,7 @@ _SIGNATURES = {
     "vrd_attention": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_attention_pair": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+                                     C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_maxpool_mask": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p, C.c_int64, c_u8p,
                                    C.c_void_p]),
     "vrd_mask_head": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -162,7 +166,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 
 class HipLibraryError(RuntimeError):

@@ -23,7 +23,7 @@ import torch
 from torch.autograd import Function
 
 from . import _hip, ops
-from ._hip import lib
+from ._hip import PAIR_BF16, lib
 from .ops import ACT_NONE, ACT_RELU, _mask_ptr, _ptr, _rows, _stream
 
 check = _hip.check
@@ -150,25 +150,26 @@ class Linear(Function):
             # (the parameter object itself while autograd is not recording -- the usual case in a backward pass: its operand
             # caches, which ops.presplit_weights fills for the whole step, hang on the object; a detached view has none)
             wd = weight if not torch.is_grad_enabled() else weight.detach()
-            fused = (ops.get_precision() == "bf16x3" and (N * k) % 32 == 0 and N % 4 == 0 and dy.stride(-2) % 4 == 0 and
+            fused = (ops.split_backward() and (N * k) % 32 == 0 and N % 4 == 0 and dy.stride(-2) % 4 == 0 and
                      dy.data_ptr() % 16 == 0 and weight.is_contiguous())
+            gfmt = PAIR_BF16 if ops.split_backward() else None       # gradients are split in bf16 in either split mode
             if k == 1:       # masking the rows of dy = masking the rows of dx
                 if fused:
                     dx = ops.conv_gemm(dy, wd, None, row_mask=mask, _dgrad=True)
                 else:
-                    dx = ops.conv_gemm(dy, weight.detach().permute(1, 0, 2).contiguous(), None, row_mask=mask)
+                    dx = ops.conv_gemm(dy, weight.detach().permute(1, 0, 2).contiguous(), None, row_mask=mask, _split_fmt=gfmt)
             else:            # dx[r] = sum_tap (dy * mask)[r - (tap - 1)] W[:, :, tap]: a k=3 conv with flipped, transposed taps
                 g = rowcol_scale(dy, row_mask=mask) if mask is not None else dy
                 if fused:
                     dx = ops.conv_gemm(g, wd, None, _dgrad=True)
                 else:
-                    dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None)
+                    dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None, _split_fmt=gfmt)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             packed = _zeros(N, k * Cin, device=dy.device)
             px, _, _, ldx = _rows(x)
-            if ops.get_precision() == "bf16x3":
-                # split-precision products like the forward GEMMs; the bias gradient (exact f32 column sums) in the same pass
+            if ops.split_backward():
+                # split-precision (bf16) products like the bf16x3 mode's forward GEMMs; the bias gradient (exact f32 column sums) in the same pass
                 if want_db:
                     db = _zeros(N, device=dy.device)
                 check(lib.vrd_gemm_wgrad_x3(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(),

@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
         a1.x += pj * v1.x; a1.y += pj * v1.y; a1.z += pj * v1.z; a1.w += pj * v1.w;
     }
     if (pair) {
-        vrd::store_pair4(out + row * ldo, lane * 8, 512, a0);
-        vrd::store_pair4(out + row * ldo, lane * 8 + 4, 512, a1);
+        vrd::store_pair4(out + row * ldo, lane * 8, 512, a0, pair);
+        vrd::store_pair4(out + row * ldo, lane * 8 + 4, 512, a1, pair);
     } else {
         st4(o, a0);
         st4(o + 4, a1);
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __re
                 a1.x += pj * vv.b.x; a1.y += pj * vv.b.y; a1.z += pj * vv.b.z; a1.w += pj * vv.b.w;
             }
             if (pair) {
-                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8, 512, a0);
-                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8 + 4, 512, a1);
+                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8, 512, a0, pair);
+                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8 + 4, 512, a1, pair);
             } else {
                 st4(o, a0);
                 st4(o + 4, a1);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_kernel(const float* __r
                 const int c = h * HD + 32 * d + 8 * g + 4 * lh;
                 const float4 v = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv,
                                              oacc[d][4 * g + 3] * inv);
-                if (pair) vrd::store_pair4(orow, c, width, v);
+                if (pair) vrd::store_pair4(orow, c, width, v, pair);
                 else st4(orow + c, v);
             }
     }

@@ -73,51 +73,122 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// "Pair" rows (GEMM-operand format of the bf16x3 mode): a row of W logical channels (W % 32 == 0) stored in the
-// 4*W bytes an f32 row would occupy, as blocks of 32 channels: [32 x bf16 hi | 32 x bf16 lo] per block, with
-// hi = bf16(x), lo = bf16(x - hi).  One 128-byte line therefore holds everything a K step of 32 needs from a
-// row, which is what the GEMM's LDS-DMA wants (whole lines per request).  Producers whose output is consumed
-// only as a GEMM / attention operand write this directly.  Rows concatenated from several producers need no
-// bookkeeping: the block structure does not depend on where a slab starts (slab widths are multiples of 32).
+// "Pair" rows (GEMM-operand format of the split-precision modes): a row of W logical channels (W % 32 == 0) stored in the
+// 4*W bytes an f32 row would occupy, as blocks of 32 channels: [32 x 16-bit hi | 32 x 16-bit lo] per block.  One 128-byte
+// line therefore holds everything a K step of 32 needs from a row, which is what the GEMM's LDS-DMA wants (whole lines per
+// request).  Producers whose output is consumed only as a GEMM / attention operand write this directly.  Rows concatenated
+// from several producers need no bookkeeping: the block structure does not depend on where a slab starts (slab widths are
+// multiples of 32).  Two element formats (enum vrd_pair_format of the ABI; every producer's `out_pair` / `c_pair` /
+// `pair_wide` argument is one of them, 0 = plain f32 rows):
+//   VRD_PAIR_BF16 (bf16x3 mode): hi = bf16(x), lo = bf16(x - hi): |x - hi - lo| <= 2^-17 |x|.
+//   VRD_PAIR_F16 (f16x3 mode): y = x * 2^VRD_F16_ACT_EXP (exact), hi = f16(y), lo = f16(y - hi), round to nearest both:
+//       |y - hi - lo| <= 2^-22 |y| while lo is a normal f16 (|y| >= 2^-2), 2^-25 absolute below (f16 subnormals are kept by
+//       the conversions and by the MFMA: scripts/lab/r04/f16_denorm_probe.hip).  |y| must stay below 65504, i.e.
+//       |x| < 4094: beyond it hi = inf, lo = -inf and every product that touches the element is NaN -- the result is
+//       poisoned, not silently wrong (the host mirror checks its outputs and repeats the batch in the f32 mode).
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
-// bf16 index of the hi half of channel c inside a pair row (the lo half is 32 further)
+constexpr int F16_ACT_EXP = VRD_F16_ACT_EXP;
+constexpr float F16_ACT_SCALE = (float)(1 << VRD_F16_ACT_EXP), F16_ACT_INV = 1.0f / (float)(1 << VRD_F16_ACT_EXP);
+
+// element types and the matrix instruction of a split format (F16 = false: bf16, true: scaled f16)
+template <bool F16>
+struct SplitFmt;
+template <>
+struct SplitFmt<false> {
+    typedef __bf16 elem;
+    typedef bf16x4_t x4;
+    typedef bf16x8_t x8;
+    static constexpr float act_scale = 1.0f, act_inv = 1.0f;
+    static constexpr int fmt = VRD_PAIR_BF16;
+};
+template <>
+struct SplitFmt<true> {
+    typedef _Float16 elem;
+    typedef f16x4_t x4;
+    typedef f16x8_t x8;
+    static constexpr float act_scale = F16_ACT_SCALE, act_inv = F16_ACT_INV;
+    static constexpr int fmt = VRD_PAIR_F16;
+};
+typedef __attribute__((ext_vector_type(16))) float mfma_acc32_t;
+typedef __attribute__((ext_vector_type(4))) float mfma_acc16_t;
+__device__ __forceinline__ mfma_acc32_t mfma32(bf16x8_t a, bf16x8_t b, mfma_acc32_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ mfma_acc32_t mfma32(f16x8_t a, f16x8_t b, mfma_acc32_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ mfma_acc16_t mfma16(bf16x8_t a, bf16x8_t b, mfma_acc16_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ mfma_acc16_t mfma16(f16x8_t a, f16x8_t b, mfma_acc16_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// hi / lo planes of N values in format F16 (the f16 format scales by 2^VRD_F16_ACT_EXP first)
+template <bool F16, int N, typename V>
+__device__ __forceinline__ void split_n(const float (&x)[N], V& h, V& l) {
+    typedef typename SplitFmt<F16>::elem E;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float y = F16 ? x[j] * F16_ACT_SCALE : x[j];
+        h[j] = (E)y;
+        l[j] = (E)(y - (float)h[j]);
+    }
+}
+
+// 16-bit index of the hi half of channel c inside a pair row (the lo half is 32 further)
 __device__ __forceinline__ int pair_index(int c) { return ((c >> 5) << 6) + (c & 31); }
 
-__device__ __forceinline__ void store_pair4(float* row, int c, int /*W*/, float4 v) {      // c % 4 == 0
+// fmt: VRD_PAIR_BF16 or VRD_PAIR_F16 (wave-uniform)
+__device__ __forceinline__ void store_pair4(float* row, int c, int /*W*/, float4 v, int fmt) {      // c % 4 == 0
     const float x[4] = {v.x, v.y, v.z, v.w};
-    bf16x4_t h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = (__bf16)x[j];
-        l[j] = (__bf16)(x[j] - (float)h[j]);
+    char* r = reinterpret_cast<char*>(row) + pair_index(c) * 2;
+    if (fmt == VRD_PAIR_F16) {
+        f16x4_t h, l;
+        split_n<true>(x, h, l);
+        *reinterpret_cast<f16x4_t*>(r) = h;
+        *reinterpret_cast<f16x4_t*>(r + 64) = l;
+    } else {
+        bf16x4_t h, l;
+        split_n<false>(x, h, l);
+        *reinterpret_cast<bf16x4_t*>(r) = h;
+        *reinterpret_cast<bf16x4_t*>(r + 64) = l;
     }
-    __bf16* r = reinterpret_cast<__bf16*>(row) + pair_index(c);
-    *reinterpret_cast<bf16x4_t*>(r) = h;
-    *reinterpret_cast<bf16x4_t*>(r + 32) = l;
 }
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 // eight consecutive channels c .. c+7 (c % 8 == 0): one 16-byte store per half
-__device__ __forceinline__ void store_pair8(float* row, int c, float4 v0, float4 v1) {
+__device__ __forceinline__ void store_pair8(float* row, int c, float4 v0, float4 v1, int fmt) {
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    bf16x8_t h, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = (__bf16)x[j];
-        l[j] = (__bf16)(x[j] - (float)h[j]);
+    char* r = reinterpret_cast<char*>(row) + pair_index(c) * 2;
+    if (fmt == VRD_PAIR_F16) {
+        f16x8_t h, l;
+        split_n<true>(x, h, l);
+        *reinterpret_cast<f16x8_t*>(r) = h;
+        *reinterpret_cast<f16x8_t*>(r + 64) = l;
+    } else {
+        bf16x8_t h, l;
+        split_n<false>(x, h, l);
+        *reinterpret_cast<bf16x8_t*>(r) = h;
+        *reinterpret_cast<bf16x8_t*>(r + 64) = l;
     }
-    __bf16* r = reinterpret_cast<__bf16*>(row) + pair_index(c);
-    *reinterpret_cast<bf16x8_t*>(r) = h;
-    *reinterpret_cast<bf16x8_t*>(r + 32) = l;
 }
 
-__device__ __forceinline__ void store_pair1(float* row, int c, int /*W*/, float x) {
-    __bf16* r = reinterpret_cast<__bf16*>(row) + pair_index(c);
-    const __bf16 h = (__bf16)x;
-    r[0] = h;
-    r[32] = (__bf16)(x - (float)h);
+__device__ __forceinline__ void store_pair1(float* row, int c, int /*W*/, float x, int fmt) {
+    char* r = reinterpret_cast<char*>(row) + pair_index(c) * 2;
+    if (fmt == VRD_PAIR_F16) {
+        const float y = x * F16_ACT_SCALE;
+        const _Float16 h = (_Float16)y;
+        *reinterpret_cast<_Float16*>(r) = h;
+        *reinterpret_cast<_Float16*>(r + 64) = (_Float16)(y - (float)h);
+    } else {
+        const __bf16 h = (__bf16)x;
+        *reinterpret_cast<__bf16*>(r) = h;
+        *reinterpret_cast<__bf16*>(r + 64) = (__bf16)(x - (float)h);
+    }
 }
 
 // Branch-free, single-path erf (the library erff branches on |z| < 1 per lane, and both sides run under exec masks in

@@ -250,6 +250,11 @@ int validate_gemm_args(const vrd_gemm_args* a) {
     VRD_CHECK_ARG(a->a_pair_width == 0 || (a->W_split && a->Cin % 32 == 0 && a->lda % 32 == 0 &&
                                            aligned16(a->A) && aligned16(a->W_split)),
                   "vrd_gemm: pair-row A needs W_split, Cin %% 32 == 0 and rows that start on a 128-byte block");
+    VRD_CHECK_ARG(a->split_fmt == 0 || a->split_fmt == VRD_PAIR_BF16 || a->split_fmt == VRD_PAIR_F16, "vrd_gemm: bad split_fmt %d", a->split_fmt);
+    VRD_CHECK_ARG(a->split_fmt != VRD_PAIR_F16 || !a->W_split || a->w_scale, "vrd_gemm: a VRD_PAIR_F16 W_split needs w_scale");
+    VRD_CHECK_ARG(a->c_pair == VRD_PAIR_NONE || a->c_pair == VRD_PAIR_BF16 || a->c_pair == VRD_PAIR_F16, "vrd_gemm: bad c_pair %d", a->c_pair);
+    VRD_CHECK_ARG(!a->c_pair || !a->W_split || a->c_pair == (a->split_fmt ? a->split_fmt : (int)VRD_PAIR_BF16),
+                  "vrd_gemm: pair output (format %d) of a split-precision GEMM must be in its operand format (%d)", a->c_pair, a->split_fmt);
     VRD_CHECK_ARG(!a->row_blocks || (a->row_blocks_active && a->M % 32 == 0 && a->row_block_seg_len >= 8 &&
                                      a->row_block_seg_len % 8 == 0),
                   "vrd_gemm: a row-block list needs its active counts, M %% 32 == 0 and a segment length that is a multiple of 8 (M = %lld, seg_len %d)",
@@ -309,7 +314,7 @@ extern "C" int vrd_gemm_batch(const vrd_gemm_args* a, int count, void* stream) {
                x.res_masked == y.res_masked && x.res2 == y.res2 && x.ldres2 == y.ldres2 && x.a_pair_width == y.a_pair_width &&
                x.c_pair == y.c_pair && x.row_blocks == y.row_blocks && x.row_blocks_active == y.row_blocks_active &&
                x.row_block_seg_len == y.row_block_seg_len && (x.bias != nullptr) == (y.bias != nullptr) &&
-               (x.W_split != nullptr) == (y.W_split != nullptr);
+               (x.W_split != nullptr) == (y.W_split != nullptr) && x.split_fmt == y.split_fmt;
     }
     static const int batch_env = [] { const char* e = getenv("VRD_GEMM_BATCH"); return e ? atoi(e) : 1; }();
     if (same && batch_env) {

@@ -1,4 +1,4 @@
-// Epilogue shared by the f32 and the split-bf16 GEMM kernels: both leave a 64 x 64 sub-tile per
+// Epilogue shared by the f32 and the split-precision GEMM kernels: both leave a 64 x 64 sub-tile per
 // wave as 2 x 2 MFMA accumulators of 32 x 32, whose element e of lane (li = lane & 31, lh = lane >> 5)
 // is C[row (e&3) + 8*(e>>2) + 4*lh][col li].
 #pragma once
@@ -21,9 +21,15 @@ __device__ __forceinline__ float epilogue_value(const vrd_gemm_args& p, float v,
 // before its main loop so that their latency is not paid, exposed, by the tile's epilogue.
 struct EpiCols {
     float bias[4], scale[4];
+    float alpha;        // accumulator factor: 1, or (VRD_PAIR_F16) the power of two that undoes the operand scaling
 };
+// the factor on the accumulators of a split-precision GEMM (wave-uniform; a scalar load)
+__device__ __forceinline__ float acc_alpha(const vrd_gemm_args& p) {
+    return (p.split_fmt == VRD_PAIR_F16 && p.w_scale) ? *p.w_scale : 1.0f;
+}
 __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw, int lane) {
     EpiCols c;
+    c.alpha = acc_alpha(p);
     const int n = nw + (lane & 15) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) c.bias[j] = 0.f, c.scale[j] = 1.f;
@@ -106,7 +112,9 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 t = *reinterpret_cast<const float4*>(stg + (srow + 4 * j) * STG_PITCH + c4);
-            v[j][0] = t.x + cols.bias[0], v[j][1] = t.y + cols.bias[1], v[j][2] = t.z + cols.bias[2], v[j][3] = t.w + cols.bias[3];
+            // (alpha = 1 outside the f16 format: fmaf(t, 1, b) is t + b to the last bit)
+            v[j][0] = fmaf(t.x, cols.alpha, cols.bias[0]), v[j][1] = fmaf(t.y, cols.alpha, cols.bias[1]);
+            v[j][2] = fmaf(t.z, cols.alpha, cols.bias[2]), v[j][3] = fmaf(t.w, cols.alpha, cols.bias[3]);
         }
         if (ACT == VRD_ACT_GELU) {
 #pragma unroll
@@ -148,17 +156,24 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
             }
         }
         if (pair) {
+            if (p.c_pair == VRD_PAIR_F16) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                char* const rowp = c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0);
-                bf16x4_t h, l;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    h[c] = (__bf16)v[j][c];
-                    l[c] = (__bf16)(v[j][c] - (float)h[c]);
+                for (int j = 0; j < 4; ++j) {
+                    char* const rowp = c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0);
+                    f16x4_t h, l;
+                    split_n<true>(v[j], h, l);
+                    *reinterpret_cast<f16x4_t*>(rowp) = h;
+                    *reinterpret_cast<f16x4_t*>(rowp + 64) = l;
                 }
-                *reinterpret_cast<bf16x4_t*>(rowp) = h;
-                *reinterpret_cast<bf16x4_t*>(rowp + 64) = l;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    char* const rowp = c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0);
+                    bf16x4_t h, l;
+                    split_n<false>(v[j], h, l);
+                    *reinterpret_cast<bf16x4_t*>(rowp) = h;
+                    *reinterpret_cast<bf16x4_t*>(rowp + 64) = l;
+                }
             }
         } else {
 #pragma unroll
@@ -255,6 +270,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
         const int c4 = (lane & 15) * 4, rb0 = lane >> 4;
         const int n = nw + c4;
         const bool nfull = n + 3 < p.N;
+        const float alpha = acc_alpha(p);
         float bias[4] = {0.f, 0.f, 0.f, 0.f}, scale[4] = {1.f, 1.f, 1.f, 1.f};
         if (nfull && ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.scale)) & 15) == 0) {
             if (p.bias) {
@@ -364,7 +380,8 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 t = *reinterpret_cast<const float4*>(stg + (slab_row0 + rb0 + h * 16 + 4 * j) * STG_PITCH + c4);
-                v[j][0] = t.x + bias[0], v[j][1] = t.y + bias[1], v[j][2] = t.z + bias[2], v[j][3] = t.w + bias[3];
+                v[j][0] = fmaf(t.x, alpha, bias[0]), v[j][1] = fmaf(t.y, alpha, bias[1]);
+                v[j][2] = fmaf(t.z, alpha, bias[2]), v[j][3] = fmaf(t.w, alpha, bias[3]);
             }
             // activation (one wave-uniform choice per pass), then mask * scale + residuals
             if (p.act == VRD_ACT_GELU) {
@@ -392,7 +409,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
                 if (m >= p.M || n >= p.N) continue;
                 float* crow = p.C + m * p.ldc + n;
                 if (p.c_pair) {          // pair rows of width N (host checks N % 8 == 0, so a float4 group is whole)
-                    store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
+                    store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]), p.c_pair);
                 } else if (nfull) {
                     *reinterpret_cast<float4*>(crow) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 } else {
@@ -406,6 +423,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
         return;
     }
     // fallback straight from the accumulator layout (rows that are not 16-byte aligned, e.g. ldc = 133)
+    const float alpha = acc_alpha(p);
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) {
         const int n = nw + nj * 32 + li;
@@ -421,8 +439,8 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
                 const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
                 const float r1 = p.res ? p.res[m * p.ldres + n] : 0.f;
                 const float r2 = p.res2 ? p.res2[m * p.ldres2 + n] : 0.f;
-                const float v = epilogue_value(p, acc[mi][nj][e] + bias, mk, scale, r1, p.res_masked ? mk : 1.f, r2);
-                if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v);
+                const float v = epilogue_value(p, fmaf(acc[mi][nj][e], alpha, bias), mk, scale, r1, p.res_masked ? mk : 1.f, r2);
+                if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v, p.c_pair);
                 else p.C[m * p.ldc + n] = v;
             }
         }
@@ -437,6 +455,7 @@ __device__ __forceinline__ void gemm_epilogue_tile32(const vrd_gemm_args& p, con
     if (n >= p.N) return;
     const float bias = p.bias ? p.bias[n] : 0.f;
     const float scale = p.scale ? p.scale[n] : 1.f;
+    const float alpha = acc_alpha(p);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int64_t m = mw + (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -444,8 +463,8 @@ __device__ __forceinline__ void gemm_epilogue_tile32(const vrd_gemm_args& p, con
         const float mk = p.row_mask ? (float)p.row_mask[m] : 1.f;
         const float r1 = p.res ? p.res[m * p.ldres + n] : 0.f;
         const float r2 = p.res2 ? p.res2[m * p.ldres2 + n] : 0.f;
-        const float v = epilogue_value(p, acc[e] + bias, mk, scale, r1, p.res_masked ? mk : 1.f, r2);
-        if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v);
+        const float v = epilogue_value(p, fmaf(acc[e], alpha, bias), mk, scale, r1, p.res_masked ? mk : 1.f, r2);
+        if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v, p.c_pair);
         else p.C[m * p.ldc + n] = v;
     }
 }

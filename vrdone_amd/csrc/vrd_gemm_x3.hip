@@ -1,5 +1,5 @@
 // Split-precision variant of the conv GEMM: the same C = epilogue(A' . W^T) as vrd_gemm.hip, with
-// every f32 product replaced by three bf16 MFMA products (v_mfma_f32_32x32x16_bf16, f32 accumulate):
+// every f32 product replaced by three 16-bit MFMA products (v_mfma_f32_32x32x16_bf16 / _f16, f32 accumulate):
 //
 //     x = x_hi + x_lo,  x_hi = bf16(x),  x_lo = bf16(x - x_hi)            (|x - x_hi - x_lo| <= 2^-17 |x|)
 //     a * w  ~=  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi                          (drops a_lo*w_lo ~ 2^-18 |a w|)
@@ -8,7 +8,9 @@
 // per product (relative error ~1e-5 per GEMM) at 3/16 of the f32-MFMA instruction time.  Weights are
 // split once on the host side of the ABI (W_split = [hi | lo], each N x K bf16).  Activations come either
 // as f32 rows, split while being staged into LDS, or (APAIR) as "pair" rows already holding [hi | lo]
-// bf16 planes written by the producing kernel, staged as plain 16-byte copies.
+// 16-bit planes written by the producing kernel, staged as plain 16-byte copies.
+// F16 (VRD_PAIR_F16, the f16x3 mode): the same with f16 planes of power-of-two scaled operands (vrd_common.h): 2^-22 per
+// plane pair, ~2^-22 |a w| dropped; the epilogue multiplies the accumulator by the power of two that undoes the scaling.
 //
 // Tiling: 128 x 128 x 32 per 256-thread workgroup, four waves x (2 x 2) accumulators of 32 x 32, operand
 // tiles [row][k] in bf16 with an 80-byte row pitch (16 consecutive rows hit 16 distinct 16-byte LDS slots,
@@ -23,9 +25,6 @@
 namespace {
 
 using vrd::f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-
 constexpr int BK = 32;
 constexpr int XP = 40;                                   // row pitch in bf16 elements (80 B)
 // SMALL: 64 x 64 tiles, one 32 x 32 accumulator per wave -- for problems whose 128 x 128 tiles would leave most of the
@@ -38,17 +37,20 @@ struct X3Geo {
     static constexpr int WT = BM / 2;                                    // rows / columns of a wave's sub-tile
     static constexpr int NT = WT / 32;                                   // 32 x 32 accumulators per wave and dimension
     static constexpr int TILE = BM * XP;                                 // elements per operand tile
-    static constexpr size_t LDS = 2 * 4 * TILE * sizeof(__bf16);         // 2 buffers x (a_hi, a_lo, w_hi, w_lo): 80 / 40 KiB
+    static constexpr size_t LDS = 2 * 4 * TILE * 2;         // 2 buffers x (a_hi, a_lo, w_hi, w_lo): 80 / 40 KiB
     static constexpr int NPA = BM / 32, NPAP = BM / 64, NPW = BN / 64;   // staging pieces per thread: f32 A, pair A, W
 };
 
-template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false>
+template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     using G = X3Geo<SMALL>;
+    typedef typename vrd::SplitFmt<F16>::elem e16;          // the 16-bit element of this instantiation (bf16 or f16)
+    typedef typename vrd::SplitFmt<F16>::x8 e16x8;
+    typedef typename vrd::SplitFmt<F16>::x4 e16x4;
     constexpr int BM = G::BM, BN = G::BN, TILE = G::TILE, WT = G::WT, NT = G::NT;
     constexpr int NPA = G::NPA, NPAP = G::NPAP, NPW = G::NPW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* const lds = reinterpret_cast<__bf16*>(smem);      // buffer b: lds + b*4*TILE; tiles a_hi, a_lo, w_hi, w_lo
+    e16* const lds = reinterpret_cast<e16*>(smem);      // buffer b: lds + b*4*TILE; tiles a_hi, a_lo, w_hi, w_lo
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
     const int li = lane & 31, lh = lane >> 5;
     const int K = p.Cin * TAPS;          // multiple of 32 (checked on the host)
     const int nkt = K / BK;
-    const __bf16* Wsp = reinterpret_cast<const __bf16*>(p.W_split);      // [N][K/32][32 hi | 32 lo]
+    const e16* Wsp = reinterpret_cast<const e16*>(p.W_split);      // [N][K/32][32 hi | 32 lo]
 
     // A staging: 4 float4 pieces per thread, piece i = (row = (tid + 256 i) / 8, k = 4 * ((tid + 256 i) % 8))
     // W staging: 2 x (hi, lo) 16-byte pieces per thread, piece i = (row = (tid + 256 i) / 4, k = 8 * (f % 4))
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
                         ok = tt >= 0 && tt < p.T;
                     }
                     if (ok) {
-                        const __bf16* row = reinterpret_cast<const __bf16*>(p.A + (r + tap - (TAPS == 3 ? 1 : 0)) * p.lda) +
+                        const e16* row = reinterpret_cast<const e16*>(p.A + (r + tap - (TAPS == 3 ? 1 : 0)) * p.lda) +
                                             vrd::pair_index(ci);
                         h = *reinterpret_cast<const uint4*>(row);
                         l = *reinterpret_cast<const uint4*>(row + 32);
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             const int k = kt * BK + (f & 3) * 8;
             uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
             if (n < p.N) {
-                const __bf16* wrow = Wsp + (int64_t)n * K * 2 + vrd::pair_index(k);
+                const e16* wrow = Wsp + (int64_t)n * K * 2 + vrd::pair_index(k);
                 h = *reinterpret_cast<const uint4*>(wrow);
                 l = *reinterpret_cast<const uint4*>(wrow + 32);
             }
@@ -141,10 +143,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
         }
     };
     auto stage = [&](int buf) {
-        __bf16* a_hi = lds + buf * 4 * TILE;
-        __bf16* a_lo = a_hi + TILE;
-        __bf16* w_hi = a_lo + TILE;
-        __bf16* w_lo = w_hi + TILE;
+        e16* a_hi = lds + buf * 4 * TILE;
+        e16* a_lo = a_hi + TILE;
+        e16* w_hi = a_lo + TILE;
+        e16* w_lo = w_hi + TILE;
         if (APAIR) {
 #pragma unroll
             for (int i = 0; i < NPAP; ++i) {
@@ -159,14 +161,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
             const int f = tid + 256 * i;
             const int off = (f >> 3) * XP + (f & 7) * 4;
             const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-            bf16x4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                h[j] = (__bf16)x[j];
-                l[j] = (__bf16)(x[j] - (float)h[j]);
-            }
-            *reinterpret_cast<bf16x4*>(a_hi + off) = h;
-            *reinterpret_cast<bf16x4*>(a_lo + off) = l;
+            e16x4 h, l;
+            vrd::split_n<F16>(x, h, l);
+            *reinterpret_cast<e16x4*>(a_hi + off) = h;
+            *reinterpret_cast<e16x4*>(a_lo + off) = l;
         }
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
@@ -192,27 +190,27 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int t
     const int arow = (wm * WT + li) * XP + 8 * lh, wrow = (wn * WT + li) * XP + 8 * lh;
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        const __bf16* a_hi = lds + cur * 4 * TILE;
-        const __bf16* a_lo = a_hi + TILE;
-        const __bf16* w_hi = a_lo + TILE;
-        const __bf16* w_lo = w_hi + TILE;
+        const e16* a_hi = lds + cur * 4 * TILE;
+        const e16* a_lo = a_hi + TILE;
+        const e16* w_hi = a_lo + TILE;
+        const e16* w_lo = w_hi + TILE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[NT], al[NT], wh[NT], wl[NT];
+            e16x8 ah[NT], al[NT], wh[NT], wl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                ah[t] = *reinterpret_cast<const bf16x8*>(a_hi + arow + t * 32 * XP + 16 * s);
-                al[t] = *reinterpret_cast<const bf16x8*>(a_lo + arow + t * 32 * XP + 16 * s);
-                wh[t] = *reinterpret_cast<const bf16x8*>(w_hi + wrow + t * 32 * XP + 16 * s);
-                wl[t] = *reinterpret_cast<const bf16x8*>(w_lo + wrow + t * 32 * XP + 16 * s);
+                ah[t] = *reinterpret_cast<const e16x8*>(a_hi + arow + t * 32 * XP + 16 * s);
+                al[t] = *reinterpret_cast<const e16x8*>(a_lo + arow + t * 32 * XP + 16 * s);
+                wh[t] = *reinterpret_cast<const e16x8*>(w_hi + wrow + t * 32 * XP + 16 * s);
+                wl[t] = *reinterpret_cast<const e16x8*>(w_lo + wrow + t * 32 * XP + 16 * s);
             }
 #pragma unroll
             for (int mi = 0; mi < NT; ++mi)
 #pragma unroll
                 for (int nj = 0; nj < NT; ++nj) {
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], wh[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = vrd::mfma32(al[mi], wh[nj], acc[mi][nj]);
+                    acc[mi][nj] = vrd::mfma32(ah[mi], wl[nj], acc[mi][nj]);
+                    acc[mi][nj] = vrd::mfma32(ah[mi], wh[nj], acc[mi][nj]);
                 }
             if (s == 0 && kt + 1 < nkt) {
                 // the registers hold step kt+1 (loaded one iteration ago): split + write them into the
@@ -234,7 +232,7 @@ namespace vrd {
 // called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
 template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false>
 static int launch_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t s) {
-    auto kern = gemm_bf16x3_kernel<TAPS, STAGED, APAIR, SMALL>;
+    auto kern = a.split_fmt == VRD_PAIR_F16 ? gemm_bf16x3_kernel<TAPS, STAGED, APAIR, SMALL, true> : gemm_bf16x3_kernel<TAPS, STAGED, APAIR, SMALL, false>;
     constexpr size_t lds = X3Geo<SMALL>::LDS;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3)")) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);

@@ -23,7 +23,6 @@
 namespace {
 
 using vrd::f32x16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int TM = 256, TN = 256;
@@ -74,13 +73,18 @@ struct BigBatch {
     const uint16_t* W_split[3];
     const float* bias[3];
     float* C[3];
+    const float* w_scale[3];
 };
 
-template <int TAPS, bool M16, bool PERSIST>
+// F16: operands in the scaled-f16 format (VRD_PAIR_F16) on v_mfma_f32_32x32x16_f16 -- the same bytes, instruction count and
+// cycles; the epilogue multiplies the accumulators by *w_scale
+template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, BigBatch bb) {
+    typedef typename vrd::SplitFmt<F16>::x8 e16x8;      // fragment of eight 16-bit elements (bf16 or f16)
     if (blockIdx.y) {                                    // uniform selects, no indexed access to the arguments
         const int z = blockIdx.y;
         p.A = z == 1 ? bb.A[0] : z == 2 ? bb.A[1] : bb.A[2];
+        p.w_scale = z == 1 ? bb.w_scale[0] : z == 2 ? bb.w_scale[1] : bb.w_scale[2];
         p.W_split = z == 1 ? bb.W_split[0] : z == 2 ? bb.W_split[1] : bb.W_split[2];
         p.bias = z == 1 ? bb.bias[0] : z == 2 ? bb.bias[1] : bb.bias[2];
         p.C = z == 1 ? bb.C[0] : z == 2 ? bb.C[1] : bb.C[2];
@@ -242,14 +246,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
     // group over the next eight groups (a DMA issue stalls its wave for 100-200 cycles while MFMAs run; the
     // two waves of a SIMD place theirs half a group apart).
     constexpr int NWF = M16 ? 4 : 2;                 // W fragments (column blocks) held at a time
-    struct AF { bf16x8 hi, lo; };
-    struct WF { bf16x8 hi[NWF], lo[NWF]; };
+    struct AF { e16x8 hi, lo; };
+    struct WF { e16x8 hi[NWF], lo[NWF]; };
     // 32x32x16: (s2, mi) = k16 half, 32-row block.  M16: s2 unused, mi = 16-row block 0..7 (g of the group)
     auto load_a = [&](const char* sa, int s2, int mi) {
         AF f;
         const int off = M16 ? a_base + mi * 16 * ROWB : (a_base ^ (s2 * 32)) + mi * 32 * ROWB;
-        f.hi = *reinterpret_cast<const bf16x8*>(sa + off);
-        f.lo = *reinterpret_cast<const bf16x8*>(sa + (off ^ 64));
+        f.hi = *reinterpret_cast<const e16x8*>(sa + off);
+        f.lo = *reinterpret_cast<const e16x8*>(sa + (off ^ 64));
         return f;
     };
     auto load_w = [&](const char* sw, int s2) {
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
 #pragma unroll
         for (int t = 0; t < NWF; ++t) {
             const int off = M16 ? w_base + t * 16 * ROWB : (w_base ^ (s2 * 32)) + t * 32 * ROWB;
-            f.hi[t] = *reinterpret_cast<const bf16x8*>(sw + off);
-            f.lo[t] = *reinterpret_cast<const bf16x8*>(sw + (off ^ 64));
+            f.hi[t] = *reinterpret_cast<const e16x8*>(sw + off);
+            f.lo[t] = *reinterpret_cast<const e16x8*>(sw + (off ^ 64));
         }
         return f;
     };
@@ -320,14 +324,14 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
                 if (M16) {
 #pragma unroll
                     for (int t = 2 * nj; t < 2 * nj + 2; ++t) {
-                        acc16[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur.lo, w_cur.hi[t], acc16[g][t], 0, 0, 0);
-                        acc16[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur.hi, w_cur.lo[t], acc16[g][t], 0, 0, 0);
-                        acc16[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur.hi, w_cur.hi[t], acc16[g][t], 0, 0, 0);
+                        acc16[g][t] = vrd::mfma16(a_cur.lo, w_cur.hi[t], acc16[g][t]);
+                        acc16[g][t] = vrd::mfma16(a_cur.hi, w_cur.lo[t], acc16[g][t]);
+                        acc16[g][t] = vrd::mfma16(a_cur.hi, w_cur.hi[t], acc16[g][t]);
                     }
                 } else {
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.lo, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.lo[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur.hi, w_cur.hi[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = vrd::mfma32(a_cur.lo, w_cur.hi[nj], acc[mi][nj]);
+                    acc[mi][nj] = vrd::mfma32(a_cur.hi, w_cur.lo[nj], acc[mi][nj]);
+                    acc[mi][nj] = vrd::mfma32(a_cur.hi, w_cur.hi[nj], acc[mi][nj]);
                 }
                 if ((wave >> 2) == nj) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -466,9 +470,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, i
 
 namespace vrd {
 
-template <int TAPS, bool M16, bool PERSIST>
+template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
 static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch& bb = BigBatch{}, int count = 1) {
-    auto kern = gemm_bf16x3_big_kernel<TAPS, M16, PERSIST>;
+    auto kern = gemm_bf16x3_big_kernel<TAPS, M16, PERSIST, F16>;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), BIG_LDS, "vrd_gemm(bf16x3 256x256)")) return rc;
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
     const int nwg = tiles_m * tiles_n;
@@ -484,7 +488,10 @@ int launch_gemm_bf16x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t 
         bb.W_split[i - 1] = a[i].W_split;
         bb.bias[i - 1] = a[i].bias;
         bb.C[i - 1] = a[i].C;
+        bb.w_scale[i - 1] = a[i].w_scale;
     }
+    if (a[0].split_fmt == VRD_PAIR_F16)
+        return a[0].taps == 1 ? launch_big_one<1, false, false, true>(a[0], s, bb, count) : launch_big_one<3, false, false, true>(a[0], s, bb, count);
     return a[0].taps == 1 ? launch_big_one<1, false, false>(a[0], s, bb, count) : launch_big_one<3, false, false>(a[0], s, bb, count);
 }
 
@@ -505,6 +512,8 @@ int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s) {
     static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
     // VRD_BIG_PERSIST=1: one workgroup per CU walking its tiles, the next tile's first stage requested under the epilogue
     static const int persist = [] { const char* e = getenv("VRD_BIG_PERSIST"); return e ? atoi(e) : 0; }();
+    if (a.split_fmt == VRD_PAIR_F16)        // (the two opt-in variants exist for the bf16 format only)
+        return a.taps == 1 ? launch_big_one<1, false, false, true>(a, s) : launch_big_one<3, false, false, true>(a, s);
     if (m16) return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
     if (persist) return a.taps == 1 ? launch_big_one<1, false, true>(a, s) : launch_big_one<3, false, true>(a, s);
     return a.taps == 1 ? launch_big_one<1, false, false>(a, s) : launch_big_one<3, false, false>(a, s);

@@ -90,8 +90,9 @@ __device__ unsigned long long g_lab_phase[16 * 4096];   // [wg][group][5 phase a
 #define LAB_PHASE_FLUSH(grp)
 #endif
 
-template <int TAPS, int DBK, int DBM, int NSTG, bool PP, bool BLK>
+template <int TAPS, int DBK, int DBM, int NSTG, bool PP, bool BLK, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+    typedef typename vrd::SplitFmt<F16>::x8 bf16x8;      // fragment of eight 16-bit elements: bf16, or f16 (VRD_PAIR_F16)
     using G = Geo<DBK, DBM, NSTG, BLK>;
     constexpr int NJ = G::NJ;
     constexpr int ROWB = G::ROWB, A_PLANE = G::A_PLANE, W_PLANE = G::W_PLANE, STAGE = G::STAGE;
@@ -287,9 +288,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 const int s = u / (2 * NJ), mi = (u / NJ) % 2, nj = u % NJ;
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s][mi], wh[s][nj], acc[mi][nj], 0, 0, 0);
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi], wl[s][nj], acc[mi][nj], 0, 0, 0);
-                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s][mi], wh[s][nj], acc[mi][nj], 0, 0, 0);
+                acc[mi][nj] = vrd::mfma32(al[s][mi], wh[s][nj], acc[mi][nj]);
+                acc[mi][nj] = vrd::mfma32(ah[s][mi], wl[s][nj], acc[mi][nj]);
+                acc[mi][nj] = vrd::mfma32(ah[s][mi], wh[s][nj], acc[mi][nj]);
                 if (u % 2 == 0 && u / 2 < H) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (dma) {
@@ -344,9 +345,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int nj = 0; nj < NJ; ++nj) {
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], wh[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wl[nj], acc[mi][nj], 0, 0, 0);
-                    acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], wh[nj], acc[mi][nj], 0, 0, 0);
+                    acc[mi][nj] = vrd::mfma32(al[mi], wh[nj], acc[mi][nj]);
+                    acc[mi][nj] = vrd::mfma32(ah[mi], wl[nj], acc[mi][nj]);
+                    acc[mi][nj] = vrd::mfma32(ah[mi], wh[nj], acc[mi][nj]);
                 }
         }
 #ifdef VRD_LAB_STAMP
@@ -382,9 +383,9 @@ __global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, i
 
 namespace vrd {
 
-template <int TAPS, int DBK, int DBM, int NSTG, bool PP = false, bool BLK = false>
+template <int TAPS, int DBK, int DBM, int NSTG, bool PP = false, bool BLK = false, bool F16 = false>
 static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
-    auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK, DBM, NSTG, PP, BLK>;
+    auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK, DBM, NSTG, PP, BLK, F16>;
     constexpr size_t lds = Geo<DBK, DBM, NSTG, BLK>::LDS;
     static_assert(lds >= 8 * 16384 && lds <= 160 * 1024, "ring must hold the epilogue slabs and fit the CU");
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3 dma)")) return rc;
@@ -432,6 +433,8 @@ int launch_gemm_bf16x3_dma_variant(const vrd_gemm_args& a, hipStream_t s, int va
     if (var == 3) return a.taps == 1 ? launch_dma_one<1, 32, 128, 3, true, true>(a, s) : launch_dma_one<3, 32, 128, 3, true, true>(a, s);
 #endif
     (void)var;
+    if (a.split_fmt == VRD_PAIR_F16)
+        return a.taps == 1 ? launch_dma_one<1, 32, 128, 3, false, true, true>(a, s) : launch_dma_one<3, 32, 128, 3, false, true, true>(a, s);
     return a.taps == 1 ? launch_dma_one<1, 32, 128, 3, false, true>(a, s) : launch_dma_one<3, 32, 128, 3, false, true>(a, s);
 }
 

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict
     for (int t = ty; t < 64; t += 4)
         if (tt + t < T && ct + tx < count) {
             float* row = dst + ((int64_t)b * T + tt + t) * ld_dst;
-            if (pair) vrd::store_pair1(row, ct + tx, count, tile[tx][t]);
+            if (pair) vrd::store_pair1(row, ct + tx, count, tile[tx][t], pair);
             else row[ct + tx] = tile[tx][t];
         }
 }
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void bct_to_btc_vec_kernel(const float* __rest
         if (tt + t >= T || ct + 4 * cg >= count) continue;
         const float4 v = make_float4(tile[4 * cg][t], tile[4 * cg + 1][t], tile[4 * cg + 2][t], tile[4 * cg + 3][t]);
         float* row = dst + ((int64_t)b * T + tt + t) * ld_dst;
-        if (pair) vrd::store_pair4(row, ct + 4 * cg, count, v);
+        if (pair) vrd::store_pair4(row, ct + 4 * cg, count, v, pair);
         else st4(row + ct + 4 * cg, v);
     }
 }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict
 __device__ __forceinline__ void pack_segment(const float* src, bool live, int lane, int width, float* dst, int pair) {
     for (int c = lane; c < width; c += 64) {
         const float v = live ? src[c] : 0.f;
-        if (pair) vrd::store_pair1(dst, c, width, v);
+        if (pair) vrd::store_pair1(dst, c, width, v, pair);
         else dst[c] = v;
     }
 }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        if (pair) vrd::store_pair4(y + row * ldy, i * 256 + lane * 4, 256 * NV, v[i]);
+        if (pair) vrd::store_pair4(y + row * ldy, i * 256 + lane * 4, 256 * NV, v[i], pair);
         else st4(y + row * ldy + i * 256 + lane * 4, v[i]);
     }
 }
@@ -398,12 +398,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 for (int to = to0; to < to1; ++to) {
                     const int64_t row = (int64_t)b * Tout + to;
                     if (WIDE && p.out_pair[o]) {
-                        vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, val[0], val[NV - 1]);
+                        vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, val[0], val[NV - 1], p.out_pair[o]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < NV; ++i) {
                             const int c = lane_chan<NV, WIDE>(i, lane);
-                            if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, val[i]);
+                            if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, val[i], p.out_pair[o]);
                             else st4(p.y[o] + row * p.ldy[o] + c, val[i]);
                         }
                     }
@@ -471,12 +471,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 }
             }
             if (WIDE && p.out_pair[o]) {
-                vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, acc[0], acc[NV - 1]);
+                vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, acc[0], acc[NV - 1], p.out_pair[o]);
             } else {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     const int c = lane_chan<NV, WIDE>(i, lane);
-                    if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, acc[i]);
+                    if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, acc[i], p.out_pair[o]);
                     else st4(p.y[o] + row * p.ldy[o] + c, acc[i]);
                 }
             }

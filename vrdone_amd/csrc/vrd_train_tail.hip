@@ -110,21 +110,75 @@ int vrd_ema_update(float* const* ema, const float* const* model, const int64_t* 
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------------------------
-// f32 weight (any 3-stride view) -> blocked [hi | lo] bf16 operand of the split-precision GEMMs; thread = one element
+// f32 weight (any 3-stride view) -> blocked [hi | lo] 16-bit operand of the split-precision GEMMs; thread = one element
+// VRD_PAIR_F16: the weight is multiplied by a per-tensor power of two first (vrd_split_weight in the header): a pass for
+// max |w| (atomic maximum of the f32 bit patterns: non-negative floats order like their bits), then the split, which reads
+// the exponent from it.  scale[2] holds the maximum's bits between the two.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
+// e_w from the bits of max |w|: max * 2^e_w in [2^14, 2^15); clamped so that 2^e_w and 2^-(e_w + VRD_F16_ACT_EXP) are normal floats
+__device__ __forceinline__ int weight_exp(unsigned max_bits) {
+    const int E = (int)((max_bits >> 23) & 0xffu);          // max in [2^(E-127), 2^(E-126))
+    if (E == 0 || E == 255) return 0;                      // zero / subnormal / non-finite maximum: leave the weight alone
+    const int e = 141 - E;
+    return e > 100 ? 100 : e;
+}
+__device__ __forceinline__ float pow2i(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+template <bool F16>
+__device__ __forceinline__ void put_split(void* out, int64_t at, float w, float wmul) {
+    typedef typename vrd::SplitFmt<F16>::elem E;
+    E* o = reinterpret_cast<E*>(out) + at;
+    const float y = F16 ? w * wmul : w;
+    const E hi = (E)y;
+    o[0] = hi;
+    o[32] = (E)(y - (float)hi);
+}
+
+__global__ __launch_bounds__(256) void split_clear_kernel(const vrd_split_job* __restrict__ jobs, float* one, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float* sc = jobs ? jobs[i].scale : one;
+    if (sc) reinterpret_cast<unsigned*>(sc)[2] = 0u;
+}
+
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ src, int R, int Q, int taps, int64_t sr, int64_t st,
+                                                            int64_t sq, float* __restrict__ scale) {
+    const int K = taps * Q;
+    const int64_t n = (int64_t)R * K;
+    unsigned m = 0u;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int r = (int)(idx / K), c = (int)(idx - (int64_t)r * K);
+        const int tap = c / Q, q = c - tap * Q;
+        const unsigned b = __builtin_bit_cast(unsigned, src[r * sr + tap * st + q * sq]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned*>(scale) + 2, m);
+}
+
+template <bool F16>
 __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ src, int R, int Q, int taps, int64_t sr, int64_t st,
-                                                           int64_t sq, __bf16* __restrict__ out) {
+                                                           int64_t sq, void* __restrict__ out, float* __restrict__ scale) {
     const int K = taps * Q;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float wmul = 1.f;
+    if (F16) {
+        const int ew = weight_exp(reinterpret_cast<const unsigned*>(scale)[2]);
+        wmul = pow2i(ew);
+        if (idx == 0) {
+            scale[0] = pow2i(-(ew + vrd::F16_ACT_EXP));
+            scale[1] = wmul;
+        }
+    }
     if (idx >= (int64_t)R * K) return;
     const int r = (int)(idx / K), c = (int)(idx - (int64_t)r * K);
     const int tap = c / Q, q = c - tap * Q;
-    const float w = src[r * sr + tap * st + q * sq];
-    const __bf16 hi = (__bf16)w;
-    __bf16* o = out + ((int64_t)r * K + (c >> 5) * 32) * 2 + (c & 31);      // block (r, c / 32): [32 hi | 32 lo]
-    o[0] = hi;
-    o[32] = (__bf16)(w - (float)hi);
+    put_split<F16>(out, ((int64_t)r * K + (c >> 5) * 32) * 2 + (c & 31), src[r * sr + tap * st + q * sq], wmul);   // block (r, c / 32): [32 hi | 32 lo]
 }
 }  // namespace
 
@@ -135,53 +189,92 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
 // are Cin * k floats apart in the parameter, consecutive rows k apart) and turned in LDS, so reads and writes both coalesce
 // (thread-per-element reads of the transposed form ran at 0.9 TB/s: 0.43 ms per step).
 namespace {
+// MODE 0: split (either format, per job); MODE 1: max |w| of the VRD_PAIR_F16 jobs' tiles
+template <int MODE>
 __global__ __launch_bounds__(256) void split_weights_kernel(const vrd_split_job* __restrict__ jobs, const int32_t* __restrict__ chunk_job,
                                                             const int32_t* __restrict__ chunk_index) {
     __shared__ float tile[32][33];
     const vrd_split_job j = jobs[chunk_job[blockIdx.x]];
+    const bool f16 = j.fmt == VRD_PAIR_F16;            // block-uniform
+    if (MODE == 1 && !f16) return;
     const int K = j.taps * j.Q, kb = K >> 5;
     const int r0 = (chunk_index[blockIdx.x] / kb) * 32, c0 = (chunk_index[blockIdx.x] % kb) * 32;
     const int64_t asr = j.sr < 0 ? -j.sr : j.sr, asq = j.sq < 0 ? -j.sq : j.sq;
     const bool rows_fastest = asr < asq;                 // block-uniform
+    unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = threadIdx.x + 256 * i;
         const int rr = rows_fastest ? (e & 31) : (e >> 5), cc = rows_fastest ? (e >> 5) : (e & 31);
         const int r = r0 + rr, c = c0 + cc;
         const int tap = c / j.Q, q = c - tap * j.Q;
-        tile[rr][cc] = r < j.R ? j.src[r * j.sr + tap * j.st + q * j.sq] : 0.f;
+        const float w = r < j.R ? j.src[r * j.sr + tap * j.st + q * j.sq] : 0.f;
+        if (MODE == 1) {
+            const unsigned b = __builtin_bit_cast(unsigned, w) & 0x7fffffffu;
+            m = b > m ? b : m;
+        } else {
+            tile[rr][cc] = w;
+        }
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+            m = t > m ? t : m;
+        }
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned*>(j.scale) + 2, m);
+        return;
     }
     __syncthreads();
-    __bf16* const out = reinterpret_cast<__bf16*>(j.out);
+    float wmul = 1.f;
+    if (f16) {
+        const int ew = weight_exp(reinterpret_cast<const unsigned*>(j.scale)[2]);
+        wmul = pow2i(ew);
+        if (chunk_index[blockIdx.x] == 0 && threadIdx.x == 0) {
+            j.scale[0] = pow2i(-(ew + vrd::F16_ACT_EXP));
+            j.scale[1] = wmul;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = threadIdx.x + 256 * i;
         const int rr = e >> 5, cc = e & 31;
         if (r0 + rr >= j.R) continue;
-        const float w = tile[rr][cc];
-        const __bf16 hi = (__bf16)w;
-        __bf16* o = out + ((int64_t)(r0 + rr) * K + c0) * 2 + cc;        // block (r, c0 / 32): [32 hi | 32 lo]
-        o[0] = hi;
-        o[32] = (__bf16)(w - (float)hi);
+        const int64_t at = ((int64_t)(r0 + rr) * K + c0) * 2 + cc;        // block (r, c0 / 32): [32 hi | 32 lo]
+        if (f16) put_split<true>(j.out, at, tile[rr][cc], wmul);
+        else put_split<false>(j.out, at, tile[rr][cc], 1.f);
     }
 }
 }  // namespace
 
-extern "C" int vrd_split_weights(const vrd_split_job* jobs, const int32_t* chunk_job, const int32_t* chunk_index, int n_chunks, void* stream) {
-    VRD_CHECK_ARG(jobs && chunk_job && chunk_index && n_chunks > 0, "vrd_split_weights: bad arguments");
+extern "C" int vrd_split_weights(const vrd_split_job* jobs, int n_jobs, const int32_t* chunk_job, const int32_t* chunk_index, int n_chunks,
+                                 void* stream) {
+    VRD_CHECK_ARG(jobs && n_jobs > 0 && chunk_job && chunk_index && n_chunks > 0, "vrd_split_weights: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(n_chunks), dim3(256), 0, s, jobs, chunk_job, chunk_index);
+    // (jobs is a device table: whether any job is VRD_PAIR_F16 is not known here; the two extra launches return at once otherwise)
+    hipLaunchKernelGGL(split_clear_kernel, dim3((n_jobs + 255) / 256), dim3(256), 0, s, jobs, (float*)nullptr, n_jobs);
+    hipLaunchKernelGGL(split_weights_kernel<1>, dim3(n_chunks), dim3(256), 0, s, jobs, chunk_job, chunk_index);
+    hipLaunchKernelGGL(split_weights_kernel<0>, dim3(n_chunks), dim3(256), 0, s, jobs, chunk_job, chunk_index);
     VRD_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, void* stream) {
+extern "C" int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, int fmt,
+                                float* scale, void* stream) {
     VRD_CHECK_ARG(src && out, "vrd_split_weight: null pointer");
     VRD_CHECK_ARG(R > 0 && Q > 0 && taps > 0 && ((int64_t)taps * Q) % 32 == 0, "vrd_split_weight: K = taps * Q must be a positive multiple of 32");
+    VRD_CHECK_ARG(fmt == VRD_PAIR_BF16 || (fmt == VRD_PAIR_F16 && scale), "vrd_split_weight: fmt must be VRD_PAIR_BF16 or VRD_PAIR_F16 (with scale)");
     const int64_t n = (int64_t)R * taps * Q;
     VRD_CHECK_ARG((n + 255) / 256 < ((int64_t)1 << 31), "vrd_split_weight: too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, R, Q, taps, sr, st, sq, reinterpret_cast<__bf16*>(out));
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (fmt == VRD_PAIR_F16) {
+        hipLaunchKernelGGL(split_clear_kernel, dim3(1), dim3(256), 0, s, (const vrd_split_job*)nullptr, scale, 1);
+        hipLaunchKernelGGL(weight_absmax_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(256), 0, s, src, R, Q, taps, sr, st, sq, scale);
+        hipLaunchKernelGGL(split_weight_kernel<true>, dim3(blocks), dim3(256), 0, s, src, R, Q, taps, sr, st, sq, (void*)out, scale);
+    } else {
+        hipLaunchKernelGGL(split_weight_kernel<false>, dim3(blocks), dim3(256), 0, s, src, R, Q, taps, sr, st, sq, (void*)out, (float*)nullptr);
+    }
     VRD_LAUNCH_CHECK();
     return 0;
 }

@@ -573,6 +573,16 @@ class MaskVRD(nn.Module):
         cand = self.pair_candidates(feats, lens, mine, t_pad, k, source=source)
         if world > 1:
             cand = parallel.gather_candidates(cand, P, shard[0])       # (P, Q, 2k + 2) in `order`
+        ops = _ops()
+        if ops.get_precision() == "f16x3" and not bool(torch.isfinite(cand[:, :, :k]).all()):
+            # the f16x3 mode's operand planes hold |x| < 4094 (vrd_common.h): a larger activation comes out as NaN, never as a
+            # wrong number.  The reference computes such a video in float32: so does the repeat.  (After the exchange: every
+            # rank of a sharded run sees the same candidates and takes the same branch.)
+            import warnings
+            warnings.warn("vrdone_amd: non-finite scores in the f16x3 precision mode (an activation beyond the f16 operand range, "
+                          "or non-finite inputs): repeating this video in the f32 mode")
+            with ops.use_precision("f32"):
+                return self.forward_test(input_data)
         cand = cand[unsort]                             # back to the dataloader's pair order
         ints = cand.view(torch.int32)
         top_score = cand[:, :, :k].contiguous()

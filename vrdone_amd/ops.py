@@ -60,28 +60,31 @@ def _param_ptr(t, like, what="parameter"):
 
 
 class Pair:
-    """A channels-last tensor stored in the GEMM-operand "pair" format of the bf16x3 mode: the 4*C bytes of a
-    C-channel row (C % 32 == 0) hold, per block of 32 channels, [32 x bf16 hi | 32 x bf16 lo] (hi = bf16(x),
-    lo = bf16(x - hi)) instead of 32 floats.  `t` is the f32-typed buffer (same shape / strides as the f32
-    tensor would have); `width` records the width of the producer's slab (the format itself does not depend on
-    it).  Only conv_gemm() and attention() consume a Pair."""
-    __slots__ = ("t", "width")
+    """A channels-last tensor stored in the GEMM-operand "pair" format of the split-precision modes: the 4*C bytes of a
+    C-channel row (C % 32 == 0) hold, per block of 32 channels, [32 x 16-bit hi | 32 x 16-bit lo] instead of 32 floats --
+    bf16 planes of x (fmt PAIR_BF16, the bf16x3 mode) or f16 planes of x * 2^F16_ACT_EXP (PAIR_F16, the f16x3 mode).  `t` is
+    the f32-typed buffer (same shape / strides as the f32 tensor would have); `width` records the width of the producer's
+    slab (the format itself does not depend on it).  Only conv_gemm() and attention() consume a Pair."""
+    __slots__ = ("t", "width", "fmt")
 
-    def __init__(self, t, width):
-        self.t, self.width = t, width
+    def __init__(self, t, width, fmt=None):
+        self.t, self.width, self.fmt = t, width, pair_fmt() if fmt is None else fmt
+        assert self.fmt in (_hip.PAIR_BF16, _hip.PAIR_F16)
 
     @property
     def shape(self):
         return self.t.shape
 
     def __getitem__(self, idx):      # batch slicing (rows) keeps the format
-        return Pair(self.t[idx], self.width)
+        return Pair(self.t[idx], self.width, self.fmt)
 
     def float(self):
         """Decode to f32 (hi + lo); for tests."""
-        raw = self.t.contiguous().view(torch.bfloat16)                 # (..., 2*C)
+        f16 = self.fmt == _hip.PAIR_F16
+        raw = self.t.contiguous().view(torch.float16 if f16 else torch.bfloat16)                 # (..., 2*C)
         blocks = raw.reshape(*raw.shape[:-1], -1, 2, 32).float()
-        return (blocks[..., 0, :] + blocks[..., 1, :]).reshape(*self.t.shape)
+        val = (blocks[..., 0, :] + blocks[..., 1, :]).reshape(*self.t.shape)
+        return val * 2.0 ** -_hip.F16_ACT_EXP if f16 else val
 
 
 def flash_pair_ok(n_head, channels, Tq):
@@ -90,9 +93,25 @@ def flash_pair_ok(n_head, channels, Tq):
 
 
 def pair_mode():
-    """True when producers should emit pair rows for GEMM-only consumers: bf16x3 precision and autograd not recording
+    """True when producers should emit pair rows for GEMM-only consumers: a split-precision mode and autograd not recording
     (a differentiable forward keeps every activation as plain f32 rows, see vrdone_amd/autograd.py)."""
-    return _precision == "bf16x3" and not torch.is_grad_enabled()
+    return _precision in ("bf16x3", "f16x3") and not torch.is_grad_enabled()
+
+
+def pair_fmt():
+    """enum vrd_pair_format of the current precision mode's pair rows and split weights (0 in the f32 mode)."""
+    return {"bf16x3": _hip.PAIR_BF16, "f16x3": _hip.PAIR_F16}.get(_precision, _hip.PAIR_NONE)
+
+
+def split_backward():
+    """True when the backward GEMMs (input and weight gradients) run as split-precision products.  Always the bf16 split --
+    gradients have no fixed scale, bf16 has f32's range -- so the f16x3 mode's backward is the bf16x3 mode's."""
+    return _precision in ("bf16x3", "f16x3")
+
+
+def _fmt(pair):
+    """an op's `pair=` flag -> the out_pair argument of its C entry point"""
+    return pair_fmt() if pair else _hip.PAIR_NONE
 
 
 def recording(*tensors):
@@ -168,14 +187,21 @@ def packed_conv_weight(w):
 
 
 # GEMM precision mode.
-#   "bf16x3" (default): every f32 product a*w is formed as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16
+#   "bf16x3": every f32 product a*w is formed as a_hi*w_hi + a_hi*w_lo + a_lo*w_hi on the bf16
 #            MFMA with f32 accumulation (x = x_hi + x_lo split in bf16): ~17 significand bits per product.
 #            Measured end to end: logits within 7e-5 of the reference (stated tolerance 1e-3).
+#   "f16x3": the same three products on the f16 MFMA, operands scaled by exact powers of two (activations 2^4, weights per
+#            tensor): ~22 significand bits per product.  The reference-grade mode: end to end it is as far from a float64
+#            run of the reference as the reference's own float32 run is (x1.0-1.3, tests/golden/mask_vrd_f64.npz), at the
+#            speed of bf16x3.  Forward products only: the backward GEMMs of this mode are bf16x3's (gradients have no
+#            fixed scale to split an f16 pair at).  The default.
+#            Activations beyond +-4094 overflow the f16 planes and come out as NaN (never as a wrong finite number);
+#            MaskVRD repeats such a batch in the f32 mode.
 #   "f32":   exact f32 MFMA products (bit-level fmaf chains); logits within 9e-6; ~2.8x slower end to end (bench.py).
 # Select with set_precision() or the VRDONE_PRECISION environment variable.  Everything outside the
-# conv GEMMs (LayerNorm, depthwise convs, softmax, attention) is f32 in both modes.
-_PRECISIONS = ("f32", "bf16x3")
-_precision = os.environ.get("VRDONE_PRECISION", "bf16x3")
+# conv GEMMs and the global attention (LayerNorm, depthwise convs, softmax, banded attention) is f32 in all modes.
+_PRECISIONS = ("f32", "bf16x3", "f16x3")
+_precision = os.environ.get("VRDONE_PRECISION", "f16x3")
 if _precision not in _PRECISIONS:
     raise ValueError(f"VRDONE_PRECISION must be one of {_PRECISIONS}, got {_precision!r}")
 
@@ -191,26 +217,68 @@ def get_precision():
     return _precision
 
 
-def _split_weight(w, offset, R, Q, taps, sr, st, sq):
+class use_precision:
+    """`with ops.use_precision("f32"):` -- the mode inside the block, the previous one after it."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_precision()
+        set_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_precision(self.prev)
+        return False
+
+
+class SplitWeight:
+    """A weight's split-precision operand: `t` the (R, K/32, 2, 32) 16-bit planes, `fmt` their element format and (PAIR_F16)
+    `scale` the 4 device floats vrd_split_weight wrote: [0] = 2^-(e_w + F16_ACT_EXP), the GEMM's accumulator factor."""
+    __slots__ = ("t", "fmt", "scale")
+
+    def __init__(self, t, fmt, scale=None):
+        self.t, self.fmt, self.scale = t, fmt, scale
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def set_args(self, a):
+        """W_split, split_fmt and w_scale of a GemmArgs"""
+        a.W_split, a.split_fmt = self.t.data_ptr(), self.fmt
+        a.w_scale = self.scale.data_ptr() if self.scale is not None else None
+
+
+def _split_weight(w, offset, R, Q, taps, sr, st, sq, fmt=None):
     assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and (taps * Q) % 32 == 0
-    out = torch.empty(R, taps * Q // 32, 2, 32, device=w.device, dtype=torch.bfloat16)
-    _hip.check(lib.vrd_split_weight(w.data_ptr() + 4 * offset, R, Q, taps, sr, st, sq, out.data_ptr(), _stream()), "vrd_split_weight")
-    return out
+    fmt = pair_fmt() if fmt is None else fmt
+    f16 = fmt == _hip.PAIR_F16
+    out = torch.empty(R, taps * Q // 32, 2, 32, device=w.device, dtype=torch.float16 if f16 else torch.bfloat16)
+    scale = torch.empty(4, device=w.device, dtype=torch.float32) if f16 else None
+    _hip.check(lib.vrd_split_weight(w.data_ptr() + 4 * offset, R, Q, taps, sr, st, sq, out.data_ptr(), fmt, _ptr(scale), _stream()),
+               "vrd_split_weight")
+    return SplitWeight(out, fmt, scale)
 
 
-def split_conv_weight(w):
-    """(N, K/32, 2, 32) bf16 of the tap-major packed weight (K = Cin*k, K % 32 == 0): per block of 32 K positions
-    [32 x bf16(W) | 32 x bf16(W - bf16(W))] -- the pair-row block format of vrd_common.h, so one 128-byte line
-    holds what a K step needs from a weight row.  One launch (vrd_split_weight) per weight and weight version."""
+def _split_slot(base, fmt=None):
+    """the cache attribute of a weight's split operand: one per element format"""
+    return base + ("_f16" if (pair_fmt() if fmt is None else fmt) == _hip.PAIR_F16 else "")
+
+
+def split_conv_weight(w, fmt=None):
+    """SplitWeight of the tap-major packed weight (K = Cin*k, K % 32 == 0): (N, K/32, 2, 32) 16-bit, per block of 32 K
+    positions [32 x hi | 32 x lo] -- the pair-row block format of vrd_common.h, so one 128-byte line holds what a K step
+    needs from a weight row -- in the current mode's element format.  Built once per weight, weight version and format."""
     N, Cin, k = w.shape
-    return _cached(w, "_vrd_split", lambda: _split_weight(w.detach(), 0, N, Cin, k, Cin * k, 1, k))
+    return _cached(w, _split_slot("_vrd_split", fmt), lambda: _split_weight(w.detach(), 0, N, Cin, k, Cin * k, 1, k, fmt))
 
 
 def split_conv_weight_dgrad(w):
     """The same operand for the input-gradient GEMM of the conv: the (Cin, k*N) matrix [c][tap*N + n] = w[n][c][k-1-tap]
-    (transposed, taps flipped), straight from the parameter."""
+    (transposed, taps flipped), straight from the parameter.  bf16x3 mode only (gradients have no fixed scale)."""
     N, Cin, k = w.shape
-    return _cached(w, "_vrd_split_t", lambda: _split_weight(w.detach(), k - 1, Cin, N, k, k, -1, Cin * k))
+    return _cached(w, "_vrd_split_t", lambda: _split_weight(w.detach(), k - 1, Cin, N, k, k, -1, Cin * k, _hip.PAIR_BF16))
 
 
 # ---- all split operands of a training step in one launch
@@ -243,9 +311,14 @@ def presplit_weights(weights, plans):
     persistent operand buffers); it lives as long as the model and the graphs recorded for it, which read those buffers.
     The job table is built (and uploaded) on the first call for a set of weights -- outside any graph capture: inside one,
     without a table, nothing is done and the per-weight launches run as before."""
-    if _precision != "bf16x3" or not weights or not _presplit_on:
+    if _precision not in ("bf16x3", "f16x3") or not weights or not _presplit_on:
         return
-    key = tuple(w.data_ptr() for w in weights)
+    fmt = pair_fmt()
+    # (the plan is keyed on the weights' addresses, shapes and the element format: another model whose parameters land on
+    # the same addresses with other shapes, or a change of mode, builds its own)
+    key = (fmt,) + tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+    for old in [k for k in plans if k != key]:        # operands of another mode / of parameters that were replaced
+        del plans[old]
     plan = plans.get(key)
     if plan is None:
         if _capturing():
@@ -257,24 +330,29 @@ def presplit_weights(weights, plans):
             N, Cin, k = w.shape
             forms = []
             if (Cin * k) % 32 == 0:
-                forms.append(("_vrd_split", 0, N, Cin, k, Cin * k, 1, k))                       # = split_conv_weight
-            if (N * k) % 32 == 0:
-                forms.append(("_vrd_split_t", k - 1, Cin, N, k, k, -1, Cin * k))                 # = split_conv_weight_dgrad
+                forms.append((_split_slot("_vrd_split"), 0, N, Cin, k, Cin * k, 1, k))           # = split_conv_weight
+            if (N * k) % 32 == 0:       # = split_conv_weight_dgrad: bf16 in either mode (split_backward)
+                forms.append(("_vrd_split_t", k - 1, Cin, N, k, k, -1, Cin * k))
             for slot, offset, R, Q, taps, sr, st, sq in forms:
-                out = torch.empty(R, taps * Q // 32, 2, 32, device=w.device, dtype=torch.bfloat16)
-                jobs.append(_hip.SplitJob(src=w.data_ptr() + 4 * offset, out=out.data_ptr(), R=R, Q=Q, taps=taps, reserved=0, sr=sr, st=st, sq=sq))
+                jf = _hip.PAIR_BF16 if slot == "_vrd_split_t" else fmt
+                jf16 = jf == _hip.PAIR_F16
+                out = torch.empty(R, taps * Q // 32, 2, 32, device=w.device, dtype=torch.float16 if jf16 else torch.bfloat16)
+                scale = torch.empty(4, device=w.device, dtype=torch.float32) if jf16 else None
+                jobs.append(_hip.SplitJob(src=w.data_ptr() + 4 * offset, out=out.data_ptr(), R=R, Q=Q, taps=taps, fmt=jf, sr=sr, st=st,
+                                          sq=sq, scale=_ptr(scale)))
                 n_tiles = -(-R // 32) * (taps * Q // 32)          # 32 x 32 tiles: row block x K block
                 chunk_job.extend([len(jobs) - 1] * n_tiles)
                 chunk_index.extend(range(n_tiles))
-                outs.append((w.data_ptr(), slot, out))
+                outs.append((w.data_ptr(), slot, SplitWeight(out, jf, scale)))
         if not jobs:
             return
         raw = bytes((_hip.SplitJob * len(jobs))(*jobs))
         dev = weights[0].device
         table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-        plan = (table, torch.tensor(chunk_job, dtype=torch.int32, device=dev), torch.tensor(chunk_index, dtype=torch.int32, device=dev), outs)
+        plan = (table, torch.tensor(chunk_job, dtype=torch.int32, device=dev), torch.tensor(chunk_index, dtype=torch.int32, device=dev), outs,
+                len(jobs))
         plans[key] = plan
-    table, cj, ci, outs = plan
+    table, cj, ci, outs, n_jobs = plan
     by_ptr = {w.data_ptr(): w for w in weights}
     if not _capturing():        # nothing moved since the last call (an evaluation of the same weights, a second forward): keep the operands
         def current(ptr, slot):
@@ -282,7 +360,7 @@ def presplit_weights(weights, plans):
             return hit is not None and hit[0] == (ptr, by_ptr[ptr]._version) and hit[1] is not None
         if all(current(ptr, slot) for ptr, slot, _ in outs):
             return
-    _hip.check(lib.vrd_split_weights(table.data_ptr(), cj.data_ptr(), ci.data_ptr(), cj.numel(), _stream()), "vrd_split_weights")
+    _hip.check(lib.vrd_split_weights(table.data_ptr(), n_jobs, cj.data_ptr(), ci.data_ptr(), cj.numel(), _stream()), "vrd_split_weights")
     for ptr, slot, out in outs:
         w = by_ptr[ptr]
         setattr(w, slot, ((ptr, w._version), out, _presplit_scope if _capturing() else None))
@@ -294,8 +372,9 @@ def bct_to_btc(x, c0, count, out, pair=False):
     assert x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
     p, rows, cols, ld = _rows(out)
     assert rows == B * T and cols == count
-    _hip.check(lib.vrd_bct_to_btc(x.data_ptr(), B, Ct, T, c0, count, p, ld, 1 if pair else 0, _stream()), "vrd_bct_to_btc")
-    return Pair(out, count) if pair else out
+    fmt = _fmt(pair)
+    _hip.check(lib.vrd_bct_to_btc(x.data_ptr(), B, Ct, T, c0, count, p, ld, fmt, _stream()), "vrd_bct_to_btc")
+    return Pair(out, count, fmt) if fmt else out
 
 
 def pair_table(feats):
@@ -326,12 +405,12 @@ def pack_pairs(table, lens, T, V, Cc, S, E, pair_wide):
     a.src, a.lens = table.data_ptr(), lens.data_ptr()
     a.P, a.C_in, a.T, a.V, a.Cc, a.S, a.E = B, 2 * V + 2 * Cc + S + 2 * E, T, V, Cc, S, E
     a.vis, a.clip, a.so_box, a.ent = vis.data_ptr(), _ptr(clip), so_box.data_ptr(), ent.data_ptr()
-    a.pair_wide = 1 if pair_wide else 0
+    a.pair_wide = _fmt(pair_wide)
     _hip.check(lib.vrd_pack_pairs(C.byref(a), _stream()), "vrd_pack_pairs")
     mask = torch.arange(T, device=dev)[None, :] < lens[:, None]
-    if pair_wide:
-        vis = Pair(vis, V)
-        clip = Pair(clip, Cc) if Cc else None
+    if a.pair_wide:
+        vis = Pair(vis, V, a.pair_wide)
+        clip = Pair(clip, Cc, a.pair_wide) if Cc else None
     return vis, clip, so_box, ent, mask
 
 
@@ -362,12 +441,12 @@ def gather_rows(source, s_row, o_row, lens, T, S, E, pair_wide, boxes_only=False
     a.P, a.T, a.V, a.Cc, a.stride = B, T, V, Cc, source.stride
     a.w, a.h = source.wh
     a.out_vis, a.out_clip, a.out_so_box, a.out_ent = _ptr(vis), _ptr(clip), so_box.data_ptr(), ent.data_ptr()
-    a.pair_wide = 1 if pair_wide else 0
+    a.pair_wide = _fmt(pair_wide)
     _hip.check(lib.vrd_gather_pairs(C.byref(a), _stream()), "vrd_gather_pairs")
     mask = torch.arange(T, device=dev)[None, :] < lens[:, None]
-    if pair_wide and not boxes_only:
-        vis = Pair(vis, V)
-        clip = Pair(clip, Cc) if Cc else None
+    if a.pair_wide and not boxes_only:
+        vis = Pair(vis, V, a.pair_wide)
+        clip = Pair(clip, Cc, a.pair_wide) if Cc else None
     return vis, clip, so_box, ent, mask
 
 
@@ -442,7 +521,7 @@ def row_blocks(mask):
 
 
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
-              res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None, _dgrad=False):
+              res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None, _dgrad=False, _split_fmt=None):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
     vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
     out_pair: write the result as pair rows of width N (returns a Pair).
@@ -450,6 +529,7 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     row_mask, which is then the default; without row_mask those rows hold bias-only filler, so pass it only where
     no valid row ever reads a padded one: projections feeding masked attention, an MLP's hidden layer).
     row_scale (rows,): per-row factor on the branch term (stochastic depth, blocks.py:1107-1120); autograd path only.
+    _split_fmt: element format of the split products instead of the mode's (the backward GEMMs pass PAIR_BF16: split_backward).
     Under autograd (`recording`) the op runs as autograd.conv_gemm and returns a fresh tensor (`out` is ignored)."""
     # row_scale (stochastic depth, sampled whenever the model trains) lives in the autograd form's epilogue: it goes there even
     # when nothing of this call needs a gradient (a frozen sub-module under requires_grad_(False), reference blocks.py:1107-1120
@@ -463,6 +543,7 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     N, Cin, k = weight.shape
     if _dgrad:          # the conv's input gradient: weight (Cin_of_x... = N_w, Cin_w, k) acts as the (Cin_w, N_w, k) flipped conv
         N, Cin = Cin, N
+    x_fmt = x.fmt if isinstance(x, Pair) else 0
     x, a_width = _unwrap(x)
     pa, rows, cols, lda = _rows(x)
     assert cols == Cin, f"input has {cols} channels, weight expects {Cin}"
@@ -475,9 +556,10 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     if _dgrad:
         # split-precision only (autograd.Linear checks): the operand is built from the parameter in one launch; the f32
         # weight pointer is not read by the split-precision kernels and points at the same buffer
-        assert _precision == "bf16x3" and (Cin * k) % 32 == 0 and not a_width
+        assert split_backward() and (Cin * k) % 32 == 0 and not a_width
         wt = split_conv_weight_dgrad(weight)
-        a.W, a.W_split = wt.data_ptr(), wt.data_ptr()
+        a.W = wt.data_ptr()
+        wt.set_args(a)
     else:
         a.W = _param_ptr(packed_conv_weight(weight), x, "conv weight")
     a.A, a.lda, a.bias = pa, lda, _param_ptr(bias, x, "conv bias")
@@ -487,11 +569,13 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     a.row_mask = _mask_ptr(row_mask, rows)
     a.scale = _param_ptr(scale, x, "drop-path scale")
     if a_width:
-        assert _precision == "bf16x3" and Cin % 32 == 0, "pair input needs bf16x3 precision and Cin % 32 == 0"
-    if not _dgrad and _precision == "bf16x3" and (Cin * k) % 32 == 0:
-        a.W_split = split_conv_weight(weight).data_ptr()
+        assert pair_fmt() and x_fmt == pair_fmt() and Cin % 32 == 0, "pair input needs the split-precision mode it was made in and Cin % 32 == 0"
+    w_fmt = pair_fmt() if _split_fmt is None else _split_fmt
+    assert not (a_width and w_fmt != x_fmt) and not (out_pair and w_fmt != pair_fmt())
+    if not _dgrad and w_fmt and (Cin * k) % 32 == 0:
+        split_conv_weight(weight, w_fmt).set_args(a)
     a.a_pair_width = a_width
-    a.c_pair = 1 if out_pair else 0
+    a.c_pair = _fmt(out_pair)
     if skip_rows is None:
         skip_rows = row_mask
     if _skip_padding and skip_rows is not None and a_width and rows >= SKIP_MIN_ROWS and skip_rows.numel() == rows:
@@ -511,7 +595,7 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
         _launch.append(a)
     else:
         _hip.check(lib.vrd_gemm(C.byref(a), _stream()), "vrd_gemm")
-    return Pair(out, N) if out_pair else out
+    return Pair(out, N, a.c_pair) if a.c_pair else out
 
 
 def conv_gemm_batch(calls):
@@ -548,8 +632,8 @@ def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False
     assert gamma.numel() == cols and beta.numel() == cols
     _hip.check(lib.vrd_layernorm(px, ldx, py, ldy, rows, cols, _param_ptr(gamma, x, "LayerNorm weight"),
                                  _param_ptr(beta, x, "LayerNorm bias"), 1 if relu else 0,
-                                 pa, lda, period, 1 if pair else 0, _stream()), "vrd_layernorm")
-    return Pair(out, cols) if pair else out
+                                 pa, lda, period, _fmt(pair), _stream()), "vrd_layernorm")
+    return Pair(out, cols) if _fmt(pair) else out
 
 
 _CONST_ROWS = {}
@@ -624,8 +708,8 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
         a.packed[i] = _dwconv_block(s["weight"], s.get("bias"), s.get("gamma"), s.get("beta")).data_ptr()
         a.relu[i] = 1 if s.get("relu") else 0
         a.y[i], a.ldy[i] = po, ldo
-        a.out_pair[i] = 1 if s.get("pair") else 0
-        outs.append(Pair(o, Cout) if s.get("pair") else o)
+        a.out_pair[i] = _fmt(s.get("pair"))
+        outs.append(Pair(o, Cout) if _fmt(s.get("pair")) else o)
     _hip.check(lib.vrd_dwconv_ln(C.byref(a), _stream()), "vrd_dwconv_ln")
     return outs
 
@@ -651,8 +735,8 @@ def local_attention(q, k, v, mask, n_head, half_win, pair=False, rel_pe=None):
     assert ld == ldk == ldv
     out = torch.empty(B, T, Cc, device=q.device, dtype=torch.float32)
     _hip.check(lib.vrd_local_attn(pq, pk, pv, ld, _mask_ptr(mask, rows), rel, B, T, Cc, n_head, half_win,
-                                  out.data_ptr(), Cc, 1 if pair else 0, _stream()), "vrd_local_attn")
-    return Pair(out, Cc) if pair else out
+                                  out.data_ptr(), Cc, _fmt(pair), _stream()), "vrd_local_attn")
+    return Pair(out, Cc) if _fmt(pair) else out
 
 
 def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
@@ -665,6 +749,8 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
         return autograd.Attention.apply(q, k, v, kv_mask, n_head)
     if isinstance(q, Pair):
         assert isinstance(k, Pair) and isinstance(v, Pair) and q.width == k.width == v.width == q.shape[-1]
+        assert q.fmt == k.fmt == v.fmt
+        fmt = q.fmt
         q, k, v = q.t, k.t, v.t
         B, Tq, Cc = q.shape
         Tk = k.shape[1]
@@ -674,9 +760,9 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
         assert ldk == ldv
         out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
         _hip.check(lib.vrd_attention_pair(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), _mask_ptr(q_mask, B * Tq), B, Tq, Tk, n_head,
-                                          Cc // n_head, out.data_ptr(), Cc, 1 if pair else 0, _stream()),
+                                          Cc // n_head, out.data_ptr(), Cc, fmt if pair else 0, fmt, _stream()),
                    "vrd_attention_pair")
-        return Pair(out, Cc) if pair else out
+        return Pair(out, Cc, fmt) if pair else out
     B, Tq, Cc = q.shape
     Tk = k.shape[1]
     pq, _, _, ldq = _rows(q)
@@ -686,9 +772,9 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
     out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
     hd = Cc // n_head
     flash = algo == 2 or (algo == 0 and hd in (64, 128))      # mirrors vrd_attention's auto choice
-    pair = bool(pair and flash)
+    pair = bool(pair and flash and pair_fmt())
     _hip.check(lib.vrd_attention(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), B, Tq, Tk, n_head, hd,
-                                 out.data_ptr(), Cc, algo, 1 if pair else 0, _stream()), "vrd_attention")
+                                 out.data_ptr(), Cc, algo, _fmt(pair), _stream()), "vrd_attention")
     return Pair(out, Cc) if pair else out
 
 
