@@ -189,7 +189,20 @@ def main():
     dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 with --gpus 1: a process group of ONE rank over RCCL, and the exchange step, the barrier and the
+    # max-over-ranks reduction run through it like in an N > 1 job (how a single-GPU box executes that code at all)
+    force_dist = world == 1 and os.environ.get("BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if force_dist:
+        import socket
+        os.environ["VRDONE_FORCE_COLLECTIVE"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    elif world > 1:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -215,12 +228,12 @@ def main():
 
     def step():
         out = model._mask_vrd(batch["x"], batch["m"], with_aux=False)
-        if world > 1:
+        if use_dist:
             return gather_predictions(out["pred_logits"], out["pred_masks"], args.pairs, world)
         return out["pred_logits"], out["pred_masks"]
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -243,7 +256,7 @@ def main():
             _hip.prof_enable(False)
         assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         log(f"[{mode}] timed region: {steps} steps in {float(t.item()):.3f} s")
         return float(t.item()), (_hip.prof_read() if (rank == 0 and not args.no_prof) else {})
@@ -331,10 +344,35 @@ def main():
             shares[str(n)] = {"pairs_per_rank": args.pairs // n, "ms_per_step": 1e3 * (time.perf_counter() - t0) / max(args.steps, 3)}
         q, k1 = cfg["predictor"]["num_queries"], cfg["num_classes"] + 1
         one = 1e3 * elapsed / args.steps
+        # BASELINE config 4 (8192 pairs x 256 frames, 1024 per rank at N = 8): the whole job on this one GPU (four launch waves
+        # of pair_chunk pairs) against one rank's 1024 pairs
+        cfg4 = None
+        if args.pairs == 2048 and "2" in shares:
+            del full_x, full_m
+            batch.clear()
+            torch.cuda.empty_cache()
+            batch["x"], batch["m"] = synth.synth_pairs(8192, c_in, t_pad, [args.frames] * 8192, seed=1234, device=dev)
+            with torch.no_grad():
+                step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+            whole = 1e3 * (time.perf_counter() - t0) / 2
+            cfg4 = {"job": "8192 pairs x 256 frames (BASELINE config 4)", "ms_per_step_n1": whole,
+                    "ms_per_step_rank_of_8": shares["2"]["ms_per_step"], "pairs_per_rank_of_8": 1024,
+                    "projected_speedup_n8": round(whole / shares["2"]["ms_per_step"], 2),
+                    "allgather_payload_bytes_per_step": 8192 * (cfg["predictor"]["num_queries"] * (cfg["num_classes"] + 1) +
+                                                                cfg["predictor"]["num_queries"] * t_pad) * 4}
+            batch.clear()
+            full_x = full_m = None
         projection = {"kind": "projection, not a measurement: per-rank share of the same batch timed on one GPU; no collective, no skew",
                       "ms_per_step_n1": one, "ranks": shares,
                       "projected_speedup": {n: round(one / v["ms_per_step"], 2) for n, v in shares.items()},
                       "allgather_payload_bytes_per_step": args.pairs * (q * k1 + q * t_pad) * 4}
+        if cfg4 is not None:
+            projection["cfg4_8192_pairs"] = cfg4
         del full_x, full_m
 
     ft = None
@@ -481,9 +519,9 @@ def main():
                        "padding": f"{t_pad - args.frames} of {t_pad} rows per pair are padding; GEMM tiles, attention key tiles and "
                                   "depthwise-conv strips made of padding only are not computed (outputs identical to computing "
                                   "them, tests/test_gpu_model.py; VRDONE_SKIP_PADDING=0 switches the GEMM part off)",
-                       "parallelism": f"pair-sharded x{world}" + (" + all-gather of predictions" if world > 1 else ""),
-                       "world_size": dist.get_world_size() if world > 1 else 1,
-                       "backend": dist.get_backend() if world > 1 else None},
+                       "parallelism": f"pair-sharded x{world}" + (" + all-gather of predictions" if use_dist else ""),
+                       "world_size": dist.get_world_size() if use_dist else 1,
+                       "backend": dist.get_backend() if use_dist else None},
         }
         if fpp:
             line["algorithmic_tflops"] = fpp * args.pairs * args.steps / elapsed / 1e12
@@ -518,7 +556,7 @@ def main():
             sd_cpu = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, c_in, args.frames, t_pad, args.cpu_pairs)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -12,7 +12,7 @@ Per kernel (sums over its dispatches in one bench step):
   mfma_util_vs_time   SQ_VALU_MFMA_BUSY_CYCLES / (duration x clock x 256 CUs x 4 SIMDs), clock from GRBM_GUI_ACTIVE / 8 /
                       duration (the guide's effective-clock recipe; reads high on dispatches < 0.3 ms)
   wait fractions      SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_WAIT_INST_LDS, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES
-  mfma_bf16_ops       SQ_INSTS_VALU_MFMA_MOPS_BF16 (units of 512 FLOP-ish "MOPS" as the counter defines them; reported raw)
+  mfma_mops           SQ_INSTS_VALU_MFMA_MOPS_BF16 / _F16 / _F32 by mode (units of 512 FLOP-ish "MOPS" as the counter defines them; reported raw)
 """
 import collections
 import csv
@@ -43,8 +43,8 @@ def main(src, dst, suffix=""):
     import bench
     sha_file = os.path.join(src, "kernel_src_sha.txt")
     out = {"source": "rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES "
-                     "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE "
-                     "-- python3 bench.py --steps 1 --warmup 1 --precision " + ("f32" if suffix == "_f32" else "bf16x3") + " (all dispatches of the process: warm-up + 1 step)",
+                     "SQ_INSTS_VALU_MFMA_MOPS_<BF16|F16|F32 by mode> SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE "
+                     "-- python3 bench.py --steps 1 --warmup 1 --precision " + (suffix[1:] if suffix else "bf16x3") + " (all dispatches of the process: warm-up + 1 step)",
            "kernel_src_sha": open(sha_file).read().strip() if os.path.exists(sha_file) else bench.kernel_source_sha(),
            "units": "SQ_VALU_MFMA_BUSY_CYCLES in cycles (summed over SIMDs); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in "
                     "quad-cycles summed over waves; clock = GRBM_GUI_ACTIVE / 8 / duration",
@@ -59,7 +59,7 @@ def main(src, dst, suffix=""):
         out["kernels"][k] = {
             "dispatches": len(seen[k]), "total_ms": ns / 1e6, "vgprs": int(c["_vgpr"]), "clock_ghz": round(clock_ghz, 3),
             "mfma_util_vs_time": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4),
-            "mfma_bf16_mops": c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0),
+            "mfma_mops": sum(v for n, v in c.items() if n.startswith("SQ_INSTS_VALU_MFMA_MOPS_")),
             "busy_cu_frac": round(4.0 * c.get("SQ_BUSY_CU_CYCLES", 0.0) / (ns * clock_ghz * N_CU), 4),
             "wait_any_frac": round(c["SQ_WAIT_ANY"] / wave, 4), "wait_inst_any_frac": round(c["SQ_WAIT_INST_ANY"] / wave, 4),
             "wait_inst_lds_frac": round(c["SQ_WAIT_INST_LDS"] / wave, 4), "active_inst_frac": round(c["SQ_ACTIVE_INST_ANY"] / wave, 4)}

@@ -40,7 +40,7 @@ def per_kernel(path):
 
 
 def main(src, dst, suffix=""):
-    """suffix: "" for the bf16x3 passes, "_f32" for the f32 ones (collect_profiles.sh names)."""
+    """suffix: "_<mode>" of the passes (collect_profiles.sh names; "" = the bf16x3 passes of rounds 1-3)."""
     fetch, write = per_kernel(f"{src}/pmc_FETCH_SIZE{suffix}.csv"), per_kernel(f"{src}/pmc_WRITE_SIZE{suffix}.csv")
     import bench
     sha_file = os.path.join(src, "kernel_src_sha.txt")        # written on the GPU box by collect_profiles.sh
@@ -52,7 +52,7 @@ def main(src, dst, suffix=""):
     except OSError:
         git_sha, dirty = "", False
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over "
-                     f"bench.py --steps 1 --warmup 1 --precision {'f32' if suffix else 'bf16x3'}; FETCH_SIZE doubled (gfx950; wide reads only), KiB -> bytes",
+                     f"bench.py --steps 1 --warmup 1 --precision {suffix[1:] if suffix else 'bf16x3'}; FETCH_SIZE doubled (gfx950; wide reads only), KiB -> bytes",
            "kernel_src_sha": src_sha, "git_sha": git_sha + ("+uncommitted" if dirty else ""),
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):

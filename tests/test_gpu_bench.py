@@ -55,3 +55,28 @@ def test_bench_starts_its_own_ranks():
     b = json.loads(lines[0])
     assert b["n_gpus"] == 2 and b["config"]["world_size"] == 2 and b["config"]["pairs_per_gpu"] == 32
     assert b["scaling"] == "strong" and abs(b["value"] - 64 / (b["ms_per_step"] * 1e-3)) <= 1e-6 * b["value"]
+
+
+def test_rccl_path_on_one_rank():
+    """The code an N > 1 job runs through RCCL -- init_process_group("nccl", device_id=...), the all-gather of the predictions
+    on device tensors, dist.barrier(), the float64 all_reduce(MAX) of the step time -- executed on this one-GPU box by a
+    process group of ONE rank (BENCH_FORCE_DIST=1), in a fresh child process; then MaskVRD.shard_pairs() under such a group
+    (its candidate all-gather forced the same way) against the unsharded forward_test."""
+    import socket
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BENCH_REHEARSAL")}
+    env.update(BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    b = run_bench("--gpus", "1", "--pairs", "64", "--steps", "2", "--warmup", "1", "--no-alt", "--no-ragged", "--no-forward-test",
+                  "--no-train-step", "--no-cpu-baseline", "--no-shard-projection", env=env)
+    assert b["n_gpus"] == 1 and b["config"]["backend"] == "nccl" and b["config"]["world_size"] == 1
+    assert "all-gather" in b["config"]["parallelism"] and b["value"] > 0
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env.pop("BENCH_FORCE_DIST")
+    env.update(VRDONE_FORCE_COLLECTIVE="1", OMP_NUM_THREADS="4")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(REPO, "scripts", "sharded_eval_check.py")],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["backend"] == "nccl" and line["world_size"] == 1 and line["equal_on_rank"] == [True] and line["triplets"] > 0

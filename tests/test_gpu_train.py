@@ -410,19 +410,22 @@ def test_device_assignment_terminates_on_nan_and_infinite_costs():
     first = [0, 3, 7, 16, 18, 23]
     cost[first[1] + 2] = float("nan")                       # pair 1: one relation's whole row
     cost[first[2]:first[2] + 9] = float("inf")              # pair 2: everything
-    cost[first[4] + 1, 3] = float("nan")                    # pair 4: a single entry (may or may not block the search)
+    cost[first[4] + 1, 3] = float("nan")                    # pair 4: a single entry, which the search itself need not visit
+    cost[first[3], 8] = float("-inf")                       # pair 3: a single -inf (scipy: "invalid numeric entries" too)
     got = ops.assign(cost.to(DEV), sizes)
     torch.cuda.synchronize()                                # returns at all
     got = got.cpu()
     assert bool((got[first[1]:first[1] + 4] == -1).all()) and bool((got[first[2]:first[2] + 9] == -1).all())
-    for p in (0, 3, 5):
+    for p in (3, 4):        # scipy raises on ANY NaN / -inf entry of a pair's block: so the whole pair comes back unassigned
+        with pytest.raises(ValueError):
+            linear_sum_assignment(cost[first[p]:first[p] + sizes[p]].T.numpy())
+        assert bool((got[first[p]:first[p] + sizes[p]] == -1).all())
+    for p in (0, 5):
         n, at = sizes[p], first[p]
         rows, cols = linear_sum_assignment(cost[at:at + n].T.numpy())
         want = torch.empty(n, dtype=torch.int32)
         want[torch.as_tensor(cols)] = torch.as_tensor(rows, dtype=torch.int32)
         assert torch.equal(got[at:at + n], want)
-    blk = got[first[4]:first[4] + 5]
-    assert bool((blk == -1).all()) or (len(set(blk.tolist())) == 5 and int(blk.min()) >= 0)
     # the matcher's host form raises like scipy does
     model, mc, _ = build()
     lens, x, m, data = train_batch(mc, c_in(mc), device=DEV)
@@ -492,6 +495,40 @@ def test_fused_criterion_equals_the_tensor_form(fuzzy, L, Q, K1, T):
         (want * coef[l]).sum().backward()
         for a, b in zip(got_grads[l], (lg.grad, mk.grad)):
             assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max())) + 1e-7, l
+
+
+def test_fused_criterion_poisons_a_class_id_out_of_range_and_large_batches_take_the_tensor_form():
+    """A ground-truth class id outside [0, K1): the reference's F.cross_entropy raises (models/maskvrd.py:510); the fused
+    criterion, which never waits for the device, reads nothing out of bounds and returns NaN losses for the step.  A batch
+    whose (pair, query) table exceeds the fused kernel's LDS goes through the tensor form instead of raising."""
+    from vrdone_amd.models import losses
+    g = torch.Generator().manual_seed(3)
+    B, Q, K1, T = 5, 9, 133, 96
+    sizes = [2, 1, 3, 0, 1]
+    G = sum(sizes)
+    valid = torch.ones(B, T, dtype=torch.bool)
+    tgt = (torch.rand(G, T, generator=g) > 0.5).float()
+    layers = [(torch.randn(B, Q, K1, generator=g).to(DEV).requires_grad_(True), torch.randn(B, Q, T, generator=g).to(DEV).requires_grad_(True))]
+    weight = torch.ones(K1)
+    for bad in (K1, K1 + 1000, -1):
+        ids = torch.randint(1, K1, (G,), generator=g)
+        ids[3] = bad
+        vals, q_of, failed = losses.device_criterion(layers, valid.to(DEV), sizes, ids.to(DEV), tgt.to(DEV), None, 1.0, weight, (2.0, 5.0, 5.0))
+        torch.cuda.synchronize()
+        assert bool(failed) and bool((q_of[0, 3:6] == -1).all()) and bool((q_of[0, :3] >= 0).all())
+    # 1,400 pairs x 9 queries = 12,600 rows > the 12,224 the fused kernel's table holds: MaskVRD.criterion falls through
+    model, mc, _ = build()
+    Bb = 1400
+    preds = {"pred_logits": torch.randn(Bb, Q, K1, generator=g).to(DEV), "pred_masks": torch.randn(Bb, Q, T, generator=g).to(DEV),
+             "output_mask": torch.ones(Bb, 1, T, dtype=torch.bool, device=DEV),
+             "aux_outputs": [{"pred_logits": torch.randn(Bb, Q, K1, generator=g).to(DEV), "pred_masks": torch.randn(Bb, Q, T, generator=g).to(DEV)}
+                             for _ in range(3)]}
+    data = {"preds_list": [torch.randint(1, K1, (1,), generator=g) for _ in range(Bb)],
+            "masks_list": [(torch.rand(1, T, generator=g) > 0.5).float() for _ in range(Bb)],
+            "segs_list": [torch.tensor([[3, 40]]) for _ in range(Bb)]}
+    with torch.no_grad():
+        big = model.criterion(preds, data)
+    assert all(bool(torch.isfinite(v)) for v in big.values()) and "total_loss" in big
 
 
 def test_device_matching_gives_the_host_matchings():

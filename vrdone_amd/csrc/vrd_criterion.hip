@@ -18,6 +18,10 @@
 
 namespace {
 
+__device__ __forceinline__ bool class_ok(const vrd_criterion_args& a, int g) {
+    return (unsigned long long)a.tgt_ids[g] < (unsigned long long)a.K1;
+}
+
 constexpr float PI_F = 3.14159265358979323846f;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -84,7 +88,8 @@ __global__ void criterion_costs_kernel(vrd_criterion_args a, float* __restrict__
     const float* lr = a.logits[l] + ((int64_t)b * a.Q + q) * a.K1;
     const float lse = wave_lse(lr, a.K1, lane);
     if (lane == 0) {
-        const float c_class = lse - lr[a.tgt_ids[g]];
+        // a class id outside [0, K1) (F.cross_entropy raises on one): NaN cost -> the pair comes back unassigned -> poisoned losses
+        const float c_class = class_ok(a, g) ? lse - lr[a.tgt_ids[g]] : __builtin_nanf("");
         const float c_mask = (s_pos + s_neg) / n_valid;
         const float c_dice = 1.0f - (2.0f * s_st + 1.0f) / (s_sig + s_t + 1.0f);
         cost[((int64_t)l * a.G + g) * a.Q + q] = a.w_class * c_class + a.w_mask * c_mask + a.w_dice * c_dice;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(LOSS_WAVES * 64) void criterion_losses_kernel(vrd_c
     __syncthreads();
     for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
         const int q = qo[g] < 0 ? 0 : qo[g];
-        tgt_cls[a.owner[g] * a.Q + q] = (int)a.tgt_ids[g];
+        tgt_cls[a.owner[g] * a.Q + q] = class_ok(a, g) ? (int)a.tgt_ids[g] : 0;       // (never an index out of range)
     }
     __syncthreads();
     // ---- class term: sum_r w[t_r] * (lse_r - x_r[t_r]) / sum_r w[t_r]
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(64) void criterion_backward_kernel(vrd_criterion_ar
     {
         const float* lr = a.logits[l] + (int64_t)r * a.K1;
         float* go = gr.logits[l] + (int64_t)r * a.K1;
-        const int t = g_match >= 0 ? (int)a.tgt_ids[g_match] : 0;
+        const int t = (g_match >= 0 && class_ok(a, g_match)) ? (int)a.tgt_ids[g_match] : 0;
         const float lse = wave_lse(lr, a.K1, lane);
         const float coef = g_class * class_weight[t] / fwd_out[l * 4 + 3];
         for (int k = lane; k < a.K1; k += 64) go[k] = coef * (expf(lr[k] - lse) - (k == t ? 1.0f : 0.0f));

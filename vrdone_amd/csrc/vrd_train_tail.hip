@@ -25,6 +25,17 @@ __global__ __launch_bounds__(64) void assign_kernel(const float* __restrict__ co
         for (int i = 0; i < n; ++i) query_of[r0 + i] = -1;      // never end); the host routes such pairs to scipy
         return;
     }
+    // scipy's linear_sum_assignment refuses a matrix with a NaN or a -inf anywhere ("matrix contains invalid numeric entries",
+    // which the reference lets propagate: models/maskvrd.py:492): such a pair comes back unassigned, whichever entries the
+    // search itself would have visited
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < Q; ++j) {
+            const float c = cost[(int64_t)(r0 + i) * ld + j];
+            if (!(c == c) || c == -INFINITY) {
+                for (int r = 0; r < n; ++r) query_of[r0 + r] = -1;
+                return;
+            }
+        }
     // rows = relations 1..n, columns = queries 1..Q (1-based like the textbook form); way / minv per column
     double u[AS_MAX + 1], v[AS_MAX + 1], minv[AS_MAX + 1];
     int match[AS_MAX + 1], way[AS_MAX + 1];

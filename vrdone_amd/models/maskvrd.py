@@ -119,6 +119,17 @@ class MaskVRD(nn.Module):
             outs.append(self._heads(*self.backbone.cl(x, m), with_aux))
         return self._merge(outs)
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) (ModelEma does it, utils/train_utils.py:13): the derived-operand caches stay behind -- their
+        job tables point at THIS model's buffers, and the copy builds its own on first use."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ("_split_plans", "_dense_convs"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def _dense_conv_weights(self):
         """The Conv1d weights that reach vrd_gemm (groups == 1), in module order; looked up on every call: training graphs swap
         the modules' parameters for aliases of the same storage while they record."""
@@ -165,7 +176,9 @@ class MaskVRD(nn.Module):
 
     def enable_training_graphs(self, enable=True):
         """Training steps replay the network's forward and backward as HIP graphs, recorded once per batch shape
-        (vrdone_amd/train_graph.py: what is recorded, and the limits -- one backward per forward, no DDP)."""
+        (vrdone_amd/train_graph.py: what is recorded, and the limits -- one backward per forward; gradients are cleared with
+        zero_grad(set_to_none=True) between steps, a kept .grad is added to through a copy.  Works under DDP: the graphs are
+        recorded on aliases of the parameters, the reducer's hooks fire outside them)."""
         train_graph.enable(self, enable)
         return self
 
@@ -190,7 +203,10 @@ class MaskVRD(nn.Module):
         aux = predictions['aux_outputs'] if self.deep_supervision else None
         sizes = [len(p) for p in gt_preds]
         Q = pred_logits.shape[1]
-        if (self.device_matching and self.device_criterion and pred_logits.is_cuda and sizes and 0 < max(sizes) <= Q <= 16
+        # the fused criterion keeps one int per (pair, query) row in its workgroup's 48 KiB of LDS (vrd_criterion_losses): batches
+        # beyond ~12 k rows take the tensor form below, like anything else it does not cover
+        fits = pred_logits.shape[0] * Q * 4 + 256 <= 48 * 1024
+        if (self.device_matching and self.device_criterion and pred_logits.is_cuda and sizes and 0 < max(sizes) <= Q <= 16 and fits
                 and 'bipartite_match' not in self.__dict__):          # (tests pin the matching by replacing the method)
             loss_dict = self._criterion_on_device(pred_logits, pred_masks, out_mask, aux, sizes, gt_preds, gt_masks, gt_segs)
         else:
@@ -571,7 +587,7 @@ class MaskVRD(nn.Module):
         unsort[torch.tensor(order, dtype=torch.int64)] = torch.arange(P)
         unsort = unsort.to(dev)                         # uploaded before the first kernel is queued
         cand = self.pair_candidates(feats, lens, mine, t_pad, k, source=source)
-        if world > 1:
+        if world > 1 or (shard and parallel.forced()):
             cand = parallel.gather_candidates(cand, P, shard[0])       # (P, Q, 2k + 2) in `order`
         ops = _ops()
         if ops.get_precision() == "f16x3" and not bool(torch.isfinite(cand[:, :, :k]).all()):

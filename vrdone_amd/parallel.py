@@ -11,8 +11,16 @@ Two payloads:
   gather_predictions  raw pred_logits + pred_masks (15.2 kB per pair at T_pad 288): BASELINE config 4's "all-gather of
                       per-pair masks", used by bench.py --gpus N.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def forced():
+    """VRDONE_FORCE_COLLECTIVE=1: run the exchange step even in a group of ONE rank (an all-gather with itself), so that a
+    single-GPU box executes the RCCL calls of the N > 1 path (tests/test_gpu_model.py::test_rccl_path_on_one_rank)."""
+    return os.environ.get("VRDONE_FORCE_COLLECTIVE") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def rank_world(group=None):
@@ -50,7 +58,7 @@ def gather_candidates(cand, n_pairs, group=None):
     ONE collective: shards are padded to ceil(n_pairs / world) rows; position j * world + r of the interleaved result is
     rank r's j-th record, so the padding lands behind the last real record and needs no index table."""
     rank, world = rank_world(group)
-    if world == 1:
+    if world == 1 and not forced():
         return cand
     per = (n_pairs + world - 1) // world
     mine = (n_pairs - rank + world - 1) // world
@@ -65,7 +73,7 @@ def gather_predictions(pred_logits, pred_masks, n_pairs, world, group=None):
     """All-gather per-pair predictions of contiguous shards (shard_range) into full (n_pairs, ...) tensors.
     One collective per tensor; uneven shards are padded to the largest shard for the exchange and the padding rows
     (the tail of the short shards) are dropped by slicing, shard by shard."""
-    if world == 1:
+    if world == 1 and not forced():
         return pred_logits, pred_masks
     per = (n_pairs + world - 1) // world
     sizes = [shard_range(n_pairs, r, world) for r in range(world)]

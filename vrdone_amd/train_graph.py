@@ -124,7 +124,20 @@ class _Replay(torch.autograd.Function):
                 else:
                     buf.copy_(g)
         rec.bwd.replay()
-        return (None, None, None) + tuple(None if g is None else g.detach() for g in rec.static_gin)
+        # The gradients handed back are views of the recording's static buffers, which AccumulateGrad may adopt as `.grad`.
+        # A step that KEEPS its .grad (zero_grad(set_to_none=False), gradient accumulation) would have it overwritten in place
+        # by the next replay and then added to itself: such a parameter gets a copy instead.
+        out = []
+        for p, g in zip(rec.params, rec.static_gin):
+            if g is None:
+                out.append(None)
+            elif p.grad is not None and p.grad.untyped_storage().data_ptr() == g.untyped_storage().data_ptr():
+                raise RuntimeError("training graphs: a parameter's .grad is the recording's own gradient buffer from the previous "
+                                   "step and would be overwritten -- clear gradients with zero_grad(set_to_none=True), or clone "
+                                   ".grad before the next step (gradient accumulation)")
+            else:
+                out.append(g.detach().clone() if p.grad is not None else g.detach())
+        return (None, None, None) + tuple(out)
 
 
 def enable(model, on=True):
