@@ -77,21 +77,43 @@ def train_batch(mc, c_in, device="cpu", spec=TRAIN):
     return lens, x, m, data
 
 
-def replay_matching(model, recorded):
+def replay_matching(model, recorded, tie_tol=1e-5):
     """Make model.bipartite_match return the reference's recorded assignments (final head, then the auxiliary layers, in
     call order) instead of its own: both sides then differentiate the same loss function even where a cost matrix
     has a near-tie (pairs shorter than 16 frames have ONE valid frame at the predictor's T/8 level: their queries cost
     the same to ~1e-5, tests/test_oracle_golden.py::test_criterion_train24).  Returns a list that collects, per call,
-    the pairs on which the model's own matching differs from the recorded one."""
+    the pairs on which the model's own matching differs from the recorded one.
+    A differing pair has to BE such a tie: under the model's own cost matrix (the one its own assignment minimises) the
+    recorded assignment of that pair costs at most tie_tol more than the model's -- a different prediction, or a broken
+    cost kernel, would show as a gap (asserted here, per call and pair)."""
+    from vrdone_amd.models import losses
     real = model.bipartite_match
     state = {"call": 0}
     differing = []
 
-    def match(*a, **kw):
-        idx, lm = real(*a, **kw)
+    def own_costs(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask):
+        dev = pred_logits.device
+        sizes = [len(p) for p in gt_preds]
+        owner = torch.repeat_interleave(torch.arange(len(sizes), device=dev), torch.tensor(sizes, device=dev))
+        segs, scale_range = model._fuzzy([t.to(dev) for t in gt_segs] if gt_segs is not None else None)
+        cc, cm, cd = losses.pair_costs(pred_logits, pred_masks, _mask[:, 0], torch.cat([t.to(dev) for t in gt_preds]),
+                                       torch.cat([t.to(dev) for t in gt_masks]), owner, segs, scale_range)
+        cost = model.cost_factor['cost_class'] * cc + model.cost_factor['cost_mask'] * cm + model.cost_factor['cost_dice'] * cd
+        return cost.double().cpu().split(sizes, dim=0)                    # per pair: (N_i, Q)
+
+    def match(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask):
+        idx, lm = real(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask=_mask)
         rec = recorded[state["call"]]
         state["call"] += 1
-        differing.append([n for n, ((i, j), r) in enumerate(zip(idx, rec)) if not (i.tolist() == r[0] and j.tolist() == r[1])])
+        diff = [n for n, ((i, j), r) in enumerate(zip(idx, rec)) if not (i.tolist() == r[0] and j.tolist() == r[1])]
+        if diff:
+            blocks = own_costs(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask)
+            for n in diff:
+                total = lambda q, r: float(sum(blocks[n][rr, qq] for qq, rr in zip(q, r)))       # noqa: E731
+                own, ref = total(idx[n][0].tolist(), idx[n][1].tolist()), total(rec[n][0], rec[n][1])
+                assert abs(own - ref) <= tie_tol * max(1.0, abs(own)), \
+                    f"matcher call {state['call'] - 1}, pair {n}: own assignment costs {own:.7f}, the reference's {ref:.7f} -- not a tie"
+        differing.append(diff)
         return [(torch.tensor(r[0], dtype=torch.int64), torch.tensor(r[1], dtype=torch.int64)) for r in rec], lm
     model.bipartite_match = match
     return differing
