@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 24
+#define VRD_ABI_VERSION 25
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -78,9 +78,13 @@ int vrd_prof_select(unsigned long long family_mask);
 /* ---- layout change at the boundary ------------------------------------------------------
  * (B, C_total, T) -> rows (b*T+t) of `dst`, channels [c0, c0+count) of the source.
  * Replaces the channel slicing of models/backbones.py:161-166 / :329-341 and the
- * transposing copy of models/maskvrd.py:382-385. */
+ * transposing copy of models/maskvrd.py:382-385.
+ * T_src (0: = T): frames per channel row of the source, of which the first T are converted; src_batch (nullable, B
+ * device int32): output sequence b is source sequence src_batch[b].  Together: a batch of selected pairs at a shorter
+ * padded length straight from the caller's (B_all, C_total, T_src) tensor (MaskVRD's tight padding). */
 int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count,
-                   float* dst, int64_t ld_dst, int out_pair /* enum vrd_pair_format */, void* stream);
+                   float* dst, int64_t ld_dst, int out_pair /* enum vrd_pair_format */, int T_src, const int32_t* src_batch,
+                   void* stream);
 /* Eval batching (models/maskvrd.py:363-414 + backbones.py:161-166) without the (B, C_in, T) intermediate: pair p
  * is an (L_p, C_in) frame-major matrix src[p] (how dataloaders/vidvrd.py:693 builds it, before its permute view)
  * laid out [s_vis V | o_vis V | (s_clip Cc | o_clip Cc) | so_box S | s_box E | o_box E].  Writes the backbone's

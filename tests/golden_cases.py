@@ -99,7 +99,7 @@ def replay_matching(model, recorded, tie_tol=1e-5):
         cc, cm, cd = losses.pair_costs(pred_logits, pred_masks, _mask[:, 0], torch.cat([t.to(dev) for t in gt_preds]),
                                        torch.cat([t.to(dev) for t in gt_masks]), owner, segs, scale_range)
         cost = model.cost_factor['cost_class'] * cc + model.cost_factor['cost_mask'] * cm + model.cost_factor['cost_dice'] * cd
-        return cost.double().cpu().split(sizes, dim=0)                    # per pair: (N_i, Q)
+        return cost.detach().double().cpu().split(sizes, dim=0)           # per pair: (N_i, Q)
 
     def match(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask):
         idx, lm = real(pred_logits, gt_preds, pred_masks, gt_masks, gt_segs, _mask=_mask)

@@ -151,6 +151,41 @@ def test_reference_grade_against_float64(name, T, mode):
             f"{name} T{T} {mode} {k}: max {e_max:.3e} vs ref32 {e32_max:.3e} (x{r_max:.2f}), rms x{r_rms:.2f}"
 
 
+def test_tight_padding_gives_the_same_outputs(precision):
+    """MaskVRD's tight padding (pairs computed at the shortest padded length that leaves a padded frame behind them at every
+    pyramid level, bucket by bucket) against the same batch computed at the batch's own padded length: the same numbers up to
+    the rounding of differently shaped launches, in the reference's layout (mask logits -10 behind every pair's frames)."""
+    model, mc, _, _ = get_model("vidvrd")
+    gen = torch.Generator().manual_seed(77)
+    B, T = 300, 288
+    lens = torch.randint(2, 257, (B,), generator=gen)
+    lens[:6] = torch.tensor([288, 287, 281, 280, 256, 2])           # pairs that cannot shrink, and the shortest one
+    x, m = O.synth_pairs(B, c_in(mc), T, lens.tolist(), seed=78)
+    xd, md = x.to(DEV), m.to(DEV)
+    assert model.tight_padding
+    try:
+        model.TIGHT_MIN_ROWS = 16384           # (buckets this small only here: the default merges a 300-pair batch into one)
+        plan = model._tight_plan(md, md.reshape(B, T))
+        assert plan is not None and len(plan) >= 3 and sum(n for _, _, n in plan) == B and max(t for t, _, _ in plan) == T
+        for t2, idx, n in plan:
+            assert all(model.tight_len(int(lens[i]), T) <= t2 for i in idx.tolist())
+        tight = model._mask_vrd(xd, md)
+        model.tight_padding = False
+        full = model._mask_vrd(xd, md.clone())
+    finally:
+        model.tight_padding = True
+        del model.TIGHT_MIN_ROWS
+    tol = 2e-4 if precision == "bf16x3" else 2e-5
+    close(tight["pred_logits"], full["pred_logits"], tol)
+    close(tight["pred_masks"], full["pred_masks"], 10 * tol)
+    assert torch.equal(tight["output_mask"], full["output_mask"]) and len(tight["aux_outputs"]) == len(full["aux_outputs"]) == 3
+    for a, b in zip(tight["aux_outputs"], full["aux_outputs"]):
+        close(a["pred_logits"], b["pred_logits"], tol)
+        close(a["pred_masks"], b["pred_masks"], 10 * tol)
+    pad = ~m[:, 0][:, None, :].expand(-1, tight["pred_masks"].shape[1], -1)
+    assert bool((tight["pred_masks"].cpu()[pad] == -10.0).all())
+
+
 def test_f16x3_overflow_is_loud_and_forward_test_repeats_in_f32():
     """Inputs beyond the f16x3 mode's operand range (|x| >= 4094): the path returns NaN, never a wrong finite number, and
     forward_test repeats the video in the f32 mode -- whose result it then returns (the reference computes float32)."""
@@ -279,17 +314,22 @@ def test_mask_vrd_b256_matches_reference_golden(precision):
     lens = b256_lengths()
     x, m = O.synth_pairs(B256["B"], c_in(mc), B256["T"], lens, seed=B256["seed"])
     assert 2 * B256["B"] * B256["T"] >= ops.SKIP_MIN_ROWS
-    _hip.prof_enable(True)
-    _hip.prof_reset()
-    out = model._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
-    torch.cuda.synchronize()
-    prof = _hip.prof_read()
-    _hip.prof_enable(False)
     e = B256["every"]
-    close(out["pred_logits"][::e], g["pred_logits"], LOGIT_TOL)
-    close(out["pred_masks"][::e], g["pred_masks"], MASK_TOL)
-    if precision in ("bf16x3", "f16x3"):       # the kernel this case exists for did run, and skipped padded tiles
-        assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
+    for tight in (False, True):        # at the batch's own padded length (padding maps), and in tight-padding buckets
+        _hip.prof_enable(True)
+        _hip.prof_reset()
+        try:
+            model.tight_padding = tight
+            out = model._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
+        finally:
+            model.tight_padding = True
+        torch.cuda.synchronize()
+        prof = _hip.prof_read()
+        _hip.prof_enable(False)
+        close(out["pred_logits"][::e], g["pred_logits"], LOGIT_TOL)
+        close(out["pred_masks"][::e], g["pred_masks"], MASK_TOL)
+        if not tight and precision in ("bf16x3", "f16x3"):       # the kernel this case exists for did run, and skipped padded tiles
+            assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
 
 
 def test_mask_vrd_cfg2_at_size_matches_reference_golden(precision):

@@ -475,3 +475,30 @@ def test_relative_position_encoding_matches_reference(name, B, T, lens, weights)
     np.testing.assert_allclose(out["pred_masks"].numpy(), g[f"{name}/T{T}_pred_masks"], atol=MASK_TOL, rtol=0)
     off = O.mask_vrd({k: v for k, v in sd.items() if not k.endswith("rel_pe")}, mc, x, m, with_aux=False)
     assert float((off["pred_logits"] - out["pred_logits"]).abs().max()) > 100 * LOGIT_TOL
+
+
+def test_result_is_independent_of_the_padded_length_above_the_tight_one():
+    """What MaskVRD's tight padding rests on (vrdone_amd/models/maskvrd.py): in exact arithmetic a pair's outputs depend on its
+    padded length T only through "is there a padded frame behind the last valid one at every pyramid level" -- T / 8 >
+    ceil(L / 8) for the shipped three-level pyramid.  The oracle in float64: any T at or above 8 * (ceil(L / 8) + 1) gives the
+    outputs of the reference's own padded length to 1e-12; one step of 8 below it does not (the FPN's top level then ends on a
+    valid frame: zero padding instead of LayerNorm(0) = beta behind it)."""
+    mc, _, keys = load_case("vidvrd")
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"]).items()}
+    c_in = 2 * mc["visual_dim"] + mc["bbox_so_dim"] + 2 * mc["bbox_entity_dim"]
+    for L, t_ref in ((41, 96), (100, 288), (7, 96)):
+        feat = torch.randn(1, c_in, L, generator=torch.Generator().manual_seed(L), dtype=torch.float64)
+
+        def run(T):
+            x = torch.zeros(1, c_in, T, dtype=torch.float64)
+            x[..., :L] = feat
+            o = O.mask_vrd(sd, mc, x, (torch.arange(T) < L)[None, None], with_aux=False)
+            return o["pred_logits"], o["pred_masks"][..., :L]
+        want = run(t_ref)
+        tight = 8 * (-(-L // 8) + 1)
+        for T in (tight, tight + 8):
+            got = run(T)
+            assert float((got[0] - want[0]).abs().max()) < 1e-12 and float((got[1] - want[1]).abs().max()) < 1e-12, (L, T)
+        if L > 8:
+            below = run(tight - 8)
+            assert float((below[1] - want[1]).abs().max()) > 1e-3, (L, tight - 8)

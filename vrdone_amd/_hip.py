@@ -110,7 +110,8 @@ _SIGNATURES = {
                                 C.POINTER(C.c_double)]),
     "vrd_prof_read_skipped": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "vrd_prof_select": (C.c_int, [C.c_uint64]),
-    "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+    "vrd_bct_to_btc": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_int, c_i32p,
+                                 C.c_void_p]),
     "vrd_btc_to_bct": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "vrd_pack_pairs": (C.c_int, [C.POINTER(PackArgs), C.c_void_p]),
     "vrd_gather_pairs": (C.c_int, [C.POINTER(GatherArgs), C.c_void_p]),
@@ -166,7 +167,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 class HipLibraryError(RuntimeError):

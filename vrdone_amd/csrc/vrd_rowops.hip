@@ -19,14 +19,17 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // ------------------------------------------------------------------------------------------
 // (B, C_total, T) slab -> channels-last rows, 64 x 64 tiles through LDS
 // ------------------------------------------------------------------------------------------
+// Source sequence of output sequence b: src_batch[b] (a gather over the batch) or b; a source channel row holds T_src >= T
+// frames, of which the first T are converted (the tail is padding the caller leaves out: MaskVRD's tight padding).
 __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict__ src, int C_total, int T, int c0,
-                                                         int count, float* __restrict__ dst, int64_t ld_dst, int pair) {
+                                                         int count, float* __restrict__ dst, int64_t ld_dst, int pair, int T_src,
+                                                         const int32_t* __restrict__ src_batch) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const float* s = src + ((int64_t)b * C_total + c0) * T;
+    const float* s = src + ((int64_t)(src_batch ? src_batch[b] : b) * C_total + c0) * T_src;
     for (int c = ty; c < 64; c += 4)
-        tile[c][tx] = (ct + c < count && tt + tx < T) ? s[(int64_t)(ct + c) * T + tt + tx] : 0.f;
+        tile[c][tx] = (ct + c < count && tt + tx < T) ? s[(int64_t)(ct + c) * T_src + tt + tx] : 0.f;
     __syncthreads();
     for (int t = ty; t < 64; t += 4)
         if (tt + t < T && ct + tx < count) {
@@ -39,16 +42,17 @@ __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict
 // same, 16-byte accesses on both sides (T % 4 == 0, count % 4 == 0, 16-byte aligned rows): float4 reads along t,
 // float4 / pair-row writes of four channels
 __global__ __launch_bounds__(256) void bct_to_btc_vec_kernel(const float* __restrict__ src, int C_total, int T, int c0,
-                                                             int count, float* __restrict__ dst, int64_t ld_dst, int pair) {
+                                                             int count, float* __restrict__ dst, int64_t ld_dst, int pair, int T_src,
+                                                             const int32_t* __restrict__ src_batch) {
     __shared__ float tile[64][65];
     const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
-    const float* s = src + ((int64_t)b * C_total + c0) * T;
+    const float* s = src + ((int64_t)(src_batch ? src_batch[b] : b) * C_total + c0) * T_src;
     {
         const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;     // 16 float4 along t, 16 channels per sweep
 #pragma unroll
         for (int c = ty; c < 64; c += 16) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ct + c < count && tt + 4 * tx < T) v = ld4(s + (int64_t)(ct + c) * T + tt + 4 * tx);
+            if (ct + c < count && tt + 4 * tx < T) v = ld4(s + (int64_t)(ct + c) * T_src + tt + 4 * tx);
             tile[c][4 * tx] = v.x, tile[c][4 * tx + 1] = v.y, tile[c][4 * tx + 2] = v.z, tile[c][4 * tx + 3] = v.w;
         }
     }
@@ -615,8 +619,10 @@ __global__ __launch_bounds__(RB_THREADS) void row_blocks_kernel(const uint8_t* _
 extern "C" {
 
 int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int count, float* dst, int64_t ld_dst,
-                   int out_pair, void* stream) {
+                   int out_pair, int T_src, const int32_t* src_batch, void* stream) {
     VRD_CHECK_ARG(src && dst, "vrd_bct_to_btc: null pointer");
+    if (T_src == 0) T_src = T;
+    VRD_CHECK_ARG(T_src >= T, "vrd_bct_to_btc: T_src (%d) < T (%d)", T_src, T);
     VRD_CHECK_ARG(B > 0 && T > 0 && count > 0 && c0 >= 0 && c0 + count <= C_total && ld_dst >= count,
                   "vrd_bct_to_btc: bad slab c0=%d count=%d C=%d ld=%lld", c0, count, C_total, (long long)ld_dst);
     VRD_CHECK_ARG(B <= 65535, "vrd_bct_to_btc: B too large for one launch (%d)", B);
@@ -624,9 +630,9 @@ int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int coun
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * B * (double)count * T);
     dim3 grid((T + 63) / 64, (count + 63) / 64, B);
     VRD_CHECK_ARG(!out_pair || (count % 32 == 0 && ld_dst % 4 == 0 && aligned16(dst)), "vrd_bct_to_btc: pair rows need count %% 32 == 0");
-    const bool vec = T % 4 == 0 && count % 4 == 0 && ld_dst % 4 == 0 && aligned16(dst) && aligned16(src) && ((int64_t)c0 * T) % 4 == 0;
-    if (vec) hipLaunchKernelGGL(bct_to_btc_vec_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
-    else hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair);
+    const bool vec = T % 4 == 0 && T_src % 4 == 0 && count % 4 == 0 && ld_dst % 4 == 0 && aligned16(dst) && aligned16(src);
+    if (vec) hipLaunchKernelGGL(bct_to_btc_vec_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair, T_src, src_batch);
+    else hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair, T_src, src_batch);
     VRD_LAUNCH_CHECK();
     return 0;
 }

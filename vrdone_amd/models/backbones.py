@@ -78,25 +78,30 @@ class MaskConvTransformerBackbone(nn.Module):
         return 2 * self.n_visual + 2 * self.n_clip + self.n_bbox_so + 2 * self.n_bbox_entity
 
     # -------------------------------------------------------------------------------------
-    def _unpack(self, x):
+    def _unpack(self, x, frames=None, index=None):
         """Boundary layout (B, C_in, T) -> the channels-last operand buffers of cl_parts: the subject and
         object slabs of every shared-weight stage are stacked on the batch axis (2B sequences); the wide
-        visual / clip slabs feed GEMMs only, so they are pair rows in bf16x3 mode."""
+        visual / clip slabs feed GEMMs only, so they are pair rows in the split-precision modes.
+        frames / index: only the first `frames` frames of the pairs x[index] (ops.bct_to_btc)."""
         ops = _ops()
         B, _, T = x.shape
+        if index is not None:
+            B = index.numel()
+        if frames is not None:
+            T = frames
         V, Cc, S, E = self.n_visual, self.n_clip, self.n_bbox_so, self.n_bbox_entity
         pair = ops.pair_mode()
 
         def stacked(c0, width, as_pair):
             h = torch.empty(2, B, T, width, device=x.device, dtype=torch.float32)
-            ops.bct_to_btc(x, c0, width, h[0], pair=as_pair)
-            ops.bct_to_btc(x, c0 + width, width, h[1], pair=as_pair)
+            ops.bct_to_btc(x, c0, width, h[0], pair=as_pair, frames=frames, index=index)
+            ops.bct_to_btc(x, c0 + width, width, h[1], pair=as_pair, frames=frames, index=index)
             h = h.view(2 * B, T, width)
             return ops.Pair(h, width) if as_pair else h
 
         o0 = 2 * V + 2 * Cc
         so_box = torch.empty(B, T, S, device=x.device, dtype=torch.float32)
-        ops.bct_to_btc(x, o0, S, so_box)
+        ops.bct_to_btc(x, o0, S, so_box, frames=frames, index=index)
         return (stacked(0, V, pair), stacked(2 * V, Cc, pair) if Cc else None, so_box, stacked(o0 + S, E, False))
 
     @staticmethod

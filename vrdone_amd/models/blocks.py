@@ -264,7 +264,8 @@ class LocalMaskedMHCA(_ConvAttention):
         s = self.n_kv_stride
         if mask_out is None:
             mask_out = mask if s == 1 else mask[:, ::s].contiguous()
-        assert (x.shape[1] // s) % (2 * self.window_overlap) == 0      # reference blocks.py:828
+        # (the reference's sliding-chunk form needs T / s to be a multiple of 2 * window_overlap, blocks.py:828, and its callers
+        # pad for that; the banded kernel here does not: MaskVRD's tight padding runs pairs at shorter padded lengths)
         q, k, v = self._prep(x, x, x, mask_out, mask_out, stride=s, pre_ln=pre_ln)
         q, k, v = self._project(q, k, v, q_mask=mask_out, kv_mask=mask_out)
         att = ops.local_attention(q, k, v, mask_out, self.n_head, self.window_overlap, pair=ops.pair_mode(),
@@ -272,6 +273,7 @@ class LocalMaskedMHCA(_ConvAttention):
         return ops.conv_gemm(att, self.proj.weight, self.proj.bias, row_mask=mask_out, **epilogue), mask_out
 
     def forward(self, x, mask):
+        assert (x.shape[-1] // self.n_kv_stride) % (2 * self.window_overlap) == 0      # reference blocks.py:828
         y, m = self.cl(_to_cl(x), _mask2d(mask))
         return _from_cl(y), m[:, None, :]
 

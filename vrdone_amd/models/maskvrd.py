@@ -9,6 +9,7 @@ call is a validation pass on the fused inference kernels (no drop-path sampling)
 """
 import gc
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -100,6 +101,106 @@ class MaskVRD(nn.Module):
         return self.forward_training(input_data) if self.training else self.forward_test(input_data)
 
     # ------------------------------------------------------------------------------------------
+    # ---- tight padding --------------------------------------------------------------------------------------------------
+    # The reference pads every pair of a batch to one length (max_seq_len, or the longest pair of the slice rounded up:
+    # models/maskvrd.py:363-414) and computes every padded frame.  A pair's result does not depend on HOW MANY padded frames
+    # follow it, only on there being one at every pyramid level (the frame behind the last valid one is what the depthwise
+    # convs, the pools and the FPN read across the end: LayerNorm(0) = beta there, zero padding if the sequence simply
+    # ends): with `down` = the coarsest level's stride, any padded length T' with T' / down > ceil(L / down) gives the
+    # same outputs on the pair's frames (checked in float64 on the oracle: 1e-14; tests/test_oracle_golden.py).  So a
+    # pair of L frames is computed at the smallest such multiple of TIGHT_UNIT below the batch's padded length, pairs of
+    # equal T' as one batch; the outputs are laid out at the batch's padded length like the reference's.
+    tight_padding = os.environ.get("VRDONE_TIGHT_PADDING", "1") != "0"
+    TIGHT_UNIT = int(os.environ.get("VRDONE_TIGHT_UNIT", "32"))
+    # a bucket of fewer rows (2 * pairs * T') joins the next longer one: below ~4 rounds of 256 x 256 GEMM tiles the small-shape
+    # kernels take over and cost more than the padding saves (scripts/dev/tight_sweep.sh, profiles/r04_lab_tight_padding.txt:
+    # ragged U[2, 256] batch of 2048 pairs 105.7 ms without, 106.8 / 100.7 ms with buckets of >= 131 k / 262 k rows)
+    TIGHT_MIN_ROWS = int(os.environ.get("VRDONE_TIGHT_MIN_ROWS", "262144"))
+
+    def tight_len(self, L, T):
+        """The padded length a pair of L valid frames is computed at inside a batch padded to T frames."""
+        down = self.scale_factor ** self.backbone_arch[-1]
+        if not self.tight_padding or self.use_abs_pe or L >= T or T % down:
+            return T            # (absolute position rows are interpolated to the padded length: it is part of the input there)
+        need = down * (-(-L // down) + 1)
+        unit = self.TIGHT_UNIT * down // math.gcd(self.TIGHT_UNIT, down)
+        t = -(-need // unit) * unit
+        return t if t < T else T
+
+    def tight_buckets(self, lens, t_refs):
+        """Padded length per pair: tight_len of its reference length t_refs[i], then buckets of fewer than TIGHT_MIN_ROWS rows
+        hand their pairs to the next longer bucket (a longer padding gives the same result; a handful of pairs per launch
+        wave would run the small-shape kernels at a fraction of the large ones' rate).  Pairs that cannot shrink (no padded
+        frame to spare: tight_len == their reference length) stay where the reference puts them."""
+        tight = [self.tight_len(L, T) for L, T in zip(lens, t_refs)]
+        out = list(tight)
+        flexible = {}
+        rows = {}
+        for i, (t, T) in enumerate(zip(tight, t_refs)):
+            rows[t] = rows.get(t, 0) + 2 * t
+            if t < T:
+                flexible.setdefault(t, []).append(i)
+        sizes = sorted(rows)
+        for k, t in enumerate(sizes[:-1]):
+            if rows[t] < self.TIGHT_MIN_ROWS and t in flexible:
+                nxt = sizes[k + 1]
+                moved = flexible.pop(t)
+                for i in moved:
+                    out[i] = nxt
+                rows[t] -= 2 * t * len(moved)
+                rows[nxt] += 2 * nxt * len(moved)
+                flexible.setdefault(nxt, []).extend(moved)
+        return out
+
+    def _tight_plan(self, batched_masks, masks2d):
+        """[(T', pair indices (n,) int32 on the device, n)] for a batch whose masks are prefixes (t < len), or None when the
+        batch runs as it is (nothing to gain, masks with holes).  One small device-to-host copy per mask tensor (cached on it)."""
+        key = (batched_masks.data_ptr(), batched_masks._version, tuple(batched_masks.shape))
+        hit = getattr(batched_masks, "_vrd_tight_plan", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        B, T = masks2d.shape
+        lens = masks2d.sum(dim=1)
+        last = T - torch.argmax(masks2d.flip(1).to(torch.uint8), dim=1)            # index behind the last valid frame
+        host = torch.stack([lens, last]).cpu()
+        plan = None
+        if bool((host[0] == host[1]).logical_or(host[0] == 0).all()):
+            want = {}
+            for i, t2 in enumerate(self.tight_buckets(host[0].tolist(), [T] * B)):
+                want.setdefault(t2, []).append(i)
+            if not (len(want) == 1 and T in want):
+                dev = masks2d.device
+                plan = [(t2, torch.tensor(idx, dtype=torch.int32, device=dev), len(idx)) for t2, idx in sorted(want.items())]
+        batched_masks._vrd_tight_plan = (key, plan)
+        return plan
+
+    def _mask_vrd_tight(self, x, masks2d, plan, with_aux):
+        """_mask_vrd bucket by bucket (see `tight padding` above); outputs in the batch's own padded length."""
+        B, T = masks2d.shape
+        dev = x.device
+        out = None
+        fill = -10.0                                    # the predictor's value on padded frames (predictor.py:39)
+        for t2, idx, n in plan:
+            idx64 = idx.long()
+            m_all = masks2d[idx64, :t2].contiguous()
+            step = self._chunk_size(n)
+            for c0 in range(0, n, step):
+                sel, sel64 = idx[c0:c0 + step].contiguous(), idx64[c0:c0 + step]
+                m = m_all[c0:c0 + step]
+                o = self._heads(*self.backbone.cl_parts(*self.backbone._unpack(x, frames=t2, index=sel), m), with_aux)
+                if out is None:
+                    Q, K1 = o["pred_logits"].shape[1:]
+                    new = lambda: {"pred_logits": torch.empty(B, Q, K1, device=dev),                       # noqa: E731
+                                   "pred_masks": torch.full((B, Q, T), fill, device=dev)}
+                    out = new()
+                    if "aux_outputs" in o:
+                        out["aux_outputs"] = [new() for _ in o["aux_outputs"]]
+                for dst, src in [(out, o)] + list(zip(out.get("aux_outputs", []), o.get("aux_outputs", []))):
+                    dst["pred_logits"][sel64] = src["pred_logits"]
+                    dst["pred_masks"][sel64, :, :t2] = src["pred_masks"]
+        out["output_mask"] = masks2d[:, None, :]
+        return out
+
     def _mask_vrd(self, batched_inputs, batched_masks, with_aux=None):
         """(B, C_in, T) fp32, (B, 1, T) bool -> dict(pred_logits (B,Q,K+1), pred_masks (B,Q,T),
         [aux_outputs], output_mask (B,1,T)); backbone -> neck -> predictor like the reference."""
@@ -107,6 +208,10 @@ class MaskVRD(nn.Module):
             raise RuntimeError("MaskVRD._mask_vrd runs on the HIP device only; move the model and inputs to 'cuda'")
         B = batched_inputs.shape[0]
         masks2d = batched_masks.reshape(B, batched_masks.shape[-1]).contiguous()
+        if self.tight_padding and not torch.is_grad_enabled() and batched_masks.dtype == torch.bool and batched_inputs.is_contiguous():
+            plan = self._tight_plan(batched_masks, masks2d)
+            if plan is not None:
+                return self._mask_vrd_tight(batched_inputs, masks2d, plan, with_aux)
         if self.training and torch.is_grad_enabled():
             # a training step: the split-precision operands of all dense conv weights (forward and input-gradient form) in one
             # launch instead of one per weight and form (they are rebuilt after every optimiser update)
@@ -441,6 +546,8 @@ class MaskVRD(nn.Module):
             t_long = (max([lens[i] for i in sl] + [self.max_seq_len]) + d - 1) // d * d
             for i in sl:
                 t_pad[i] = self.max_seq_len if lens[i] <= self.max_seq_len else t_long
+        # (the reference's padded length of every pair; then the shortest ones that give the same results: `tight padding`)
+        t_pad = self.tight_buckets(lens, t_pad)
         return sorted(range(P), key=lambda i: (t_pad[i], lens[i], i)), t_pad
 
     def _entity_streams(self, source, ids):

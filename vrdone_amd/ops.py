@@ -366,14 +366,18 @@ def presplit_weights(weights, plans):
         setattr(w, slot, ((ptr, w._version), out, _presplit_scope if _capturing() else None))
 
 
-def bct_to_btc(x, c0, count, out, pair=False):
-    """channels [c0, c0+count) of x (B, C, T) -> out (B, T, count-wide slab)."""
-    B, Ct, T = x.shape
+def bct_to_btc(x, c0, count, out, pair=False, frames=None, index=None):
+    """channels [c0, c0+count) of x (B, C, T) -> out (B, T, count-wide slab).
+    frames: only the first `frames` of the T frames; index (n,) int32 device: out sequence i = x[index[i]] (n sequences)."""
+    Bx, Ct, Tx = x.shape
     assert x.is_contiguous() and x.dtype == torch.float32 and x.is_cuda
+    T = Tx if frames is None else frames
+    B = Bx if index is None else index.numel()
+    assert index is None or (index.dtype == torch.int32 and index.is_cuda and index.is_contiguous())
     p, rows, cols, ld = _rows(out)
-    assert rows == B * T and cols == count
+    assert rows == B * T and cols == count and T <= Tx
     fmt = _fmt(pair)
-    _hip.check(lib.vrd_bct_to_btc(x.data_ptr(), B, Ct, T, c0, count, p, ld, fmt, _stream()), "vrd_bct_to_btc")
+    _hip.check(lib.vrd_bct_to_btc(x.data_ptr(), B, Ct, T, c0, count, p, ld, fmt, Tx, _ptr(index), _stream()), "vrd_bct_to_btc")
     return Pair(out, count, fmt) if fmt else out
 
 
