@@ -518,7 +518,8 @@ def main():
                        "pairs_per_gpu": hi - lo, "pair_chunk": model.pair_chunk, "gemm_precision": main_mode,
                        "padding": f"{t_pad - args.frames} of {t_pad} rows per pair are padding; GEMM tiles, attention key tiles and "
                                   "depthwise-conv strips made of padding only are not computed (outputs identical to computing "
-                                  "them, tests/test_gpu_model.py; VRDONE_SKIP_PADDING=0 switches the GEMM part off)",
+                                  "them, tests/test_gpu_model.py; VRDONE_SKIP_PADDING=0 switches the GEMM part off); tight padding "
+                                  f"(MaskVRD.tight_len) computes these pairs at T' = {model.tight_len(args.frames, t_pad)}",
                        "parallelism": f"pair-sharded x{world}" + (" + all-gather of predictions" if use_dist else ""),
                        "world_size": dist.get_world_size() if use_dist else 1,
                        "backend": dist.get_backend() if use_dist else None},

@@ -79,8 +79,16 @@ struct BigBatch {
 // F16: operands in the scaled-f16 format (VRD_PAIR_F16) on v_mfma_f32_32x32x16_f16 -- the same bytes, instruction count and
 // cycles; the epilogue multiplies the accumulators by *w_scale
 template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
-__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, BigBatch bb) {
+__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, BigBatch bb, int stagger) {
     typedef typename vrd::SplitFmt<F16>::x8 e16x8;      // fragment of eight 16-bit elements (bf16 or f16)
+    // Phase stagger.  Every tile of a launch takes the same time, so without it all CUs reach their epilogues together and
+    // 256 x 256 KiB of stores meet an HBM that was idle a moment before.  The first workgroup of every CU (the first 256 of
+    // the grid: one per CU) starts `slot * stagger` x 1,024 cycles late, slot = its place among the 32 CUs of its XCD; the
+    // offsets then persist through the launch (a CU's next workgroup starts when its last one ends).
+    if (stagger && blockIdx.y == 0 && blockIdx.x < 256) {
+        const int n = ((blockIdx.x >> 3) & 31) * stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     if (blockIdx.y) {                                    // uniform selects, no indexed access to the arguments
         const int z = blockIdx.y;
         p.A = z == 1 ? bb.A[0] : z == 2 ? bb.A[1] : bb.A[2];
@@ -476,7 +484,11 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch&
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), BIG_LDS, "vrd_gemm(bf16x3 256x256)")) return rc;
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
     const int nwg = tiles_m * tiles_n;
-    hipLaunchKernelGGL(kern, dim3(PERSIST ? (nwg < 256 ? nwg : 256) : nwg, count), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n, bb);
+    // (measured, scripts/dev/stagger_sweep.sh, profiles/r04_lab_gemm_stagger.txt: 0 / 1 / 2 / 4 / 8 units -> 98.1-98.2 / 97.4 / 97.1 /
+    // 97.8 / 99.4 ms of this kernel per step: about 1 %, so the epilogues were not waiting for each other's stores much)
+    static const int stagger = [] { const char* e = getenv("VRD_BIG_STAGGER"); return e ? atoi(e) : 2; }();
+    hipLaunchKernelGGL(kern, dim3(PERSIST ? (nwg < 256 ? nwg : 256) : nwg, count), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n, bb,
+                       (PERSIST || nwg < 512) ? 0 : stagger);
     return 0;
 }
 
