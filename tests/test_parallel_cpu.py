@@ -85,14 +85,24 @@ def test_eval_plan_follows_the_reference_slice_rule():
     model = MaskVRD(mc, device="cpu")
     g = torch.Generator().manual_seed(3)
     lens = torch.randint(2, 260, (431,), generator=g).tolist()
-    order, t_pad = model.eval_plan(lens)
     feats = [torch.empty(1, n) for n in lens]
     step = mc["max_so_pair"]
+    model.tight_padding = False         # first the reference's own padded lengths ...
+    order, t_pad = model.eval_plan(lens)
     for s0 in range(0, len(lens), step):
         for part in O.preprocess_eval(mc, feats[s0:s0 + step]):
             if part is not None:
                 x, _, ids = part
                 assert all(t_pad[s0 + i] == x.shape[-1] for i in ids)
+    t_ref = t_pad
+    model.tight_padding = True          # ... then the tight ones: never longer than the reference's, a padded frame left at every
+    assert model.eval_plan(lens)[1] == t_ref    # (431 pairs are fewer rows than one bucket: the default policy leaves them alone)
+    model.TIGHT_MIN_ROWS = 8192
+    order, t_pad = model.eval_plan(lens)    # pyramid level unless the reference has none either, multiples of 32
+    down = 8
+    for L, t, T in zip(lens, t_pad, t_ref):
+        assert t <= T and t % 32 == 0 and (t == T or t // down > -(-L // down))
+    assert sum(t_pad) < 0.8 * sum(t_ref)
     assert sorted(order) == list(range(len(lens)))
     keys = [(t_pad[i], lens[i]) for i in order]
     assert keys == sorted(keys)

@@ -130,8 +130,9 @@ class MaskVRD(nn.Module):
     def tight_buckets(self, lens, t_refs):
         """Padded length per pair: tight_len of its reference length t_refs[i], then buckets of fewer than TIGHT_MIN_ROWS rows
         hand their pairs to the next longer bucket (a longer padding gives the same result; a handful of pairs per launch
-        wave would run the small-shape kernels at a fraction of the large ones' rate).  Pairs that cannot shrink (no padded
-        frame to spare: tight_len == their reference length) stay where the reference puts them."""
+        wave would run the small-shape kernels at a fraction of the large ones' rate) -- up to the pair's own reference length,
+        never beyond.  Pairs that cannot shrink (no padded frame to spare: tight_len == their reference length) stay where the
+        reference puts them."""
         tight = [self.tight_len(L, T) for L, T in zip(lens, t_refs)]
         out = list(tight)
         flexible = {}
@@ -144,7 +145,8 @@ class MaskVRD(nn.Module):
         for k, t in enumerate(sizes[:-1]):
             if rows[t] < self.TIGHT_MIN_ROWS and t in flexible:
                 nxt = sizes[k + 1]
-                moved = flexible.pop(t)
+                moved = [i for i in flexible[t] if t_refs[i] >= nxt]        # (never beyond the reference's own padded length)
+                flexible[t] = [i for i in flexible[t] if t_refs[i] < nxt]
                 for i in moved:
                     out[i] = nxt
                 rows[t] -= 2 * t * len(moved)
