@@ -428,6 +428,19 @@ def test_gemm_split_bf16_precision(M, N, Cin, taps, T, precision):
     close(got16.float(), ref.float(), 1e-5)
 
 
+def test_gemm_that_does_not_qualify_for_a_split_kernel_is_exact_f32(precision):
+    """K % 32 == 0 (so the call carries the weight's split operand and, in the f16 format, its scale) but rows that are not
+    16-byte aligned: vrd_gemm falls back to the exact-f32 kernel, which must ignore the split operand's accumulator factor."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    big = torch.randn(2, 40, 66, generator=gen).to(DEV)
+    x = big[..., 1:65]                                       # 64 channels, rows start 4 bytes off a 16-byte boundary
+    w, b = torch.randn(96, 64, 1, generator=gen) * 0.02, torch.randn(96, generator=gen)
+    got = ops.conv_gemm(x, w.to(DEV), b.to(DEV))
+    want = torch.nn.functional.conv1d(x.cpu().double().transpose(1, 2), w.double(), b.double()).transpose(1, 2)
+    close(got, want.float(), 2e-6)
+
+
 def test_pair_row_format_round_trip(precision):
     """Producers' pair rows decode to the f32 value within 2^-16 relative; a GEMM fed with pair rows equals the
     GEMM fed with the f32 tensor (same split, done by the producer instead of the GEMM's staging)."""

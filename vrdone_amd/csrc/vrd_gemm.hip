@@ -292,9 +292,15 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
         VRD_LAUNCH_CHECK();
         return 0;
     }
+    // exact f32 products on the unscaled W: the split operand's format and scale (the epilogue's accumulator factor) do not apply
+    // -- a call that carries W_split but does not qualify for a split kernel (K % 32, alignment) lands here
+    vrd_gemm_args f = *a;
+    f.split_fmt = 0;
+    f.w_scale = nullptr;
+    VRD_CHECK_ARG(!f.c_pair || f.c_pair == VRD_PAIR_BF16 || f.c_pair == VRD_PAIR_F16, "vrd_gemm: bad c_pair");
     int rc;
-    if (bk == 32) rc = staged ? launch_bk<32, true>(*a, vec, tiles_m, tiles_n, s) : launch_bk<32, false>(*a, vec, tiles_m, tiles_n, s);
-    else          rc = staged ? launch_bk<16, true>(*a, vec, tiles_m, tiles_n, s) : launch_bk<16, false>(*a, vec, tiles_m, tiles_n, s);
+    if (bk == 32) rc = staged ? launch_bk<32, true>(f, vec, tiles_m, tiles_n, s) : launch_bk<32, false>(f, vec, tiles_m, tiles_n, s);
+    else          rc = staged ? launch_bk<16, true>(f, vec, tiles_m, tiles_n, s) : launch_bk<16, false>(f, vec, tiles_m, tiles_n, s);
     if (rc) return rc;
     VRD_LAUNCH_CHECK();
     return 0;
