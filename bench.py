@@ -264,7 +264,7 @@ def main():
     def roofline(mode, prof):
         """Dominant kernel family of the mode: algorithmic FLOPs (2*M*N*K per launch) / HIP-event time."""
         if mode in SPLIT_MODES:    # the split-precision GEMM family that takes the most time (256x256 or 128x256 tile)
-            fam = max(("gemm_bf16x3_big", "gemm_bf16x3_dma"), key=lambda f: prof[f]["ms"])
+            fam = max(("gemm_x3_big", "gemm_x3_dma"), key=lambda f: prof[f]["ms"])
         else:
             fam = "gemm_f32_mfma"
         g = prof[fam]
@@ -296,7 +296,7 @@ def main():
     if world > 1:
         # a rank's shard is a short step of ~520 launches: recording two events around each costs ~8 % of it, so the
         # multi-GPU runs record the GEMM families only (what `roofline` needs); N = 1 records every family
-        _hip.prof_select(["gemm_f32_mfma", "gemm_bf16x3_mfma", "gemm_bf16x3_dma", "gemm_bf16x3_big"])
+        _hip.prof_select(["gemm_f32_mfma", "gemm_x3_mfma", "gemm_x3_dma", "gemm_x3_big"])
     main_mode = args.precision or ops.get_precision()
     elapsed, prof = run(main_mode, args.warmup, args.steps)
     alts = {}

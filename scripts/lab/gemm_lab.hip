@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
             float ms = 0;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0);
-                int rc = var == 14 ? vrd::launch_gemm_bf16x3_row_nw(&a, vrd::GemmBatch{}, 1, 4, 0) : var == 12 ? vrd::launch_gemm_bf16x3_row_nw(&a, vrd::GemmBatch{}, 1, 8, 0) : var == 11 ? vrd::launch_gemm_bf16x3_big(a, 0) : vrd::launch_gemm_bf16x3_dma_variant(a, 0, var);
+                int rc = var == 14 ? vrd::launch_gemm_x3_row_nw(&a, vrd::GemmBatch{}, 1, 4, 0) : var == 12 ? vrd::launch_gemm_x3_row_nw(&a, vrd::GemmBatch{}, 1, 8, 0) : var == 11 ? vrd::launch_gemm_x3_big(a, 0) : vrd::launch_gemm_x3_dma_variant(a, 0, var);
                 hipEventRecord(e1);
                 hipEventSynchronize(e1);
                 if (rc) { printf("launch failed: %s\n", vrd_last_error()); return 1; }

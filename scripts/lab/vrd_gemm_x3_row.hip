@@ -93,7 +93,7 @@ __device__ unsigned long long g_row_skipped_kn;                    // as g_big_s
 __device__ constexpr int swz(int row) { return (row >> 1) & 7; }
 
 template <int TAPS, int NWV>
-__global__ __launch_bounds__(64 * NWV, 2) void gemm_bf16x3_row_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, vrd::GemmBatch bb) {
+__global__ __launch_bounds__(64 * NWV, 2) void gemm_x3_row_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, vrd::GemmBatch bb) {
     using G = RowGeo<NWV>;
     constexpr int PER = G::PER, SLAB_OFF = G::SLAB_OFF;
     constexpr bool ALIAS = G::ALIAS;
@@ -360,12 +360,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void gemm_bf16x3_row_kernel(vrd_gemm_a
 namespace vrd {
 
 // the LDS-DMA 256 x 256 kernel's eligibility (checked by the caller), k = 1, and K % 128 == 0 (K loop unrolled by four)
-bool gemm_bf16x3_row_ok(const vrd_gemm_args& a) { return a.taps == 1 && a.Cin % 128 == 0; }
+bool gemm_x3_row_ok(const vrd_gemm_args& a) { return a.taps == 1 && a.Cin % 128 == 0; }
 
-int launch_gemm_bf16x3_row_nw(const vrd_gemm_args* a, const GemmBatch& bb, int count, int nwv, hipStream_t s);
+int launch_gemm_x3_row_nw(const vrd_gemm_args* a, const GemmBatch& bb, int count, int nwv, hipStream_t s);
 
 // `count` (1 .. 4) problems that differ only in A, W_split, bias and C, as one launch
-int launch_gemm_bf16x3_row(const vrd_gemm_args* a, int count, hipStream_t s) {
+int launch_gemm_x3_row(const vrd_gemm_args* a, int count, hipStream_t s) {
     GemmBatch bb{};
     for (int i = 1; i < count; ++i) {
         bb.A[i - 1] = a[i].A;
@@ -375,20 +375,20 @@ int launch_gemm_bf16x3_row(const vrd_gemm_args* a, int count, hipStream_t s) {
     }
     // VRD_BIG_ROW=1: 8 waves, one 256 x 256 workgroup per CU; =2: 4 waves, two 128 x 256 workgroups per CU
     static const int nwv = [] { const char* e = getenv("VRD_BIG_ROW"); return e && atoi(e) == 2 ? 4 : 8; }();
-    return launch_gemm_bf16x3_row_nw(a, bb, count, nwv, s);
+    return launch_gemm_x3_row_nw(a, bb, count, nwv, s);
 }
 
-int launch_gemm_bf16x3_row_nw(const vrd_gemm_args* a, const GemmBatch& bb, int count, int nwv, hipStream_t s) {
+int launch_gemm_x3_row_nw(const vrd_gemm_args* a, const GemmBatch& bb, int count, int nwv, hipStream_t s) {
     const int tm_rows = 32 * nwv;
     const int tiles_m = (int)((a[0].M + tm_rows - 1) / tm_rows), tiles_n = (a[0].N + rowk::TN - 1) / rowk::TN;
     const dim3 grid(tiles_m * tiles_n, count);
     // k = 1 only (a k = 3 conv keeps the LDS-DMA kernel)
     if (nwv == 4) {
-        auto kern = rowk::gemm_bf16x3_row_kernel<1, 4>;
+        auto kern = rowk::gemm_x3_row_kernel<1, 4>;
         if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), rowk::RowGeo<4>::LDS, "vrd_gemm(bf16x3 128x256 row)")) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(256), rowk::RowGeo<4>::LDS, s, a[0], tiles_m, tiles_n, bb);
     } else {
-        auto kern = rowk::gemm_bf16x3_row_kernel<1, 8>;
+        auto kern = rowk::gemm_x3_row_kernel<1, 8>;
         if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), rowk::RowGeo<8>::LDS, "vrd_gemm(bf16x3 256x256 row)")) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(512), rowk::RowGeo<8>::LDS, s, a[0], tiles_m, tiles_n, bb);
     }

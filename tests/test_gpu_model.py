@@ -352,7 +352,7 @@ def test_mask_vrd_b256_matches_reference_golden(precision):
         close(out["pred_logits"][::e], g["pred_logits"], LOGIT_TOL)
         close(out["pred_masks"][::e], g["pred_masks"], MASK_TOL)
         if not tight and precision in ("bf16x3", "f16x3"):       # the kernel this case exists for did run, and skipped padded tiles
-            assert prof["gemm_bf16x3_big"]["launches"] > 0 and prof["gemm_bf16x3_big"]["flops_skipped"] > 0
+            assert prof["gemm_x3_big"]["launches"] > 0 and prof["gemm_x3_big"]["flops_skipped"] > 0
 
 
 def test_mask_vrd_cfg2_at_size_matches_reference_golden(precision):
@@ -752,7 +752,7 @@ def test_extension_is_loaded_and_profiled():
     torch.cuda.synchronize()
     prof = _hip.prof_read()
     _hip.prof_enable(False)
-    gemm = {k: sum(prof[f][k] for f in ("gemm_f32_mfma", "gemm_bf16x3_mfma", "gemm_bf16x3_dma"))
+    gemm = {k: sum(prof[f][k] for f in ("gemm_f32_mfma", "gemm_x3_mfma", "gemm_x3_dma"))
             for k in ("launches", "ms", "flops")}
     assert gemm["launches"] > 50 and gemm["ms"] > 0 and gemm["flops"] > 1e9
     # 8 SOS self/cross attentions + the predictor's 4 x (self, cross) on the MFMA kernels; 5 banded attentions

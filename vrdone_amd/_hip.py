@@ -17,8 +17,8 @@ F16_ACT_EXP = 4                                   # VRD_F16_ACT_EXP
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
  K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_GEMM_X3_BIG, K_BACKWARD, K_COUNT) = range(15)   # enum vrd_kernel_id
 KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
-                "maxpool_mask", "mask_head", "transpose", "postprocess", "gemm_bf16x3_mfma", "gemm_bf16x3_dma",
-                "gemm_bf16x3_big", "backward"]
+                "maxpool_mask", "mask_head", "transpose", "postprocess", "gemm_x3_mfma", "gemm_x3_dma",
+                "gemm_x3_big", "backward"]
 assert len(KERNEL_NAMES) == K_COUNT
 
 c_f32p = C.c_void_p      # device pointers travel as plain integers

@@ -201,11 +201,11 @@ int launch_bk(const vrd_gemm_args& a, bool vec, int tiles_m, int tiles_n, hipStr
 }  // namespace
 
 namespace vrd {
-int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s);
-bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged);
-int launch_gemm_bf16x3_dma(const vrd_gemm_args& a, hipStream_t s);
-int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s);
-int launch_gemm_bf16x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s);
+int launch_gemm_x3(const vrd_gemm_args& a, bool staged, hipStream_t s);
+bool gemm_x3_dma_ok(const vrd_gemm_args& a, bool staged);
+int launch_gemm_x3_dma(const vrd_gemm_args& a, hipStream_t s);
+int launch_gemm_x3_big(const vrd_gemm_args& a, hipStream_t s);
+int launch_gemm_x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s);
 }  // namespace vrd
 
 namespace {
@@ -220,7 +220,7 @@ X3Choice choose_x3(const vrd_gemm_args* a, bool vec, bool staged) {
     // the 128 x 256 DMA kernel runs one workgroup per CU: below ~2 rounds of tiles the 128 x 128 kernel (two
     // workgroups per CU, four times the tiles) fills the chip better
     static const int64_t dma_min_tiles = [] { const char* e = getenv("VRD_X3_DMA_MIN_TILES"); return e ? atoll(e) : 512; }();
-    const bool dma = x3 && dma_env && vrd::gemm_bf16x3_dma_ok(*a, staged) &&
+    const bool dma = x3 && dma_env && vrd::gemm_x3_dma_ok(*a, staged) &&
                      ((a->M + 127) / 128) * ((a->N + 255) / 256) >= dma_min_tiles;
     // the 256 x 256 kernel (DMA-issue cost per MFMA a third lower) once there are about two rounds of its tiles
     static const int64_t big_min_tiles = [] { const char* e = getenv("VRD_X3_BIG_MIN_TILES"); return e ? atoll(e) : 512; }();
@@ -286,8 +286,8 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     const bool x3 = pick.x3, dma = pick.dma, big = pick.big;
     vrd::ProfScope prof(big ? VRD_K_GEMM_X3_BIG : dma ? VRD_K_GEMM_X3_DMA : (x3 ? VRD_K_GEMM_X3 : VRD_K_GEMM), s, flops, bytes);
     if (x3) {
-        int rc3 = big ? vrd::launch_gemm_bf16x3_big(*a, s)
-                      : dma ? vrd::launch_gemm_bf16x3_dma(*a, s) : vrd::launch_gemm_bf16x3(*a, staged, s);
+        int rc3 = big ? vrd::launch_gemm_x3_big(*a, s)
+                      : dma ? vrd::launch_gemm_x3_dma(*a, s) : vrd::launch_gemm_x3(*a, staged, s);
         if (rc3) return rc3;
         VRD_LAUNCH_CHECK();
         return 0;
@@ -341,7 +341,7 @@ extern "C" int vrd_gemm_batch(const vrd_gemm_args* a, int count, void* stream) {
             const double bytes = 4.0 * count * ((double)a[0].M * a[0].Cin + (double)a[0].N * K + (double)a[0].M * a[0].N *
                                                 (1.0 + (a[0].res ? 1.0 : 0.0) + (a[0].res2 ? 1.0 : 0.0)));
             vrd::ProfScope prof(VRD_K_GEMM_X3_BIG, s, flops, bytes);
-            int rc = vrd::launch_gemm_bf16x3_big_batch(a, count, s);
+            int rc = vrd::launch_gemm_x3_big_batch(a, count, s);
             if (rc) return rc;
             VRD_LAUNCH_CHECK();
             return 0;

@@ -42,7 +42,7 @@ struct X3Geo {
 };
 
 template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false, bool F16 = false>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     using G = X3Geo<SMALL>;
     typedef typename vrd::SplitFmt<F16>::elem e16;          // the 16-bit element of this instantiation (bf16 or f16)
     typedef typename vrd::SplitFmt<F16>::x8 e16x8;
@@ -232,7 +232,7 @@ namespace vrd {
 // called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
 template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false>
 static int launch_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t s) {
-    auto kern = a.split_fmt == VRD_PAIR_F16 ? gemm_bf16x3_kernel<TAPS, STAGED, APAIR, SMALL, true> : gemm_bf16x3_kernel<TAPS, STAGED, APAIR, SMALL, false>;
+    auto kern = a.split_fmt == VRD_PAIR_F16 ? gemm_x3_kernel<TAPS, STAGED, APAIR, SMALL, true> : gemm_x3_kernel<TAPS, STAGED, APAIR, SMALL, false>;
     constexpr size_t lds = X3Geo<SMALL>::LDS;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3)")) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);
@@ -248,7 +248,7 @@ static int launch_taps(const vrd_gemm_args& a, bool staged, int tiles_m, int til
 }
 
 // called by vrd_gemm() after argument validation when W_split is given and the shape qualifies
-int launch_gemm_bf16x3(const vrd_gemm_args& a, bool staged, hipStream_t s) {
+int launch_gemm_x3(const vrd_gemm_args& a, bool staged, hipStream_t s) {
     // 64 x 64 tiles while the 128 x 128 ones would not give every CU a workgroup (VRD_X3_SMALL=0: never)
     static const int small_env = [] { const char* e = getenv("VRD_X3_SMALL"); return e ? atoi(e) : 1; }();
     const int64_t tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);

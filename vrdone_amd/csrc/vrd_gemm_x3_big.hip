@@ -79,7 +79,7 @@ struct BigBatch {
 // F16: operands in the scaled-f16 format (VRD_PAIR_F16) on v_mfma_f32_32x32x16_f16 -- the same bytes, instruction count and
 // cycles; the epilogue multiplies the accumulators by *w_scale
 template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
-__global__ __launch_bounds__(512) void gemm_bf16x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, BigBatch bb, int stagger) {
+__global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, BigBatch bb, int stagger) {
     typedef typename vrd::SplitFmt<F16>::x8 e16x8;      // fragment of eight 16-bit elements (bf16 or f16)
     // Phase stagger.  Every tile of a launch takes the same time, so without it all CUs reach their epilogues together and
     // 256 x 256 KiB of stores meet an HBM that was idle a moment before.  The first workgroup of every CU (the first 256 of
@@ -480,7 +480,7 @@ namespace vrd {
 
 template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
 static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch& bb = BigBatch{}, int count = 1) {
-    auto kern = gemm_bf16x3_big_kernel<TAPS, M16, PERSIST, F16>;
+    auto kern = gemm_x3_big_kernel<TAPS, M16, PERSIST, F16>;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), BIG_LDS, "vrd_gemm(bf16x3 256x256)")) return rc;
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
     const int nwg = tiles_m * tiles_n;
@@ -493,7 +493,7 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch&
 }
 
 // `count` (2 .. 4) problems that differ only in A, W_split, bias and C, as one launch of the default kernel
-int launch_gemm_bf16x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
+int launch_gemm_x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
     BigBatch bb{};
     for (int i = 1; i < count; ++i) {
         bb.A[i - 1] = a[i].A;
@@ -516,7 +516,7 @@ double take_big_skipped_flops() {
 }
 
 // same eligibility as the 128 x 256 DMA kernel (pair-row A, staged epilogue); the caller picks by tile count
-int launch_gemm_bf16x3_big(const vrd_gemm_args& a, hipStream_t s) {
+int launch_gemm_x3_big(const vrd_gemm_args& a, hipStream_t s) {
     // MFMA shape: 32x32x16 (default) or 16x16x32 (VRD_BIG_M16=1).  Same fragments, LDS traffic and MFMA cycles per K
     // step; interleaved A/B runs in one process put 16x16x32 0.5-1 % ahead on the whole step, but it sums the K
     // dimension in a different order than the 32x32x16 kernels that serve small batches, and the path keeps its

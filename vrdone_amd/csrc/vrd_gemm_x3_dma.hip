@@ -91,7 +91,7 @@ __device__ unsigned long long g_lab_phase[16 * 4096];   // [wg][group][5 phase a
 #endif
 
 template <int TAPS, int DBK, int DBM, int NSTG, bool PP, bool BLK, bool F16 = false>
-__global__ __launch_bounds__(512) void gemm_bf16x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void gemm_x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
     typedef typename vrd::SplitFmt<F16>::x8 bf16x8;      // fragment of eight 16-bit elements: bf16, or f16 (VRD_PAIR_F16)
     using G = Geo<DBK, DBM, NSTG, BLK>;
     constexpr int NJ = G::NJ;
@@ -385,7 +385,7 @@ namespace vrd {
 
 template <int TAPS, int DBK, int DBM, int NSTG, bool PP = false, bool BLK = false, bool F16 = false>
 static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
-    auto kern = gemm_bf16x3_dma_kernel<TAPS, DBK, DBM, NSTG, PP, BLK, F16>;
+    auto kern = gemm_x3_dma_kernel<TAPS, DBK, DBM, NSTG, PP, BLK, F16>;
     constexpr size_t lds = Geo<DBK, DBM, NSTG, BLK>::LDS;
     static_assert(lds >= 8 * 16384 && lds <= 160 * 1024, "ring must hold the epilogue slabs and fit the CU");
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3 dma)")) return rc;
@@ -397,7 +397,7 @@ static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
 #ifdef VRD_LAB_STAMP
 template <int TAPS, bool BLK, int NPROD, int NCONS = 8>
 static int launch_ws_one(const vrd_gemm_args& a, hipStream_t s) {
-    auto kern = gemm_bf16x3_ws_kernel<TAPS, BLK, NPROD, NCONS>;
+    auto kern = gemm_x3_ws_kernel<TAPS, BLK, NPROD, NCONS>;
     constexpr size_t lds = Geo<32, 128, 3, BLK>::LDS;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3 dma)")) return rc;
     const int tiles_m = (int)((a.M + 127) / 128), tiles_n = (a.N + DBN - 1) / DBN;
@@ -408,17 +408,17 @@ static int launch_ws_one(const vrd_gemm_args& a, hipStream_t s) {
 #endif
 
 // eligibility: pair-row A whose slab width and Cin are multiples of 32, 16-byte aligned output rows
-bool gemm_bf16x3_dma_ok(const vrd_gemm_args& a, bool staged) {
+bool gemm_x3_dma_ok(const vrd_gemm_args& a, bool staged) {
     return staged && a.a_pair_width > 0 && a.N >= 192;
 }
 
-int launch_gemm_bf16x3_dma_variant(const vrd_gemm_args& a, hipStream_t s, int var);
+int launch_gemm_x3_dma_variant(const vrd_gemm_args& a, hipStream_t s, int var);
 
 // The library builds schedule 0 only; the study variants are instantiated by the lab harness
 // (scripts/lab/gemm_lab.hip defines VRD_LAB_STAMP), which is where they were measured.
-int launch_gemm_bf16x3_dma(const vrd_gemm_args& a, hipStream_t s) { return launch_gemm_bf16x3_dma_variant(a, s, 0); }
+int launch_gemm_x3_dma(const vrd_gemm_args& a, hipStream_t s) { return launch_gemm_x3_dma_variant(a, s, 0); }
 
-int launch_gemm_bf16x3_dma_variant(const vrd_gemm_args& a, hipStream_t s, int var) {
+int launch_gemm_x3_dma_variant(const vrd_gemm_args& a, hipStream_t s, int var) {
     // schedules of the 128 x 256 x 32 tile (all measured at 2,700-3,000 cycles per K step: DMA-issue-bound):
     //   0: every MFMA wave issues its share of a stage's DMA (8 waves)
     //   3: the same with the ping-pong schedule (two wave groups one barrier phase apart)
