@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 25
+#define VRD_ABI_VERSION 26
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -402,6 +402,21 @@ int vrd_attn_bwd_probs(const float* q, int64_t ldq, const float* k, const float*
  * two vrd_bmm products (both (B, n_head, Tq, Tk)), turn them in place into P = softmax_j(P | kv_mask) (masked keys: 0) and
  * dS = P * (dS - sum_j P dS).  Tk <= 1024. */
 int vrd_attn_bwd_softmax(float* P, float* dS, const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, void* stream);
+
+/* Global attention backward without the (B, n_head, Tq, Tk) matrices (round 4): dq, dk, dv from the forward's inputs, its output
+ * `out` and dO, the scores recomputed tile by tile in the bf16 split of the other backward GEMMs (two kernels: dq -- which also
+ * leaves every query's log-sum-exp and sum_d dO O in `scratch` -- then dk / dv).  head_dim 64; q / out / dO / dq rows of
+ * leading dimension ldq / ldo / ldo / ldq, k / v / dk / dv of ldkv; scratch: 2 * B * n_head * Tq floats.  The five-product form
+ * above stays for other head sizes and for the exact-f32 mode. */
+int vrd_attention_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* out, const float* dO,
+                      int64_t ldo, const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim, float* dq, float* dk,
+                      float* dv, const float* lse /* (B, n_head, Tq) from vrd_attention_rows, or NULL: recomputed */, float* scratch,
+                      void* stream);
+/* The forward of that pair for a training step: vrd_attention on f32 rows in split precision (fmt: VRD_PAIR_BF16 / VRD_PAIR_F16 --
+ * the operands are split while they are staged, no pair rows), f32 rows out, plus every query's log-sum-exp of the scaled
+ * scores, lse (B, n_head, Tq), which the backward then does not recompute.  head_dim 64. */
+int vrd_attention_rows(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, int B, int Tq,
+                       int Tk, int n_head, int head_dim, int fmt, float* out, int64_t ldo, float* lse, void* stream);
 
 /* Strided batched matmul, f32: C[z][i][n] (= or +=) alpha * sum_k A[z][i][k] * B[z][k][n], z = (z0 < Z0, z1 < Z1); every
  * operand is addressed by (stride of z0, stride of z1, stride of its row index, stride of its column index) in floats.

@@ -291,6 +291,46 @@ def test_global_attention_backward(n_head, C, Tq, Tk, masked):
         rel_close(a, cl(r), 2e-5, name)
 
 
+@pytest.mark.parametrize("n_head,C,Tq,Tk,masked", [(8, 512, 96, 96, True), (8, 512, 40, 77, True), (4, 256, 130, 64, False),
+                                                   (8, 512, 288, 512, True)])
+def test_global_attention_backward_fused(n_head, C, Tq, Tk, masked, precision):
+    """vrd_attention_bwd (head_dim 64, the split modes' backward): dq, dk, dv against float64 autograd of the oracle's attention,
+    key masks with a short and a nearly empty sequence, partial last tiles on both axes, and against the five-product form."""
+    from vrdone_amd import autograd, ops
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    B = 3
+    km = mask_for(B, Tk, [Tk, max(Tk // 2 + 3, 1), 2]) if masked else None
+    q, dO = torch.randn(B, C, Tq, generator=g), torch.randn(B, C, Tq, generator=g)
+    k, v = torch.randn(B, C, Tk, generator=g), torch.randn(B, C, Tk, generator=g)
+    qr, kr, vr = ref64(q), ref64(k), ref64(v)
+    mk = km[:, None] if masked else torch.ones(B, 1, Tk, dtype=torch.bool)
+    outr = O.full_attention(qr, kr, vr, mk, n_head)
+    outr.backward(dO.double())
+
+    def run():
+        qd, kd, vd = leaf(cl(q)), leaf(cl(k)), leaf(cl(v))
+        with torch.enable_grad():
+            out = ops.attention(qd, kd, vd, km.to(DEV) if masked else None, n_head)
+        out.backward(cl(dO).to(DEV))
+        return qd.grad, kd.grad, vd.grad, out.detach()
+    got = run()
+    fused = precision != "f32"
+    tol = 1e-4 if fused else 2e-5          # bf16-split products (2^-17 each, five in a chain) against exact f32 ones
+    for name, a, r in zip(("dq", "dk", "dv"), got, (qr.grad, kr.grad, vr.grad)):
+        rel_close(a, cl(r), tol, name)
+    # the forward of the pair (vrd_attention_rows in the split modes): f16 planes are held to the f32 kernels' bound
+    rel_close(got[3], cl(outr), 1e-4 if precision == "bf16x3" else 2e-5, "out")
+    if fused:
+        try:
+            autograd.FUSED_ATTN_BWD = False
+            old = run()
+        finally:
+            autograd.FUSED_ATTN_BWD = True
+        for name, a, r in zip(("dq", "dk", "dv", "out"), got, old):
+            rel_close(a, r, 1e-4, name + " vs five-product form")
+        assert not bool(got[1][2, 2:].any()) and not bool(got[2][2, 2:].any()) if masked else True       # masked keys: zero dk / dv
+
+
 def test_maxpool_and_mask_head_backward():
     from vrdone_amd import ops
     g = torch.Generator().manual_seed(3)

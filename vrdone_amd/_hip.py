@@ -157,6 +157,10 @@ _SIGNATURES = {
     "vrd_attn_bwd_probs": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p]),
     "vrd_bmm": (C.c_int, [C.POINTER(BmmArgs), C.c_void_p]),
+    "vrd_attention_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "vrd_attention_rows": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "vrd_assign": (C.c_int, [c_f32p, C.c_int64, c_i32p, c_i32p, C.c_int, C.c_int, c_i32p, C.c_void_p]),
     "vrd_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_i32p, c_i32p, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "vrd_attn_bwd_softmax": (C.c_int, [c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -167,7 +171,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 
 class HipLibraryError(RuntimeError):

@@ -85,6 +85,9 @@ def bmm(A, a_strides, B, b_strides, Cmat, c_strides, Z0, Z1, M, N, K, alpha=1.0,
     return Cmat
 
 
+FUSED_ATTN_BWD = os.environ.get("VRDONE_FUSED_ATTN_BWD", "1") != "0"      # A/B switch: 0 = the five-product form everywhere
+
+
 # ------------------------------------------------------------------------------------------------------ Functions
 class _ZeroArena:
     """Zero-initialised accumulators for the gradient kernels (weight / bias / LayerNorm / scale gradients are summed with
@@ -343,19 +346,40 @@ class Attention(Function):
 
     @staticmethod
     def forward(ctx, q, k, v, kv_mask, n_head):
-        out = ops.attention(q, k, v, kv_mask, n_head)
-        ctx.save_for_backward(q, k, v)
-        ctx.kv_mask, ctx.n_head = kv_mask, n_head
+        B, Tq, Cc = q.shape
+        Tk = k.shape[1]
+        lse = None
+        if (FUSED_ATTN_BWD and ops.split_backward() and Cc // n_head == 64 and Tq >= 32 and Tk >= 32 and
+                q.is_contiguous() and k.is_contiguous() and v.is_contiguous()):
+            # the split-precision flash forward on f32 rows (operands split while they are staged), which keeps every query's
+            # log-sum-exp for the backward
+            out = torch.empty_like(q)
+            lse = torch.empty(B, n_head, Tq, device=q.device, dtype=torch.float32)
+            check(lib.vrd_attention_rows(q.data_ptr(), Cc, k.data_ptr(), v.data_ptr(), Cc, _mask_ptr(kv_mask, B * Tk), B, Tq, Tk, n_head,
+                                         Cc // n_head, ops.pair_fmt(), out.data_ptr(), Cc, lse.data_ptr(), _stream()), "vrd_attention_rows")
+        else:
+            out = ops.attention(q, k, v, kv_mask, n_head)
+        ctx.save_for_backward(q, k, v, out)
+        ctx.kv_mask, ctx.n_head, ctx.lse = kv_mask, n_head, lse
         return out
 
     @staticmethod
     def backward(ctx, dO):
-        q, k, v = (t.contiguous() for t in ctx.saved_tensors)
+        q, k, v, out = (t.contiguous() for t in ctx.saved_tensors)
         dO = dO.contiguous()
         B, Tq, Cc = q.shape
         Tk, H = k.shape[1], ctx.n_head
         hd = Cc // H
         dev = q.device
+        if FUSED_ATTN_BWD and ops.split_backward() and hd == 64 and Tq >= 32 and Tk >= 32:
+            # flash style (vrd_attention_bwd): the scores are recomputed tile by tile in the bf16 split of the other backward
+            # GEMMs; no (B, H, Tq, Tk) matrix exists
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            scratch = torch.empty(2, B, H, Tq, device=dev, dtype=torch.float32)
+            check(lib.vrd_attention_bwd(q.data_ptr(), Cc, k.data_ptr(), v.data_ptr(), Cc, out.data_ptr(), dO.data_ptr(), Cc,
+                                        _mask_ptr(ctx.kv_mask, B * Tk), B, Tq, Tk, H, hd, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                        _ptr(ctx.lse), scratch.data_ptr(), _stream()), "vrd_attention_bwd")
+            return dq, dk, dv, None, None
         P = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)
         dS = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)
         scale = hd ** -0.5
