@@ -253,6 +253,70 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const float* __restrict
     }
 }
 
+// The same for a handful of queries over a short key row (the predictor's decoder under vidor*.yaml: 10 queries, 8 heads of 32,
+// 64 keys; round 4): ONE workgroup per (b, head) stages K and V of the head in LDS once and its four waves take the queries in
+// turn -- the kernel above re-read K and V from global memory for every query (ceil(Tq / 4) workgroups per head, a dependent chain
+// of Tk strided loads per output element): 1.4 ms per call at 4096 pairs against ~0.2 ms.  Tk * (2 hd + 1) floats of LDS.
+constexpr int SL_MAX_FLOATS = 12 * 1024;       // K (pitch hd + 1) | V | 4 query rows | 4 score rows within 48 KiB
+
+__global__ __launch_bounds__(256) void attn_small_lds_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                             const float* __restrict__ v, int64_t ldkv,
+                                                             const uint8_t* __restrict__ kv_mask, int Tq, int Tk, int hd, float scale,
+                                                             float* __restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    const int kp = hd + 1;                                   // K row pitch: lanes read different rows at the same d
+    float* const ks = sl;
+    float* const vs = ks + Tk * kp;
+    float* const qs = vs + Tk * hd;                          // [4][hd]
+    float* const ps = qs + 4 * SM_MAX_HD;                    // [4][Tk]
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float* kb = k + (int64_t)b * Tk * ldkv + h * hd;
+    const float* vb = v + (int64_t)b * Tk * ldkv + h * hd;
+    const int hq = hd >> 2;
+    for (int i = threadIdx.x; i < Tk * hq; i += 256) {
+        const int j = i / hq, d = (i - j * hq) * 4;
+        const bool ok = !kv_mask || kv_mask[(int64_t)b * Tk + j];
+        const float4 kk = ok ? ld4(kb + (int64_t)j * ldkv + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 vv = ok ? ld4(vb + (int64_t)j * ldkv + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ks[j * kp + d] = kk.x, ks[j * kp + d + 1] = kk.y, ks[j * kp + d + 2] = kk.z, ks[j * kp + d + 3] = kk.w;
+        st4(vs + j * hd + d, vv);
+    }
+    __syncthreads();
+    for (int tq = wave; tq < Tq; tq += 4) {
+        const float* qr = q + ((int64_t)b * Tq + tq) * ldq + h * hd;
+        for (int d = lane; d < hd; d += 64) qs[wave * SM_MAX_HD + d] = qr[d] * scale;
+        __builtin_amdgcn_wave_barrier();
+        float m = -INFINITY;
+        for (int j = lane; j < Tk; j += 64) {
+            float sc = -INFINITY;
+            if (!kv_mask || kv_mask[(int64_t)b * Tk + j]) {
+                sc = 0.f;
+                for (int d = 0; d < hd; ++d) sc += qs[wave * SM_MAX_HD + d] * ks[j * kp + d];      // same order of terms as the kernel above
+            }
+            ps[wave * Tk + j] = sc;
+            m = fmaxf(m, sc);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float den = 0.f;
+        for (int j = lane; j < Tk; j += 64) {
+            const float e = __expf(ps[wave * Tk + j] - m);
+            ps[wave * Tk + j] = e;
+            den += e;
+        }
+        den = vrd::wave_sum(den);
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.0f / den;
+        for (int d = lane; d < hd; d += 64) {
+            float acc = 0.f;
+            for (int j = 0; j < Tk; ++j) acc += ps[wave * Tk + j] * vs[j * hd + d];
+            out[((int64_t)b * Tq + tq) * ldo + h * hd + d] = acc * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // flash attention on v_mfma_f32_32x32x2_f32.
 //
@@ -508,10 +572,17 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
     if (algo == 1) {
         VRD_CHECK_ARG(Tk <= SM_MAX_TK, "vrd_attention: generic kernel supports Tk <= %d", SM_MAX_TK);
         vrd::ProfScope prof(VRD_K_ATTN_SMALL, s, flops, bytes);
-        int gx = (Tq + 3) / 4;
-        if (gx > 64) gx = 64;
-        hipLaunchKernelGGL(attn_small_kernel, dim3(gx, n_head, B), dim3(256), 0, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk,
-                           head_dim, scale, out, ldo);
+        const int lds_floats = Tk * (2 * head_dim + 1) + 4 * SM_MAX_HD + 4 * Tk;
+        if (Tq <= 16 && lds_floats <= SL_MAX_FLOATS) {
+            // a few queries over a short key row: K / V of a head staged in LDS once per (b, head)
+            hipLaunchKernelGGL(attn_small_lds_kernel, dim3(n_head, B), dim3(256), (size_t)lds_floats * sizeof(float), s, q, ldq, k, v, ldkv,
+                               kv_mask, Tq, Tk, head_dim, scale, out, ldo);
+        } else {
+            int gx = (Tq + 3) / 4;
+            if (gx > 64) gx = 64;
+            hipLaunchKernelGGL(attn_small_kernel, dim3(gx, n_head, B), dim3(256), 0, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk,
+                               head_dim, scale, out, ldo);
+        }
     } else {
         vrd::ProfScope prof(VRD_K_ATTN_FLASH, s, flops, bytes);
         const int tiles = (Tq + 31) / 32;
