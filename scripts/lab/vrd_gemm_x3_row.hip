@@ -53,6 +53,16 @@
 #include <cstdlib>
 #include <type_traits>
 
+// (lab) operands of problems 1 .. 3 of a batched launch; the product's batched kernel carries its own BigBatch
+namespace vrd {
+struct GemmBatch {
+    const float* A[3];
+    const uint16_t* W_split[3];
+    const float* bias[3];
+    float* C[3];
+};
+}  // namespace vrd
+
 #ifndef LAB_STAMP           // the lab harness (scripts/lab/gemm_lab.hip) defines these through vrd_gemm_x3_big.hip
 #define LAB_STAMP(slot)
 #define LAB_REAL(slot)

@@ -183,6 +183,10 @@ def _load():
         raise HipLibraryError(
             f"{LIB_PATH} is missing: the HIP extension was not built "
             "(run `make -C vrdone_amd/csrc`); there is no CPU fallback for this path")
+    # PyTorch ships its own libamdhip64.so: it has to be in the process first, so that the library binds to that runtime.
+    # Loaded the other way round, the process holds two HIP runtimes and the library's launches fail on torch's memory
+    # ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)        # AttributeError if the symbol is not exported

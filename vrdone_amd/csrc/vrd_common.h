@@ -24,15 +24,6 @@ struct ProfScope {
     ~ProfScope();
 };
 
-// operands of problems 1 .. 3 of a batched 256 x 256 GEMM launch (blockIdx.y; problem 0 is the argument struct itself): GEMMs
-// that differ only in A, the weights, the bias and C -- the q / k / v projections of one attention block -- run as one grid
-struct GemmBatch {
-    const float* A[3];
-    const uint16_t* W_split[3];
-    const float* bias[3];
-    float* C[3];
-};
-
 #define VRD_CHECK_ARG(cond, ...)                      \
     do {                                              \
         if (!(cond)) {                                \
