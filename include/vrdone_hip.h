@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 26
+#define VRD_ABI_VERSION 27
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -334,9 +334,14 @@ int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, con
 /* The same gradient in the split precision of the forward path (bf16x3 mode): every product as g_lo x_hi + g_hi x_lo + g_hi x_hi
  * on v_mfma_f32_32x32x16_bf16, f32 accumulate (~2^-17 relative product error, ~5x the rate of the exact-f32 MFMA).  Same
  * arguments and accumulation rules as vrd_gemm_wgrad; dbias (nullable, N floats) additionally receives the bias gradient
- * dbias[n] += sum_r G[r, n] * row_mask[r] in the same pass (exact f32 sums). */
+ * dbias[n] += sum_r G[r, n] * row_mask[r] in the same pass (exact f32 sums).
+ * The rows are cut into chunks that fill the chip, one workgroup per (chunk, 128 x 128 tile of dW).  `scratch` (nullable; 16-byte
+ * aligned, `scratch_floats` floats, never read before it is written) takes the chunks' partial tiles, which a second launch sums
+ * into dW in chunk order: 4 * CUs * 16,384 + N * taps * Cin floats always suffice.  Without it, or when it is too small, the
+ * partial tiles are added to dW with float atomics (slower: L2 retires about one float atomic per clock and channel; and the
+ * order of the additions then varies from run to run). */
 int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
-                      int taps, int T, float* dW, float* dbias, void* stream);
+                      int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, void* stream);
 
 /* out[c] += sum_r a[r, c] * (b ? b[brow(r), c * b_cstride + b_coffset] : 1) * (row_mask ? row_mask[r] : 1) * (row_scale ?
  * row_scale[r] : 1), brow(r = s*T + t) = s * (b_rstride*T) + b_rstride*t + shift when that stays inside the sequence
@@ -366,9 +371,12 @@ int vrd_activation(const float* x, int64_t ldx, const float* dy, int64_t lddy, i
             void* stream);
 
 /* Channel LayerNorm backward (models/blocks.py:143-158 under autograd), C in {256, 512}; with relu != 0 the forward was
- * ReLU(LN(x)).  dx written; dgamma / dbeta (C floats each) accumulated. */
+ * ReLU(LN(x)).  dx written; dgamma / dbeta (C floats each) accumulated.  `scratch` (nullable, 16-byte aligned;
+ * ceil(rows / 32) * 2 C floats always suffice, ~520 * 2 C up to 131,072 rows) takes the workgroups' partial column sums, which a second launch adds up; without it every workgroup
+ * ends in one float atomic per channel, and atomics on one address are retired one after the other. */
 int vrd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int C, const float* gamma,
-                      const float* beta, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream);
+                      const float* beta, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
+                      int64_t scratch_floats, void* stream);
 
 /* Input gradient of the depthwise convolution of vrd_dwconv_ln (without its LayerNorms: in a training step those run as
  * separate vrd_layernorm calls): dD[o] = gradient w.r.t. the masked conv output of set o, (B*Tin/stride, C) rows;

@@ -1,5 +1,5 @@
 # vidor.yaml training step (48 pairs x 512 frames) with the fused attention backward on / off
-for f in 1 0 1 0; do
+for f in ${FLAGS:-1 0 1 0}; do
 VRDONE_FUSED_ATTN_BWD=$f python - <<PY
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "scripts"))

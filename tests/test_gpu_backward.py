@@ -108,6 +108,42 @@ def test_linear_weight_gradient_over_many_row_chunks(k, Cin, N, B, T, precision)
     rel_close(xd.grad, cl(xr.grad), tol(precision), "dx")
 
 
+@pytest.mark.parametrize("M,N,Cin,k,T", [(24576, 512, 512, 1, 512), (3000, 133, 63, 1, 100), (4096, 96, 40, 3, 64), (640, 2048, 512, 1, 64)])
+def test_weight_gradient_through_partial_tiles(M, N, Cin, k, T):
+    """vrd_gemm_wgrad_x3 with a scratch buffer (the row chunks' partial tiles stored, then summed in chunk order by a second
+    launch) against the same call without one (float atomics) and against float64; with the buffer the result is the same bits
+    from run to run, it accumulates into dW like the atomics do, and a buffer that is too small falls back to the atomics."""
+    from vrdone_amd import _hip
+    g = torch.Generator().manual_seed(M + N)
+    G, X = torch.randn(M, N, generator=g), torch.randn(M, Cin, generator=g)
+    mask = (torch.rand(M, generator=g) < 0.8).to(torch.uint8)
+    Gd, Xd, md = G.to(DEV), X.to(DEV), mask.to(DEV)
+    part = torch.full((4 * 256 * 16384 + N * k * Cin + 8,), float("nan"), device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(scratch, floats):
+        dW = torch.ones(N, k * Cin, device=DEV)
+        db = torch.zeros(N, device=DEV)
+        _hip.check(_hip.lib.vrd_gemm_wgrad_x3(Gd.data_ptr(), N, Xd.data_ptr(), Cin, md.data_ptr(), M, N, Cin, k, T, dW.data_ptr(),
+                                              db.data_ptr(), scratch, floats, stream), "vrd_gemm_wgrad_x3")
+        return dW, db
+
+    a, ba = run(None, 0)
+    b, bb = run(part.data_ptr(), part.numel())
+    b2, _ = run(part.data_ptr(), part.numel())
+    c, _ = run(part.data_ptr(), 1000)                       # too small: atomics
+    Gm = (G * mask[:, None]).double()
+    Xs = X.double().view(M // T, T, Cin)
+    taps = [torch.nn.functional.pad(Xs, (0, 0, 1, 1))[:, t:t + T].reshape(M, Cin) for t in range(3)] if k == 3 else [X.double()]
+    want = torch.cat([Gm.t() @ xt for xt in taps], 1) + 1.0
+    rel_close(b, want, 2e-4, "dW (partial tiles)")
+    rel_close(a, want, 2e-4, "dW (atomics)")
+    rel_close(c, want, 2e-4, "dW (scratch too small)")
+    rel_close(bb, Gm.sum(0), 2e-5, "db")
+    assert torch.equal(b, b2), "the chunk-ordered sum is not reproducible"
+    assert float((a - b).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
 def test_conv_gemm_epilogue_backward(precision):
     """GELU + mask + AffineDropPath scale + per-sample keep factors + masked residual + second residual."""
     from vrdone_amd import ops
@@ -137,11 +173,12 @@ def test_conv_gemm_epilogue_backward(precision):
 
 
 # ---------------------------------------------------------------------------------------------------------- LayerNorm
-@pytest.mark.parametrize("C,relu,post", [(512, False, False), (256, True, False), (256, False, True)])
-def test_layernorm_backward(C, relu, post):
+@pytest.mark.parametrize("C,relu,post,B,T", [(512, False, False, 5, 9), (256, True, False, 5, 9), (256, False, True, 5, 9),
+                                             (512, True, False, 37, 71), (256, False, False, 64, 96)])
+def test_layernorm_backward(C, relu, post, B, T):
+    """(the last two: enough rows for the two-step column sums -- per-workgroup partial sums, then their reduction)"""
     from vrdone_amd import ops
     g = torch.Generator().manual_seed(C + relu)
-    B, T = 5, 9
     x = torch.randn(B, C, T, generator=g) * 2 + 0.3
     gamma = 1 + 0.1 * torch.randn(1, C, 1, generator=g)
     beta = 0.1 * torch.randn(1, C, 1, generator=g)

@@ -141,7 +141,7 @@ _SIGNATURES = {
     "vrd_gemm_wgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                  c_f32p, C.c_void_p]),
     "vrd_gemm_wgrad_x3": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                                    c_f32p, c_f32p, C.c_void_p]),
+                                    c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_dwconv_wgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, c_u8p, C.c_int64,
                                    C.c_int, c_f32p, c_f32p, C.c_void_p]),
     "vrd_colsum": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p,
@@ -150,7 +150,7 @@ _SIGNATURES = {
                                    c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_activation": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_layernorm_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p,
-                                    C.c_int64, c_f32p, c_f32p, C.c_void_p]),
+                                    C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_dwconv_bwd": (C.c_int, [C.POINTER(DwconvBwdArgs), C.c_void_p]),
     "vrd_local_attn_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, c_f32p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
@@ -171,7 +171,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 
 class HipLibraryError(RuntimeError):

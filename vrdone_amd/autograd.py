@@ -127,6 +127,23 @@ def _zeros(*shape, device):
     return _arena.take(n, torch.device(device)).view(*shape)
 
 
+_partial_scratch = {}
+_LN_PARTIALS = os.environ.get("VRD_LN_PARTIALS", "1") != "0"      # A/B switch (lab)
+
+
+def _partials(device):
+    """The buffer the gradient kernels park their workgroups' partial sums in before a second launch adds them up
+    (vrd_gemm_wgrad_x3: the row chunks' partial tiles, include/vrdone_hip.h: 4 * CUs * 16,384 + N * K floats
+    suffice; sized for weights of up to 4 M elements, beyond that the kernel falls back to atomics).  One per device, and one
+    more for launches recorded into a graph (that one lives in the graph's pool); only ever live between two adjacent launches."""
+    key = (torch.device(device), torch.cuda.is_current_stream_capturing())
+    buf = _partial_scratch.get(key)
+    if buf is None:
+        cus = torch.cuda.get_device_properties(key[0]).multi_processor_count
+        buf = _partial_scratch[key] = torch.empty(4 * cus * 16384 + (4 << 20), device=key[0], dtype=torch.float32)
+    return buf
+
+
 class Linear(Function):
     """y = Conv1d(x; W (N, Cin, k), b) * row_mask, k in {1, 3}, on channels-last rows (vrd_gemm without epilogue terms)."""
 
@@ -175,8 +192,10 @@ class Linear(Function):
                 # split-precision (bf16) products like the bf16x3 mode's forward GEMMs; the bias gradient (exact f32 column sums) in the same pass
                 if want_db:
                     db = _zeros(N, device=dy.device)
+                part = _partials(dy.device)
                 check(lib.vrd_gemm_wgrad_x3(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(),
-                                            db.data_ptr() if want_db else None, _stream()), "vrd_gemm_wgrad_x3")
+                                            db.data_ptr() if want_db else None, part.data_ptr(), part.numel(), _stream()),
+                      "vrd_gemm_wgrad_x3")
                 want_db = False
             else:            # exact f32 products
                 check(lib.vrd_gemm_wgrad(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(), _stream()),
@@ -249,8 +268,10 @@ class LayerNormFn(Function):
         pdx, _, _, lddx = _rows(dx)
         dg = _zeros(cols, device=x.device)
         db = _zeros(cols, device=x.device)
+        part = _partials(dy.device) if _LN_PARTIALS else torch.empty(0, device=dy.device)
         check(lib.vrd_layernorm_bwd(px, ldx, pd, ldd, rows, cols, gamma.data_ptr(), beta.data_ptr(), 1 if ctx.relu else 0,
-                                    pdx, lddx, dg.data_ptr(), db.data_ptr(), _stream()), "vrd_layernorm_bwd")
+                                    pdx, lddx, dg.data_ptr(), db.data_ptr(), part.data_ptr(), part.numel(), _stream()),
+              "vrd_layernorm_bwd")
         dpost = None
         if ctx.period is not None and ctx.needs_input_grad[4]:
             # y[r] += post_add[r % period]: sum dy over the rows of each residue = column sums of the (rows/period, period*C) view

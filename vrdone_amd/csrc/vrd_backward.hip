@@ -294,120 +294,170 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------------------------------------
 // The split-precision weight gradient with operand reuse: the wave-per-tile kernel above moves 8 KiB from L2 per twelve
-// MFMAs (16 FLOP per byte: measured 150 TFLOP/s, the rate of its L2 traffic).  Here a block owns a 128 x 128 tile of dW for a
-// chunk of rows; per step of 32 rows its 256 threads load the 32 x 128 slabs of G and X once (four float4 each), split them
+// MFMAs (16 FLOP per byte: measured 150 TFLOP/s, the rate of its L2 traffic).  Here a block owns a TILE x TILE tile of dW for
+// a chunk of rows; per step of 32 rows its threads load the 32 x TILE slabs of G and X once (four float4 each), split them
 // into bf16 hi / lo and write four row-major planes into LDS (two stages, one barrier per step); each wave then forms its
-// 64 x 64 sub-tile, taking the transposed fragments the MFMA wants -- eight consecutive ROWS of one column per lane --
-// with ds_read_b64_tr_b16 (the read the attention kernels use for V^T; 16-byte chunks swizzled by row & 3).  64 FLOP per
-// byte of L2 traffic.  float4 loads when N, Cin, ldg, ldx are multiples of 4 and the operands 16-byte aligned (a group of four
-// columns then never straddles a tap), guarded scalar loads otherwise; the wave kernel above serves inputs of fewer than 256 rows.
+// 64 x SJ sub-tile, taking the transposed fragments the MFMA wants -- eight consecutive ROWS of one column per lane --
+// with ds_read_b64_tr_b16 (the read the attention kernels use for V^T; 16-byte chunks swizzled by row & 3).
+//   BIG = 0: TILE 128, 4 waves x (64 x 64), two blocks per CU -- every input of >= 256 rows
+//   BIG = 1: TILE 256, 8 waves x (64 x 128), one block per CU -- inputs with enough rows per chunk.  The kernel is bound by
+//            its vector instructions, not by its MFMAs: the split costs ~3 instructions per element and wave, ~150 per wave
+//            and step whatever the tile, against 24 MFMAs per wave and step at TILE 128 and 48 at TILE 256.
+// float4 loads when N, Cin, ldg, ldx are multiples of 4 and the operands 16-byte aligned (a group of four columns then never
+// straddles a tap), scalar loads otherwise; the wave kernel above serves inputs of fewer than 256 rows.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int WL_ROWS = 32;                 // rows per step
-constexpr int WL_ROWB = 256;                // bytes per plane row: 128 bf16
-constexpr int WL_PLANE = WL_ROWS * WL_ROWB; // 8 KiB
-constexpr int WL_STAGE = 4 * WL_PLANE;      // g_hi | g_lo | x_hi | x_lo
+
+template <int BIG>
+struct WlGeo {
+    static constexpr int TILE = BIG ? 256 : 128;
+    static constexpr int NTHR = BIG ? 512 : 256;
+    static constexpr int CGS = TILE / 4;                // column groups (four floats) per slab row; NTHR / CGS = 8 rows per pass
+    static constexpr int ROWB = TILE * 2;               // bytes per plane row
+    static constexpr int PLANE = WL_ROWS * ROWB;
+    static constexpr int STAGE = 4 * PLANE;             // g_hi | g_lo | x_hi | x_lo: 32 / 64 KiB
+    static constexpr int SJ = BIG ? 128 : 64;           // a wave's sub-tile: 64 (n) x SJ (j)
+};
 
 typedef __attribute__((ext_vector_type(4))) short wl_s16x4;
 typedef __attribute__((address_space(3))) wl_s16x4* wl_lds_s16x4_ptr;
 typedef __attribute__((ext_vector_type(8))) short wl_s16x8;
 
-template <bool VEC>
-__global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
-                                                              int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M, int N,
-                                                              int Cin, int taps, int T, int tiles_k, int chunk,
-                                                              float* __restrict__ dW, float* __restrict__ dbias) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * WL_STAGE];
+template <int BIG, bool VEC, int TAPS>
+__global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_kernel(
+    const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M,
+    int N, int Cin, int T, int tiles_k, int chunk, float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ partial) {
+    using Geo = WlGeo<BIG>;
+    constexpr int TILE = Geo::TILE, ROWB = Geo::ROWB, PLANE = Geo::PLANE, STAGE = Geo::STAGE, SJ = Geo::SJ, NJ = SJ / 32;
+    extern __shared__ __attribute__((aligned(16))) char lds[];          // 2 * STAGE
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int K = Cin * taps;
-    const int n0 = ((int)blockIdx.x / tiles_k) * 128, j0 = ((int)blockIdx.x % tiles_k) * 128;
-    const int64_t r_begin = (int64_t)blockIdx.y * chunk;
+    const int K = Cin * TAPS;
+    // XCD-aware renumbering (as in the GEMM kernels): workgroups are dealt round-robin to the eight XCDs; a contiguous range of
+    // (chunk, tile) ids per XCD keeps all tiles of a chunk -- which share its G and X slabs -- on one L2
+    const int tiles = (int)gridDim.x, nwg = tiles * (int)gridDim.y, bid = (int)blockIdx.x + tiles * (int)blockIdx.y;
+    const int xcd = bid & 7, xq = nwg >> 3, xrem = nwg & 7;
+    const int lid = (xcd < xrem ? xcd * (xq + 1) : xrem * (xq + 1) + (xcd - xrem) * xq) + (bid >> 3);
+    const int tile = lid % tiles, chunk_id = lid / tiles;
+    const int n0 = (tile / tiles_k) * TILE, j0 = (tile % tiles_k) * TILE;
+    const int64_t r_begin = (int64_t)chunk_id * chunk;
     const int64_t r_end = r_begin + chunk < M ? r_begin + chunk : M;
-    // ---- loader: thread -> column group cg (4 columns) of both slabs, rows lr, lr + 8, lr + 16, lr + 24 of the step.
-    // VEC: float4 loads (N, Cin, both leading dimensions multiples of 4, 16-byte aligned bases: a group never straddles a tap
-    // or the matrix edge); otherwise four guarded scalar loads per group, each column with its own tap.
-    const int cg = tid & 31, lr = tid >> 5;
+    // ---- loader: thread -> column group cg (4 columns) of both slabs, rows lr, lr + 8, lr + 16, lr + 24 of the step (BIG: a
+    // wave is one slab row, so the row arithmetic is scalar).
+    // VEC: float4 loads; otherwise four scalar loads per group, each column with its own tap.
+    // Every fetch issues the same loads whatever the step looks like: rows past the end of the input and taps outside the
+    // row's sequence read a valid address and are zeroed when the slab is written to LDS, and the row mask bytes come with the
+    // slab instead of deciding its loads.  (The compiler counts vmcnt per path: with a path without loads, or a mask byte that
+    // had to arrive before the row's load was issued, every wait was a vmcnt(0).)
+    const int cg = tid % Geo::CGS;
+    const int lr = BIG ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / Geo::CGS;
     const int gn = n0 + 4 * cg, xj = j0 + 4 * cg;
-    bool g_ok[4], x_ok[4];
-    int shift[4];
+    int g_ok[4], x_ok[4], shift[4], gcol[4];
     int64_t xoff[4];                             // element offset of column e's source inside row r of X: shift * ldx + ci
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         g_ok[e] = gn + e < N;
         x_ok[e] = xj + e < K;
+        gcol[e] = g_ok[e] ? gn + e : 0;
         const int tap = x_ok[e] ? (xj + e) / Cin : 0;
         const int ci = x_ok[e] ? (xj + e) - tap * Cin : 0;
-        shift[e] = tap - taps / 2;
+        shift[e] = tap - TAPS / 2;
         xoff[e] = (int64_t)shift[e] * ldx + ci;
     }
-    const float* gptr = G + (r_begin + lr) * ldg + (g_ok[0] ? gn : 0);
-    const float* xptr = X + (r_begin + lr) * ldx;
-    const uint8_t* mp = row_mask ? row_mask + r_begin + lr : nullptr;
-    int tt[4] = {0, 0, 0, 0};                    // positions of the thread's four rows in their sequences (k = 3)
-    if (taps == 3) {
+    const int step_t = WL_ROWS % T;              // what 32 rows add to a row's position in its sequence (k = 3)
+    int tt[4] = {0, 0, 0, 0};                    // positions of the thread's four rows of the next fetch
+    if (TAPS == 3) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) tt[i] = (int)((r_begin + lr + 8 * i) % T);
     }
-    float4 g4[4], x4[4];
+    struct Slab {
+        float4 g[4], x[4];
+        int mk[4];               // row mask bytes
+        int sq;                  // k = 3, bit 4 i + e: column e's tap of row i lies inside the row's sequence
+    };
+    const uint8_t* mbytes = row_mask ? row_mask : reinterpret_cast<const uint8_t*>(G);      // (any M readable bytes)
+    const int64_t last = M - 1;
+    int64_t frow = r_begin + lr;                 // the thread's first row of the next fetch
     // bias gradient on the way (the blocks of the first tile column only): column sums of the masked G slab this thread loads
-    const bool do_bias = dbias != nullptr && (int)blockIdx.x % tiles_k == 0;          // (block-uniform)
+    const bool do_bias = dbias != nullptr && tile % tiles_k == 0;                     // (block-uniform)
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto fetch = [&](int64_t r0) {
+    auto fetch = [&](Slab& sl) {
+        sl.sq = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool in = r0 + lr + 8 * i < r_end;
-            const bool live = in && (!mp || mp[8 * i]);
-            auto seq_ok = [&](int e) { return taps == 1 || (tt[i] + shift[e] >= 0 && tt[i] + shift[e] < T); };
-            if (VEC) {
-                g4[i] = live && g_ok[0] ? ld4(gptr + (int64_t)(8 * i) * ldg) : make_float4(0.f, 0.f, 0.f, 0.f);
-                x4[i] = in && x_ok[0] && seq_ok(0) ? ld4(xptr + (int64_t)(8 * i) * ldx + xoff[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const float* gr = gptr + (int64_t)(8 * i) * ldg;
-                const float* xr = xptr + (int64_t)(8 * i) * ldx;
-                g4[i].x = live && g_ok[0] ? gr[0] : 0.f;
-                g4[i].y = live && g_ok[1] ? gr[1] : 0.f;
-                g4[i].z = live && g_ok[2] ? gr[2] : 0.f;
-                g4[i].w = live && g_ok[3] ? gr[3] : 0.f;
-                x4[i].x = in && x_ok[0] && seq_ok(0) ? xr[xoff[0]] : 0.f;
-                x4[i].y = in && x_ok[1] && seq_ok(1) ? xr[xoff[1]] : 0.f;
-                x4[i].z = in && x_ok[2] && seq_ok(2) ? xr[xoff[2]] : 0.f;
-                x4[i].w = in && x_ok[3] && seq_ok(3) ? xr[xoff[3]] : 0.f;
-            }
-        }
-        gptr += (int64_t)WL_ROWS * ldg;
-        xptr += (int64_t)WL_ROWS * ldx;
-        if (mp) mp += WL_ROWS;
-        if (taps == 3) {
+            const int64_t rr = frow + 8 * i;
+            const int64_t rc = rr < last ? rr : last;
+            sl.mk[i] = mbytes[rc];
+            const float* gr = G + rc * ldg;
+            const float* xr = X + rc * ldx;
+            int sq[4] = {1, 1, 1, 1};
+            if (TAPS == 3) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                tt[i] += WL_ROWS;
-                while (tt[i] >= T) tt[i] -= T;
+                for (int e = 0; e < 4; ++e) {
+                    sq[e] = (unsigned)(tt[i] + shift[e]) < (unsigned)T && rr <= last;      // (a row past the input has no taps:
+                                                                                           // row `last` + 1 is not memory)
+                    sl.sq |= sq[e] << (4 * i + e);
+                }
+                const int nt = tt[i] + step_t;
+                tt[i] = nt >= T ? nt - T : nt;
+            }
+            if (VEC) {
+                sl.g[i] = ld4(gr + gcol[0]);
+                sl.x[i] = ld4(xr + (x_ok[0] & sq[0] ? xoff[0] : 0));
+            } else {
+                sl.g[i].x = gr[gcol[0]];
+                sl.g[i].y = gr[gcol[1]];
+                sl.g[i].z = gr[gcol[2]];
+                sl.g[i].w = gr[gcol[3]];
+                sl.x[i].x = xr[x_ok[0] & sq[0] ? xoff[0] : 0];
+                sl.x[i].y = xr[x_ok[1] & sq[1] ? xoff[1] : 0];
+                sl.x[i].z = xr[x_ok[2] & sq[2] ? xoff[2] : 0];
+                sl.x[i].w = xr[x_ok[3] & sq[3] ? xoff[3] : 0];
             }
         }
+        frow += WL_ROWS;
     };
     auto put = [&](char* plane_hi, int row, const float4& v) {
         const vrd::bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
         const vrd::bf16x4_t l = {(__bf16)(v.x - (float)h[0]), (__bf16)(v.y - (float)h[1]), (__bf16)(v.z - (float)h[2]), (__bf16)(v.w - (float)h[3])};
-        const int off = row * WL_ROWB + (((cg >> 1) ^ ((row & 3) << 2)) * 16) + (cg & 1) * 8;
+        const int off = row * ROWB + (((cg >> 1) ^ ((row & 3) << 2)) * 16) + (cg & 1) * 8;
         *reinterpret_cast<vrd::bf16x4_t*>(plane_hi + off) = h;
-        *reinterpret_cast<vrd::bf16x4_t*>(plane_hi + WL_PLANE + off) = l;
+        *reinterpret_cast<vrd::bf16x4_t*>(plane_hi + PLANE + off) = l;
     };
-    auto store = [&](char* st) {
+    // (a row contributes G[r, n] X[r', j]: zeroing G's row takes care of masked rows and of rows past the chunk -- their X values
+    // are real rows of the input --, and columns of X at or beyond K only reach entries of dW that are never stored; what X
+    // needs is the zero of a tap outside the row's sequence, and without float4 groups the zero of a column beyond K next to
+    // valid ones is cheap enough to keep)
+    auto store = [&](char* st, const Slab& sl, int64_t r0) {       // r0: the slab's first row
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            put(st, lr + 8 * i, g4[i]);
-            put(st + 2 * WL_PLANE, lr + 8 * i, x4[i]);
-            if (do_bias) bsum.x += g4[i].x, bsum.y += g4[i].y, bsum.z += g4[i].z, bsum.w += g4[i].w;
+            const int in = r0 + lr + 8 * i < r_end;
+            const int live = in & (row_mask ? sl.mk[i] != 0 : 1);
+            float4 g = sl.g[i], x = sl.x[i];
+            g.x = live & g_ok[0] ? g.x : 0.f;
+            g.y = live & g_ok[VEC ? 0 : 1] ? g.y : 0.f;
+            g.z = live & g_ok[VEC ? 0 : 2] ? g.z : 0.f;
+            g.w = live & g_ok[VEC ? 0 : 3] ? g.w : 0.f;
+            if (TAPS == 3 || !VEC) {
+                const int sq = TAPS == 3 ? sl.sq >> (4 * i) : 15;
+                x.x = x_ok[0] & sq ? x.x : 0.f;
+                x.y = x_ok[VEC ? 0 : 1] & (sq >> (VEC ? 0 : 1)) ? x.y : 0.f;
+                x.z = x_ok[VEC ? 0 : 2] & (sq >> (VEC ? 0 : 2)) ? x.z : 0.f;
+                x.w = x_ok[VEC ? 0 : 3] & (sq >> (VEC ? 0 : 3)) ? x.w : 0.f;
+            }
+            put(st, lr + 8 * i, g);
+            put(st + 2 * PLANE, lr + 8 * i, x);
+            if (do_bias) bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
         }
     };
-    // ---- compute: wave (wn, wj) owns the 64 x 64 sub-tile at (64 wn, 64 wj) as 2 x 2 accumulators
+    // ---- compute: wave (wn, wj) owns the 64 x SJ sub-tile at (64 wn, SJ wj) as 2 x NJ accumulators
     const int wn = wave >> 1, wj = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int vq = (lane >> 2) & 3, vp = lane & 3, vcol0 = 16 * ((lane >> 4) & 1) + 4 * vp;
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
-        for (int hj = 0; hj < 2; ++hj)
+        for (int hj = 0; hj < NJ; ++hj)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[hn][hj][e] = 0.f;
     // fragment (k16 step s, 32 columns from colbase) of the plane pair at `pl`: lane (column lane & 31, half) <- rows 16 s + 8 half .. + 7
@@ -418,9 +468,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __res
         for (int part = 0; part < 2; ++part) {
             const int row = 16 * s + 8 * part + 4 * lh + vq;
             const int col = colbase + vcol0;
-            const int off = row * WL_ROWB + ((((col * 2) >> 4) ^ ((row & 3) << 2)) * 16) + ((col * 2) & 15);
+            const int off = row * ROWB + ((((col * 2) >> 4) ^ ((row & 3) << 2)) * 16) + ((col * 2) & 15);
             const wl_s16x4 th = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wl_lds_s16x4_ptr)(pl + off));
-            const wl_s16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wl_lds_s16x4_ptr)(pl + WL_PLANE + off));
+            const wl_s16x4 tl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wl_lds_s16x4_ptr)(pl + PLANE + off));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 rh[4 * part + q] = th[q];
@@ -434,60 +484,185 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_lds_kernel(const float* __res
     auto compute = [&](const char* st) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const WFrag fa0 = frag(st, s, 64 * wn), fa1 = frag(st, s, 64 * wn + 32);
-            const WFrag fb0 = frag(st + 2 * WL_PLANE, s, 64 * wj), fb1 = frag(st + 2 * WL_PLANE, s, 64 * wj + 32);
+            WFrag fa[2], fb[NJ];
+#pragma unroll
+            for (int hn = 0; hn < 2; ++hn) fa[hn] = frag(st, s, 64 * wn + 32 * hn);
+#pragma unroll
+            for (int hj = 0; hj < NJ; ++hj) fb[hj] = frag(st + 2 * PLANE, s, SJ * wj + 32 * hj);
 #pragma unroll
             for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
-                for (int hj = 0; hj < 2; ++hj) {
-                    const WFrag& fa = hn ? fa1 : fa0;
-                    const WFrag& fb = hj ? fb1 : fb0;
-                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.l, fb.h, acc[hn][hj], 0, 0, 0);
-                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.l, acc[hn][hj], 0, 0, 0);
-                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.h, acc[hn][hj], 0, 0, 0);
+                for (int hj = 0; hj < NJ; ++hj) {
+                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hn].l, fb[hj].h, acc[hn][hj], 0, 0, 0);
+                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hn].h, fb[hj].l, acc[hn][hj], 0, 0, 0);
+                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hn].h, fb[hj].h, acc[hn][hj], 0, 0, 0);
                 }
         }
     };
-    // ---- rows: the loads of step i + 1 are in flight under the MFMAs of step i; one barrier per step (a stage is rewritten only
-    // after every wave has passed the barrier behind its last read)
-    fetch(r_begin);
-    store(lds);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t r0 = r_begin; r0 < r_end; r0 += WL_ROWS) {
-        const bool more = r0 + WL_ROWS < r_end;
-        if (more) fetch(r0 + WL_ROWS);
-        compute(lds + cur * WL_STAGE);
-        if (more) store(lds + (cur ^ 1) * WL_STAGE);
+    // ---- rows: the loads of the next step(s) are in flight under the MFMAs of step i; one barrier per step (a stage is rewritten
+    // only after every wave has passed the barrier behind its last read)
+    // (two steps in flight where the registers allow it: 64 accumulators, float4 loads, no tap bookkeeping)
+    constexpr int DEPTH = (!BIG && VEC && TAPS == 1) ? 2 : 1;
+    if (DEPTH == 2) {
+        // (even steps live in stage 0 and slab `sa`, odd ones in stage 1 and `sb`; a fetch past the chunk's end loads rows of the
+        // input again and is never stored)
+        Slab sa, sb;
+        fetch(sa);
+        fetch(sb);
+        store(lds, sa, r_begin);
         __syncthreads();
-        cur ^= 1;
+        for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * WL_ROWS) {
+            fetch(sa);                                   // step r0 + 64
+            compute(lds);
+            if (r0 + WL_ROWS < r_end) store(lds + STAGE, sb, r0 + WL_ROWS);
+            __syncthreads();
+            if (r0 + WL_ROWS >= r_end) break;
+            fetch(sb);                                   // step r0 + 96
+            compute(lds + STAGE);
+            if (r0 + 2 * WL_ROWS < r_end) store(lds, sa, r0 + 2 * WL_ROWS);
+            __syncthreads();
+        }
+    } else {
+        // One slab: written to the other stage during the step before its own, and fetched again right behind that.  The MFMAs of
+        // a step and the split of the next step's slab do not depend on each other, and measured alone each is about as long as
+        // the other (and as the loads): run one after the other by every wave -- the barrier puts all waves of a block into the
+        // same phase -- the step cost their sum.  BIG: waves w and w + 4 share a SIMD; the first four take compute -> split,
+        // the other four split -> compute, so that a SIMD has one wave on the MFMA pipe and one on the vector ALU all along.
+        Slab sa;
+        fetch(sa);
+        store(lds, sa, r_begin);
+        fetch(sa);                                       // step 1
+        __syncthreads();
+        const bool split_first = BIG && wave >= 4;
+        int cur = 0;
+        for (int64_t r0 = r_begin; r0 < r_end; r0 += WL_ROWS) {
+            const bool more = r0 + WL_ROWS < r_end;
+            if (split_first) {
+                if (more) {
+                    store(lds + (cur ^ 1) * STAGE, sa, r0 + WL_ROWS);
+                    fetch(sa);                           // step r0 + 64
+                }
+                compute(lds + cur * STAGE);
+            } else {
+                compute(lds + cur * STAGE);
+                if (more) {
+                    store(lds + (cur ^ 1) * STAGE, sa, r0 + WL_ROWS);
+                    fetch(sa);
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     if (do_bias) {       // the eight row threads of a column add up in LDS (free behind the loop's last barrier): one atomic per
                          // column and block -- same-address atomics queue up one behind the other in L2
         float* red = reinterpret_cast<float*>(lds);
-        *reinterpret_cast<float4*>(red + lr * 128 + 4 * cg) = bsum;
+        *reinterpret_cast<float4*>(red + lr * TILE + 4 * cg) = bsum;
         __syncthreads();
-        if (tid < 128 && n0 + tid < N) {     // (columns beyond N carry zeros)
+        if (tid < TILE && n0 + tid < N) {     // (columns beyond N carry zeros)
             float t = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) t += red[q * 128 + tid];
+            for (int q = 0; q < 8; ++q) t += red[q * TILE + tid];
             atomicAdd(dbias + n0 + tid, t);
         }
     }
+    // the chunk's share of the tile: straight into dW when there is one chunk; otherwise as plain stores into the chunk's slice of
+    // `partial` (summed by wgrad_reduce_kernel: every (chunk, n, j) is written by exactly one block), or -- without a scratch
+    // buffer -- as atomics.  L2 works float atomics off at about one element per clock and channel: the 16 k atomics of each of
+    // ~512 blocks were 12-17 us of a 70 us launch at M = 24,576, N = K = 512, whatever the number of rows.
     const bool single = gridDim.y == 1;
+    float* dst = single ? dW : partial ? partial + (int64_t)chunk_id * N * K : dW;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int j = j0 + 64 * wj + 32 * (q & 1) + li;
+    for (int q = 0; q < 2 * NJ; ++q) {
+        const int hn = q / NJ, hj = q % NJ;
+        const int j = j0 + SJ * wj + 32 * hj + li;
         if (j >= K) continue;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int nn = n0 + 64 * wn + 32 * (q >> 1) + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int nn = n0 + 64 * wn + 32 * hn + (e & 3) + 8 * (e >> 2) + 4 * lh;
             if (nn < N) {
-                if (single) dW[(int64_t)nn * K + j] += acc[q >> 1][q & 1][e];
-                else atomicAdd(dW + (int64_t)nn * K + j, acc[q >> 1][q & 1][e]);
+                if (single) dst[(int64_t)nn * K + j] += acc[hn][hj][e];
+                else if (partial) dst[(int64_t)nn * K + j] = acc[hn][hj][e];
+                else atomicAdd(dst + (int64_t)nn * K + j, acc[hn][hj][e]);
             }
         }
     }
+}
+
+// dW[i] += sum_c partial[c * NK + i]: the row chunks' partial tiles of wgrad_x3_lds_kernel, in chunk order (so the sum does not
+// depend on the order the blocks ran in, as the atomics' did).  float4 per thread when NK % 4 == 0.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int64_t NK,
+                                                           float* __restrict__ dW) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= NK) return;
+    if ((NK & 3) == 0) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int c = 0;
+        for (; c + 4 <= chunks; c += 4) {       // four loads in flight
+            const float4 a = ld4(partial + (int64_t)c * NK + i), b = ld4(partial + (int64_t)(c + 1) * NK + i);
+            const float4 d = ld4(partial + (int64_t)(c + 2) * NK + i), e = ld4(partial + (int64_t)(c + 3) * NK + i);
+            s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+            s.x += b.x, s.y += b.y, s.z += b.z, s.w += b.w;
+            s.x += d.x, s.y += d.y, s.z += d.z, s.w += d.w;
+            s.x += e.x, s.y += e.y, s.z += e.z, s.w += e.w;
+        }
+        for (; c < chunks; ++c) {
+            const float4 a = ld4(partial + (int64_t)c * NK + i);
+            s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w;
+        }
+        float4 o = ld4(dW + i);
+        o.x += s.x, o.y += s.y, o.z += s.z, o.w += s.w;
+        *reinterpret_cast<float4*>(dW + i) = o;
+    } else {
+        for (int64_t k = i; k < i + 4 && k < NK; ++k) {
+            float s = 0.f;
+            for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * NK + k];
+            dW[k] += s;
+        }
+    }
+}
+
+constexpr int WL_BIG_ROWS = 256;     // rows per block from which the 256 x 256 tiles pay
+
+// one launch of wgrad_x3_lds_kernel<BIG, ...> (+ the reduction of its partial tiles): as few row chunks as still give
+// 2 (BIG: 1) blocks per CU
+template <int BIG>
+int launch_wgrad_lds(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
+                     int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, bool vec, int n_cu, hipStream_t s) {
+    using Geo = WlGeo<BIG>;
+    const int K = Cin * taps;
+    const int tiles_n = (N + Geo::TILE - 1) / Geo::TILE, tiles_k = (K + Geo::TILE - 1) / Geo::TILE;
+    const int64_t tiles = (int64_t)tiles_n * tiles_k;
+    int64_t want = ((BIG ? 1 : 2) * (int64_t)n_cu + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    int64_t chunk = (M + want - 1) / want;
+    chunk = (chunk + WL_ROWS - 1) / WL_ROWS * WL_ROWS;
+    if (chunk < 4 * WL_ROWS) chunk = 4 * WL_ROWS;
+    const int64_t chunks = (M + chunk - 1) / chunk;
+    VRD_CHECK_ARG(chunks <= 65535 && chunk < (1ll << 30) && tiles < (1 << 20), "vrd_gemm_wgrad_x3: too many rows (%lld)", (long long)M);
+    const dim3 grid((unsigned)tiles, (unsigned)chunks);
+    // the chunks' partial tiles go through `scratch` when it holds them (chunks x N x K floats, 16-byte aligned); else atomics
+    const int64_t NK = (int64_t)N * K;
+    float* partial = chunks > 1 && scratch && aligned16(scratch) && aligned16(dW) && scratch_floats >= chunks * NK ? scratch : nullptr;
+    constexpr size_t lds = 2 * Geo::STAGE;
+#define VRD_WGRAD_LAUNCH(VEC_, TAPS_)                                                                                              \
+    do {                                                                                                                           \
+        auto kern = wgrad_x3_lds_kernel<BIG, VEC_, TAPS_>;                                                                         \
+        if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm_wgrad_x3")) return rc;                   \
+        hipLaunchKernelGGL(kern, grid, dim3(Geo::NTHR), lds, s, G, ldg, X, ldx, row_mask, M, N, Cin, T, tiles_k, (int)chunk, dW,   \
+                           dbias, partial);                                                                                        \
+    } while (0)
+    if (vec && taps == 1) VRD_WGRAD_LAUNCH(true, 1);
+    else if (vec) VRD_WGRAD_LAUNCH(true, 3);
+    else if (taps == 1) VRD_WGRAD_LAUNCH(false, 1);
+    else VRD_WGRAD_LAUNCH(false, 3);
+#undef VRD_WGRAD_LAUNCH
+    VRD_LAUNCH_CHECK();
+    if (partial) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((NK + 1023) / 1024)), dim3(256), 0, s, partial, (int)chunks, NK, dW);
+        VRD_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -683,7 +858,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             int64_t lddy, int64_t rows, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu, float* __restrict__ dx,
                                                             int64_t lddx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int rpw) {
+                                                            int rpw, float* __restrict__ partial) {
     constexpr float inv_c = 1.0f / (256.0f * NV);
     const int lane = threadIdx.x & 63;
     const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -781,11 +956,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 g.x += pg.x, g.y += pg.y, g.z += pg.z, g.w += pg.w;
                 b.x += pb.x, b.y += pb.y, b.z += pb.z, b.w += pb.w;
             }
+            if (partial) {       // the block's row of the (blocks, 2 C) partial sums: colpartial_reduce_kernel adds them up
+                float* pp = partial + (int64_t)blockIdx.x * (2 * 256 * NV) + i * 256 + lane * 4;
+                st4(pp, g);
+                st4(pp + 256 * NV, b);
+                continue;
+            }
             float* dgp = dgamma + i * 256 + lane * 4;
             float* dbp = dbeta + i * 256 + lane * 4;
             atomicAdd(dgp + 0, g.x), atomicAdd(dgp + 1, g.y), atomicAdd(dgp + 2, g.z), atomicAdd(dgp + 3, g.w);
             atomicAdd(dbp + 0, b.x), atomicAdd(dbp + 1, b.y), atomicAdd(dbp + 2, b.z), atomicAdd(dbp + 3, b.w);
         }
+    }
+}
+
+// out[c] += sum_p partial[p * cols + c]: the per-block column sums of a kernel whose blocks would otherwise each end in one
+// atomic per column (atomics on one address are worked off one after the other, ~50 ns each: 512 blocks = 25 us).  Block =
+// 64 columns x 32 partial rows (a wave takes eight of them), one atomic per column and block: parts / 32 per address.
+__global__ __launch_bounds__(256) void colpartial_reduce_kernel(const float* __restrict__ partial, int parts, int cols,
+                                                                float* __restrict__ out0, float* __restrict__ out1, int split) {
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int p0 = blockIdx.y * 32 + wave * 8;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (c < cols && p0 + q < parts) ? partial[(int64_t)(p0 + q) * cols + c] : 0.f;
+    float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < cols) {
+        s += red[0][lane] + red[1][lane] + red[2][lane];
+        atomicAdd(c < split ? out0 + c : out1 + (c - split), s);
     }
 }
 
@@ -1280,7 +1482,7 @@ int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, con
 }
 
 int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
-                      int taps, int T, float* dW, float* dbias, void* stream) {
+                      int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, void* stream) {
     VRD_CHECK_ARG(G && X && dW, "vrd_gemm_wgrad_x3: null pointer");
     VRD_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && (taps == 1 || taps == 3), "vrd_gemm_wgrad_x3: bad sizes M=%lld N=%d Cin=%d taps=%d", (long long)M, N, Cin, taps);
     VRD_CHECK_ARG(ldg >= N && ldx >= Cin, "vrd_gemm_wgrad_x3: leading dimension too small");
@@ -1294,23 +1496,17 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * (double)M * N * K, 4.0 * ((double)M * (N + Cin) + (double)N * K));
     static const bool use_lds = [] { const char* e = getenv("VRD_WGRAD_LDS"); return !(e && e[0] == '0'); }();
+    // VRD_WGRAD_BIG: 0 = 128 x 128 tiles only, 2 = 256 x 256 tiles whenever the shape allows (lab); default: by rows per chunk
+    static const int big_mode = [] { const char* e = getenv("VRD_WGRAD_BIG"); return e ? atoi(e) : 1; }();
     if (use_lds && M >= 256) {
-        // 128 x 128 tiles; as few row chunks as still give ~2 blocks per CU (every block ends in 16 k atomics)
-        const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128;
-        const int64_t tiles = (int64_t)tiles_n * tiles_k;
-        int64_t want = (2 * (int64_t)n_cu + tiles - 1) / tiles;
-        if (want < 1) want = 1;
-        int64_t chunk = (M + want - 1) / want;
-        chunk = (chunk + WL_ROWS - 1) / WL_ROWS * WL_ROWS;
-        if (chunk < 4 * WL_ROWS) chunk = 4 * WL_ROWS;
-        const int64_t chunks = (M + chunk - 1) / chunk;
-        VRD_CHECK_ARG(chunks <= 65535 && chunk < (1ll << 30), "vrd_gemm_wgrad_x3: too many rows (%lld)", (long long)M);
         const bool vec = N % 4 == 0 && Cin % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 && aligned16(G) && aligned16(X);
-        const dim3 grid((unsigned)tiles, (unsigned)chunks);
-        if (vec) hipLaunchKernelGGL(wgrad_x3_lds_kernel<true>, grid, dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, tiles_k, (int)chunk, dW, dbias);
-        else hipLaunchKernelGGL(wgrad_x3_lds_kernel<false>, grid, dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, tiles_k, (int)chunk, dW, dbias);
-        VRD_LAUNCH_CHECK();
-        return 0;
+        // 256 x 256 tiles, one block per CU, when a block then still walks >= WL_BIG_ROWS rows (its start, its 64 k partial sums
+        // and their share of the reduction are paid per block); 128 x 128 tiles, two blocks per CU, otherwise
+        const int64_t big_tiles = (int64_t)((N + 255) / 256) * ((K + 255) / 256);
+        const bool big = big_mode != 0 && vec && N >= 256 && K >= 256 &&
+                         (big_mode == 2 || M * big_tiles >= (int64_t)WL_BIG_ROWS * n_cu);
+        return big ? launch_wgrad_lds<1>(G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, dW, dbias, scratch, scratch_floats, vec, n_cu, s)
+                   : launch_wgrad_lds<0>(G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, dW, dbias, scratch, scratch_floats, vec, n_cu, s);
     }
     if (dbias) {                                 // the wave kernel has no bias path: a column-sum launch of its own
         const int col_blocks = (N + 63) / 64;
@@ -1403,7 +1599,8 @@ int vrd_activation(const float* x, int64_t ldx, const float* dy, int64_t lddy, i
 }
 
 int vrd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, int64_t rows, int C, const float* gamma,
-                      const float* beta, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, void* stream) {
+                      const float* beta, int relu, float* dx, int64_t lddx, float* dgamma, float* dbeta, float* scratch,
+                      int64_t scratch_floats, void* stream) {
     VRD_CHECK_ARG(x && dy && gamma && beta && dx && dgamma && dbeta, "vrd_layernorm_bwd: null pointer");
     VRD_CHECK_ARG(C == 256 || C == 512, "vrd_layernorm_bwd: C must be 256 or 512 (got %d)", C);
     VRD_CHECK_ARG(ldx >= C && lddy >= C && lddx >= C && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && aligned16(x) && aligned16(dy) &&
@@ -1416,9 +1613,16 @@ int vrd_layernorm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy
     if (rpw < LNB_ROWS) rpw = LNB_ROWS;
     if (rpw > 64) rpw = 64;
     dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw)));
-    if (C == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta, (int)rpw);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta, (int)rpw);
+    // with a scratch buffer the blocks' column sums take two steps (rows of partial sums, then colpartial_reduce_kernel)
+    float* partial = grid.x > 32 && scratch && aligned16(scratch) && scratch_floats >= (int64_t)grid.x * 2 * C ? scratch : nullptr;
+    if (C == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta, (int)rpw, partial);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, dim3(256), 0, s, x, ldx, dy, lddy, rows, gamma, beta, relu, dx, lddx, dgamma, dbeta, (int)rpw, partial);
     VRD_LAUNCH_CHECK();
+    if (partial) {
+        hipLaunchKernelGGL(colpartial_reduce_kernel, dim3((unsigned)(2 * C / 64), (grid.x + 31) / 32), dim3(256), 0, s, partial, (int)grid.x, 2 * C,
+                           dgamma, dbeta, C);
+        VRD_LAUNCH_CHECK();
+    }
     return 0;
 }
 
