@@ -128,7 +128,7 @@ def _zeros(*shape, device):
 
 
 _partial_scratch = {}
-_LN_PARTIALS = os.environ.get("VRD_LN_PARTIALS", "1") != "0"      # A/B switch (lab)
+_PARTIAL_SUMS = os.environ.get("VRD_PARTIAL_SUMS", "1") != "0"      # A/B switch: 0 = the gradient kernels end in float atomics
 
 
 def _partials(device):
@@ -138,6 +138,8 @@ def _partials(device):
     more for launches recorded into a graph (that one lives in the graph's pool); only ever live between two adjacent launches."""
     key = (torch.device(device), torch.cuda.is_current_stream_capturing())
     buf = _partial_scratch.get(key)
+    if buf is None and not _PARTIAL_SUMS:
+        buf = _partial_scratch[key] = torch.empty(0, device=key[0], dtype=torch.float32)
     if buf is None:
         cus = torch.cuda.get_device_properties(key[0]).multi_processor_count
         buf = _partial_scratch[key] = torch.empty(4 * cus * 16384 + (4 << 20), device=key[0], dtype=torch.float32)
@@ -268,7 +270,7 @@ class LayerNormFn(Function):
         pdx, _, _, lddx = _rows(dx)
         dg = _zeros(cols, device=x.device)
         db = _zeros(cols, device=x.device)
-        part = _partials(dy.device) if _LN_PARTIALS else torch.empty(0, device=dy.device)
+        part = _partials(dy.device)
         check(lib.vrd_layernorm_bwd(px, ldx, pd, ldd, rows, cols, gamma.data_ptr(), beta.data_ptr(), 1 if ctx.relu else 0,
                                     pdx, lddx, dg.data_ptr(), db.data_ptr(), part.data_ptr(), part.numel(), _stream()),
               "vrd_layernorm_bwd")
