@@ -108,7 +108,8 @@ def test_linear_weight_gradient_over_many_row_chunks(k, Cin, N, B, T, precision)
     rel_close(xd.grad, cl(xr.grad), tol(precision), "dx")
 
 
-@pytest.mark.parametrize("M,N,Cin,k,T", [(24576, 512, 512, 1, 512), (3000, 133, 63, 1, 100), (4096, 96, 40, 3, 64), (640, 2048, 512, 1, 64)])
+@pytest.mark.parametrize("M,N,Cin,k,T", [(24576, 512, 512, 1, 512), (3000, 133, 63, 1, 100), (4096, 96, 40, 3, 64), (640, 2048, 512, 1, 64),
+                                         (16400, 384, 320, 1, 100), (24576, 256, 256, 3, 512)])      # (the last two: 256 x 256 tiles with ragged edges / k = 3)
 def test_weight_gradient_through_partial_tiles(M, N, Cin, k, T):
     """vrd_gemm_wgrad_x3 with a scratch buffer (the row chunks' partial tiles stored, then summed in chunk order by a second
     launch) against the same call without one (float atomics) and against float64; with the buffer the result is the same bits
