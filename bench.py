@@ -493,7 +493,9 @@ def main():
             v_ms, v_loss = fwd_bwd(5)
             train["vidor_48x512"] = {"pairs": 48, "t_pad": vcfg["max_seq_len"], "ms_forward_backward": v_ms,
                                      "total_loss": float(v_loss.detach()),
-                                     "note": "attention backward as five matrix-core products (vrd_bmm) + a softmax / dS row kernel"}
+                                     "note": "eager, same step as above (every weight touched first); global attention forward / backward as the "
+                                             "flash-style split-precision kernels (vrd_attention_rows / vrd_attention_bwd, head_dim 64), weight "
+                                             "gradients through partial tiles + a chunk-ordered reduction (vrd_gemm_wgrad_x3)"}
             del tmodel, tdata
         except Exception as exc:
             train["vidor_48x512"] = {"error": repr(exc)[:200]}
