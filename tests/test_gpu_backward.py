@@ -85,7 +85,8 @@ def test_linear_backward(k, Cin, N, precision):
     rel_close(bd.grad, br.grad, tol(precision), "db")
 
 
-@pytest.mark.parametrize("k,Cin,N,B,T", [(3, 96, 160, 7, 100), (1, 64, 64, 40, 90), (3, 21, 132, 7, 100), (1, 130, 66, 9, 64)])
+@pytest.mark.parametrize("k,Cin,N,B,T", [(3, 96, 160, 7, 100), (1, 64, 64, 40, 90), (3, 21, 132, 7, 100), (1, 130, 66, 9, 64),
+                                         (3, 64, 128, 40, 9), (3, 32, 64, 100, 3)])      # (sequences shorter than a 32-row step)
 def test_linear_weight_gradient_over_many_row_chunks(k, Cin, N, B, T, precision):
     """dW when the rows span several waves and blocks (row chunks end inside sequences; T is not a multiple of the 16 rows of a
     step; masked tails), both wgrad kernels (exact f32 / split precision) by mode."""
