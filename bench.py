@@ -491,8 +491,10 @@ def main():
             tmodel = synth.load_synthetic_weights(MaskVRD(vcfg, device=dev)).to(dev).train()
             tdata = synthetic_batch(vcfg, configs.input_channels(vcfg), dev, n_pairs=48, seed=0)
             v_ms, v_loss = fwd_bwd(5)
+            tmodel.enable_training_graphs()
+            vg_ms, _ = fwd_bwd(6)                            # (the first of these records the graphs)
             train["vidor_48x512"] = {"pairs": 48, "t_pad": vcfg["max_seq_len"], "ms_forward_backward": v_ms,
-                                     "total_loss": float(v_loss.detach()),
+                                     "ms_forward_backward_hip_graphs": vg_ms, "total_loss": float(v_loss.detach()),
                                      "note": "eager, same step as above (every weight touched first); global attention forward / backward as the "
                                              "flash-style split-precision kernels (vrd_attention_rows / vrd_attention_bwd, head_dim 64), weight "
                                              "gradients through partial tiles + a chunk-ordered reduction (vrd_gemm_wgrad_x3)"}

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 27
+#define VRD_ABI_VERSION 28
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -346,17 +346,23 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
 /* out[c] += sum_r a[r, c] * (b ? b[brow(r), c * b_cstride + b_coffset] : 1) * (row_mask ? row_mask[r] : 1) * (row_scale ?
  * row_scale[r] : 1), brow(r = s*T + t) = s * (b_rstride*T) + b_rstride*t + shift when that stays inside the sequence
  * (else the row contributes 0).  Bias gradients (b = NULL), AffineDropPath scale gradients (b = the branch value),
- * depthwise-conv weight gradients (b = conv input, shift = k - ksize/2, b_rstride = stride, b_cstride = inputs per group). */
+ * depthwise-conv weight gradients (b = conv input, shift = k - ksize/2, b_rstride = stride, b_cstride = inputs per group).
+ * `scratch` (nullable, 16-byte aligned; 1,024 * C floats always suffice) as in vrd_layernorm_bwd, used when b is NULL or lies on the
+ * rows of a (b_cstride = b_rstride = 1, no offset, no shift) and the rows are float4-aligned: the row blocks' partial sums, added
+ * up by a second launch instead of one float atomic per column and workgroup. */
 int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_cstride, int b_coffset, int b_rstride, int shift,
-               int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, void* stream);
+               int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, float* scratch,
+               int64_t scratch_floats, void* stream);
 
 /* Weight and bias gradient of a depthwise MaskedConv1D (models/blocks.py:91-113 under autograd; k = 1 / 3, `stride`, group_in
  * = 1 or 2 inputs per group) in one pass over dD (rows x C, rows = B * T output rows):
  *   dw[(c * group_in + g) * ksize + kk] += sum_r dD[r, c] * row_mask[r] * x[in_row(r, kk), c * group_in + g]   (the Conv1d weight's own
  *   (C, group_in, ksize) layout),  dbias[c] += sum_r dD[r, c] * row_mask[r]
- * in_row(r = s*T + t, kk) = s * stride*T + stride*t + kk - ksize/2 where that stays inside sequence s; dbias may be NULL. */
+ * in_row(r = s*T + t, kk) = s * stride*T + stride*t + kk - ksize/2 where that stays inside sequence s; dbias may be NULL.
+ * `scratch` (nullable; 1,024 * 4 C floats always suffice): as in vrd_colsum, for ksize 3, group_in 1 and float4-aligned rows. */
 int vrd_dwconv_wgrad(const float* dD, int64_t lddd, const float* x, int64_t ldx, int ksize, int stride, int group_in, int T,
-                     const uint8_t* row_mask, int64_t rows, int C, float* dw, float* dbias, void* stream);
+                     const uint8_t* row_mask, int64_t rows, int C, float* dw, float* dbias, float* scratch, int64_t scratch_floats,
+                     void* stream);
 
 /* out[r,c] = v[r,c] * col_scale[c] * row_scale[r] * row_mask[r] + res[r,c] * (res_masked ? row_mask[r] : 1) + res2[r,c]
  * (every factor / term optional).  Training form of the affine drop-path residual: models/blocks.py:1074-1076 with

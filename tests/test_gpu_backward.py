@@ -146,6 +146,58 @@ def test_weight_gradient_through_partial_tiles(M, N, Cin, k, T):
     assert float((a - b).abs().max()) <= 1e-4 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("ks,gin,stride,C,B,T", [(3, 1, 1, 512, 64, 64), (3, 1, 1, 260, 37, 50), (3, 2, 1, 256, 40, 50), (1, 1, 1, 256, 33, 64),
+                                                 (3, 1, 2, 512, 16, 96), (3, 1, 1, 512, 300, 5)])
+def test_column_sums_with_and_without_scratch(ks, gin, stride, C, B, T):
+    """vrd_colsum and vrd_dwconv_wgrad with a scratch buffer (four channels per lane, the row blocks' partial sums stored, then
+    added up by a second launch -- the cases that qualify) against the same calls without one (one float atomic per column and
+    workgroup) and against float64; ragged row counts, strided inputs, sequences shorter than a block's rows."""
+    from vrdone_amd import _hip
+    lib = _hip.lib
+    g = torch.Generator().manual_seed(ks * 7 + gin + C)
+    rows = B * T                                           # output rows; the conv input has stride * T rows per sequence
+    dD = torch.randn(rows, C, generator=g)
+    x = torch.randn(B * stride * T, C * gin, generator=g)
+    other = torch.randn(rows, C, generator=g)
+    mask = (torch.rand(rows, generator=g) < 0.8).to(torch.uint8)
+    rscale = torch.rand(rows, generator=g)
+    dDd, xd, od, md, rd = dD.to(DEV), x.to(DEV), other.to(DEV), mask.to(DEV), rscale.to(DEV)
+    part = torch.full((1024 * 4 * C + 64,), float("nan"), device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def dww(scratch, floats):
+        dw, db = torch.ones(C, gin, ks, device=DEV), torch.ones(C, device=DEV)
+        _hip.check(lib.vrd_dwconv_wgrad(dDd.data_ptr(), C, xd.data_ptr(), C * gin, ks, stride, gin, T, md.data_ptr(), rows, C, dw.data_ptr(),
+                                        db.data_ptr(), scratch, floats, stream), "vrd_dwconv_wgrad")
+        return dw, db
+
+    def cs(b, scratch, floats):
+        out = torch.ones(C, device=DEV)
+        _hip.check(lib.vrd_colsum(dDd.data_ptr(), C, b.data_ptr() if b is not None else None, C, 1, 0, 1, 0, T, md.data_ptr(), rd.data_ptr(),
+                                  rows, C, out.data_ptr(), scratch, floats, stream), "vrd_colsum")
+        return out
+
+    Gm = (dD * mask[:, None]).double()
+    xs = x.double().view(B, stride * T, C, gin)
+    want_w = torch.zeros(C, gin, ks, dtype=torch.float64)
+    Gs = Gm.view(B, T, C)
+    for kk in range(ks):
+        for t in range(T):
+            ti = stride * t + kk - ks // 2
+            if 0 <= ti < stride * T:
+                want_w[:, :, kk] += torch.einsum("bc,bcg->cg", Gs[:, t], xs[:, ti])
+    (wa, ba), (wb, bb) = dww(None, 0), dww(part.data_ptr(), part.numel())
+    rel_close(wa, want_w + 1, 2e-5, "dw (atomics)")
+    rel_close(wb, want_w + 1, 2e-5, "dw (partial sums)")
+    rel_close(ba, Gm.sum(0) + 1, 2e-5, "dbias (atomics)")
+    rel_close(bb, Gm.sum(0) + 1, 2e-5, "dbias (partial sums)")
+    scaled = Gm * rscale.double()[:, None]
+    for b, want in ((None, scaled.sum(0) + 1), (od, (scaled * other.double()).sum(0) + 1)):
+        rel_close(cs(b, None, 0), want, 2e-5, "colsum (atomics)")
+        rel_close(cs(b, part.data_ptr(), part.numel()), want, 2e-5, "colsum (partial sums)")
+        rel_close(cs(b, part.data_ptr(), 100), want, 2e-5, "colsum (scratch too small)")
+
+
 def test_conv_gemm_epilogue_backward(precision):
     """GELU + mask + AffineDropPath scale + per-sample keep factors + masked residual + second residual."""
     from vrdone_amd import ops

@@ -143,9 +143,9 @@ _SIGNATURES = {
     "vrd_gemm_wgrad_x3": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_dwconv_wgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, c_u8p, C.c_int64,
-                                   C.c_int, c_f32p, c_f32p, C.c_void_p]),
+                                   C.c_int, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_colsum": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p,
-                             C.c_int64, C.c_int, c_f32p, C.c_void_p]),
+                             C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_rowcol_scale": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, c_u8p, c_f32p, C.c_int64, C.c_int,
                                    c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_activation": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, C.c_void_p]),
@@ -171,7 +171,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 
 class HipLibraryError(RuntimeError):

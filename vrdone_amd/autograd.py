@@ -38,6 +38,25 @@ def _dense(t):
     return t if (t.stride(-1) == 1 and t.is_contiguous()) else t.contiguous()
 
 
+_partial_scratch = {}
+_PARTIAL_SUMS = os.environ.get("VRD_PARTIAL_SUMS", "1") != "0"      # A/B switch: 0 = the gradient kernels end in float atomics
+
+
+def _partials(device):
+    """The buffer the gradient kernels park their workgroups' partial sums in before a second launch adds them up
+    (vrd_gemm_wgrad_x3: the row chunks' partial tiles, include/vrdone_hip.h: 4 * CUs * 16,384 + N * K floats
+    suffice; sized for weights of up to 4 M elements, beyond that the kernel falls back to atomics).  One per device, and one
+    more for launches recorded into a graph (that one lives in the graph's pool); only ever live between two adjacent launches."""
+    key = (torch.device(device), torch.cuda.is_current_stream_capturing())
+    buf = _partial_scratch.get(key)
+    if buf is None and not _PARTIAL_SUMS:
+        buf = _partial_scratch[key] = torch.empty(0, device=key[0], dtype=torch.float32)
+    if buf is None:
+        cus = torch.cuda.get_device_properties(key[0]).multi_processor_count
+        buf = _partial_scratch[key] = torch.empty(4 * cus * 16384 + (4 << 20), device=key[0], dtype=torch.float32)
+    return buf
+
+
 # ---------------------------------------------------------------------------------------------- raw launchers
 def colsum(a, out, *, b=None, b_cstride=1, b_coffset=0, b_rstride=1, shift=0, T=1, row_mask=None, row_scale=None):
     """out[c] += sum_r a[r,c] * b[...] * mask[r] * row_scale[r]  (vrd_colsum)."""
@@ -46,8 +65,9 @@ def colsum(a, out, *, b=None, b_cstride=1, b_coffset=0, b_rstride=1, shift=0, T=
     if b is not None:
         pb, _, _, ldb = _rows(b)
     assert out.numel() == cols and out.is_contiguous() and out.dtype == torch.float32
+    part = _partials(a.device)
     check(lib.vrd_colsum(pa, lda, pb, ldb, b_cstride, b_coffset, b_rstride, shift, T, _mask_ptr(row_mask, rows),
-                         _ptr(row_scale), rows, cols, out.data_ptr(), _stream()), "vrd_colsum")
+                         _ptr(row_scale), rows, cols, out.data_ptr(), part.data_ptr(), part.numel(), _stream()), "vrd_colsum")
     return out
 
 
@@ -125,25 +145,6 @@ def _zeros(*shape, device):
     for d in shape:
         n *= d
     return _arena.take(n, torch.device(device)).view(*shape)
-
-
-_partial_scratch = {}
-_PARTIAL_SUMS = os.environ.get("VRD_PARTIAL_SUMS", "1") != "0"      # A/B switch: 0 = the gradient kernels end in float atomics
-
-
-def _partials(device):
-    """The buffer the gradient kernels park their workgroups' partial sums in before a second launch adds them up
-    (vrd_gemm_wgrad_x3: the row chunks' partial tiles, include/vrdone_hip.h: 4 * CUs * 16,384 + N * K floats
-    suffice; sized for weights of up to 4 M elements, beyond that the kernel falls back to atomics).  One per device, and one
-    more for launches recorded into a graph (that one lives in the graph's pool); only ever live between two adjacent launches."""
-    key = (torch.device(device), torch.cuda.is_current_stream_capturing())
-    buf = _partial_scratch.get(key)
-    if buf is None and not _PARTIAL_SUMS:
-        buf = _partial_scratch[key] = torch.empty(0, device=key[0], dtype=torch.float32)
-    if buf is None:
-        cus = torch.cuda.get_device_properties(key[0]).multi_processor_count
-        buf = _partial_scratch[key] = torch.empty(4 * cus * 16384 + (4 << 20), device=key[0], dtype=torch.float32)
-    return buf
 
 
 class Linear(Function):
@@ -329,8 +330,10 @@ class DepthwiseConv(Function):
             gw = _zeros(Cout, gin, k, device=dev)          # the parameter's own layout and strides (DDP's bucket views expect them)
             gb = _zeros(Cout, device=dev) if ctx.has_bias[i] else None
             pd, rows_out, _, ldd = _rows(dDs[i])
+            part = _partials(dev)
             check(lib.vrd_dwconv_wgrad(pd, ldd, pxin, ldxin, k, s, gin, Tout, _mask_ptr(ctx.mask_out, rows_out), rows_out, Cout,
-                                       gw.data_ptr(), gb.data_ptr() if gb is not None else None, _stream()), "vrd_dwconv_wgrad")
+                                       gw.data_ptr(), gb.data_ptr() if gb is not None else None, part.data_ptr(), part.numel(),
+                                       _stream()), "vrd_dwconv_wgrad")
             grads.append(gw)
             grads.append(gb)
         return (dx, dx_up, None, None, *grads)

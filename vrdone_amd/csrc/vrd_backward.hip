@@ -793,6 +793,125 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const float* __restri
     if (dbias) atomicAdd(dbias + c, sb + red[0][GIN * KS][lane] + red[1][GIN * KS][lane] + red[2][GIN * KS][lane]);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The two column-sum kernels above with four channels per lane (float4 rows: 1 KiB per wave and row instead of 256 B) for their
+// common cases, and the row blocks' sums as rows of `partial` for colpartial_reduce_kernel (nullable: then one atomic per column
+// and block as above).  Block = rpb rows x 256 columns, a quarter of the rows per wave, four rows' loads in flight.
+//   colsum_vec_kernel:        out[c] += sum_r a[r, c] * (b ? b[r, c] : 1) * m[r] * rs[r]        (b on the rows of a)
+//   dwconv_wgrad_vec_kernel:  k = 3, one input per group: dw[c, kk] += sum_r dD[r, c] m[r] x[in_row(r, kk), c]; dbias[c] += ...
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fma4(float4& s, const float4& a, const float4& b) {
+    s.x = fmaf(a.x, b.x, s.x), s.y = fmaf(a.y, b.y, s.y), s.z = fmaf(a.z, b.z, s.z), s.w = fmaf(a.w, b.w, s.w);
+}
+__device__ __forceinline__ void add4(float4& s, const float4& a) { s.x += a.x, s.y += a.y, s.z += a.z, s.w += a.w; }
+
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                         const uint8_t* __restrict__ mask, const float* __restrict__ rscale,
+                                                         int64_t rows, int C, int rpb, float* __restrict__ out,
+                                                         float* __restrict__ partial) {
+    __shared__ float4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + lane * 4;
+    const bool col_ok = c < C;
+    const int wrows = rpb / 4;                   // (rpb is a multiple of 16)
+    const int64_t r0 = (int64_t)blockIdx.x * rpb + (int64_t)wave * wrows;
+    const int64_t r1 = r0 + wrows < rows ? r0 + wrows : rows;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f), one = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 s = zero;
+    for (int64_t rb = r0; rb < r1; rb += 4) {
+        float4 av[4], bv[4];
+        float fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + u;
+            const bool live = col_ok && r < r1 && (!mask || mask[r]);
+            av[u] = live ? ld4(a + r * lda + c) : zero;
+            bv[u] = live && b ? ld4(b + r * ldb + c) : one;
+            fv[u] = live && rscale ? rscale[r] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            av[u].x *= fv[u], av[u].y *= fv[u], av[u].z *= fv[u], av[u].w *= fv[u];
+            fma4(s, av[u], bv[u]);
+        }
+    }
+    if (wave > 0) red[wave - 1][lane] = s;
+    __syncthreads();
+    if (wave == 0 && col_ok) {
+        add4(s, red[0][lane]), add4(s, red[1][lane]), add4(s, red[2][lane]);
+        if (partial) st4(partial + (int64_t)blockIdx.x * C + c, s);
+        else atomicAdd(out + c, s.x), atomicAdd(out + c + 1, s.y), atomicAdd(out + c + 2, s.z), atomicAdd(out + c + 3, s.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void dwconv_wgrad_vec_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x,
+                                                               int64_t ldx, int bs, int T, const uint8_t* __restrict__ mask,
+                                                               int64_t rows, int C, int rpb, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, float* __restrict__ partial) {
+    __shared__ float4 red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + lane * 4;
+    const bool col_ok = c < C;
+    const int wrows = rpb / 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rpb + (int64_t)wave * wrows;
+    const int64_t r1 = r0 + wrows < rows ? r0 + wrows : rows;
+    int64_t seq = r0 / T;
+    int tpos = (int)(r0 - seq * T);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 sw[3] = {zero, zero, zero}, sb = zero;         // sw[kk] = the four channels' sums of tap kk
+    for (int64_t rb = r0; rb < r1; rb += 4) {
+        float4 av[4], xv[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = rb + u;
+            const bool live = col_ok && r < r1 && (!mask || mask[r]);
+            int tq = tpos + u;
+            int64_t sq = seq;
+            while (tq >= T) tq -= T, ++sq;
+            av[u] = live ? ld4(a + r * lda + c) : zero;
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int tb = bs * tq + kk - 1;
+                const bool ok = live && tb >= 0 && tb < bs * T;
+                xv[u][kk] = ok ? ld4(x + (sq * (int64_t)bs * T + tb) * ldx + c) : zero;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            add4(sb, av[u]);
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) fma4(sw[kk], av[u], xv[u][kk]);
+        }
+        tpos += 4;
+        while (tpos >= T) tpos -= T, ++seq;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) red[wave - 1][kk][lane] = sw[kk];
+        red[wave - 1][3][lane] = sb;
+    }
+    __syncthreads();
+    if (wave > 0 || !col_ok) return;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) add4(sw[kk], red[o][kk][lane]);
+        add4(sb, red[o][3][lane]);
+    }
+    // dw is (C, 1, 3): the lane's four channels are twelve consecutive floats, channel-major
+    const float o12[12] = {sw[0].x, sw[1].x, sw[2].x, sw[0].y, sw[1].y, sw[2].y, sw[0].z, sw[1].z, sw[2].z, sw[0].w, sw[1].w, sw[2].w};
+    if (partial) {
+        float* pw = partial + (int64_t)blockIdx.x * ((int64_t)C * 3 + (dbias ? C : 0));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) st4(pw + (int64_t)c * 3 + 4 * q, make_float4(o12[4 * q], o12[4 * q + 1], o12[4 * q + 2], o12[4 * q + 3]));
+        if (dbias) st4(pw + (int64_t)C * 3 + c, sb);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) atomicAdd(dw + (int64_t)c * 3 + q, o12[q]);
+        if (dbias) atomicAdd(dbias + c, sb.x), atomicAdd(dbias + c + 1, sb.y), atomicAdd(dbias + c + 2, sb.z), atomicAdd(dbias + c + 3, sb.w);
+    }
+}
+
 // out[r,c] = v[r,c] * cs[c] * rs[r] * m[r] + res[r,c] * (res_masked ? m[r] : 1) + res2[r,c]
 __global__ __launch_bounds__(256) void rowcol_scale_kernel(const float* __restrict__ v, int64_t ldv, int64_t rows, int C4,
                                                            const float* __restrict__ cs, const float* __restrict__ rs,
@@ -1024,6 +1143,43 @@ __device__ __forceinline__ float dw_bwd_elem(const DwBwdArgs& p, int b, int ti, 
     }
     return s;
 }
+// The common case -- k = 3, stride 1, one input per group, no upsample branch, C % 4 == 0 -- with four channels per thread:
+// dx[b, ti, c] = sum_o sum_k m[b, ti + 1 - k] dD_o[b, ti + 1 - k, c] w_o[c, k]: three rows x n_out float4 of dD and 3 n_out float4
+// of weights (a channel's taps are contiguous: 12 floats for 4 channels) per 4 outputs.  The element-per-thread form below spends
+// ~100 instructions per element on index arithmetic and scalar loads and ran at 3.2 TB/s of its traffic.
+template <int NOUT>
+__global__ __launch_bounds__(256) void dwconv_bwd_vec_kernel(DwBwdArgs p) {
+    const int C4 = p.C / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.B * p.Tin * C4) return;
+    const int64_t r = idx / C4;
+    const int c = (int)(idx - r * C4) * 4;
+    const int ti = (int)(r % p.Tin);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w[NOUT][3];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w[o][q] = ld4(p.w[o] + (int64_t)c * 3 + 4 * q);       // w[c .. c+3][0 .. 2], row-major
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int to = ti + 1 - k;
+        if (to < 0 || to >= p.Tin) continue;
+        const int64_t row = r + 1 - k;
+        if (p.mask_out && !p.mask_out[row]) continue;
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float4 d = ld4(p.dD[o] + row * p.lddd[o] + c);
+            const float* wf = reinterpret_cast<const float*>(&w[o][0]);          // wf[3 * ch + k]
+            acc.x = fmaf(d.x, wf[k], acc.x);
+            acc.y = fmaf(d.y, wf[3 + k], acc.y);
+            acc.z = fmaf(d.z, wf[6 + k], acc.z);
+            acc.w = fmaf(d.w, wf[9 + k], acc.w);
+        }
+    }
+    st4(p.dx + r * p.lddx + c, acc);
+}
+
 __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
     const int Cin = p.C * p.gin;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1461,6 +1617,16 @@ static int64_t colsum_rows_per_block(int64_t rows, int col_blocks) {
     return rpb;
 }
 
+// rows per block of the four-channels-per-lane column-sum kernels: ~4 blocks per CU (16 waves: the loop is bound by the latency of
+// its loads; 2 per CU: 1.67 ms per training step in dwconv_wgrad_vec_kernel, 4: 1.11, 8: 1.24), a multiple of 16 rows
+static int64_t colsum_vec_rows_per_block(int64_t rows, int col_blocks) {
+    int64_t row_blocks = 1024 / col_blocks;
+    if (row_blocks < 1) row_blocks = 1;
+    int64_t rpb = (rows + row_blocks - 1) / row_blocks;
+    rpb = (rpb + 15) / 16 * 16;
+    return rpb < 16 ? 16 : rpb;
+}
+
 extern "C" {
 
 int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
@@ -1533,12 +1699,29 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
 }
 
 int vrd_dwconv_wgrad(const float* dD, int64_t lddd, const float* x, int64_t ldx, int ksize, int stride, int group_in, int T,
-                     const uint8_t* row_mask, int64_t rows, int C, float* dw, float* dbias, void* stream) {
+                     const uint8_t* row_mask, int64_t rows, int C, float* dw, float* dbias, float* scratch, int64_t scratch_floats,
+                     void* stream) {
     VRD_CHECK_ARG(dD && x && dw && rows > 0 && C > 0 && lddd >= C, "vrd_dwconv_wgrad: bad arguments");
     VRD_CHECK_ARG((ksize == 1 || ksize == 3) && (group_in == 1 || group_in == 2) && stride >= 1 && T > 0 && rows % T == 0,
                   "vrd_dwconv_wgrad: unsupported k=%d group_in=%d stride=%d T=%d rows=%lld", ksize, group_in, stride, T, (long long)rows);
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * (1 + group_in * stride));
+    if (ksize == 3 && group_in == 1 && C % 4 == 0 && lddd % 4 == 0 && ldx % 4 == 0 && aligned16(dD) && aligned16(x)) {
+        const int col_blocks = (C + 255) / 256;
+        const int64_t rpb = colsum_vec_rows_per_block(rows, col_blocks);
+        const dim3 grid((unsigned)((rows + rpb - 1) / rpb), col_blocks);
+        const int64_t pcols = (int64_t)C * 3 + (dbias ? C : 0);
+        float* partial = grid.x > 8 && scratch && aligned16(scratch) && scratch_floats >= (int64_t)grid.x * pcols ? scratch : nullptr;
+        hipLaunchKernelGGL(dwconv_wgrad_vec_kernel, grid, dim3(256), 0, s, dD, lddd, x, ldx, stride, T, row_mask, rows, C, (int)rpb, dw, dbias,
+                           partial);
+        VRD_LAUNCH_CHECK();
+        if (partial) {
+            hipLaunchKernelGGL(colpartial_reduce_kernel, dim3((unsigned)((pcols + 63) / 64), (grid.x + 31) / 32), dim3(256), 0, s, partial,
+                               (int)grid.x, (int)pcols, dw, dbias, C * 3);
+            VRD_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const int col_blocks = (C + 63) / 64;
     const int64_t rpb = colsum_rows_per_block(rows, col_blocks);
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb), col_blocks);
@@ -1553,12 +1736,28 @@ int vrd_dwconv_wgrad(const float* dD, int64_t lddd, const float* x, int64_t ldx,
 }
 
 int vrd_colsum(const float* a, int64_t lda, const float* b, int64_t ldb, int b_cstride, int b_coffset, int b_rstride, int shift,
-               int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, void* stream) {
+               int T, const uint8_t* row_mask, const float* row_scale, int64_t rows, int C, float* out, float* scratch,
+               int64_t scratch_floats, void* stream) {
     VRD_CHECK_ARG(a && out && rows > 0 && C > 0 && lda >= C, "vrd_colsum: bad arguments");
     VRD_CHECK_ARG(!b || (T > 0 && rows % T == 0 && b_cstride >= 1 && b_rstride >= 1 && b_coffset >= 0 && b_coffset < b_cstride),
                   "vrd_colsum: bad second operand (T=%d rows=%lld)", T, (long long)rows);
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)rows * C * (b ? 2 : 1));
+    const bool same_rows = !b || (b_cstride == 1 && b_coffset == 0 && b_rstride == 1 && shift == 0);
+    if (same_rows && C % 4 == 0 && lda % 4 == 0 && aligned16(a) && (!b || (ldb % 4 == 0 && ldb >= C && aligned16(b)))) {
+        const int col_blocks = (C + 255) / 256;
+        const int64_t rpb = colsum_vec_rows_per_block(rows, col_blocks);
+        const dim3 grid((unsigned)((rows + rpb - 1) / rpb), col_blocks);
+        float* partial = grid.x > 8 && scratch && aligned16(scratch) && scratch_floats >= (int64_t)grid.x * C ? scratch : nullptr;
+        hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, s, a, lda, b, ldb, row_mask, row_scale, rows, C, (int)rpb, out, partial);
+        VRD_LAUNCH_CHECK();
+        if (partial) {
+            hipLaunchKernelGGL(colpartial_reduce_kernel, dim3((unsigned)((C + 63) / 64), (grid.x + 31) / 32), dim3(256), 0, s, partial, (int)grid.x,
+                               C, out, (float*)nullptr, C);
+            VRD_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const int col_blocks = (C + 63) / 64;
     const int64_t rpb = colsum_rows_per_block(rows, col_blocks);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((rows + rpb - 1) / rpb), col_blocks), dim3(256), 0, s, a, lda, b, ldb,
@@ -1644,7 +1843,16 @@ int vrd_dwconv_bwd(const vrd_dwconv_bwd_args* a, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)a->B * (a->dx_up ? a->Tin / 2 : a->Tin) * a->C * a->group_in;
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 0.0, 4.0 * (double)a->B * a->Tin * a->C * (a->group_in + a->n_out));
-    hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    bool vec = a->ksize == 3 && a->stride == 1 && a->group_in == 1 && !a->dx_up && a->C % 4 == 0 && a->lddx % 4 == 0 && aligned16(a->dx);
+    for (int o = 0; o < a->n_out; ++o) vec = vec && a->lddd[o] % 4 == 0 && aligned16(a->dD[o]) && aligned16(a->w[o]);
+    if (vec) {
+        const dim3 grid((unsigned)((n / 4 + 255) / 256));
+        if (a->n_out == 3) hipLaunchKernelGGL(dwconv_bwd_vec_kernel<3>, grid, dim3(256), 0, s, p);
+        else if (a->n_out == 2) hipLaunchKernelGGL(dwconv_bwd_vec_kernel<2>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(dwconv_bwd_vec_kernel<1>, grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    }
     VRD_LAUNCH_CHECK();
     return 0;
 }
