@@ -89,6 +89,43 @@ def test_c_abi_exports_every_declared_symbol():
     assert _hip.lib.vrd_abi_version() == _hip.ABI_VERSION
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/vrdone_hip.h against its ctypes binding: the same number of parameters, pointers bound as
+    pointers, 64-bit integers as c_int64, ints / enums as c_int, floats as c_float / c_double (a binding that drifts from
+    the header passes garbage in registers -- nothing else would notice before a kernel faults)."""
+    from vrdone_amd import _hip
+    header = open(os.path.join(REPO, "include", "vrdone_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = dict(re.findall(r"\b(?:int|const char\*|void)\s+(vrd_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header))
+    assert set(_hip._SIGNATURES) <= set(protos), sorted(set(_hip._SIGNATURES) - set(protos))
+
+    def kind(param):
+        param = " ".join(param.split())
+        if "*" in param:
+            return "ptr"
+        base = param.rsplit(" ", 1)[0] if " " in param else param
+        return {"int64_t": "i64", "unsigned long long": "i64", "uint64_t": "i64", "int": "i32", "int32_t": "i32", "unsigned": "i32",
+                "float": "f32", "double": "f64"}[base.replace("const ", "")]
+
+    def ckind(t):
+        if t in (ctypes.c_int64, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_ulonglong):
+            return "i64"
+        if t in (ctypes.c_int, ctypes.c_int32, ctypes.c_uint):
+            return "i32"
+        if t is ctypes.c_float:
+            return "f32"
+        if t is ctypes.c_double:
+            return "f64"
+        return "ptr"                      # c_void_p, c_char_p, POINTER(...)
+
+    for name, (_, argtypes) in _hip._SIGNATURES.items():
+        params = [p for p in protos[name].split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(argtypes), f"{name}: header has {len(params)} parameters, the binding {len(argtypes)}"
+        got = [ckind(t) for t in argtypes]
+        want = [kind(p) for p in params]
+        assert got == want, f"{name}: header {want} vs binding {got}"
+
+
 def test_ctypes_struct_layout_matches_header():
     """Field order of the ctypes mirrors vs the C structs in the header."""
     from vrdone_amd import _hip
