@@ -43,11 +43,10 @@ _PARTIAL_SUMS = os.environ.get("VRD_PARTIAL_SUMS", "1") != "0"      # A/B switch
 
 
 def _partials(device):
-    """The buffer the gradient kernels park their workgroups' partial sums in before a second launch adds them up:
-    vrd_gemm_wgrad_x3 (the row chunks' partial tiles: 4 * CUs * 16,384 + N * K floats suffice, include/vrdone_hip.h; sized for
-    weights of up to 4 M elements, beyond that the kernel falls back to atomics), vrd_layernorm_bwd, vrd_colsum and
-    vrd_dwconv_wgrad (rows of per-workgroup column sums, a few MB).  One per device, and one more for launches recorded into a
-    graph (that one lives in the graph's pool); only ever live between two adjacent launches of one stream."""
+    """The buffer the gradient kernels park their workgroups' partial sums in before a second launch adds them up
+    (vrd_gemm_wgrad_x3: the row chunks' partial tiles, include/vrdone_hip.h: 4 * CUs * 16,384 + N * K floats
+    suffice; sized for weights of up to 4 M elements, beyond that the kernel falls back to atomics).  One per device, and one
+    more for launches recorded into a graph (that one lives in the graph's pool); only ever live between two adjacent launches."""
     key = (torch.device(device), torch.cuda.is_current_stream_capturing())
     buf = _partial_scratch.get(key)
     if buf is None and not _PARTIAL_SUMS:
