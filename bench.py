@@ -108,7 +108,18 @@ def kernel_source_sha():
     for f in files:
         h.update(os.path.relpath(f, REPO).encode())
         with open(f, "rb") as fh:
-            h.update(fh.read())
+            data = fh.read()
+        if f.endswith(".py"):
+            # host code counts by what it DOES: comments and docstrings do not move a profile's stamp
+            import ast
+            tree = ast.parse(data)
+            for node in ast.walk(tree):
+                body = getattr(node, "body", None)
+                if isinstance(body, list) and body and isinstance(body[0], ast.Expr) and \
+                        isinstance(getattr(body[0], "value", None), ast.Constant) and isinstance(body[0].value.value, str):
+                    body[0] = ast.Pass()
+            data = ast.dump(tree).encode()
+        h.update(data)
     return h.hexdigest()[:16]
 
 

@@ -308,6 +308,23 @@ def test_global_attention_kernels(algo, H, hd, Tq, Tk):
     close(ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), None, H, algo=algo), want, 3e-5)
 
 
+@pytest.mark.parametrize("H,hd,Tq,Tk", [(8, 32, 10, 9), (4, 32, 9, 7), (4, 64, 5, 3)])
+def test_small_lds_attention_odd_key_counts(H, hd, Tq, Tk):
+    """attn_small_lds_kernel (algo 1, Tq <= 16): K is staged at pitch hd + 1, V behind it as float4 rows -- with an odd number
+    of keys (tight padding runs the predictor's cross-attention at Tk = t2 / down, any integer) the V region must still
+    start on a 16-byte boundary.  Key masks on, one sequence with a single valid key."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(H * hd + Tq * Tk)
+    B, C = 3, H * hd
+    q = torch.randn(B, Tq, C, generator=gen) * 2.0
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    lens = torch.tensor([Tk, max(1, Tk // 2), 1])
+    mask = torch.arange(Tk)[None] < lens[:, None]
+    want = O.full_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), mask[:, None], H).transpose(1, 2)
+    close(ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), mask.to(DEV), H, algo=1), want, 3e-5)
+
+
 def test_flash_attention_online_softmax_rescale():
     """A late key tile that dominates every earlier one forces the running-max rescale branch."""
     from vrdone_amd import ops

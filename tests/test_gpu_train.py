@@ -454,6 +454,60 @@ def test_training_graphs_take_the_same_steps():
     assert not train_graph.recordings(model)
 
 
+def test_training_graph_survives_a_step_in_another_precision_mode():
+    """A recording holds raw device pointers into the split-operand plan it captured (job table, chunk tables, operand
+    buffers).  ops.presplit_weights drops the model's plans of other modes, so a step in bf16x3 evicts the f16x3 plan from
+    the model's dict: the f16x3 recording must keep it alive itself (`_Recording.split_plans`) and its replay must still
+    give the eager step's loss and gradients."""
+    import importlib.util
+    from vrdone_amd import configs, ops, synth, train_graph
+    from vrdone_amd.models.blocks import AffineDropPath
+    from vrdone_amd.models.maskvrd import MaskVRD
+    spec = importlib.util.spec_from_file_location("train_step", os.path.join(os.path.dirname(GOLDEN), "..", "scripts", "train_step.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    cfg = configs.model_config("vidvrd")
+    model = synth.load_synthetic_weights(MaskVRD(cfg, device=DEV)).to(DEV).train()
+    for mod in model.modules():
+        if isinstance(mod, AffineDropPath):
+            mod.drop_prob = 0.0
+    data = ts.synthetic_batch(cfg, configs.input_channels(cfg), DEV, n_pairs=12, seed=11)
+
+    def step(graphs):
+        model.enable_training_graphs(graphs)
+        model.zero_grad(set_to_none=True)
+        loss = model(data)["total_loss"]
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    old = ops.get_precision()
+    try:
+        ops.set_precision("f16x3")
+        step(True)                                              # records the f16x3 graphs
+        rec = next(iter(train_graph.recordings(model).values()))
+        assert rec.split_plans, "the recording must hold the plan its captures point into"
+        ops.set_precision("bf16x3")
+        step(False)                                             # an eager step in the other mode: evicts the f16x3 plan
+        assert len(model._split_plans) == 1
+        torch.cuda.empty_cache()                                # freed operand buffers really go back to the device
+        junk = torch.full((64 << 20,), float("nan"), device=DEV)       # ... and whatever reuses their memory is not a weight operand
+        ops.set_precision("f16x3")
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.01)                                    # the replay must re-split the weights as they are now
+        want = step(False)
+        got = step(True)
+        assert len(train_graph.recordings(model)) == 1          # replayed, not re-recorded
+        del junk
+    finally:
+        ops.set_precision(old)
+        train_graph.forget(model)
+    assert np.isfinite(got[0]) and abs(got[0] - want[0]) <= 2e-5 * abs(want[0])
+    floor = 1e-6 * max(float(g.abs().max()) for g in want[1].values())
+    for k, g in want[1].items():
+        assert float((got[1][k] - g).abs().max()) <= 2e-4 * float(g.abs().max()) + floor, k
+
+
 def test_device_assignment_equals_scipy():
     """vrd_assign (one thread per pair, Hungarian with potentials) against scipy.optimize.linear_sum_assignment -- what the
     reference's matcher calls per pair (models/maskvrd.py:492) -- on random cost blocks of every size N <= Q, Q = 9, 10, 16."""

@@ -43,17 +43,27 @@ _PARTIAL_SUMS = os.environ.get("VRD_PARTIAL_SUMS", "1") != "0"      # A/B switch
 
 
 def _partials(device):
-    """The buffer the gradient kernels park their workgroups' partial sums in before a second launch adds them up
-    (vrd_gemm_wgrad_x3: the row chunks' partial tiles, include/vrdone_hip.h: 4 * CUs * 16,384 + N * K floats
-    suffice; sized for weights of up to 4 M elements, beyond that the kernel falls back to atomics).  One per device, and one
-    more for launches recorded into a graph (that one lives in the graph's pool); only ever live between two adjacent launches."""
-    key = (torch.device(device), torch.cuda.is_current_stream_capturing())
+    """The buffer the gradient kernels park their workgroups' partial sums in before a second launch adds them up (users:
+    vrd_gemm_wgrad_x3 -- the row chunks' partial tiles, include/vrdone_hip.h: 4 * CUs * 16,384 + N * K floats suffice --,
+    vrd_layernorm_bwd, vrd_colsum and vrd_dwconv_wgrad; sized for weights of up to 4 M elements, beyond that the wgrad kernel
+    falls back to atomics).  It is only ever live between two adjacent launches of ONE stream, so there is one per (device,
+    stream): two backward passes on different streams of a device (two replicas in a process, autograd on a side stream) each
+    get their own.  Launches recorded into a graph allocate theirs per call from the graph's private pool (a buffer cached
+    from one recording's pool must not be written by another recording's replays)."""
+    dev = torch.device(device)
+    if not _PARTIAL_SUMS:
+        key = (dev, None)
+        if key not in _partial_scratch:
+            _partial_scratch[key] = torch.empty(0, device=dev, dtype=torch.float32)
+        return _partial_scratch[key]
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    n = 4 * cus * 16384 + (4 << 20)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, device=dev, dtype=torch.float32)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     buf = _partial_scratch.get(key)
-    if buf is None and not _PARTIAL_SUMS:
-        buf = _partial_scratch[key] = torch.empty(0, device=key[0], dtype=torch.float32)
     if buf is None:
-        cus = torch.cuda.get_device_properties(key[0]).multi_processor_count
-        buf = _partial_scratch[key] = torch.empty(4 * cus * 16384 + (4 << 20), device=key[0], dtype=torch.float32)
+        buf = _partial_scratch[key] = torch.empty(n, device=dev, dtype=torch.float32)
     return buf
 
 

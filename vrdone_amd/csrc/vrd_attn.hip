@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_small_lds_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float sl[];
     const int kp = hd + 1;                                   // K row pitch: lanes read different rows at the same d
     float* const ks = sl;
-    float* const vs = ks + Tk * kp;
+    float* const vs = ks + ((Tk * kp + 3) & ~3);             // V rows are written as float4: start on a 16-byte boundary for any Tk
     float* const qs = vs + Tk * hd;                          // [4][hd]
     float* const ps = qs + 4 * SM_MAX_HD;                    // [4][Tk]
     const int b = blockIdx.y, h = blockIdx.x;
@@ -572,7 +572,7 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
     if (algo == 1) {
         VRD_CHECK_ARG(Tk <= SM_MAX_TK, "vrd_attention: generic kernel supports Tk <= %d", SM_MAX_TK);
         vrd::ProfScope prof(VRD_K_ATTN_SMALL, s, flops, bytes);
-        const int lds_floats = Tk * (2 * head_dim + 1) + 4 * SM_MAX_HD + 4 * Tk;
+        const int lds_floats = ((Tk * (head_dim + 1) + 3) & ~3) + Tk * head_dim + 4 * SM_MAX_HD + 4 * Tk;      // (K region rounded up to 16 bytes)
         if (Tq <= 16 && lds_floats <= SL_MAX_FLOATS) {
             // a few queries over a short key row: K / V of a head staged in LDS once per (b, head)
             hipLaunchKernelGGL(attn_small_lds_kernel, dim3(n_head, B), dim3(256), (size_t)lds_floats * sizeof(float), s, q, ldq, k, v, ldkv,

@@ -522,6 +522,7 @@ extern "C" int vrd_attention_bwd(const float* q, int64_t ldq, const float* k, co
     if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), DKV_LDS, "vrd_attention_bwd(dk, dv)")) return rc;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + NW * 32 - 1) / (NW * 32), n_head, B), dim3(NW * 64), DQ_LDS, s, q, ldq, k, v, ldkv, out, dO,
                        ldo, kv_mask, Tq, Tk, n_head, scale, dq, lse, lse_own, delta);
+    VRD_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + NW * 32 - 1) / (NW * 32), n_head, B), dim3(NW * 64), DKV_LDS, s, q, ldq, k, v, ldkv, dO, ldo,
                        kv_mask, Tq, Tk, n_head, scale, lse ? lse : lse_own, delta, dk, dv);
     VRD_LAUNCH_CHECK();

@@ -1654,11 +1654,7 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
     VRD_CHECK_ARG(ldg >= N && ldx >= Cin, "vrd_gemm_wgrad_x3: leading dimension too small");
     VRD_CHECK_ARG(T > 0 && M % T == 0, "vrd_gemm_wgrad_x3: M (%lld) must be a multiple of T (%d)", (long long)M, T);
     const int K = Cin * taps;
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    const int n_cu = vrd::device_cu_count();
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * (double)M * N * K, 4.0 * ((double)M * (N + Cin) + (double)N * K));
     static const bool use_lds = [] { const char* e = getenv("VRD_WGRAD_LDS"); return !(e && e[0] == '0'); }();

@@ -14,6 +14,9 @@ void set_error(const char* fmt, ...);
 // Remembered per (function, device) under the library mutex; 0 on success, -2 (error string set) otherwise.
 int reserve_lds(const void* kernel, size_t bytes, const char* what);
 
+// CUs of the CURRENT device (cached per device ordinal: a process may drive devices of different sizes / partition modes)
+int device_cu_count();
+
 // RAII profiling scope: when profiling is on, records a HIP event pair on `stream`
 // around the launch(es) issued inside the scope.
 struct ProfScope {

@@ -32,6 +32,14 @@ constexpr int NA_STG = 3, NW_STG = 2;
 constexpr int W_RING = NA_STG * A_STAGE;       // byte offset of the W ring
 constexpr size_t BIG_LDS = (size_t)NA_STG * A_STAGE + (size_t)NW_STG * W_STAGE;      // 163,840
 constexpr int PER = 4;                         // DMA instructions per wave, operand and K step (8 rows x 128 B each)
+#ifndef VRD_BIG_BUFDMA
+#define VRD_BIG_BUFDMA 0                       // 1: LDS-DMA by buffer_load ... lds (scalar base + offsets), 0: global_load_lds (per-lane pointers)
+#endif
+#if VRD_BIG_BUFDMA && defined(__HIP_DEVICE_COMPILE__)      // (the descriptor type exists in the device pass only)
+#define VRD_BUFDMA_DEV 1
+#else
+#define VRD_BUFDMA_DEV 0
+#endif
 
 __device__ __attribute__((aligned(128))) uint4 g_big_zero[8];      // 128 zero bytes: source of padded taps and outside pieces
 // sum over the tiles that skipped their contraction (padding map) of K * tile columns: 2 * 256 * this = FLOPs that
@@ -147,6 +155,10 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
     struct Src {
         const char *a0, *w0;
         int tseq0, a_in, w_in, w_last;
+#if VRD_BUFDMA_DEV
+        __amdgpu_buffer_rsrc_t ra, rw;          // wave-uniform descriptors: the wave's A block (one row back for k = 3), its W rows
+        unsigned va[2], vw[2];                  // per-lane byte offsets inside them, even / odd pieces (source-side swizzle)
+#endif
     };
     auto src_of = [&](const Tile& t) {
         const int my_blk = blk_of(t.tm * 8 + wave);          // the block whose A rows this wave stages
@@ -160,11 +172,31 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
         // >= N are never stored, and a uniform minimum costs the loop less than a per-lane select of the zero block
         r.w_last = (r.w_in > 0 ? (r.w_in < PER ? r.w_in : PER) : 1) - 1;
         r.w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + (r.w_in > 0 ? row0 : rin)) * K * 4 + chunk0;
+#if VRD_BUFDMA_DEV
+        {
+            // buffer form of the same requests: base (scalar) + per-lane offset (constant for the tile) + scalar offset (piece,
+            // K step, tap).  Offsets >= 2^31 are out of range: such a lane's 16 bytes arrive in LDS as zeros, which is how
+            // padded taps and pieces outside the matrix are produced here (no zero block, no per-lane pointer select).
+            const int64_t a_row_u = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 - (TAPS == 3 ? 1 : 0);
+            r.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + a_row_u * p.lda), 0, 0x80000000u, 0x00020000);
+            r.rw = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + (r.w_in > 0 ? wave * PER * 8 : 0)) * K * 4), 0,
+                0x80000000u, 0x00020000);
+            const unsigned a_lane = (unsigned)rin * (unsigned)(p.lda * 4), w_lane = (unsigned)rin * (unsigned)(K * 4);
+            r.va[0] = a_lane + chunk0, r.va[1] = a_lane + (chunk0 ^ 64);
+            r.vw[0] = w_lane + chunk0, r.vw[1] = w_lane + (chunk0 ^ 64);
+        }
+#endif
         return r;
     };
     // piece i of W(kt) / A(kt): one DMA instruction each
     auto issue_w1 = [&](const Src& c, int kt, int i) {
         char* const dst = lds + W_RING + (kt % NW_STG) * W_STAGE + wave * PER * 1024;
+#if VRD_BUFDMA_DEV
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (lds_ptr_t)(dst + i * 1024), 16, c.vw[i & 1],
+                                                 (i < c.w_last ? i : c.w_last) * (int)w_pstride + kt * 128, 0, 0);
+        return;
+#endif
         const char* src = c.w0 + (i < c.w_last ? i : c.w_last) * w_pstride + (int64_t)kt * 128;
         if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
         __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
@@ -177,6 +209,20 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
             tap = (k0 >= p.Cin) + (k0 >= 2 * p.Cin);
             ci0 = k0 - tap * p.Cin;
         }
+#if VRD_BUFDMA_DEV
+        {
+            unsigned vo = c.va[i & 1];
+            if (TAPS == 3) {
+                int tt = c.tseq0 + 8 * i;
+                if (tt >= p.T) tt -= p.T;
+                tt += tap - 1;
+                if (tt < 0 || tt >= p.T || i >= c.a_in) vo = 0x80000000u;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_ptr_t)(dst + i * 1024), 16, vo,
+                                                     i * (int)a_pstride + tap * (int)(p.lda * 4) + ci0 * 4, 0, 0);
+            return;
+        }
+#endif
         const int64_t off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 + (int64_t)ci0 * 4;
         // (k = 1: a wave whose block lies outside the matrix reads block 0 -- its accumulator rows are never stored)
         const char* src = TAPS == 1 || i < c.a_in ? c.a0 + i * a_pstride + off : zero_src + chunk0;
@@ -524,8 +570,10 @@ int launch_gemm_x3_big(const vrd_gemm_args& a, hipStream_t s) {
     static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
     // VRD_BIG_PERSIST=1: one workgroup per CU walking its tiles, the next tile's first stage requested under the epilogue
     static const int persist = [] { const char* e = getenv("VRD_BIG_PERSIST"); return e ? atoi(e) : 0; }();
-    if (a.split_fmt == VRD_PAIR_F16)        // (the two opt-in variants exist for the bf16 format only)
+    if (a.split_fmt == VRD_PAIR_F16) {      // (the persistent variant exists for the bf16 format only)
+        if (m16) return a.taps == 1 ? launch_big_one<1, true, false, true>(a, s) : launch_big_one<3, true, false, true>(a, s);
         return a.taps == 1 ? launch_big_one<1, false, false, true>(a, s) : launch_big_one<3, false, false, true>(a, s);
+    }
     if (m16) return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
     if (persist) return a.taps == 1 ? launch_big_one<1, false, true>(a, s) : launch_big_one<3, false, true>(a, s);
     return a.taps == 1 ? launch_big_one<1, false, false>(a, s) : launch_big_one<3, false, false>(a, s);

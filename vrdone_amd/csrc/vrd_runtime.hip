@@ -50,6 +50,20 @@ int reserve_lds(const void* kernel, size_t bytes, const char* what) {
     return 0;
 }
 
+int device_cu_count() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    static std::vector<int> cus;           // by device ordinal, 0 = not asked yet
+    if (dev >= (int)cus.size()) cus.resize(dev + 1, 0);
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 static hipEvent_t get_event() {
     if (!g_free_events.empty()) {
         hipEvent_t e = g_free_events.back();

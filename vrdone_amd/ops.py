@@ -288,11 +288,15 @@ _presplit_on = os.environ.get("VRDONE_PRESPLIT", "1") != "0"        # A/B switch
 
 class presplit_scope:
     """`with ops.presplit_scope():` around the graph captures of one recording: operands that presplit_weights builds inside
-    are accepted by the captures of the same scope (the backward graph reads what the forward graph's launch wrote)."""
+    are accepted by the captures of the same scope (the backward graph reads what the forward graph's launch wrote).
+    `plans` collects every plan a capture inside the scope used: the captured launches hold only raw device pointers into
+    its job table, chunk tables and operand buffers, so the recording keeps this list for as long as its graphs live
+    (presplit_weights drops a model's plans of other modes / replaced parameters from the model's own dict)."""
 
     def __enter__(self):
         global _presplit_scope
-        self.prev, _presplit_scope = _presplit_scope, object()
+        self.plans = []
+        self.prev, _presplit_scope = _presplit_scope, self
         return self
 
     def __exit__(self, *exc):
@@ -308,7 +312,9 @@ def presplit_weights(weights, plans):
     version of each weight.  A training step otherwise
     re-splits every weight with a launch of its own, twice (after every optimiser update): 242 launches on the 24-pair batch.
     plans: a dict the caller owns (the model's): tuple of weight addresses -> (job table on the device, chunk tables, the
-    persistent operand buffers); it lives as long as the model and the graphs recorded for it, which read those buffers.
+    persistent operand buffers).  Plans of another mode or of replaced parameters are dropped from it here; a graph
+    recording that captured a plan's launch keeps its own reference (presplit_scope.plans), so the buffers its replays
+    read and write outlive the dict entry.
     The job table is built (and uploaded) on the first call for a set of weights -- outside any graph capture: inside one,
     without a table, nothing is done and the per-weight launches run as before."""
     if _precision not in ("bf16x3", "f16x3") or not weights or not _presplit_on:
@@ -353,6 +359,8 @@ def presplit_weights(weights, plans):
                 len(jobs))
         plans[key] = plan
     table, cj, ci, outs, n_jobs = plan
+    if _capturing() and _presplit_scope is not None and not any(q is plan for q in _presplit_scope.plans):
+        _presplit_scope.plans.append(plan)
     by_ptr = {w.data_ptr(): w for w in weights}
     if not _capturing():        # nothing moved since the last call (an evaluation of the same weights, a second forward): keep the operands
         def current(ptr, slot):

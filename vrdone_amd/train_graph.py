@@ -86,7 +86,8 @@ class _Recording:
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
             self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with ops.presplit_scope():          # the backward graph reads the operands the forward graph's one split launch writes
+            with ops.presplit_scope() as scope:  # the backward graph reads the operands the forward graph's one split launch writes
+                self.split_plans = scope.plans   # job tables and operand buffers the captured launches point into
                 with torch.cuda.graph(self.fwd, pool=pool):
                     out = network()
                 self.static_out, self.spec = pytree.tree_flatten(out)
