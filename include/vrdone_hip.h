@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 28
+#define VRD_ABI_VERSION 29
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -60,6 +60,20 @@ enum vrd_kernel_id {
 
 int vrd_abi_version(void);
 const char* vrd_last_error(void);
+
+/* ---- operand range of the VRD_PAIR_F16 format ----
+ * A value x with |x * 2^VRD_F16_ACT_EXP| >= 65,520 does not fit the f16 planes of a pair row: it is stored as hi = inf,
+ * lo = -inf and poisons every product it enters, but a NaN does not reach the outputs reliably (the ReLU behind the embedding
+ * LayerNorms and the max-pools of the branch blocks drop it: fmax(NaN, x) = x).  Every kernel that WRITES pair rows in this
+ * format, or splits f32 rows into them while staging, therefore reports: it ORs a tag naming its family into one 32-bit flag
+ * word per device -- 1 boundary tensors (vrd_bct_to_btc, vrd_pack_pairs, vrd_gather_pairs), 2 vrd_layernorm, 4 vrd_dwconv_ln,
+ * 8 pair-row outputs of vrd_gemm / vrd_gemm_batch, 16 f32 rows split inside vrd_gemm, 32 pair-row outputs of vrd_local_attn /
+ * vrd_attention.  (vrd_attention_pair needs none: its outputs are averages of value rows that were checked when they were
+ * written.)  The word lives in device memory for the life of the process; the caller reads it together with a call's
+ * results (an asynchronous 4-byte copy on the same stream), repeats the call in another precision if it is non-zero, and
+ * clears it with a 4-byte memset.  The reference computes in float32 and has no such limit (models/blocks.py:728-737).
+ * `flag` receives the device address of the CURRENT device's word. */
+int vrd_f16_range_flag(void** flag);
 
 /* ---- profiling: HIP events around every launch of a family, on the launch stream ---- */
 int vrd_prof_enable(int on);

@@ -22,7 +22,7 @@ def run_bench(*flags, env=None):
 
 
 def test_bench_line_contract_small():
-    b = run_bench("--pairs", "64", "--steps", "2", "--warmup", "1", "--cpu-pairs", "2", "--no-alt", "--no-ragged", "--no-forward-test",
+    b = run_bench("--pairs", "64", "--steps", "2", "--warmup", "1", "--cpu-pairs", "2", "--no-ragged", "--no-forward-test",
                   "--no-train-step", "--no-shard-projection")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
@@ -39,6 +39,12 @@ def test_bench_line_contract_small():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    assert "aux" in c["sample"]                                   # says that it computes the heads the GPU leg skips
+    assert "64 pairs x 256 frames" in b["metric"]                 # the shape in `metric` is the shape that ran
+    # the exact-f32 figure of the same workload, at the top level (the driver's parser keeps top-level keys)
+    ra = b["reference_arithmetic"]
+    assert ra["gemm_precision"] == "f32" and ra["value"] > 0 and ra["unit"] == "pairs/s"
+    assert abs(ra["value"] - 64 / (ra["ms_per_step"] * 1e-3)) <= 1e-6 * ra["value"] and 0 < ra["roofline"]["frac"] < 1
 
 
 def test_bench_starts_its_own_ranks():

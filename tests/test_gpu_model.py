@@ -220,8 +220,10 @@ def test_f16x3_overflow_is_loud_and_forward_test_repeats_in_f32():
     dev_data = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in big.items()}
     inputs, masks, _ = model.preprocessing(dev_data["so_features_list"])
     with ops.use_precision("f16x3"):
+        ops.f16_range_flag().zero_()
         out = model._mask_vrd(inputs[0], masks[0], with_aux=False)
         assert not bool(torch.isfinite(out["pred_logits"]).all())          # poisoned, not silently wrong
+        assert ops.f16_range_exceeded() & 1                                 # ... and reported by the kernel that split the inputs
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             got = model(dev_data)
@@ -229,6 +231,121 @@ def test_f16x3_overflow_is_loud_and_forward_test_repeats_in_f32():
     with ops.use_precision("f32"):
         want = model(dev_data)
     assert got is not None and got["triplets"] == want["triplets"] and got["triple_scores_avg"] == want["triple_scores_avg"]
+
+
+def _model_with(sd_edit):
+    """a vidvrd model whose synthetic state dict went through `sd_edit(sd)` first (+ that state dict)"""
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, ic, keys = load_case("vidvrd")
+    sd = O.synth_state_dict(keys, eos_coef=mc["loss_coeff_dict"]["eos_coef"])
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd_edit(sd)
+    model = MaskVRD(mc, device=DEV)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    model._config_eval(ic)
+    return model, mc, sd
+
+
+def test_f16x3_heavy_tailed_weights_stay_in_range_and_reference_grade():
+    """Trained-like weight statistics instead of the synthetic state dict's even ones: LayerNorm gains up to 10 on a few
+    channels and a few rows x 30 in every block's MLP up-projection, so that INTERNAL tensors (MLP hiddens, residual streams,
+    the SOS streams) run at hundreds instead of ones -- a sizeable part of the f16 planes' +-4094.  The f16x3 mode stays within
+    2 x the float32 oracle's own distance to float64, and no producer reports its range exceeded."""
+    from vrdone_amd import ops
+
+    def edit(sd):
+        gen = torch.Generator().manual_seed(11)
+        for k, v in sd.items():
+            if (k.endswith("ln1.weight") or k.endswith("ln2.weight") or k.endswith("_norm.weight")) and v.dim() == 3 and v.shape[1] >= 256:
+                idx = torch.randperm(v.shape[1], generator=gen)[:max(2, v.shape[1] // 64)]
+                v[:, idx] *= 10.0
+            if k.endswith("mlp.0.weight"):
+                v[torch.randperm(v.shape[0], generator=gen)[:4]] *= 30.0
+    model, mc, sd = _model_with(edit)
+    x, m = O.synth_pairs(4, c_in(mc), 96, [96, 95, 41, 2], seed=4322)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    want = O.mask_vrd(sd64, mc, x.double(), m, with_aux=False)
+    own32 = O.mask_vrd(sd, mc, x, m, with_aux=False)
+    with ops.use_precision("f16x3"):
+        ops.f16_range_flag().zero_()
+        got = model._mask_vrd(x.to(DEV), m.to(DEV), with_aux=False)
+        assert ops.f16_range_exceeded() == 0
+    for k in ("pred_logits", "pred_masks"):
+        e = float((got[k].double().cpu() - want[k]).abs().max())
+        e32 = float((own32[k].double() - want[k]).abs().max())
+        print(f"{k}: |f16x3 - f64| {e:.2e}, |f32 oracle - f64| {e32:.2e} (x{e / e32:.2f})")
+        assert e <= 2.0 * e32 + 1e-7, (k, e, e32)
+
+
+def test_f16x3_internal_overflow_is_reported_and_repeated_in_f32(precision):
+    """An activation INSIDE the network beyond the f16 planes' range, with ordinary inputs: the first block's MLP
+    up-projection scaled by 4000 (its down-projection by 1 / 4000, so the float32 network computes what it computed
+    before).  The hidden tensor is a pair-row GEMM output: the kernel that writes it reports (flag bit 8), forward_test
+    repeats the video and forward_training / forward_loss the step in the f32 mode and return ITS results; the other modes
+    are untouched."""
+    import warnings
+    from vrdone_amd import ops
+    from vrdone_amd.models.blocks import AffineDropPath
+
+    def edit(sd):
+        sd["backbone.stem.0.mlp.0.weight"] *= 4000.0
+        sd["backbone.stem.0.mlp.0.bias"] *= 4000.0
+        sd["backbone.stem.0.mlp.3.weight"] /= 4000.0
+    model, mc, _ = _model_with(edit)
+    data = synth_proposal(4, c_in(mc), 20, 60, seed=98)
+    dev_data = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in data.items()}
+    with ops.use_precision("f32"):
+        want = model(dev_data)
+    inputs, masks, _ = model.preprocessing(dev_data["so_features_list"])
+    ops.f16_range_flag().zero_()
+    model._mask_vrd(inputs[0], masks[0], with_aux=False)
+    bits = ops.f16_range_exceeded()
+    assert (bits & 8) != 0 if precision == "f16x3" else bits == 0, (precision, bits)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = model(dev_data)
+    assert any("f16x3" in str(x.message) for x in w) == (precision == "f16x3")
+    if precision == "f16x3":
+        assert got is not None and got["triplets"] == want["triplets"] and got["triple_scores_avg"] == want["triple_scores_avg"]
+    # a training step and a validation pass
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train_step", os.path.join(os.path.dirname(GOLDEN), "..", "scripts", "train_step.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    from vrdone_amd import configs
+    cfg = configs.model_config("vidvrd")
+    batch = ts.synthetic_batch(cfg, configs.input_channels(cfg), DEV, n_pairs=6, seed=5)
+    model.train()
+    try:
+        for mod in model.modules():
+            if isinstance(mod, AffineDropPath):
+                mod.drop_prob = 0.0
+        with torch.enable_grad():
+            with ops.use_precision("f32"):
+                model.zero_grad(set_to_none=True)
+                want_loss = model(batch)["total_loss"]
+                want_loss.backward()
+                want_grad = model.backbone.stem[0].mlp[3].weight.grad.clone()
+            model.zero_grad(set_to_none=True)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                loss = model(batch)["total_loss"]
+            loss.backward()
+            grad = model.backbone.stem[0].mlp[3].weight.grad
+        assert bool(torch.isfinite(loss)) and bool(torch.isfinite(grad).all())
+        if precision == "f16x3":
+            assert any("f32 mode" in str(x.message) for x in w)
+            assert float((loss - want_loss).abs()) <= 1e-5 * float(want_loss.abs())
+            assert float((grad - want_grad).abs().max()) <= 1e-4 * float(want_grad.abs().max())
+        with torch.no_grad():
+            val = model(batch)["total_loss"]
+        assert bool(torch.isfinite(val))
+        if precision == "f16x3":
+            assert float((val - want_loss).abs()) <= 1e-5 * float(want_loss.abs())
+    finally:
+        model.eval()
+        model.zero_grad(set_to_none=True)
 
 
 def test_mask_vrd_matches_oracle_on_a_ragged_batch(precision):

@@ -104,6 +104,7 @@ class AssembleArgs(C.Structure):
 _SIGNATURES = {
     "vrd_abi_version": (C.c_int, []),
     "vrd_last_error": (C.c_char_p, []),
+    "vrd_f16_range_flag": (C.c_int, [C.POINTER(C.c_void_p)]),
     "vrd_prof_enable": (C.c_int, [C.c_int]),
     "vrd_prof_reset": (C.c_int, []),
     "vrd_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -171,7 +172,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 
 class HipLibraryError(RuntimeError):
@@ -204,6 +205,11 @@ lib = _load()
 def check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed ({rc}): {lib.vrd_last_error().decode()}")
+
+
+# tags of the f16 operand-range flag word (vrd_f16_range_flag)
+RANGE_TAGS = {1: "boundary tensors (bct_to_btc / pack_pairs / gather_pairs)", 2: "layernorm", 4: "dwconv_ln", 8: "gemm outputs",
+              16: "f32 rows split inside a gemm", 32: "attention outputs", 64: "other"}
 
 
 def prof_enable(on=True):

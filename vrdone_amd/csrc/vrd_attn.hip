@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
                                                          const float* __restrict__ v, int64_t ld,
                                                          const uint8_t* __restrict__ mask, const float* __restrict__ rel,
                                                          int B, int T, float scale,
-                                                         float* __restrict__ out, int64_t ldo, int pair) {
+                                                         float* __restrict__ out, int64_t ldo, int pair, unsigned* rflag) {
     constexpr int HW = W / 2;
     const int lane = threadIdx.x & 63;
     // XCD-aware renumbering (as in the GEMM / flash kernels): consecutive workgroups are dealt round-robin to the
@@ -82,8 +82,10 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
         a1.x += pj * v1.x; a1.y += pj * v1.y; a1.z += pj * v1.z; a1.w += pj * v1.w;
     }
     if (pair) {
-        vrd::store_pair4(out + row * ldo, lane * 8, 512, a0, pair);
-        vrd::store_pair4(out + row * ldo, lane * 8 + 4, 512, a1, pair);
+        vrd::RangeTrack rt;           // (q, k, v are f32 rows here: nothing upstream has checked their range)
+        vrd::store_pair4(out + row * ldo, lane * 8, 512, a0, pair, &rt);
+        vrd::store_pair4(out + row * ldo, lane * 8 + 4, 512, a1, pair, &rt);
+        rt.report(rflag, vrd::RANGE_ATTN_OUT);
     } else {
         st4(o, a0);
         st4(o + 4, a1);
@@ -99,8 +101,10 @@ __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __re
                                                                const float* __restrict__ v, int64_t ld,
                                                                const uint8_t* __restrict__ mask, const float* __restrict__ rel,
                                                                int B, int T, int strips_per_seq,
-                                                               float scale, float* __restrict__ out, int64_t ldo, int pair) {
+                                                               float scale, float* __restrict__ out, int64_t ldo, int pair,
+                                                               unsigned* rflag) {
     constexpr int HW = W / 2, R = W + 1;
+    vrd::RangeTrack rt;
     const int lane = threadIdx.x & 63;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
@@ -190,14 +194,15 @@ __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __re
                 a1.x += pj * vv.b.x; a1.y += pj * vv.b.y; a1.z += pj * vv.b.z; a1.w += pj * vv.b.w;
             }
             if (pair) {
-                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8, 512, a0, pair);
-                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8 + 4, 512, a1, pair);
+                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8, 512, a0, pair, &rt);
+                vrd::store_pair4(out + (row_b + t) * ldo, lane * 8 + 4, 512, a1, pair, &rt);
             } else {
                 st4(o, a0);
                 st4(o + 4, a1);
             }
         }
     }
+    rt.report(rflag, vrd::RANGE_ATTN_OUT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_kernel(const float* __r
                                                              const float* __restrict__ k, const float* __restrict__ v,
                                                              int64_t ldkv, const uint8_t* __restrict__ kv_mask, int Tq,
                                                              int Tk, float scale, float* __restrict__ out, int64_t ldo,
-                                                             int pair) {
+                                                             int pair, unsigned* rflag) {
     constexpr int NT = NW * 64;
     constexpr int KP = HD + 1;                    // K tile pitch: conflict-free b32 fragment reads
     constexpr int PIECES = 32 * HD / 4;           // float4 pieces per 32-key tile
@@ -471,6 +476,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_kernel(const float* __r
     const float inv = 1.0f / l_tot;
     const int tq = q0 + li;
     if (tq < Tq) {
+        vrd::RangeTrack rt;
         float* orow = out + ((int64_t)b * Tq + tq) * ldo;
         const int width = gridDim.y * HD;
 #pragma unroll
@@ -481,9 +487,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_kernel(const float* __r
                 const int c = h * HD + 32 * d + 8 * g + 4 * lh;
                 const float4 v = make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv,
                                              oacc[d][4 * g + 3] * inv);
-                if (pair) vrd::store_pair4(orow, c, width, v, pair);
+                if (pair) vrd::store_pair4(orow, c, width, v, pair, &rt);
                 else st4(orow + c, v);
             }
+        rt.report(rflag, vrd::RANGE_ATTN_OUT);
     }
 }
 
@@ -506,6 +513,7 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
     const int W = 2 * half_win + 1;
     vrd::ProfScope prof(VRD_K_LOCAL_ATTN, s, 4.0 * (double)rows * W * C, 16.0 * (double)rows * C);
     const float scale = 1.0f / sqrtf((float)(C / n_head));
+    unsigned* const rflag = out_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr;
     // strips of 16 query rows per wave (default; 32 measured the same) or, VRD_LOCAL_STRIP=0, one wave per query row
     // (6.1 vs 5.6 ms per step at the benchmark shape)
     static const int strip_env = [] { const char* e = getenv("VRD_LOCAL_STRIP"); return e ? atoi(e) : 1; }();
@@ -517,10 +525,10 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
     do {                                                                                                                  \
         if (rel_pe)                                                                                                       \
             hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW, true>), grid, block, 0, s, q, k, v, ld, mask, rel_pe,   \
-                               B, T, strips, scale, out, ldo, out_pair);                                                  \
+                               B, T, strips, scale, out, ldo, out_pair, rflag);                                                  \
         else                                                                                                              \
             hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW, false>), grid, block, 0, s, q, k, v, ld, mask, rel_pe,  \
-                               B, T, strips, scale, out, ldo, out_pair);                                                  \
+                               B, T, strips, scale, out, ldo, out_pair, rflag);                                                  \
     } while (0)
         if (half_win == 3 && n_head == 4) VRD_LS(7, 16);
         else if (half_win == 3) VRD_LS(7, 8);
@@ -535,10 +543,10 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
     do {                                                                                                                  \
         if (rel_pe)                                                                                                       \
             hipLaunchKernelGGL((local_attn_kernel<Wn, G, true>), grid, block, 0, s, q, k, v, ld, mask, rel_pe, B, T,      \
-                               scale, out, ldo, out_pair);                                                                \
+                               scale, out, ldo, out_pair, rflag);                                                                \
         else                                                                                                              \
             hipLaunchKernelGGL((local_attn_kernel<Wn, G, false>), grid, block, 0, s, q, k, v, ld, mask, rel_pe, B, T,     \
-                               scale, out, ldo, out_pair);                                                                \
+                               scale, out, ldo, out_pair, rflag);                                                                \
     } while (0)
     if (half_win == 3 && n_head == 4) VRD_LA(7, 16);
     else if (half_win == 3) VRD_LA(7, 8);
@@ -590,7 +598,7 @@ int vrd_attention(const float* q, int64_t ldq, const float* k, const float* v, i
         const int waste3 = ((tiles + 2) / 3) * 3 - tiles, waste4 = ((tiles + 3) / 4) * 4 - tiles;
         const int nw = (waste3 < waste4) ? 3 : 4;
         dim3 grid((tiles + nw - 1) / nw, n_head, B);
-#define VRD_FA(HD, NW) hipLaunchKernelGGL((attn_flash_kernel<HD, NW>), grid, dim3(NW * 64), 0, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk, scale, out, ldo, out_pair)
+#define VRD_FA(HD, NW) hipLaunchKernelGGL((attn_flash_kernel<HD, NW>), grid, dim3(NW * 64), 0, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk, scale, out, ldo, out_pair, out_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr)
         if (head_dim == 128 && nw == 3) VRD_FA(128, 3);
         else if (head_dim == 128) VRD_FA(128, 4);
         else if (nw == 3) VRD_FA(64, 3);

@@ -65,7 +65,7 @@ __device__ __forceinline__ TileRegs fetch_tile(const float* __restrict__ src, in
 }
 // ... and the hi / lo split into the swizzled planes
 template <bool ROW, bool TR, bool F16 = false>
-__device__ __forceinline__ void commit_tile(const TileRegs& t, char* row_hi, char* tr_hi) {
+__device__ __forceinline__ void commit_tile(const TileRegs& t, char* row_hi, char* tr_hi, vrd::RangeTrack* rt = nullptr) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int p = threadIdx.x + 256 * i;
@@ -73,7 +73,7 @@ __device__ __forceinline__ void commit_tile(const TileRegs& t, char* row_hi, cha
         const float4 v = t.v[i];
         const float x[4] = {v.x, v.y, v.z, v.w};
         e16x4<F16> h, l;
-        vrd::split_n<F16>(x, h, l);
+        vrd::split_n<F16>(x, h, l, rt);
         const int within = (c & 7) * 2;
         if (ROW) {
             const int off = r * ROWB + (((c >> 3) ^ rswz(r)) * 16) + within;
@@ -115,7 +115,8 @@ __device__ __forceinline__ e16x8<F16> tr_frag(const char* plane, int lane, int s
 // lane (li, lh): elements d = 16 s + 8 lh + 0..7 of row `row` of head h (f32) as hi / lo fragments (the B operand of a product
 // whose columns are this wave's 32 rows)
 template <bool F16 = false>
-__device__ __forceinline__ void load_col_frags(const float* __restrict__ rowp, int lh, bool ok, e16x8<F16> (&hi)[KS], e16x8<F16> (&lo)[KS]) {
+__device__ __forceinline__ void load_col_frags(const float* __restrict__ rowp, int lh, bool ok, e16x8<F16> (&hi)[KS], e16x8<F16> (&lo)[KS],
+                                               vrd::RangeTrack* rt = nullptr) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -124,7 +125,7 @@ __device__ __forceinline__ void load_col_frags(const float* __restrict__ rowp, i
             const float4 b = *reinterpret_cast<const float4*>(rowp + 16 * s + 8 * lh + 4);
             x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
         }
-        vrd::split_n<F16>(x, hi[s], lo[s]);
+        vrd::split_n<F16>(x, hi[s], lo[s], rt);
     }
 }
 
@@ -156,8 +157,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_rows_kernel(const float* 
                                                                   const float* __restrict__ v, int64_t ldkv,
                                                                   const uint8_t* __restrict__ kv_mask, int Tq, int Tk, int n_head,
                                                                   float scale, float* __restrict__ out, int64_t ldo,
-                                                                  float* __restrict__ lse_out) {
+                                                                  float* __restrict__ lse_out, unsigned* rflag) {
     extern __shared__ __attribute__((aligned(16))) char lds[];        // 2 stages x (k row h/l, v tr h/l) + key bias: FWD_LDS
+    vrd::RangeTrack rt;                                               // q / k / v are f32 rows, split here (vrd_common.h)
     float* const kbias = reinterpret_cast<float*>(lds + 2 * 4 * PLANE);
     const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_rows_kernel(const float* 
     const uint8_t* const mk = kv_mask ? kv_mask + (int64_t)b * Tk : nullptr;
     constexpr float s_in = F16 ? vrd::F16_ACT_INV * vrd::F16_ACT_INV : 1.0f;          // undoes the operand scaling of a product
     e16x8<F16> qh[KS], ql[KS];
-    load_col_frags<F16>(q + ((int64_t)b * Tq + (q_ok ? tq : 0)) * ldq + h * HD, lh, q_ok, qh, ql);
+    load_col_frags<F16>(q + ((int64_t)b * Tq + (q_ok ? tq : 0)) * ldq + h * HD, lh, q_ok, qh, ql, &rt);
     f32x16 oacc[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_rows_kernel(const float* 
     };
     auto commit = [&](int buf) {
         char* st = lds + buf * 4 * PLANE;
-        commit_tile<true, false, F16>(rk, st, nullptr);
-        commit_tile<false, true, F16>(rv, nullptr, st + 2 * PLANE);
+        commit_tile<true, false, F16>(rk, st, nullptr, &rt);
+        commit_tile<false, true, F16>(rv, nullptr, st + 2 * PLANE, &rt);
         if (threadIdx.x < 32) kbias[buf * 32 + threadIdx.x] = rbias;
     };
     fetch(0);
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_rows_kernel(const float* 
                     make_float4(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv, oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
         if (lh == 0) lse_out[((int64_t)b * n_head + h) * Tq + tq] = l_run > 0.f ? m_run + __logf(l_run) : 0.f;
     }
+    if (F16) rt.report(rflag, vrd::RANGE_GEMM_IN);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -546,11 +549,11 @@ extern "C" int vrd_attention_rows(const float* q, int64_t ldq, const float* k, c
     if (fmt == VRD_PAIR_F16) {
         if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_fwd_rows_kernel<true>), FWD_LDS, "vrd_attention_rows")) return rc;
         hipLaunchKernelGGL(attn_fwd_rows_kernel<true>, grid, dim3(NW * 64), FWD_LDS, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk, n_head, scale, out,
-                           ldo, lse);
+                           ldo, lse, vrd::range_flag());
     } else {
         if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_fwd_rows_kernel<false>), FWD_LDS, "vrd_attention_rows")) return rc;
         hipLaunchKernelGGL(attn_fwd_rows_kernel<false>, grid, dim3(NW * 64), FWD_LDS, s, q, ldq, k, v, ldkv, kv_mask, Tq, Tk, n_head, scale, out,
-                           ldo, lse);
+                           ldo, lse, nullptr);
     }
     VRD_LAUNCH_CHECK();
     return 0;

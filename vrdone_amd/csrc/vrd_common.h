@@ -17,6 +17,35 @@ int reserve_lds(const void* kernel, size_t bytes, const char* what);
 // CUs of the CURRENT device (cached per device ordinal: a process may drive devices of different sizes / partition modes)
 int device_cu_count();
 
+// A wave-uniform read of kernel INPUT data (written before the launch, never by it) through the scalar cache: s_load instead
+// of a flat_load, which hipcc would follow with `s_waitcnt vmcnt(0)` -- a wait for every vector memory operation the wave has
+// in flight (its LDS-DMA requests, its stores), not just for this value.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* ptr) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(ptr));
+}
+
+// A pointer out of an argument STRUCT is a generic pointer to hipcc (only direct kernel arguments are inferred to be global
+// memory), and it reads / writes through flat_ instructions -- which might address LDS, so next to LDS-DMA requests in flight
+// every one of them is preceded by `s_waitcnt vmcnt(0)`.  as_global() states what the ABI guarantees (device global memory).
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(1))) T* as_global(T* ptr) {
+    return reinterpret_cast<__attribute__((address_space(1))) T*>(reinterpret_cast<uintptr_t>(ptr));
+}
+
+typedef float f32x4_native __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float* ptr) {          // 16-byte global load
+    const f32x4_native v = *as_global(reinterpret_cast<const f32x4_native*>(ptr));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gstore4(void* ptr, float4 v) {        // 16-byte global store
+    const f32x4_native t = {v.x, v.y, v.z, v.w};
+    *as_global(reinterpret_cast<f32x4_native*>(ptr)) = t;
+}
+
+// Device address of the current device's f16 operand-range flag word (vrd_f16_range_flag of the ABI), or nullptr
+unsigned* range_flag();
+
 // RAII profiling scope: when profiling is on, records a HIP event pair on `stream`
 // around the launch(es) issued inside the scope.
 struct ProfScope {
@@ -122,9 +151,33 @@ __device__ __forceinline__ mfma_acc16_t mfma16(f16x8_t a, f16x8_t b, mfma_acc16_
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// hi / lo planes of N values in format F16 (the f16 format scales by 2^VRD_F16_ACT_EXP first)
+// Range tracking of the f16 format.  A value whose scaled magnitude reaches 65,520 becomes hi = inf, lo = -inf, and every
+// product that touches it NaN -- but a NaN does not reach the outputs reliably (a ReLU or a max-pool downstream drops it:
+// fmax(NaN, x) = x), so producers REPORT instead: each thread keeps the largest scaled magnitude it converted (one v_max3
+// per two elements) and ORs the producer's tag into the device's flag word (vrd_f16_range_flag) if that does not fit.  The
+// host mirror reads the word with a call's results and repeats the call in the f32 mode.
+enum RangeTag : unsigned {
+    RANGE_INPUT = 1u,        // boundary tensors: vrd_bct_to_btc, vrd_pack_pairs, vrd_gather_pairs / vrd_assemble_pairs
+    RANGE_LAYERNORM = 2u,    // vrd_layernorm
+    RANGE_DWCONV_LN = 4u,    // vrd_dwconv_ln
+    RANGE_GEMM_OUT = 8u,     // pair-row outputs of vrd_gemm (c_pair)
+    RANGE_GEMM_IN = 16u,     // f32 rows split inside a GEMM / attention kernel while they are staged
+    RANGE_ATTN_OUT = 32u,    // pair-row outputs of the attention kernels
+    RANGE_OTHER = 64u,
+};
+struct RangeTrack {
+    float amax = 0.f;
+    __device__ __forceinline__ void see(float y) { amax = fmaxf(amax, fabsf(y)); }
+    __device__ __forceinline__ void see(float y0, float y1) { amax = fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1))); }
+    // (NaN inputs: fmax keeps the other operand -- a NaN here means an overflow upstream, which was reported there)
+    __device__ __forceinline__ void report(unsigned* flag, unsigned tag) const {
+        if (flag && amax >= 65520.f) __hip_atomic_fetch_or(as_global(flag), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// hi / lo planes of N values in format F16 (the f16 format scales by 2^VRD_F16_ACT_EXP first); rt: see RangeTrack
 template <bool F16, int N, typename V>
-__device__ __forceinline__ void split_n(const float (&x)[N], V& h, V& l) {
+__device__ __forceinline__ void split_n(const float (&x)[N], V& h, V& l, RangeTrack* rt = nullptr) {
     typedef typename SplitFmt<F16>::elem E;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -132,18 +185,23 @@ __device__ __forceinline__ void split_n(const float (&x)[N], V& h, V& l) {
         h[j] = (E)y;
         l[j] = (E)(y - (float)h[j]);
     }
+    if (F16 && rt) {
+        if (N == 1) rt->see(x[0] * F16_ACT_SCALE);
+#pragma unroll
+        for (int j = 0; j + 1 < N; j += 2) rt->see(x[j] * F16_ACT_SCALE, x[j + 1] * F16_ACT_SCALE);
+    }
 }
 
 // 16-bit index of the hi half of channel c inside a pair row (the lo half is 32 further)
 __device__ __forceinline__ int pair_index(int c) { return ((c >> 5) << 6) + (c & 31); }
 
 // fmt: VRD_PAIR_BF16 or VRD_PAIR_F16 (wave-uniform)
-__device__ __forceinline__ void store_pair4(float* row, int c, int /*W*/, float4 v, int fmt) {      // c % 4 == 0
+__device__ __forceinline__ void store_pair4(float* row, int c, int /*W*/, float4 v, int fmt, RangeTrack* rt = nullptr) {      // c % 4 == 0
     const float x[4] = {v.x, v.y, v.z, v.w};
     char* r = reinterpret_cast<char*>(row) + pair_index(c) * 2;
     if (fmt == VRD_PAIR_F16) {
         f16x4_t h, l;
-        split_n<true>(x, h, l);
+        split_n<true>(x, h, l, rt);
         *reinterpret_cast<f16x4_t*>(r) = h;
         *reinterpret_cast<f16x4_t*>(r + 64) = l;
     } else {
@@ -155,12 +213,12 @@ __device__ __forceinline__ void store_pair4(float* row, int c, int /*W*/, float4
 }
 
 // eight consecutive channels c .. c+7 (c % 8 == 0): one 16-byte store per half
-__device__ __forceinline__ void store_pair8(float* row, int c, float4 v0, float4 v1, int fmt) {
+__device__ __forceinline__ void store_pair8(float* row, int c, float4 v0, float4 v1, int fmt, RangeTrack* rt = nullptr) {
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
     char* r = reinterpret_cast<char*>(row) + pair_index(c) * 2;
     if (fmt == VRD_PAIR_F16) {
         f16x8_t h, l;
-        split_n<true>(x, h, l);
+        split_n<true>(x, h, l, rt);
         *reinterpret_cast<f16x8_t*>(r) = h;
         *reinterpret_cast<f16x8_t*>(r + 64) = l;
     } else {
@@ -171,10 +229,11 @@ __device__ __forceinline__ void store_pair8(float* row, int c, float4 v0, float4
     }
 }
 
-__device__ __forceinline__ void store_pair1(float* row, int c, int /*W*/, float x, int fmt) {
+__device__ __forceinline__ void store_pair1(float* row, int c, int /*W*/, float x, int fmt, RangeTrack* rt = nullptr) {
     char* r = reinterpret_cast<char*>(row) + pair_index(c) * 2;
     if (fmt == VRD_PAIR_F16) {
         const float y = x * F16_ACT_SCALE;
+        if (rt) rt->see(y);
         const _Float16 h = (_Float16)y;
         *reinterpret_cast<_Float16*>(r) = h;
         *reinterpret_cast<_Float16*>(r + 64) = (_Float16)(y - (float)h);

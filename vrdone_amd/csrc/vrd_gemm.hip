@@ -82,7 +82,7 @@ __device__ __forceinline__ void load_w(const vrd_gemm_args& p, int n, int k, int
 #define VRD_F32_WAVES 3
 #endif
 template <bool VEC, int TAPS, int BK, bool STAGED>
-__global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, unsigned* rflag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float (*lds_a)[BK][LDM] = reinterpret_cast<float (*)[BK][LDM]>(smem);
     float (*lds_b)[BK][LDM] = reinterpret_cast<float (*)[BK][LDM]>(smem + 2 * BK * LDM);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_g
         cur ^= 1;
     }
 
-    vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
+    vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane, rflag);
 }
 
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
@@ -186,7 +186,7 @@ int launch_variant(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStream_t
     constexpr size_t lds = lds_bytes(BK);
     if (lds > 48 * 1024)        // opt in to a large dynamic LDS carve (per variant and device)
         if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm")) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n, a.c_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr);
     return 0;
 }
 

@@ -25,7 +25,7 @@ struct EpiCols {
 };
 // the factor on the accumulators of a split-precision GEMM (wave-uniform; a scalar load)
 __device__ __forceinline__ float acc_alpha(const vrd_gemm_args& p) {
-    return (p.split_fmt == VRD_PAIR_F16 && p.w_scale) ? *p.w_scale : 1.0f;
+    return (p.split_fmt == VRD_PAIR_F16 && p.w_scale) ? uniform_load(p.w_scale) : 1.0f;
 }
 __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw, int lane) {
     EpiCols c;
@@ -35,14 +35,31 @@ __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw,
     for (int j = 0; j < 4; ++j) c.bias[j] = 0.f, c.scale[j] = 1.f;
     if (n + 3 < p.N) {                 // (the caller guarantees 16-byte aligned bias / scale for the lean epilogue)
         if (p.bias) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            const float4 b = gload4(p.bias + n);
             c.bias[0] = b.x, c.bias[1] = b.y, c.bias[2] = b.z, c.bias[3] = b.w;
         }
         if (p.scale) {
-            const float4 b = *reinterpret_cast<const float4*>(p.scale + n);
+            const float4 b = gload4(p.scale + n);
             c.scale[0] = b.x, c.scale[1] = b.y, c.scale[2] = b.z, c.scale[3] = b.w;
         }
     }
+    return c;
+}
+
+// The same through loads the compiler does not see (inline asm): the caller waits for them itself (`s_waitcnt vmcnt`) before
+// the epilogue.  For the persistent 256 x 256 kernel: hipcc follows a loop-carried register that a tracked load once wrote
+// with `s_waitcnt vmcnt(0)` at the top of the tile loop, i.e. with a wait for the previous tile's stores.
+__device__ __forceinline__ EpiCols load_epi_cols_async(const vrd_gemm_args& p, int nw, int lane) {
+    EpiCols c;
+    c.alpha = acc_alpha(p);
+    const int n = nw + (lane & 15) * 4;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (n + 3 < p.N) {
+        if (p.bias) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b) : "v"(p.bias + n) : "memory");
+        if (p.scale) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sc) : "v"(p.scale + n) : "memory");
+    }
+    c.bias[0] = b.x, c.bias[1] = b.y, c.bias[2] = b.z, c.bias[3] = b.w;
+    c.scale[0] = sc.x, c.scale[1] = sc.y, c.scale[2] = sc.z, c.scale[3] = sc.w;
     return c;
 }
 
@@ -57,7 +74,8 @@ __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw,
 // ROWS: 64 (four passes), or 32: one 32-row block, two passes, mw1 unused (the one-block-per-wave kernel, vrd_gemm_x3_row.hip).
 template <bool ROWIN, int ACT, int SLAB, int ROWS, typename Transposer>
 __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Transposer&& transpose_into, float* stg, int64_t mw,
-                                                      int64_t mw1, int nw, int lane, const EpiCols& cols) {
+                                                      int64_t mw1, int nw, int lane, const EpiCols& cols, unsigned* rflag = nullptr) {
+    RangeTrack rt;            // largest scaled magnitude written as an f16 pair (reported once, behind the last pass)
     // rows: passes 0-1 are mw .. mw+31, passes 2-3 are mw1 .. mw1+31 (mw1 = mw + 32 unless the tile's 32-row blocks
     // come from a block list); hop = wave-uniform distance the second block is away from its contiguous place
     const int64_t hop = mw1 - (mw + 32);
@@ -81,17 +99,17 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
         if (ROWIN) {
             if (p.row_mask) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) in.mb[j] = mk_lane[pass * 16 + 4 * j + (pass >= 2 ? hop : 0)];
+                for (int j = 0; j < 4; ++j) in.mb[j] = *as_global(mk_lane + pass * 16 + 4 * j + (pass >= 2 ? hop : 0));
             }
             if (p.res) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    in.r1[j] = *reinterpret_cast<const float4*>(r1_lane + (pass * 4 + j) * r1_step + (pass >= 2 ? hop * p.ldres : 0));
+                    in.r1[j] = gload4(r1_lane + (pass * 4 + j) * r1_step + (pass >= 2 ? hop * p.ldres : 0));
             }
             if (p.res2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    in.r2[j] = *reinterpret_cast<const float4*>(r2_lane + (pass * 4 + j) * r2_step + (pass >= 2 ? hop * p.ldres2 : 0));
+                    in.r2[j] = gload4(r2_lane + (pass * 4 + j) * r2_step + (pass >= 2 ? hop * p.ldres2 : 0));
             }
         }
         return in;
@@ -109,9 +127,23 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
         if (pass + 2 < NPASS) q1 = fetch(pass + 2);
         float v[4][4];
         const int srow = (SLAB == 64 ? pass : (pass & 1)) * 16 + rb0;
+        // The slab is read back by instructions the compiler does not see: next to LDS-DMA requests in flight (the persistent
+        // kernel's look-ahead for its next tile, which lands in OTHER ring slots) hipcc puts `s_waitcnt vmcnt(0)` in front of
+        // every LDS read it cannot tell apart from them.  DS operations of a wave execute in order, so the reads see the
+        // transposition's writes.
+        float4 tr[4];
+        {
+            typedef __attribute__((address_space(3))) const float* lds_cf;
+            const unsigned a0 = (unsigned)reinterpret_cast<uintptr_t>((lds_cf)(stg + srow * STG_PITCH + c4));
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(tr[0]), "=&v"(tr[1]), "=&v"(tr[2]), "=&v"(tr[3])
+                         : "v"(a0), "n"(4 * STG_PITCH * 4), "n"(8 * STG_PITCH * 4), "n"(12 * STG_PITCH * 4)
+                         : "memory");
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float4 t = *reinterpret_cast<const float4*>(stg + (srow + 4 * j) * STG_PITCH + c4);
+            const float4 t = tr[j];
             // (alpha = 1 outside the f16 format: fmaf(t, 1, b) is t + b to the last bit)
             v[j][0] = fmaf(t.x, cols.alpha, cols.bias[0]), v[j][1] = fmaf(t.y, cols.alpha, cols.bias[1]);
             v[j][2] = fmaf(t.z, cols.alpha, cols.bias[2]), v[j][3] = fmaf(t.w, cols.alpha, cols.bias[3]);
@@ -161,9 +193,9 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
                 for (int j = 0; j < 4; ++j) {
                     char* const rowp = c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0);
                     f16x4_t h, l;
-                    split_n<true>(v[j], h, l);
-                    *reinterpret_cast<f16x4_t*>(rowp) = h;
-                    *reinterpret_cast<f16x4_t*>(rowp + 64) = l;
+                    split_n<true>(v[j], h, l, &rt);
+                    *as_global(reinterpret_cast<f16x4_t*>(rowp)) = h;
+                    *as_global(reinterpret_cast<f16x4_t*>(rowp + 64)) = l;
                 }
             } else {
 #pragma unroll
@@ -171,23 +203,23 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
                     char* const rowp = c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0);
                     bf16x4_t h, l;
                     split_n<false>(v[j], h, l);
-                    *reinterpret_cast<bf16x4_t*>(rowp) = h;
-                    *reinterpret_cast<bf16x4_t*>(rowp + 64) = l;
+                    *as_global(reinterpret_cast<bf16x4_t*>(rowp)) = h;
+                    *as_global(reinterpret_cast<bf16x4_t*>(rowp + 64)) = l;
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0)) =
-                    make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
+                gstore4(c_lane + (pass * 4 + j) * c_step + (pass >= 2 ? c_hop : 0), make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
         }
     }
+    if (p.c_pair == VRD_PAIR_F16) rt.report(rflag, RANGE_GEMM_OUT);
 }
 
 // 32 x 32 accumulators (v_mfma_f32_32x32x16): element e of lane (li, lh) is C[(e & 3) + 8 * (e >> 2) + 4 * lh][li]
 template <bool ROWIN, int ACT, int SLAB = 64>
 __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* stg, int64_t mw,
-                                                   int64_t mw1, int nw, int lane, const EpiCols& cols) {
+                                                   int64_t mw1, int nw, int lane, const EpiCols& cols, unsigned* rflag = nullptr) {
     const int li = lane & 31, lh = lane >> 5;
     gemm_epilogue_lean_tr<ROWIN, ACT, SLAB, 64>(
         p,
@@ -203,13 +235,13 @@ __device__ __forceinline__ void gemm_epilogue_lean(const vrd_gemm_args& p, const
                         slab[(r0 + (e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + nj * 32 + li] = acc[mt][nj][e];
             }
         },
-        stg, mw, mw1, nw, lane, cols);
+        stg, mw, mw1, nw, lane, cols, rflag);
 }
 
 // one 32-row block x 64 columns: two 32 x 32 accumulators side by side, rows mw .. mw+31
 template <bool ROWIN, int ACT>
 __device__ __forceinline__ void gemm_epilogue_lean_rows32(const vrd_gemm_args& p, const f32x16& acc0, const f32x16& acc1, float* stg,
-                                                          int64_t mw, int nw, int lane, const EpiCols& cols) {
+                                                          int64_t mw, int nw, int lane, const EpiCols& cols, unsigned* rflag = nullptr) {
     const int li = lane & 31, lh = lane >> 5;
     gemm_epilogue_lean_tr<ROWIN, ACT, 32, 32>(
         p,
@@ -220,14 +252,14 @@ __device__ __forceinline__ void gemm_epilogue_lean_rows32(const vrd_gemm_args& p
                 slab[((e & 3) + 8 * (e >> 2) + 4 * lh) * STG_PITCH + 32 + li] = acc1[e];
             }
         },
-        stg, mw, mw + 32, nw, lane, cols);
+        stg, mw, mw + 32, nw, lane, cols, rflag);
 }
 
 // 16 x 16 accumulators (v_mfma_f32_16x16x32): element j of lane l is C[4 * (l >> 4) + j][l & 15]
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <bool ROWIN, int ACT, int SLAB = 64>
 __device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, const f32x4_t (&acc)[4][4], float* stg, int64_t mw,
-                                                     int64_t mw1, int nw, int lane, const EpiCols& cols) {
+                                                     int64_t mw1, int nw, int lane, const EpiCols& cols, unsigned* rflag = nullptr) {
     const int lc = lane & 15, lq = lane >> 4;
     gemm_epilogue_lean_tr<ROWIN, ACT, SLAB, 64>(
         p,
@@ -242,7 +274,7 @@ __device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, con
                     for (int j = 0; j < 4; ++j) slab[(r0 + 4 * lq + j) * STG_PITCH + tj * 16 + lc] = acc[ti][tj][j];
             }
         },
-        stg, mw, mw1, nw, lane, cols);
+        stg, mw, mw1, nw, lane, cols, rflag);
 }
 
 // true when vrd_gemm arguments fit the lean epilogue (checked on the host before the 256 x 256 kernel is chosen)
@@ -256,8 +288,9 @@ inline bool gemm_epilogue_lean_ok(const vrd_gemm_args& a) {
 // transposed up front so their registers are dead for the rest of the epilogue; 32 for kernels with less LDS.
 template <bool STAGED, int SLAB_ROWS = 32>
 __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x16 (&acc)[2][2], float* smem, int64_t mw,
-                                              int nw, int wave, int lane) {
+                                              int nw, int wave, int lane, unsigned* rflag = nullptr) {
     const int li = lane & 31, lh = lane >> 5;
+    RangeTrack rt;
     if (STAGED) {
         // Through LDS: each wave transposes its sub-tile, 32 rows at a time, through a private 32 x 64 slab
         // so that global traffic is whole 256-B row segments as float4 (the raw accumulator layout would
@@ -409,7 +442,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
                 if (m >= p.M || n >= p.N) continue;
                 float* crow = p.C + m * p.ldc + n;
                 if (p.c_pair) {          // pair rows of width N (host checks N % 8 == 0, so a float4 group is whole)
-                    store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]), p.c_pair);
+                    store_pair4(p.C + m * p.ldc, n, p.N, make_float4(v[j][0], v[j][1], v[j][2], v[j][3]), p.c_pair, &rt);
                 } else if (nfull) {
                     *reinterpret_cast<float4*>(crow) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);
                 } else {
@@ -420,6 +453,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
             }
             cur = nxt;
         }
+        if (p.c_pair == VRD_PAIR_F16) rt.report(rflag, RANGE_GEMM_OUT);
         return;
     }
     // fallback straight from the accumulator layout (rows that are not 16-byte aligned, e.g. ldc = 133)
@@ -440,19 +474,22 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const f32x
                 const float r1 = p.res ? p.res[m * p.ldres + n] : 0.f;
                 const float r2 = p.res2 ? p.res2[m * p.ldres2 + n] : 0.f;
                 const float v = epilogue_value(p, fmaf(acc[mi][nj][e], alpha, bias), mk, scale, r1, p.res_masked ? mk : 1.f, r2);
-                if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v, p.c_pair);
+                if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v, p.c_pair, &rt);
                 else p.C[m * p.ldc + n] = v;
             }
         }
     }
+    if (p.c_pair == VRD_PAIR_F16) rt.report(rflag, RANGE_GEMM_OUT);
 }
 
 // One 32 x 32 accumulator straight from its register layout (lane = column, registers = rows): the epilogue of the
 // 64 x 64-tile kernels, whose problems are small enough for its 16 stores of 128-byte row pieces per lane not to matter.
-__device__ __forceinline__ void gemm_epilogue_tile32(const vrd_gemm_args& p, const f32x16& acc, int64_t mw, int nw, int lane) {
+__device__ __forceinline__ void gemm_epilogue_tile32(const vrd_gemm_args& p, const f32x16& acc, int64_t mw, int nw, int lane,
+                                                     unsigned* rflag = nullptr) {
     const int li = lane & 31, lh = lane >> 5;
     const int n = nw + li;
     if (n >= p.N) return;
+    RangeTrack rt;
     const float bias = p.bias ? p.bias[n] : 0.f;
     const float scale = p.scale ? p.scale[n] : 1.f;
     const float alpha = acc_alpha(p);
@@ -464,9 +501,10 @@ __device__ __forceinline__ void gemm_epilogue_tile32(const vrd_gemm_args& p, con
         const float r1 = p.res ? p.res[m * p.ldres + n] : 0.f;
         const float r2 = p.res2 ? p.res2[m * p.ldres2 + n] : 0.f;
         const float v = epilogue_value(p, fmaf(acc[e], alpha, bias), mk, scale, r1, p.res_masked ? mk : 1.f, r2);
-        if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v, p.c_pair);
+        if (p.c_pair) store_pair1(p.C + m * p.ldc, n, p.N, v, p.c_pair, &rt);
         else p.C[m * p.ldc + n] = v;
     }
+    if (p.c_pair == VRD_PAIR_F16) rt.report(rflag, RANGE_GEMM_OUT);
 }
 
 }  // namespace vrd

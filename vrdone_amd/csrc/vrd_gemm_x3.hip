@@ -42,7 +42,7 @@ struct X3Geo {
 };
 
 template <int TAPS, bool STAGED, bool APAIR, bool SMALL = false, bool F16 = false>
-__global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, unsigned* rflag) {
     using G = X3Geo<SMALL>;
     typedef typename vrd::SplitFmt<F16>::elem e16;          // the 16-bit element of this instantiation (bf16 or f16)
     typedef typename vrd::SplitFmt<F16>::x8 e16x8;
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles
     constexpr int NPA = G::NPA, NPAP = G::NPAP, NPW = G::NPW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     e16* const lds = reinterpret_cast<e16*>(smem);      // buffer b: lds + b*4*TILE; tiles a_hi, a_lo, w_hi, w_lo
+    vrd::RangeTrack rt_in;                              // f32 activation rows split while staged (vrd_common.h)
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles
             const int off = (f >> 3) * XP + (f & 7) * 4;
             const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
             e16x4 h, l;
-            vrd::split_n<F16>(x, h, l);
+            vrd::split_n<F16>(x, h, l, &rt_in);
             *reinterpret_cast<e16x4*>(a_hi + off) = h;
             *reinterpret_cast<e16x4*>(a_lo + off) = l;
         }
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles
         }
         __syncthreads();
     }
-    if constexpr (SMALL) vrd::gemm_epilogue_tile32(p, acc[0][0], m0 + wm * 32, n0 + wn * 32, lane);
-    else vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane);
+    if (F16 && !APAIR) rt_in.report(rflag, vrd::RANGE_GEMM_IN);
+    if constexpr (SMALL) vrd::gemm_epilogue_tile32(p, acc[0][0], m0 + wm * 32, n0 + wn * 32, lane, rflag);
+    else vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane, rflag);
 }
 
 }  // namespace
@@ -235,7 +237,7 @@ static int launch_one(const vrd_gemm_args& a, int tiles_m, int tiles_n, hipStrea
     auto kern = a.split_fmt == VRD_PAIR_F16 ? gemm_x3_kernel<TAPS, STAGED, APAIR, SMALL, true> : gemm_x3_kernel<TAPS, STAGED, APAIR, SMALL, false>;
     constexpr size_t lds = X3Geo<SMALL>::LDS;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3)")) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, s, a, tiles_m, tiles_n, a.split_fmt == VRD_PAIR_F16 ? vrd::range_flag() : nullptr);
     return 0;
 }
 

@@ -32,16 +32,11 @@ constexpr int NA_STG = 3, NW_STG = 2;
 constexpr int W_RING = NA_STG * A_STAGE;       // byte offset of the W ring
 constexpr size_t BIG_LDS = (size_t)NA_STG * A_STAGE + (size_t)NW_STG * W_STAGE;      // 163,840
 constexpr int PER = 4;                         // DMA instructions per wave, operand and K step (8 rows x 128 B each)
-#ifndef VRD_BIG_BUFDMA
-#define VRD_BIG_BUFDMA 0                       // 1: LDS-DMA by buffer_load ... lds (scalar base + offsets), 0: global_load_lds (per-lane pointers)
-#endif
-#if VRD_BIG_BUFDMA && defined(__HIP_DEVICE_COMPILE__)      // (the descriptor type exists in the device pass only)
-#define VRD_BUFDMA_DEV 1
-#else
-#define VRD_BUFDMA_DEV 0
-#endif
-
-__device__ __attribute__((aligned(128))) uint4 g_big_zero[8];      // 128 zero bytes: source of padded taps and outside pieces
+// LDS-DMA requests are buffer loads (buffer_load_dwordx4 ... lds): a wave-uniform descriptor per operand and tile, ONE per-lane
+// byte offset per operand that never changes (row inside the piece, swizzled chunk), and a scalar offset for piece, K step and
+// tap -- no vector arithmetic per request (the global_load_lds form needed a 64-bit per-lane pointer each: -4.5 % cycles per
+// K step, profiles/r05_lab_gemm_tile_stamps.txt), and a lane whose offset is out of range (>= 2^31 here) receives zeros, which
+// is how padded taps and pieces outside the matrix are produced: no zero block, no per-lane pointer select.
 // sum over the tiles that skipped their contraction (padding map) of K * tile columns: 2 * 256 * this = FLOPs that
 // were launched but not executed (vrd_prof_read_skipped; the profile keeps executed and launched work apart)
 __device__ unsigned long long g_big_skipped_kn;
@@ -84,11 +79,76 @@ struct BigBatch {
     const float* w_scale[3];
 };
 
+// The kernel's one argument.  It is read through the kernarg segment pointer (scalar loads from the constant address space),
+// and the persistent form reads it AGAIN for every tile, and once more between a tile's main loop and its epilogue: with
+// the ~40 argument words loaded once in front of a tile loop, everything derived from them stayed live across the loop and
+// hipcc spilled 100+ scalar registers into the K loop (round 3: 3 % slower than one workgroup per tile).  Re-reading costs
+// a few scalar loads per tile and leaves the K loop the register budget of the one-tile kernel.
+struct BigKArgs {
+    vrd_gemm_args p;
+    int tiles_m, tiles_n;
+    BigBatch bb;
+    int stagger;
+    int count;                // problems of the launch (1 + the BigBatch entries in use)
+    int prio;                 // issue priority between the two waves of a SIMD (VRD_BIG_PRIO): 0 none, 1 static, 2 by progress
+    unsigned* rflag;          // the device's f16 operand-range flag (vrd_common.h, RangeTrack) when C is written as f16 pair rows
+};
+typedef const __attribute__((address_space(4))) unsigned* kargs_ptr_t;
+template <typename T>
+__device__ __forceinline__ T load_karg(kargs_ptr_t base, int byte_off) {
+    constexpr int N = (sizeof(T) + 3) / 4;
+    unsigned tmp[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) tmp[i] = base[byte_off / 4 + i];
+    T out;
+    __builtin_memcpy(&out, tmp, sizeof(T));
+    return out;
+}
+
 // F16: operands in the scaled-f16 format (VRD_PAIR_F16) on v_mfma_f32_32x32x16_f16 -- the same bytes, instruction count and
 // cycles; the epilogue multiplies the accumulators by *w_scale
+// PERSIST: one workgroup per CU walks tiles vb, vb + gridDim.x, ...; behind a tile's main loop, before its epilogue, the first
+// stages of the NEXT tile are requested (A(0), A(1): the operand that comes from HBM, microseconds away; W(0)), so that tile
+// starts on landed data: the one-tile form spends ~9 k of a K = 512 tile's ~66 k cycles on its set-up and on waiting for its
+// first stage (profiles/r05_lab_gemm_tile_stamps.txt).  The epilogue then stages through 32-row slabs in the two ring
+// buffers the prefetch leaves free (activation stage 2, weight stage 1).
 template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
-__global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, BigBatch bb, int stagger) {
+__global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
+#if defined(__HIP_DEVICE_COMPILE__)       // (the buffer descriptor type exists in the device pass only)
     typedef typename vrd::SplitFmt<F16>::x8 e16x8;      // fragment of eight 16-bit elements (bf16 or f16)
+    kargs_ptr_t kp = (kargs_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    vrd_gemm_args p;
+    int tiles_m, tiles_n, K, nkt, nwg, nblk;
+    const int32_t* rb;
+    int64_t a_pstride, w_pstride;                        // bytes between DMA pieces (8 rows)
+    // problem of a batched launch (BigBatch): blockIdx.y, or (PERSIST: one grid row walks the tiles of all problems) the
+    // problem of the tile at hand
+    int zsel = PERSIST ? 0 : (int)blockIdx.y;
+    auto reload = [&]() __attribute__((always_inline)) {
+        if (PERSIST) asm volatile("" : "+s"(kp));        // (a new value as far as the compiler can tell: nothing loaded before survives)
+        p = load_karg<vrd_gemm_args>(kp, offsetof(BigKArgs, p));
+        tiles_m = load_karg<int>(kp, offsetof(BigKArgs, tiles_m));
+        tiles_n = load_karg<int>(kp, offsetof(BigKArgs, tiles_n));
+        if (zsel) {                                      // uniform selects, no indexed access to the arguments
+            const BigBatch bb = load_karg<BigBatch>(kp, offsetof(BigKArgs, bb));
+            const int z = zsel;
+            p.A = z == 1 ? bb.A[0] : z == 2 ? bb.A[1] : bb.A[2];
+            p.w_scale = z == 1 ? bb.w_scale[0] : z == 2 ? bb.w_scale[1] : bb.w_scale[2];
+            p.W_split = z == 1 ? bb.W_split[0] : z == 2 ? bb.W_split[1] : bb.W_split[2];
+            p.bias = z == 1 ? bb.bias[0] : z == 2 ? bb.bias[1] : bb.bias[2];
+            p.C = z == 1 ? bb.C[0] : z == 2 ? bb.C[1] : bb.C[2];
+        }
+        K = p.Cin * TAPS;
+        nkt = K / 32;
+        nwg = tiles_m * tiles_n;
+        nblk = (int)(p.M >> 5);
+        rb = p.row_blocks;
+        a_pstride = p.lda * 32, w_pstride = (int64_t)K * 32;
+    };
+    reload();
+    const int stagger = PERSIST ? 0 : load_karg<int>(kp, offsetof(BigKArgs, stagger));
+    const int prio = load_karg<int>(kp, offsetof(BigKArgs, prio));
+    unsigned* rflag = nullptr;
     // Phase stagger.  Every tile of a launch takes the same time, so without it all CUs reach their epilogues together and
     // 256 x 256 KiB of stores meet an HBM that was idle a moment before.  The first workgroup of every CU (the first 256 of
     // the grid: one per CU) starts `slot * stagger` x 1,024 cycles late, slot = its place among the 32 CUs of its XCD; the
@@ -97,14 +157,6 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
         const int n = ((blockIdx.x >> 3) & 31) * stagger;
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
     }
-    if (blockIdx.y) {                                    // uniform selects, no indexed access to the arguments
-        const int z = blockIdx.y;
-        p.A = z == 1 ? bb.A[0] : z == 2 ? bb.A[1] : bb.A[2];
-        p.w_scale = z == 1 ? bb.w_scale[0] : z == 2 ? bb.w_scale[1] : bb.w_scale[2];
-        p.W_split = z == 1 ? bb.W_split[0] : z == 2 ? bb.W_split[1] : bb.W_split[2];
-        p.bias = z == 1 ? bb.bias[0] : z == 2 ? bb.bias[1] : bb.bias[2];
-        p.C = z == 1 ? bb.C[0] : z == 2 ? bb.C[1] : bb.C[2];
-    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
@@ -112,18 +164,13 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
-    const int K = p.Cin * TAPS;
-    const int nkt = K / 32;
-    const int nwg = tiles_m * tiles_n;
     // ---- tiles.  Virtual block id -> tile through the XCD-aware renumbering; the tile's rows are eight 32-row blocks,
     // slots tm*8 .. tm*8+7 of the block list (identity without one).  With a padding map (vrd_row_blocks) the list is
     // cut into segments -- one per XCD's contiguous share of the tiles when there are eight -- and inside a segment
     // the blocks holding valid frames come first, so a tile is either a contraction tile or, behind those, a tile of
     // fully padded blocks that only runs the epilogue on a zero accumulator (the reference's value wherever row_mask
     // zeroes the row).
-    const int nblk = (int)(p.M >> 5);
-    const int32_t* const rb = p.row_blocks;
-    auto blk_of = [&](int slot) { return slot < nblk ? (rb ? rb[slot] : slot) : -1; };
+    auto blk_of = [&](int slot) { return slot < nblk ? (rb ? vrd::uniform_load(rb + slot) : slot) : -1; };
     struct Tile {
         int tm, n0;
         bool contract;
@@ -138,7 +185,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
         if (rb) {
             const int seg_len = p.row_block_seg_len;                          // a multiple of 8 (host-checked)
             const int seg = (t.tm * 8) / seg_len;
-            t.contract = t.tm * 8 < nblk && t.tm * 8 - seg * seg_len < p.row_blocks_active[seg];
+            t.contract = t.tm * 8 < nblk && t.tm * 8 - seg * seg_len < vrd::uniform_load(p.row_blocks_active + seg);
         }
         return t;
     };
@@ -150,117 +197,99 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
     const int rin = lane >> 3, pch = lane & 7;
     const int row0 = wave * PER * 8 + rin;                              // row inside the tile, for both operands
     const int chunk0 = (pch ^ swz(row0)) * 16;
-    const char* const zero_src = reinterpret_cast<const char*>(g_big_zero);
-    const int64_t a_pstride = p.lda * 32, w_pstride = (int64_t)K * 32;  // bytes between pieces (8 rows)
+    // per-lane byte offsets inside a descriptor, even / odd pieces (source-side swizzle); the same for every tile
+    unsigned va[2], vw[2];
+    auto lane_offsets = [&]() {
+        const unsigned a_lane = (unsigned)rin * (unsigned)(p.lda * 4), w_lane = (unsigned)rin * (unsigned)(K * 4);
+        va[0] = a_lane + chunk0, va[1] = a_lane + (chunk0 ^ 64);
+        vw[0] = w_lane + chunk0, vw[1] = w_lane + (chunk0 ^ 64);
+    };
+    lane_offsets();
     struct Src {
-        const char *a0, *w0;
-        int tseq0, a_in, w_in, w_last;
-#if VRD_BUFDMA_DEV
+        int tseq0, a_in, w_last;
         __amdgpu_buffer_rsrc_t ra, rw;          // wave-uniform descriptors: the wave's A block (one row back for k = 3), its W rows
-        unsigned va[2], vw[2];                  // per-lane byte offsets inside them, even / odd pieces (source-side swizzle)
-#endif
     };
     auto src_of = [&](const Tile& t) {
         const int my_blk = blk_of(t.tm * 8 + wave);          // the block whose A rows this wave stages
         const int64_t a_row = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 + rin;
         Src r;
-        r.a0 = reinterpret_cast<const char*>(p.A + a_row * p.lda) + chunk0;
         r.tseq0 = (TAPS == 3) ? (int)(a_row % p.T) : 0;
         r.a_in = my_blk < 0 ? 0 : PER;                                   // pieces inside (M % 32 == 0)
-        r.w_in = (p.N - t.n0 - wave * PER * 8 + 7) / 8;
+        const int w_in = (p.N - t.n0 - wave * PER * 8 + 7) / 8;
         // weight pieces beyond N re-read the last piece inside (a wave entirely beyond N: the tile's first rows): columns
-        // >= N are never stored, and a uniform minimum costs the loop less than a per-lane select of the zero block
-        r.w_last = (r.w_in > 0 ? (r.w_in < PER ? r.w_in : PER) : 1) - 1;
-        r.w0 = reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + (r.w_in > 0 ? row0 : rin)) * K * 4 + chunk0;
-#if VRD_BUFDMA_DEV
-        {
-            // buffer form of the same requests: base (scalar) + per-lane offset (constant for the tile) + scalar offset (piece,
-            // K step, tap).  Offsets >= 2^31 are out of range: such a lane's 16 bytes arrive in LDS as zeros, which is how
-            // padded taps and pieces outside the matrix are produced here (no zero block, no per-lane pointer select).
-            const int64_t a_row_u = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 - (TAPS == 3 ? 1 : 0);
-            r.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + a_row_u * p.lda), 0, 0x80000000u, 0x00020000);
-            r.rw = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char*>(reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + (r.w_in > 0 ? wave * PER * 8 : 0)) * K * 4), 0,
-                0x80000000u, 0x00020000);
-            const unsigned a_lane = (unsigned)rin * (unsigned)(p.lda * 4), w_lane = (unsigned)rin * (unsigned)(K * 4);
-            r.va[0] = a_lane + chunk0, r.va[1] = a_lane + (chunk0 ^ 64);
-            r.vw[0] = w_lane + chunk0, r.vw[1] = w_lane + (chunk0 ^ 64);
-        }
-#endif
+        // >= N are never stored, and a uniform minimum costs the loop less than a per-lane out-of-range offset
+        r.w_last = (w_in > 0 ? (w_in < PER ? w_in : PER) : 1) - 1;
+        // (k = 1: a wave whose block lies outside the matrix reads block 0 -- its accumulator rows are never stored)
+        const int64_t a_row_u = (int64_t)(my_blk < 0 ? 0 : my_blk) * 32 - (TAPS == 3 ? 1 : 0);
+        r.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + a_row_u * p.lda), 0, 0x80000000u, 0x00020000);
+        r.rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(p.W_split) + (int64_t)(t.n0 + (w_in > 0 ? wave * PER * 8 : 0)) * K * 4), 0,
+            0x80000000u, 0x00020000);
         return r;
     };
-    // piece i of W(kt) / A(kt): one DMA instruction each
-    auto issue_w1 = [&](const Src& c, int kt, int i) {
-        char* const dst = lds + W_RING + (kt % NW_STG) * W_STAGE + wave * PER * 1024;
-#if VRD_BUFDMA_DEV
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (lds_ptr_t)(dst + i * 1024), 16, c.vw[i & 1],
-                                                 (i < c.w_last ? i : c.w_last) * (int)w_pstride + kt * 128, 0, 0);
-        return;
-#endif
-        const char* src = c.w0 + (i < c.w_last ? i : c.w_last) * w_pstride + (int64_t)kt * 128;
-        if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+    // piece i of W / A of K step `ks` of the tile `c` describes, into the ring slot of GLOBAL step `gk` (the ring runs on
+    // across the tiles of a persistent workgroup: gk = steps of the earlier tiles + ks): one DMA instruction each
+    auto issue_w1 = [&](const Src& c, int gk, int ks, int i) {
+        char* const dst = lds + W_RING + (gk % NW_STG) * W_STAGE + wave * PER * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rw, (lds_ptr_t)(dst + i * 1024), 16, vw[i & 1],
+                                                 (i < c.w_last ? i : c.w_last) * (int)w_pstride + ks * 128, 0, 0);
     };
-    auto issue_a1 = [&](const Src& c, int kt, int i) {
-        char* const dst = lds + (kt % NA_STG) * A_STAGE + wave * PER * 1024;
-        const int k0 = kt * 32;
+    auto issue_a1 = [&](const Src& c, int gk, int ks, int i) {
+        char* const dst = lds + (gk % NA_STG) * A_STAGE + wave * PER * 1024;
+        const int k0 = ks * 32;
         int tap = 0, ci0 = k0;
+        unsigned vo = va[i & 1];
         if (TAPS == 3) {
             tap = (k0 >= p.Cin) + (k0 >= 2 * p.Cin);
             ci0 = k0 - tap * p.Cin;
-        }
-#if VRD_BUFDMA_DEV
-        {
-            unsigned vo = c.va[i & 1];
-            if (TAPS == 3) {
-                int tt = c.tseq0 + 8 * i;
-                if (tt >= p.T) tt -= p.T;
-                tt += tap - 1;
-                if (tt < 0 || tt >= p.T || i >= c.a_in) vo = 0x80000000u;
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_ptr_t)(dst + i * 1024), 16, vo,
-                                                     i * (int)a_pstride + tap * (int)(p.lda * 4) + ci0 * 4, 0, 0);
-            return;
-        }
-#endif
-        const int64_t off = (int64_t)(tap - (TAPS == 3 ? 1 : 0)) * p.lda * 4 + (int64_t)ci0 * 4;
-        // (k = 1: a wave whose block lies outside the matrix reads block 0 -- its accumulator rows are never stored)
-        const char* src = TAPS == 1 || i < c.a_in ? c.a0 + i * a_pstride + off : zero_src + chunk0;
-        if (TAPS == 3) {
             int tt = c.tseq0 + 8 * i;                   // position of this piece's row in its sequence (T >= 32)
             if (tt >= p.T) tt -= p.T;
             tt += tap - 1;
-            if (tt < 0 || tt >= p.T) src = zero_src + chunk0;
+            if (tt < 0 || tt >= p.T || i >= c.a_in) vo = 0x80000000u;       // zero padding of the taps / a block outside the matrix
         }
-        if (i & 1) src = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(src) ^ 64);
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+        // (k = 3: the descriptor starts one row early, so tap t is t rows further)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_ptr_t)(dst + i * 1024), 16, vo,
+                                                 i * (int)a_pstride + tap * (int)(p.lda * 4) + ci0 * 4, 0, 0);
     };
-    auto issue_w = [&](const Src& c, int kt) {
+    auto issue_w = [&](const Src& c, int gk, int ks) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) issue_w1(c, kt, i);
+        for (int i = 0; i < PER; ++i) issue_w1(c, gk, ks, i);
     };
-    auto issue_a = [&](const Src& c, int kt) {
+    auto issue_a = [&](const Src& c, int gk, int ks) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) issue_a1(c, kt, i);
+        for (int i = 0; i < PER; ++i) issue_a1(c, gk, ks, i);
     };
 
-    // PERSIST (VRD_BIG_PERSIST=1, off by default): one workgroup per CU walks tiles vb, vb + gridDim.x, ...; behind a
-    // tile's main loop, before its epilogue, stage 0 of the NEXT tile's operands is requested, so that tile does not
-    // start with an HBM round trip (the epilogue then stages through 32-row slabs inside activation stages 1-2, which
-    // stage 0 of either ring leaves free).  Measured: correct, but 3 % SLOWER on the whole step (98.8 vs 96.1 ms of
-    // this kernel): with the tile loop around the body everything derived from the arguments stays live across it --
-    // 100 SGPRs spilled to VGPR lanes and 39 VGPRs to scratch, inside the K loop -- and re-reading the arguments per
-    // tile through a laundered kernarg pointer moved them into VGPRs instead (99 spills).  The ~4 k cycles of tile
-    // setup it would hide are 5 % of a tile; not worth a second, argument-light kernel this round.
-    bool staged0 = false;
-    int vb = blockIdx.x;
+    bool staged = false;          // PERSIST: A(0), A(1), W(0) of this tile were requested inside the previous tile's last two K steps
+    bool stored_all = false;      // PERSIST: this wave stored both 64-row halves in the previous tile's epilogue (>= 32 stores)
+    int g0 = 0;                   // PERSIST: K steps of this workgroup's earlier tiles, modulo 6 (the rings run on across tiles)
+    // PERSIST: vq walks the tiles of all `count` problems of the launch, problem after problem; vb = the tile inside its problem
+    const int count = PERSIST ? load_karg<int>(kp, offsetof(BigKArgs, count)) : 1;
+    int vq = blockIdx.x, vb = blockIdx.x;
     do {
+    if (PERSIST) {
+        zsel = vq / nwg;                 // (nwg does not depend on the problem)
+        vb = vq - zsel * nwg;
+        if (vq != (int)blockIdx.x || zsel) reload();      // (the per-lane request offsets do not depend on the tile: not recomputed)
+    }
     LAB_STAMP(0);
     LAB_REAL(4);
     const Tile tile = tile_of(vb);
     const int tm = tile.tm, n0 = tile.n0;
     const bool contract = tile.contract;
     const Src cur = src_of(tile);
+    // PERSIST: the tile this workgroup computes next, if it is a contraction tile too (its first stages are requested inside
+    // this tile's last two K steps); otherwise those requests re-read this tile's own first stages into the free ring slots
+    // (harmless, keeps the loop free of tests) and the next tile starts like a first one
+    bool next_staged = false;
+    Src nx = cur;
+    if (PERSIST && contract && nkt >= 3 && vb + (int)gridDim.x < nwg) {      // (inside the same problem)
+        const Tile nt = tile_of(vb + (int)gridDim.x);
+        if (nt.contract) {
+            nx = src_of(nt);
+            next_staged = true;
+        }
+    }
     if (!contract && tid == 0 && tm * 8 < nblk)
         atomicAdd(&g_big_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
 
@@ -275,7 +304,9 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
     const int w_base = W_RING + (M16 ? (wn * 64 + l15) * ROWB + ((l4 ^ swz(l15)) * 16) : (wn * 64 + li) * ROWB + ((lh ^ swz(li)) * 16));
 
     // bias / scale of this lane's columns: requested now, used by the epilogue
-    const vrd::EpiCols cols = vrd::load_epi_cols(p, n0 + wn * 64, lane);
+    // (through loads the compiler does not track: see load_epi_cols_async; they are older than every K-loop request, so the
+    // first counted wait of the loop covers them)
+    const vrd::EpiCols cols = vrd::load_epi_cols_async(p, n0 + wn * 64, lane);
     f32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
     vrd::f32x4_t acc16[M16 ? 8 : 1][M16 ? 4 : 1];        // M16: 8 x 4 tiles of 16 x 16
 #pragma unroll
@@ -321,21 +352,36 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
         return f;
     };
     if (contract) {
-    if (!(PERSIST && staged0)) {
-        issue_a(cur, 0);
-        issue_w(cur, 0);
+    if (!(PERSIST && staged)) {
+        issue_a(cur, g0, 0);
+        issue_w(cur, g0, 0);
+        if (nkt > 1) {
+            issue_a(cur, g0 + 1, 1);
+            issue_w(cur, g0 + 1, 1);
+        }
+        LAB_STAMP(1);
+        // stage 0: what was issued after A(0), W(0) may stay in flight (A(2) follows inside step 0, see below)
+        if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // In this wave's queue, oldest first: A(0), W(0), A(1) (requested inside the previous tile's last two K steps), that
+        // tile's epilogue loads and stores, and now W(1).  The counter retires in order, so the wait for W(0) must not ask
+        // for more than it needs: a wave that stored its whole sub-tile has >= 32 epilogue operations behind A(1) and leaves
+        // the youngest 40 (W(1), 32 stores, A(1)) alone -- it does not wait for its stores to be acknowledged.
+        issue_w(cur, g0 + 1, 1);
+        LAB_STAMP(1);
+        if (stored_all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER + 32) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
     }
-    if (nkt > 1) {
-        issue_a(cur, 1);
-        issue_w(cur, 1);
-    }
-    LAB_STAMP(1);
-    // stage 0: what was issued after A(0), W(0) may stay in flight (A(2) follows inside step 0, see below)
-    if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    WF w_cur = load_w(lds, 0), w_nxt = w_cur;
-    AF a_cur = load_a(lds, 0, 0), a_nxt = a_cur;
+    // The two waves of a SIMD share its matrix pipe, and between equals the older one (waves 0-3) wins every arbitration: it
+    // runs its 48 MFMAs of a K step nearly alone, waits ~1,100 cycles at the step's barrier, and the younger one then issues its
+    // requests with nobody to cover their stalls (profiles/r05_lab_gemm_tile_stamps.txt).  prio 1: the younger half runs at
+    // priority 1 throughout; prio 2: a wave holds priority 1 through the first half of its K step and 0 through the second, so
+    // whichever wave is behind wins.
+    if (prio == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    WF w_cur = load_w(lds + (g0 % NW_STG) * W_STAGE, 0), w_nxt = w_cur;
+    AF a_cur = load_a(lds + (g0 % NA_STG) * A_STAGE, 0, 0), a_nxt = a_cur;
     LAB_PHASE_DECL;
     // DMA slot d (0..7) of the batch opened by the barrier inside step kt: W(kt+2) pieces 0..3, A(kt+3) pieces 0..3
     // Which of these requests exist depends only on where the step stands in the K loop, so the loop body exists in five
@@ -346,23 +392,29 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
     auto kstep = [&](int kt, auto pos_c) __attribute__((always_inline)) {
         constexpr int POS = decltype(pos_c)::value;
         // W(kt_open+2) pieces / A(kt_open+3) pieces exist?
-        auto has_w = [&](int kt_open) { return POS == POS_GENERIC ? kt_open + 2 < nkt : true; };
         auto dma_slot = [&](int kt_open, int d, bool w_ok, bool a_ok) {
             if (d < PER) {
-                if (w_ok) issue_w1(cur, kt_open + 2, d);
+                if (w_ok) issue_w1(cur, g0 + kt_open + 2, kt_open + 2, d);
             } else {
-                if (a_ok) issue_a1(cur, kt_open + 3, d - PER);
+                if (a_ok) issue_a1(cur, g0 + kt_open + 3, kt_open + 3, d - PER);
             }
         };
-        (void)has_w;
-        const char* sa = lds + (kt % NA_STG) * A_STAGE;
-        const char* sw = lds + (kt % NW_STG) * W_STAGE;
-        const char* sa1 = lds + ((kt + 1) % NA_STG) * A_STAGE;
-        const char* sw1 = lds + ((kt + 1) % NW_STG) * W_STAGE;
+        // PERSIST: the same slots of the tile's last two steps, where this tile has nothing left to request, carry the NEXT
+        // tile's first stages -- the rings run on: its step j is global step g0 + nkt + j
+        auto dma_slot_next = [&](int j_w, int j_a, int d) {
+            if (d < PER) issue_w1(nx, g0 + nkt + j_w, j_w, d);
+            else issue_a1(nx, g0 + nkt + j_a, j_a, d - PER);
+        };
+        const char* sa = lds + ((g0 + kt) % NA_STG) * A_STAGE;
+        const char* sw = lds + ((g0 + kt) % NW_STG) * W_STAGE;
+        const char* sa1 = lds + ((g0 + kt + 1) % NA_STG) * A_STAGE;
+        const char* sw1 = lds + ((g0 + kt + 1) % NW_STG) * W_STAGE;
         const bool last = POS == POS_GENERIC ? kt + 1 == nkt : POS == POS_LAST;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int mi = g & 3;
+            if (prio == 2 && g == 0) __builtin_amdgcn_s_setprio(1);
+            if (prio == 2 && g == 4) __builtin_amdgcn_s_setprio(0);
             // ---- reads for what comes next
             if (g < 7) a_nxt = M16 ? load_a(sa, 0, g + 1) : load_a(sa, (g + 1) >> 2, (g + 1) & 3);
             if (!M16 && g == 2) w_nxt = load_w(sw, 1);
@@ -394,17 +446,23 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
                         // the batch opened in step kt-1: W(kt+1) pieces 1..3, A(kt+2) pieces 0..3
                         if (POS == POS_GENERIC) {
                             if (kt > 0) dma_slot(kt - 1, g + 1, kt + 1 < nkt, kt + 2 < nkt);
-                            else if (g < PER && nkt > 2) issue_a1(cur, 2, g);      // step 0 has no batch of its own yet
+                            else if (g < PER && nkt > 2) issue_a1(cur, g0 + 2, 2, g);      // step 0 has no batch of its own yet
                         } else if (POS == POS_FIRST) {
-                            if (g < PER) issue_a1(cur, 2, g);
+                            if (g < PER) issue_a1(cur, g0 + 2, 2, g);
                         } else if (POS == POS_STEADY) {
                             dma_slot(kt - 1, g + 1, true, true);
                         } else if (POS == POS_PEN) {
-                            dma_slot(kt - 1, g + 1, true, false);
+                            // W(nkt-1) pieces 1..3; then (PERSIST) the next tile's A(0)
+                            if (g + 1 < PER) dma_slot(kt - 1, g + 1, true, false);
+                            else if (PERSIST) dma_slot_next(0, 0, g + 1);
+                        } else if (POS == POS_LAST && PERSIST) {
+                            dma_slot_next(0, 1, g + 1);        // the next tile's W(0) pieces 1..3, A(1) pieces 0..3
                         }
                     } else if (!last) {
-                        // slot 0 of this step's own batch: W(kt+2) piece 0
-                        dma_slot(kt, 0, POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN, false);
+                        // slot 0 of this step's own batch: W(kt+2) piece 0 -- in the step before the last (PERSIST) the next
+                        // tile's W(0) piece 0
+                        if (POS == POS_PEN && PERSIST) dma_slot_next(0, 0, 0);
+                        else dma_slot(kt, 0, POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN, false);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -436,7 +494,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
                 // starts reading it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 LAB_PHASE(3);
-                if (POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                if (POS == POS_GENERIC ? kt + 2 < nkt : (POS != POS_PEN || PERSIST)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 LAB_PHASE(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -455,30 +513,27 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
         for (int kt = 0; kt < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_GENERIC>{});
     }
     LAB_PHASE_FLUSH(wave >> 2);
+    if (prio) __builtin_amdgcn_s_setprio(0);
     }       // contract
 #ifdef VRD_LAB_STAMP
     asm volatile("" ::"v"(acc[0][0][0]), "v"(acc16[0][0][0]));
 #endif
     // every wave must be done with the rings before they are reused as epilogue staging
+    if (!contract || nkt < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the bias / scale loads; otherwise waited for in step 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     LAB_STAMP(2);
+    rflag = load_karg<unsigned*>(kp, offsetof(BigKArgs, rflag));
     if (PERSIST) {
-        // stage 0 of the next tile (activation stage 0, weight stage 0): in flight during this tile's epilogue
-        const int vn = vb + (int)gridDim.x;
-        staged0 = false;
-        if (vn < nwg) {
-            const Tile nt = tile_of(vn);
-            if (nt.contract) {
-                const Src nx = src_of(nt);
-                issue_a(nx, 0);
-                issue_w(nx, 0);
-                staged0 = true;
-            }
-        }
+        reload();          // (the epilogue's arguments are read here, not carried across the main loop)
+        staged = next_staged;
     }
-    // staging slab of this wave: 64 rows at the front of LDS, or (PERSIST) 32 rows inside activation stages 1-2
-    float* const stg = PERSIST ? smem + (A_STAGE + wave * (32 * vrd::STG_PITCH * 4)) / 4 : smem + wave * (64 * vrd::STG_PITCH);
+    // staging slab of this wave: 64 rows at the front of LDS, or (PERSIST) 32 rows inside the two ring slots the next tile's
+    // requested stages do not occupy: the slots its A(2) (waves 0-3) and its W(1) (waves 4-7) will take
+    const int slab_a = ((g0 + nkt + 2) % NA_STG) * A_STAGE, slab_w = W_RING + ((g0 + nkt + 1) % NW_STG) * W_STAGE;
+    float* const stg = PERSIST ? smem + ((wave < 4 ? slab_a : slab_w - 4 * (32 * vrd::STG_PITCH * 4)) + wave * (32 * vrd::STG_PITCH * 4)) / 4
+                               : smem + wave * (64 * vrd::STG_PITCH);
+    bool all_stored = true;
     constexpr int SLAB = PERSIST ? 32 : 64;
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {          // the epilogue works on 64 x 64 halves of the wave's 128 x 64
@@ -486,38 +541,49 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(vrd_gemm_args p, int t
         const int slot = tm * 8 + wm * 4 + hm * 2;
         const int blk_a = blk_of(slot), blk_b = blk_of(slot + 1);
         const int nw = n0 + wn * 64;
-        if (blk_a < 0 || nw >= p.N) continue;
+        if (blk_a < 0 || nw >= p.N) {
+            all_stored = false;
+            continue;
+        }
         const int64_t mw = (int64_t)blk_a * 32, mw1 = (int64_t)blk_b * 32;      // rows of passes 0-1 / 2-3
-        const bool rowin = p.row_mask || p.scale || p.res || p.res2;
+        // (PERSIST: the host sends no GEMM with per-row epilogue inputs here.  Their loads are the only vector loads of the tile
+        // loop the compiler tracks, and with them in the loop it opens every tile with `s_waitcnt vmcnt(0)` -- a wait for the
+        // previous tile's stores to be acknowledged; their waits also queue behind the look-ahead requests.)
+        const bool rowin = !PERSIST && (p.row_mask || p.scale || p.res || p.res2);
         if (M16) {
             vrd::f32x4_t part[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[i][j] = acc16[M16 ? 4 * hm + i : 0][M16 ? j : 0];
-            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
-            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
+            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
+            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
         } else {
             f32x16 part[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) part[i][j] = acc[M16 ? 0 : 2 * hm + i][M16 ? 0 : j];
-            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
-            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols);
+            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
+            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
         }
     }
     LAB_STAMP(3);
     LAB_REAL(5);
     if (PERSIST) {
-        // the slabs lie where the next tile's stage-1 / stage-2 DMAs land: everybody is done reading theirs first
+        // the slabs lie where the next tile's W(1) and A(2) land: everybody is done reading theirs first
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    vb += (int)gridDim.x;
-    } while (PERSIST && vb < nwg);       // tiles of this workgroup
+    stored_all = all_stored;
+    g0 = (g0 + nkt) % 6;
+    vq += (int)gridDim.x;
+    } while (PERSIST && vq < nwg * count);       // tiles of this workgroup
+    // (the last tile's look-ahead requests wrote into this workgroup's LDS: nothing may be in flight when it is handed on)
+    if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
 }  // namespace
@@ -533,9 +599,23 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch&
     // (measured, scripts/dev/stagger_sweep.sh, profiles/r04_lab_gemm_stagger.txt: 0 / 1 / 2 / 4 / 8 units -> 98.1-98.2 / 97.4 / 97.1 /
     // 97.8 / 99.4 ms of this kernel per step: about 1 %, so the epilogues were not waiting for each other's stores much)
     static const int stagger = [] { const char* e = getenv("VRD_BIG_STAGGER"); return e ? atoi(e) : 2; }();
-    hipLaunchKernelGGL(kern, dim3(PERSIST ? (nwg < 256 ? nwg : 256) : nwg, count), dim3(512), BIG_LDS, s, a, tiles_m, tiles_n, bb,
-                       (PERSIST || nwg < 512) ? 0 : stagger);
+    const int n_cu = PERSIST ? device_cu_count() : 0;
+    BigKArgs ka;
+    ka.p = a, ka.tiles_m = tiles_m, ka.tiles_n = tiles_n, ka.bb = bb, ka.stagger = (PERSIST || nwg < 512) ? 0 : stagger;
+    ka.rflag = a.c_pair == VRD_PAIR_F16 ? range_flag() : nullptr;
+    ka.count = count;
+    static const int prio_env = [] { const char* e = getenv("VRD_BIG_PRIO"); return e ? atoi(e) : 0; }();
+    ka.prio = prio_env;
+    if (PERSIST) hipLaunchKernelGGL(kern, dim3(nwg * count < n_cu ? nwg * count : n_cu), dim3(512), BIG_LDS, s, ka);
+    else hipLaunchKernelGGL(kern, dim3(nwg, count), dim3(512), BIG_LDS, s, ka);
     return 0;
+}
+
+// The persistent form (one workgroup per CU walking its tiles, the next tile's first stages requested inside the current tile's
+// last K steps) takes k = 1 GEMMs without per-row epilogue inputs and at least three K steps; VRD_BIG_PERSIST=0 switches it off.
+static bool big_persist(const vrd_gemm_args& a) {
+    static const int persist = [] { const char* e = getenv("VRD_BIG_PERSIST"); return e ? atoi(e) : 1; }();
+    return persist && a.taps == 1 && a.Cin >= 96 && !(a.row_mask || a.scale || a.res || a.res2);
 }
 
 // `count` (2 .. 4) problems that differ only in A, W_split, bias and C, as one launch of the default kernel
@@ -548,8 +628,9 @@ int launch_gemm_x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
         bb.C[i - 1] = a[i].C;
         bb.w_scale[i - 1] = a[i].w_scale;
     }
-    if (a[0].split_fmt == VRD_PAIR_F16)
-        return a[0].taps == 1 ? launch_big_one<1, false, false, true>(a[0], s, bb, count) : launch_big_one<3, false, false, true>(a[0], s, bb, count);
+    const bool f16 = a[0].split_fmt == VRD_PAIR_F16;
+    if (big_persist(a[0])) return f16 ? launch_big_one<1, false, true, true>(a[0], s, bb, count) : launch_big_one<1, false, true, false>(a[0], s, bb, count);
+    if (f16) return a[0].taps == 1 ? launch_big_one<1, false, false, true>(a[0], s, bb, count) : launch_big_one<3, false, false, true>(a[0], s, bb, count);
     return a[0].taps == 1 ? launch_big_one<1, false, false>(a[0], s, bb, count) : launch_big_one<3, false, false>(a[0], s, bb, count);
 }
 
@@ -568,14 +649,13 @@ int launch_gemm_x3_big(const vrd_gemm_args& a, hipStream_t s) {
     // dimension in a different order than the 32x32x16 kernels that serve small batches, and the path keeps its
     // results independent of the batch composition to the last bit (tests/test_gpu_model.py), so it stays opt-in.
     static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
-    // VRD_BIG_PERSIST=1: one workgroup per CU walking its tiles, the next tile's first stage requested under the epilogue
-    static const int persist = [] { const char* e = getenv("VRD_BIG_PERSIST"); return e ? atoi(e) : 0; }();
-    if (a.split_fmt == VRD_PAIR_F16) {      // (the persistent variant exists for the bf16 format only)
-        if (m16) return a.taps == 1 ? launch_big_one<1, true, false, true>(a, s) : launch_big_one<3, true, false, true>(a, s);
-        return a.taps == 1 ? launch_big_one<1, false, false, true>(a, s) : launch_big_one<3, false, false, true>(a, s);
+    const bool f16 = a.split_fmt == VRD_PAIR_F16;
+    if (m16) {
+        if (f16) return a.taps == 1 ? launch_big_one<1, true, false, true>(a, s) : launch_big_one<3, true, false, true>(a, s);
+        return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
     }
-    if (m16) return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
-    if (persist) return a.taps == 1 ? launch_big_one<1, false, true>(a, s) : launch_big_one<3, false, true>(a, s);
+    if (big_persist(a)) return f16 ? launch_big_one<1, false, true, true>(a, s) : launch_big_one<1, false, true, false>(a, s);
+    if (f16) return a.taps == 1 ? launch_big_one<1, false, false, true>(a, s) : launch_big_one<3, false, false, true>(a, s);
     return a.taps == 1 ? launch_big_one<1, false, false>(a, s) : launch_big_one<3, false, false>(a, s);
 }
 

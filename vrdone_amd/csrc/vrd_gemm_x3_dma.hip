@@ -91,7 +91,7 @@ __device__ unsigned long long g_lab_phase[16 * 4096];   // [wg][group][5 phase a
 #endif
 
 template <int TAPS, int DBK, int DBM, int NSTG, bool PP, bool BLK, bool F16 = false>
-__global__ __launch_bounds__(512) void gemm_x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512) void gemm_x3_dma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, unsigned* rflag) {
     typedef typename vrd::SplitFmt<F16>::x8 bf16x8;      // fragment of eight 16-bit elements: bf16, or f16 (VRD_PAIR_F16)
     using G = Geo<DBK, DBM, NSTG, BLK>;
     constexpr int NJ = G::NJ;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm_x3_dma_kernel(vrd_gemm_args p, int t
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) part[i][j] = acc[i][2 * hn + j];
-        vrd::gemm_epilogue<true, 64>(p, part, smem, m0 + wm * 64, n0 + wn * (32 * NJ) + hn * 64, wave, lane);
+        vrd::gemm_epilogue<true, 64>(p, part, smem, m0 + wm * 64, n0 + wn * (32 * NJ) + hn * 64, wave, lane, rflag);
     }
     LAB_STAMP(3);
     LAB_REAL(5);
@@ -390,7 +390,7 @@ static int launch_dma_one(const vrd_gemm_args& a, hipStream_t s) {
     static_assert(lds >= 8 * 16384 && lds <= 160 * 1024, "ring must hold the epilogue slabs and fit the CU");
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm(bf16x3 dma)")) return rc;
     const int tiles_m = (int)((a.M + DBM - 1) / DBM), tiles_n = (a.N + DBN - 1) / DBN;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), lds, s, a, tiles_m, tiles_n, a.c_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr);
     return 0;
 }
 

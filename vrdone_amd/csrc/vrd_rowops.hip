@@ -23,8 +23,9 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // frames, of which the first T are converted (the tail is padding the caller leaves out: MaskVRD's tight padding).
 __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict__ src, int C_total, int T, int c0,
                                                          int count, float* __restrict__ dst, int64_t ld_dst, int pair, int T_src,
-                                                         const int32_t* __restrict__ src_batch) {
+                                                         const int32_t* __restrict__ src_batch, unsigned* rflag) {
     __shared__ float tile[64][65];
+    vrd::RangeTrack rt;
     const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float* s = src + ((int64_t)(src_batch ? src_batch[b] : b) * C_total + c0) * T_src;
@@ -34,17 +35,19 @@ __global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict
     for (int t = ty; t < 64; t += 4)
         if (tt + t < T && ct + tx < count) {
             float* row = dst + ((int64_t)b * T + tt + t) * ld_dst;
-            if (pair) vrd::store_pair1(row, ct + tx, count, tile[tx][t], pair);
+            if (pair) vrd::store_pair1(row, ct + tx, count, tile[tx][t], pair, &rt);
             else row[ct + tx] = tile[tx][t];
         }
+    rt.report(rflag, vrd::RANGE_INPUT);
 }
 
 // same, 16-byte accesses on both sides (T % 4 == 0, count % 4 == 0, 16-byte aligned rows): float4 reads along t,
 // float4 / pair-row writes of four channels
 __global__ __launch_bounds__(256) void bct_to_btc_vec_kernel(const float* __restrict__ src, int C_total, int T, int c0,
                                                              int count, float* __restrict__ dst, int64_t ld_dst, int pair, int T_src,
-                                                             const int32_t* __restrict__ src_batch) {
+                                                             const int32_t* __restrict__ src_batch, unsigned* rflag) {
     __shared__ float tile[64][65];
+    vrd::RangeTrack rt;
     const int b = blockIdx.z, ct = blockIdx.y * 64, tt = blockIdx.x * 64;
     const float* s = src + ((int64_t)(src_batch ? src_batch[b] : b) * C_total + c0) * T_src;
     {
@@ -64,9 +67,10 @@ __global__ __launch_bounds__(256) void bct_to_btc_vec_kernel(const float* __rest
         if (tt + t >= T || ct + 4 * cg >= count) continue;
         const float4 v = make_float4(tile[4 * cg][t], tile[4 * cg + 1][t], tile[4 * cg + 2][t], tile[4 * cg + 3][t]);
         float* row = dst + ((int64_t)b * T + tt + t) * ld_dst;
-        if (pair) vrd::store_pair4(row, ct + 4 * cg, count, v, pair);
+        if (pair) vrd::store_pair4(row, ct + 4 * cg, count, v, pair, &rt);
         else st4(row + ct + 4 * cg, v);
     }
+    rt.report(rflag, vrd::RANGE_INPUT);
 }
 
 __global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict__ src, int64_t ld_src, int C, int T,
@@ -88,15 +92,17 @@ __global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict
 // wide visual / clip slabs when requested.  Replaces the zero-padded (B, C_in, T) batch of
 // models/maskvrd.py:382-385 and the channel slicing of models/backbones.py:161-166.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pack_segment(const float* src, bool live, int lane, int width, float* dst, int pair) {
+__device__ __forceinline__ void pack_segment(const float* src, bool live, int lane, int width, float* dst, int pair,
+                                             vrd::RangeTrack* rt = nullptr) {
     for (int c = lane; c < width; c += 64) {
         const float v = live ? src[c] : 0.f;
-        if (pair) vrd::store_pair1(dst, c, width, v, pair);
+        if (pair) vrd::store_pair1(dst, c, width, v, pair, rt);
         else dst[c] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void pack_pairs_kernel(vrd_pack_args a) {
+__global__ __launch_bounds__(256) void pack_pairs_kernel(vrd_pack_args a, unsigned* rflag) {
+    vrd::RangeTrack rt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
     if (row >= (int64_t)a.P * a.T) return;
@@ -105,15 +111,16 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(vrd_pack_args a) {
     const float* src = a.src[p] + (int64_t)t * a.C_in;
     const int64_t half = (int64_t)a.P * a.T;             // rows per (subject | object) half of the stacked buffers
     int c0 = 0;
-    pack_segment(src + c0, live, lane, a.V, a.vis + row * a.V, a.pair_wide);              c0 += a.V;
-    pack_segment(src + c0, live, lane, a.V, a.vis + (half + row) * a.V, a.pair_wide);     c0 += a.V;
+    pack_segment(src + c0, live, lane, a.V, a.vis + row * a.V, a.pair_wide, &rt);              c0 += a.V;
+    pack_segment(src + c0, live, lane, a.V, a.vis + (half + row) * a.V, a.pair_wide, &rt);     c0 += a.V;
     if (a.Cc) {
-        pack_segment(src + c0, live, lane, a.Cc, a.clip + row * a.Cc, a.pair_wide);          c0 += a.Cc;
-        pack_segment(src + c0, live, lane, a.Cc, a.clip + (half + row) * a.Cc, a.pair_wide); c0 += a.Cc;
+        pack_segment(src + c0, live, lane, a.Cc, a.clip + row * a.Cc, a.pair_wide, &rt);          c0 += a.Cc;
+        pack_segment(src + c0, live, lane, a.Cc, a.clip + (half + row) * a.Cc, a.pair_wide, &rt); c0 += a.Cc;
     }
     pack_segment(src + c0, live, lane, a.S, a.so_box + row * a.S, 0);                     c0 += a.S;
     pack_segment(src + c0, live, lane, a.E, a.ent + row * a.E, 0);                        c0 += a.E;
     pack_segment(src + c0, live, lane, a.E, a.ent + (half + row) * a.E, 0);
+    rt.report(rflag, vrd::RANGE_INPUT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -169,7 +176,8 @@ __device__ __forceinline__ void entity_feats(const float* boxes, int64_t row0, i
     for (int i = 0; i < 4; ++i) f[2 * i] = g[i], f[2 * i + 1] = d[i];
 }
 
-__global__ __launch_bounds__(256) void gather_pairs_kernel(vrd_gather_args a) {
+__global__ __launch_bounds__(256) void gather_pairs_kernel(vrd_gather_args a, unsigned* rflag) {
+    vrd::RangeTrack rt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (row >= (int64_t)a.P * a.T) return;
@@ -179,12 +187,13 @@ __global__ __launch_bounds__(256) void gather_pairs_kernel(vrd_gather_args a) {
     const int64_t rs = a.s_row[p] + (int64_t)t * a.stride, ro = a.o_row[p] + (int64_t)t * a.stride;
     const int64_t half = (int64_t)a.P * a.T;
     if (a.out_vis) {        // NULL: box features only (the wide rows come from the per-tracklet streams, vrd_assemble_pairs)
-        pack_segment(a.vis + (live ? rs : 0) * a.V, live, lane, a.V, a.out_vis + row * a.V, a.pair_wide);
-        pack_segment(a.vis + (live ? ro : 0) * a.V, live, lane, a.V, a.out_vis + (half + row) * a.V, a.pair_wide);
+        pack_segment(a.vis + (live ? rs : 0) * a.V, live, lane, a.V, a.out_vis + row * a.V, a.pair_wide, &rt);
+        pack_segment(a.vis + (live ? ro : 0) * a.V, live, lane, a.V, a.out_vis + (half + row) * a.V, a.pair_wide, &rt);
         if (a.Cc) {
-            pack_segment(a.clip + (live ? rs : 0) * a.Cc, live, lane, a.Cc, a.out_clip + row * a.Cc, a.pair_wide);
-            pack_segment(a.clip + (live ? ro : 0) * a.Cc, live, lane, a.Cc, a.out_clip + (half + row) * a.Cc, a.pair_wide);
+            pack_segment(a.clip + (live ? rs : 0) * a.Cc, live, lane, a.Cc, a.out_clip + row * a.Cc, a.pair_wide, &rt);
+            pack_segment(a.clip + (live ? ro : 0) * a.Cc, live, lane, a.Cc, a.out_clip + (half + row) * a.Cc, a.pair_wide, &rt);
         }
+        rt.report(rflag, vrd::RANGE_INPUT);
     }
     // box features: lanes 0 (subject-object), 1 (subject), 2 (object) compute, everybody stores zeros for padded frames
     float* const so = a.out_so_box + row * 5;
@@ -279,7 +288,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         int64_t ldy, int64_t rows, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int relu,
                                                         const float* __restrict__ post_add, int64_t ld_add, int period,
-                                                        int pair) {
+                                                        int pair, unsigned* rflag) {
+    vrd::RangeTrack rt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
     if (row >= rows) return;
@@ -294,9 +304,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        if (pair) vrd::store_pair4(y + row * ldy, i * 256 + lane * 4, 256 * NV, v[i], pair);
+        if (pair) vrd::store_pair4(y + row * ldy, i * 256 + lane * 4, 256 * NV, v[i], pair, &rt);
         else st4(y + row * ldy + i * 256 + lane * 4, v[i]);
     }
+    rt.report(rflag, vrd::RANGE_LAYERNORM);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -313,7 +324,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 constexpr int DW_RW = 16;                      // output rows per wave (default; the launcher may pick 8..32, see vrd_dwconv_ln)
 
 template <int NV, int KS, int GIN>
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq, int strips_per_wave, int rw) {
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq, int strips_per_wave, int rw, unsigned* rflag) {
+    vrd::RangeTrack rt;
     constexpr int C = 256 * NV, NT = GIN * KS, SETF = (NT + 3) * C;
     constexpr bool WIDE = NV == 2 && GIN == 1;
     extern __shared__ __attribute__((aligned(16))) float dw_lds[];
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     for (int si = 0; si < strips_per_wave; ++si) {
     const int64_t ws = ((int64_t)lid * 4 + wave) * strips_per_wave + si;
     const int b = (int)(ws / strips_per_seq);
-    if (b >= p.B) return;
+    if (b >= p.B) break;
     const int to0 = (int)(ws - (int64_t)b * strips_per_seq) * rw;
     const int to1 = min(to0 + rw, Tout);
 
@@ -402,12 +414,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 for (int to = to0; to < to1; ++to) {
                     const int64_t row = (int64_t)b * Tout + to;
                     if (WIDE && p.out_pair[o]) {
-                        vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, val[0], val[NV - 1], p.out_pair[o]);
+                        vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, val[0], val[NV - 1], p.out_pair[o], &rt);
                     } else {
 #pragma unroll
                         for (int i = 0; i < NV; ++i) {
                             const int c = lane_chan<NV, WIDE>(i, lane);
-                            if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, val[i], p.out_pair[o]);
+                            if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, val[i], p.out_pair[o], &rt);
                             else st4(p.y[o] + row * p.ldy[o] + c, val[i]);
                         }
                     }
@@ -475,12 +487,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 }
             }
             if (WIDE && p.out_pair[o]) {
-                vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, acc[0], acc[NV - 1], p.out_pair[o]);
+                vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, acc[0], acc[NV - 1], p.out_pair[o], &rt);
             } else {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     const int c = lane_chan<NV, WIDE>(i, lane);
-                    if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, acc[i], p.out_pair[o]);
+                    if (p.out_pair[o]) vrd::store_pair4(p.y[o] + row * p.ldy[o], c, 256 * NV, acc[i], p.out_pair[o], &rt);
                     else st4(p.y[o] + row * p.ldy[o] + c, acc[i]);
                 }
             }
@@ -500,6 +512,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
         }
     }
     }       // strips of this wave
+    rt.report(rflag, vrd::RANGE_DWCONV_LN);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -631,8 +644,8 @@ int vrd_bct_to_btc(const float* src, int B, int C_total, int T, int c0, int coun
     dim3 grid((T + 63) / 64, (count + 63) / 64, B);
     VRD_CHECK_ARG(!out_pair || (count % 32 == 0 && ld_dst % 4 == 0 && aligned16(dst)), "vrd_bct_to_btc: pair rows need count %% 32 == 0");
     const bool vec = T % 4 == 0 && T_src % 4 == 0 && count % 4 == 0 && ld_dst % 4 == 0 && aligned16(dst) && aligned16(src);
-    if (vec) hipLaunchKernelGGL(bct_to_btc_vec_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair, T_src, src_batch);
-    else hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair, T_src, src_batch);
+    if (vec) hipLaunchKernelGGL(bct_to_btc_vec_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair, T_src, src_batch, out_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr);
+    else hipLaunchKernelGGL(bct_to_btc_kernel, grid, dim3(256), 0, s, src, C_total, T, c0, count, dst, ld_dst, out_pair, T_src, src_batch, out_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr);
     VRD_LAUNCH_CHECK();
     return 0;
 }
@@ -646,7 +659,7 @@ int vrd_pack_pairs(const vrd_pack_args* a, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t rows = (int64_t)a->P * a->T;
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * a->C_in);
-    hipLaunchKernelGGL(pack_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(pack_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a, a->pair_wide == VRD_PAIR_F16 ? vrd::range_flag() : nullptr);
     VRD_LAUNCH_CHECK();
     return 0;
 }
@@ -661,7 +674,7 @@ int vrd_gather_pairs(const vrd_gather_args* a, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t rows = (int64_t)a->P * a->T;
     vrd::ProfScope prof(VRD_K_TRANSPOSE, s, 0.0, 8.0 * (double)rows * ((a->out_vis ? 2 * a->V + 2 * a->Cc : 0) + 21));
-    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(gather_pairs_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a, a->pair_wide == VRD_PAIR_F16 ? vrd::range_flag() : nullptr);
     VRD_LAUNCH_CHECK();
     return 0;
 }
@@ -717,11 +730,12 @@ int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t ro
     if (rows <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_LAYERNORM, s, 0.0, 8.0 * (double)rows * C);
+    unsigned* const rflag = out_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr;
     dim3 grid((unsigned)((rows + 3) / 4));
     if (C == 256)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair, rflag);
     else
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair, rflag);
     VRD_LAUNCH_CHECK();
     return 0;
 }
@@ -779,7 +793,10 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     const int64_t total_strips = (int64_t)a->B * strips;
     const int spw = spw_env > 0 ? spw_env : 1;
     dim3 grid((unsigned)((total_strips + 4 * spw - 1) / (4 * spw))), block(256);
-#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips, spw, rw)
+    bool any_f16 = false;
+    for (int o = 0; o < a->n_out; ++o) any_f16 |= a->out_pair[o] == VRD_PAIR_F16;
+    unsigned* const rflag = any_f16 ? vrd::range_flag() : nullptr;
+#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips, spw, rw, rflag)
     if (a->group_in == 2) VRD_DW(1, 3, 2);
     else if (a->C == 256 && a->ksize == 3) VRD_DW(1, 3, 1);
     else if (a->C == 256) VRD_DW(1, 1, 1);

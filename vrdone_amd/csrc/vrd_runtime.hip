@@ -64,6 +64,24 @@ int device_cu_count() {
     return cus[dev];
 }
 
+// The f16 operand-range flag of the CURRENT device: one word of device memory per device ordinal, allocated on first use and
+// kept for the life of the process.  Every producer of VRD_PAIR_F16 rows ORs its tag into it when an element's scaled value
+// does not fit an f16 (vrd_common.h, RangeTrack).  nullptr when the allocation fails (producers then skip the report).
+unsigned* range_flag() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    static std::vector<unsigned*> flags;
+    if (dev >= (int)flags.size()) flags.resize(dev + 1, nullptr);
+    if (!flags[dev]) {
+        unsigned* q = nullptr;
+        if (hipMalloc(&q, 64) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, 64) != hipSuccess) return nullptr;
+        flags[dev] = q;
+    }
+    return flags[dev];
+}
+
 static hipEvent_t get_event() {
     if (!g_free_events.empty()) {
         hipEvent_t e = g_free_events.back();
@@ -124,6 +142,16 @@ extern "C" {
 
 int vrd_abi_version(void) { return VRD_ABI_VERSION; }
 const char* vrd_last_error(void) { return vrd::g_err; }
+
+int vrd_f16_range_flag(void** flag) {
+    VRD_CHECK_ARG(flag, "vrd_f16_range_flag: null pointer");
+    *flag = vrd::range_flag();
+    if (!*flag) {
+        vrd::set_error("vrd_f16_range_flag: cannot allocate the flag word");
+        return -2;
+    }
+    return 0;
+}
 
 int vrd_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(vrd::g_mu);

@@ -274,12 +274,32 @@ class MaskVRD(nn.Module):
         With autograd recording (a training step, train.py:182-186) the network runs the differentiable HIP ops of
         vrdone_amd/autograd.py, AffineDropPath samples per-sample keep factors, and total_loss.backward() reaches
         every parameter.  Under torch.no_grad() it is the validation loss on the fused inference kernels."""
+        ops = _ops()
+        # f16x3 mode: an activation beyond the f16 operand range (+-4094) is reported by the kernel that met it in a flag word
+        # on the device (ops.f16_range_flag; a NaN would not reach the loss reliably).  The word is read once, behind the
+        # step's own launches, and such a step is taken again in the f32 mode -- the arithmetic of the reference (train.py:182-186).
+        pdev = next(self.parameters()).device
+        guard = ops.get_precision() == "f16x3" and pdev.type == "cuda"
+        if guard:
+            flag = ops.f16_range_flag(pdev)
+            flag.zero_()
         x, m = self._train_batch(input_data['so_features_list'])
         if torch.is_grad_enabled() and self.training and train_graph.enabled(self):
             predictions = train_graph.mask_vrd(self, x, m)        # two HIP-graph replays instead of ~2,000 launches
         else:
             predictions = self._mask_vrd(x, m, with_aux=self.deep_supervision)
-        return self.criterion(predictions, input_data)
+        losses = self.criterion(predictions, input_data)
+        if guard:
+            bits = int(flag.item())
+            if bits:
+                import warnings
+                flag.zero_()
+                warnings.warn("vrdone_amd: an activation beyond the f16x3 mode's operand range (" + ops.describe_range(bits) +
+                              "): taking this step in the f32 mode")
+                del losses, predictions
+                with ops.use_precision("f32"):
+                    return self.forward_training(input_data)
+        return losses
 
     def enable_training_graphs(self, enable=True):
         """Training steps replay the network's forward and backward as HIP graphs, recorded once per batch shape
@@ -695,17 +715,26 @@ class MaskVRD(nn.Module):
         unsort = torch.empty(P, dtype=torch.int64)
         unsort[torch.tensor(order, dtype=torch.int64)] = torch.arange(P)
         unsort = unsort.to(dev)                         # uploaded before the first kernel is queued
+        ops = _ops()
+        f16 = ops.get_precision() == "f16x3"
+        if f16:
+            flag = ops.f16_range_flag(next(self.parameters()).device)
+            flag.zero_()
         cand = self.pair_candidates(feats, lens, mine, t_pad, k, source=source)
+        if f16:
+            # an activation beyond the f16 operand range is reported in the device's flag word (a NaN would not reach the
+            # scores reliably: the ReLUs and max-pools on the way drop it).  Without leaving the stream the flag poisons this
+            # rank's scores, so that the finite-scores test below -- after the exchange, identical on every rank -- sees it
+            cand[:, :, :k] += torch.where(flag > 0, float("nan"), 0.0).to(cand.dtype)
         if world > 1 or (shard and parallel.forced()):
             cand = parallel.gather_candidates(cand, P, shard[0])       # (P, Q, 2k + 2) in `order`
-        ops = _ops()
-        if ops.get_precision() == "f16x3" and not bool(torch.isfinite(cand[:, :, :k]).all()):
-            # the f16x3 mode's operand planes hold |x| < 4094 (vrd_common.h): a larger activation comes out as NaN, never as a
-            # wrong number.  The reference computes such a video in float32: so does the repeat.  (After the exchange: every
-            # rank of a sharded run sees the same candidates and takes the same branch.)
+        if f16 and not bool(torch.isfinite(cand[:, :, :k]).all()):
+            # the f16x3 mode's operand planes hold |x| < 4094 (vrd_common.h).  The reference computes such a video in float32:
+            # so does the repeat.  (After the exchange: every rank of a sharded run sees the same candidates and takes the
+            # same branch.)
             import warnings
-            warnings.warn("vrdone_amd: non-finite scores in the f16x3 precision mode (an activation beyond the f16 operand range, "
-                          "or non-finite inputs): repeating this video in the f32 mode")
+            warnings.warn("vrdone_amd: an activation beyond the f16x3 mode's operand range (or non-finite inputs): repeating "
+                          "this video in the f32 mode")
             with ops.use_precision("f32"):
                 return self.forward_test(input_data)
         cand = cand[unsort]                             # back to the dataloader's pair order

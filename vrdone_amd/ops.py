@@ -195,8 +195,9 @@ def packed_conv_weight(w):
 #            run of the reference as the reference's own float32 run is (x1.0-1.3, tests/golden/mask_vrd_f64.npz), at the
 #            speed of bf16x3.  Forward products only: the backward GEMMs of this mode are bf16x3's (gradients have no
 #            fixed scale to split an f16 pair at).  The default.
-#            Activations beyond +-4094 overflow the f16 planes and come out as NaN (never as a wrong finite number);
-#            MaskVRD repeats such a batch in the f32 mode.
+#            Activations beyond +-4094 overflow the f16 planes.  Every kernel that writes such planes reports it in a flag word
+#            on the device (f16_range_flag()); MaskVRD.forward_test, forward_training and forward_loss read the word with their
+#            results and repeat the call in the f32 mode; a direct caller of _mask_vrd checks f16_range_exceeded() itself.
 #   "f32":   exact f32 MFMA products (bit-level fmaf chains); logits within 9e-6; ~2.8x slower end to end (bench.py).
 # Select with set_precision() or the VRDONE_PRECISION environment variable.  Everything outside the
 # conv GEMMs and the global attention (LayerNorm, depthwise convs, softmax, banded attention) is f32 in all modes.
@@ -231,6 +232,49 @@ class use_precision:
     def __exit__(self, *exc):
         set_precision(self.prev)
         return False
+
+
+# ---- the f16x3 mode's operand range (include/vrdone_hip.h, vrd_f16_range_flag)
+_range_flags = {}
+
+
+class _DeviceWord:
+    """one int32 of library-owned device memory, presented to torch through __cuda_array_interface__"""
+
+    def __init__(self, ptr):
+        self.__cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def f16_range_flag(device=None):
+    """The device's f16 operand-range flag as a 1-element int32 tensor (a view of the library's word, not a copy): non-zero
+    once any producer of f16 pair rows met a value beyond +-4094 since the word was last cleared; the bits name the
+    producing kernel families (_hip.RANGE_TAGS).  Read it WITH a call's results (`.clone()` on the same stream, or one
+    `.item()` where the results are synchronised anyway) and clear it with `.zero_()`."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    flag = _range_flags.get(dev.index)
+    if flag is None:
+        import ctypes as C
+        with torch.cuda.device(dev):
+            ptr = C.c_void_p()
+            _hip.check(lib.vrd_f16_range_flag(C.byref(ptr)), "vrd_f16_range_flag")
+            flag = _range_flags[dev.index] = torch.as_tensor(_DeviceWord(ptr.value), device=dev)
+    return flag
+
+
+def f16_range_exceeded(device=None, clear=True):
+    """True when the flag is set (one 4-byte read: a host synchronisation); clears it by default.  `describe_range(bits)` names
+    the producers."""
+    flag = f16_range_flag(device)
+    bits = int(flag.item())
+    if bits and clear:
+        flag.zero_()
+    return bits
+
+
+def describe_range(bits):
+    return ", ".join(name for bit, name in _hip.RANGE_TAGS.items() if bits & bit) or "none"
 
 
 class SplitWeight:
