@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 29
+#define VRD_ABI_VERSION 30
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -223,6 +223,10 @@ typedef struct {
     const float* w_scale;   /* VRD_PAIR_F16 only: device pointer to the factor that turns the accumulator of the scaled
                                operands back into the product, 2^-(e_w + VRD_F16_ACT_EXP) -- element 0 of vrd_split_weight's
                                `scale` output for W_split */
+    const float* a_scale;   /* VRD_PAIR_F16 with f32-row A (a_pair_width == 0) only, nullable: device pointer to two floats
+                               (2^e, 2^-e), vrd_absmax_scale's output for A: the rows are split as f16 planes of A * 2^e instead
+                               of A * 2^VRD_F16_ACT_EXP, for operands without a known range -- the gradients of the training
+                               step's input-gradient GEMMs (the reference differentiates in float32, train.py:182-186) */
 } vrd_gemm_args;
 int vrd_gemm(const vrd_gemm_args* a, void* stream);
 /* `count` (1..4) GEMMs of an array of argument structs.  Problems that differ only in A, W / W_split, bias and C and
@@ -353,9 +357,18 @@ int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, con
  * aligned, `scratch_floats` floats, never read before it is written) takes the chunks' partial tiles, which a second launch sums
  * into dW in chunk order: 4 * CUs * 16,384 + N * taps * Cin floats always suffice.  Without it, or when it is too small, the
  * partial tiles are added to dW with float atomics (slower: L2 retires about one float atomic per clock and channel; and the
- * order of the additions then varies from run to run). */
+ * order of the additions then varies from run to run).
+ * g_scale (nullable): device pointer to {2^e, 2^-e} from vrd_absmax_scale(G): the products are then formed on f16 planes --
+ * G * 2^e, X * 2^VRD_F16_ACT_EXP -- at ~2^-22 relative error (the f16x3 mode's backward); NULL: bf16 planes, ~2^-17. */
 int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
-                      int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, void* stream);
+                      int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, const float* g_scale,
+                      void* stream);
+
+/* scale[0] = 2^e, scale[1] = 2^-e with e such that max |x| * 2^e lies in [2^13, 2^14) over the (rows x cols) matrix x (e = 0 for
+ * an all-zero or non-finite matrix; |e| <= 100): the power-of-two factor that puts a tensor of unknown range -- a gradient -- into
+ * the f16 planes of VRD_PAIR_F16 with headroom.  One launch; `scale` is FOUR floats of device memory that the caller zeroed
+ * once: elements 2 and 3 are the running maximum's bits and the workgroup ticket, which the last workgroup leaves zeroed again. */
+int vrd_absmax_scale(const float* x, int64_t ldx, int64_t rows, int cols, float* scale, void* stream);
 
 /* out[c] += sum_r a[r, c] * (b ? b[brow(r), c * b_cstride + b_coffset] : 1) * (row_mask ? row_mask[r] : 1) * (row_scale ?
  * row_scale[r] : 1), brow(r = s*T + t) = s * (b_rstride*T) + b_rstride*t + shift when that stays inside the sequence

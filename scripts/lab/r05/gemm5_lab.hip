@@ -121,6 +121,15 @@ int main(int argc, char** argv) {
             printf("%-20s K=%5d N=%4d var %d: %7.3f ms  %6.1f TF/s | per tile (wave 0): setup %6.0f  loop %7.0f (%5.0f/kstep)  epilogue %6.0f  total %7.0f cyc @ %.2f GHz | tiles/CU %.1f -> busy %.3f ms\n",
                    sh.label, K, sh.N, var, ms, 2.0 * sh.M * sh.N * K / ms / 1e9, median(pro), median(loop), median(loop) / nkt, median(epi),
                    median(tot), ghz, tiles / 256.0, tiles / 256.0 * median(tot) / ghz * 1e-6);
+            {
+                std::vector<double> t6, t7;
+                for (int i = 0; i < n; ++i) {
+                    const unsigned long long* s_ = &st[(size_t)i * 8];
+                    t6.push_back((double)(s_[6] - s_[1]));
+                    t7.push_back((double)(s_[7] - s_[6]));
+                }
+                printf("      tile start: first-stage wait (vmcnt) %6.0f, barrier %6.0f\n", median(t6), median(t7));
+            }
             if (var == 12 || var == 14) {
                 std::vector<double> t6, t7, tb;
                 for (int i = 0; i < n; ++i) {

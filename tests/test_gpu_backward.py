@@ -123,11 +123,11 @@ def test_weight_gradient_through_partial_tiles(M, N, Cin, k, T):
     part = torch.full((4 * 256 * 16384 + N * k * Cin + 8,), float("nan"), device=DEV)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def run(scratch, floats):
-        dW = torch.ones(N, k * Cin, device=DEV)
+    def run(scratch, floats, g_scale=None, init=1.0):
+        dW = torch.full((N, k * Cin), init, device=DEV)
         db = torch.zeros(N, device=DEV)
         _hip.check(_hip.lib.vrd_gemm_wgrad_x3(Gd.data_ptr(), N, Xd.data_ptr(), Cin, md.data_ptr(), M, N, Cin, k, T, dW.data_ptr(),
-                                              db.data_ptr(), scratch, floats, stream), "vrd_gemm_wgrad_x3")
+                                              db.data_ptr(), scratch, floats, g_scale, stream), "vrd_gemm_wgrad_x3")
         return dW, db
 
     a, ba = run(None, 0)
@@ -144,6 +144,28 @@ def test_weight_gradient_through_partial_tiles(M, N, Cin, k, T):
     rel_close(bb, Gm.sum(0), 2e-5, "db")
     assert torch.equal(b, b2), "the chunk-ordered sum is not reproducible"
     assert float((a - b).abs().max()) <= 1e-4 * float(want.abs().max())
+    # the f16x3 mode's form: f16 planes, the gradient at the power-of-two factor of vrd_absmax_scale -- a tensor far outside the
+    # f16 range as it stands (x 1e-9), the products ~2^-22 instead of the bf16 planes' ~2^-17
+    if N % 4 == 0:
+        tiny = 1e-9
+        Gs = (Gd * tiny).contiguous()
+        scale = torch.zeros(4, device=DEV)
+        _hip.check(_hip.lib.vrd_absmax_scale(Gs.data_ptr(), N, M, N, scale.data_ptr(), stream), "vrd_absmax_scale")
+        mx = float(Gs.abs().max())
+        assert 2.0 ** 13 <= mx * float(scale[0]) < 2.0 ** 14 and float(scale[0] * scale[1]) == 1.0 and float(scale[2]) == 0.0 and float(scale[3]) == 0.0
+        keep = Gd
+        Gd = Gs
+        try:
+            f, bf = run(part.data_ptr(), part.numel(), scale.data_ptr(), init=0.0)
+            e, _ = run(part.data_ptr(), part.numel(), init=0.0)
+        finally:
+            Gd = keep
+        want_s = (want - 1.0) * tiny
+        err16 = float((f.double().cpu() - want_s).abs().max()) / float(want_s.abs().max())
+        errbf = float((e.double().cpu() - want_s).abs().max()) / float(want_s.abs().max())
+        print(f"dW error relative to the largest entry: f16 planes {err16:.2e}, bf16 planes {errbf:.2e}")
+        assert err16 <= 2e-6 and err16 <= 0.5 * errbf + 1e-7
+        rel_close(bf, Gm.sum(0) * tiny, 2e-5, "db (scaled gradient)")
 
 
 @pytest.mark.parametrize("ks,gin,stride,C,B,T", [(3, 1, 1, 512, 64, 64), (3, 1, 1, 260, 37, 50), (3, 2, 1, 256, 40, 50), (1, 1, 1, 256, 33, 64),

@@ -243,17 +243,19 @@ def test_training_step_gradients_against_float64_reference(case, precision):
     print(f"[{case}/{precision}] |ours - ref64| in units of the reference's own f32 error: median {np.median(v):.1f}, 90 % "
           f"{np.percentile(v, 90):.1f}, max {v.max():.0f}; downstream of the pools: median {np.median(pool_free):.1f}, max {pool_free.max():.0f}; "
           f"total_loss |ours - ref64| {e_loss:.2e} (ref32: {e32_loss:.2e})")
-    # Bounds in units of e32, by mode (measured, profiles/r04_grad_f64_distance.txt): f32 -- downstream of the pools at most
-    # 2 x, median 1.1-1.7 x: the backward kernels are at the reference's own float32 error; f16x3 (its backward products are
-    # the bf16 split's: ops.split_backward) at most 16 x, median 8-11 x; bf16x3 at most 81 x, median 32-49 x.
+    # Bounds in units of e32, by mode (measured, profiles/r05_grad_f64_distance.txt): f32 -- downstream of the pools at most
+    # 2 x, median 1.0-1.7 x: the backward kernels are at the reference's own float32 error; f16x3 -- its backward GEMMs form
+    # their products on f16 planes too, the gradient at a per-tensor power of two (ops.grad_scale) -- at most 2 x, median
+    # 0.8-1.1 x, held to the f32 mode's bounds (on bf16 planes, VRDONE_F16_BACKWARD=0, it sat at 5-11 x median, 16-26 x
+    # worst); bf16x3 at most 80 x, median 21-49 x.
     # Held to the bound: every parameter downstream of the branch pools (POOL_FREE) in both cases, and in the no-drop case all
     # parameters except the first visual embedding layer (FIRST_LAYER: its LayerNorm feeds a ReLU whose gates, ~2 million
     # elements, flip where |y| < 1e-6: 12-388 x in f32).  Upstream of branch.1's pool the pinned case carries the arg-max flip
     # of POOL_FREE's comment: every such parameter sits at 400-3,700 x in f32 -- they are the complement of POOL_FREE, listed in
     # the failure message if one of them is NOT the reason.
     FIRST_LAYER = r"backbone\.visual_embd(_norm)?\.0\."
-    bound = {"f32": 4.0, "f16x3": 40.0, "bf16x3": 500.0}[precision]
-    median_bound = {"f32": 3.0, "f16x3": 20.0, "bf16x3": 80.0}[precision]
+    bound = {"f32": 4.0, "f16x3": 4.0, "bf16x3": 500.0}[precision]
+    median_bound = {"f32": 3.0, "f16x3": 3.0, "bf16x3": 80.0}[precision]
     held = [n for n in ratio if re.match(POOL_FREE, n) or (case == "nodrop" and not re.match(FIRST_LAYER, n))]
     assert len(held) >= (500 if case == "nodrop" else 250)
     beyond = sorted((n, round(ratio[n], 1)) for n in held if ratio[n] > bound)
@@ -313,7 +315,8 @@ def test_presplit_weights_equal_the_per_weight_launches(mode):
     builds a new plan and drops the old one."""
     from vrdone_amd import ops
     fwd = "_vrd_split_f16" if mode == "f16x3" else "_vrd_split"
-    slots = (fwd, "_vrd_split_t")
+    bwd = "_vrd_split_t_f16" if mode == "f16x3" else "_vrd_split_t"       # (the backward GEMMs' operands are in the mode's format too)
+    slots = (fwd, bwd)
     bits = lambda sw: sw.t.view(torch.int16)        # noqa: E731
     with ops.use_precision(mode):
         model, _, _ = build()
@@ -327,7 +330,7 @@ def test_presplit_weights_equal_the_per_weight_launches(mode):
                 want[(id(w), fwd)] = (sw.t.clone(), None if sw.scale is None else sw.scale.clone(), sw.fmt)
             if (N * k) % 32 == 0:
                 sw = ops.split_conv_weight_dgrad(w)
-                want[(id(w), "_vrd_split_t")] = (sw.t.clone(), None, sw.fmt)
+                want[(id(w), bwd)] = (sw.t.clone(), None if sw.scale is None else sw.scale.clone(), sw.fmt)
             for slot in slots:
                 if hasattr(w, slot):
                     delattr(w, slot)

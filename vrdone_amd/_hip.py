@@ -47,7 +47,7 @@ class GemmArgs(C.Structure):
                 ("res2", c_f32p), ("ldres2", C.c_int64), ("W_split", C.c_void_p),
                 ("a_pair_width", C.c_int32), ("c_pair", C.c_int32),
                 ("row_blocks", C.c_void_p), ("row_blocks_active", C.c_void_p), ("row_block_seg_len", C.c_int32),
-                ("split_fmt", C.c_int32), ("w_scale", c_f32p)]
+                ("split_fmt", C.c_int32), ("w_scale", c_f32p), ("a_scale", c_f32p)]
 
 
 class DwconvLnArgs(C.Structure):
@@ -142,7 +142,8 @@ _SIGNATURES = {
     "vrd_gemm_wgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                  c_f32p, C.c_void_p]),
     "vrd_gemm_wgrad_x3": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, c_u8p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                                    c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
+                                    c_f32p, c_f32p, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
+    "vrd_absmax_scale": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, C.c_void_p]),
     "vrd_dwconv_wgrad": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, c_u8p, C.c_int64,
                                    C.c_int, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "vrd_colsum": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_u8p, c_f32p,
@@ -172,7 +173,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 
 class HipLibraryError(RuntimeError):

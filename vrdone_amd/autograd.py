@@ -23,7 +23,7 @@ import torch
 from torch.autograd import Function
 
 from . import _hip, ops
-from ._hip import PAIR_BF16, lib
+from ._hip import PAIR_BF16, PAIR_F16, lib
 from .ops import ACT_NONE, ACT_RELU, _mask_ptr, _ptr, _rows, _stream
 
 check = _hip.check
@@ -185,16 +185,20 @@ class Linear(Function):
             wd = weight if not torch.is_grad_enabled() else weight.detach()
             fused = (ops.split_backward() and (N * k) % 32 == 0 and N % 4 == 0 and dy.stride(-2) % 4 == 0 and
                      dy.data_ptr() % 16 == 0 and weight.is_contiguous())
-            gfmt = PAIR_BF16 if ops.split_backward() else None       # gradients are split in bf16 in either split mode
+            gfmt = PAIR_BF16 if ops.split_backward() else None       # (the unfused fallback splits gradients in bf16 in either mode)
+            # f16x3 mode: the gradient's power-of-two factor for its f16 planes (one absmax launch, shared with the weight gradient)
+            gs = ops.grad_scale(dy) if (fused and ops.backward_fmt() == PAIR_F16) else None
+            if fused and ops.backward_fmt() == PAIR_F16 and gs is None:
+                fused = False
             if k == 1:       # masking the rows of dy = masking the rows of dx
                 if fused:
-                    dx = ops.conv_gemm(dy, wd, None, row_mask=mask, _dgrad=True)
+                    dx = ops.conv_gemm(dy, wd, None, row_mask=mask, _dgrad=True, _a_scale=gs)
                 else:
                     dx = ops.conv_gemm(dy, weight.detach().permute(1, 0, 2).contiguous(), None, row_mask=mask, _split_fmt=gfmt)
             else:            # dx[r] = sum_tap (dy * mask)[r - (tap - 1)] W[:, :, tap]: a k=3 conv with flipped, transposed taps
                 g = rowcol_scale(dy, row_mask=mask) if mask is not None else dy
                 if fused:
-                    dx = ops.conv_gemm(g, wd, None, _dgrad=True)
+                    dx = ops.conv_gemm(g, wd, None, _dgrad=True, _a_scale=gs)
                 else:
                     dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None, _split_fmt=gfmt)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -202,12 +206,19 @@ class Linear(Function):
             packed = _zeros(N, k * Cin, device=dy.device)
             px, _, _, ldx = _rows(x)
             if ops.split_backward():
-                # split-precision (bf16) products like the bf16x3 mode's forward GEMMs; the bias gradient (exact f32 column sums) in the same pass
+                # split-precision products like the forward GEMMs of the mode (bf16 planes; f16x3 mode: f16 planes, the gradient at
+                # its own power-of-two factor); the bias gradient (exact f32 column sums) in the same pass
                 if want_db:
                     db = _zeros(N, device=dy.device)
                 part = _partials(dy.device)
+                if ops.backward_fmt() == PAIR_F16:
+                    if not (ctx.needs_input_grad[0] and gs is not None):
+                        gs = ops.grad_scale(dy)
+                else:
+                    gs = None
                 check(lib.vrd_gemm_wgrad_x3(pg, ldg, px, ldx, _mask_ptr(mask, rows), rows, N, Cin, k, T, packed.data_ptr(),
-                                            db.data_ptr() if want_db else None, part.data_ptr(), part.numel(), _stream()),
+                                            db.data_ptr() if want_db else None, part.data_ptr(), part.numel(),
+                                            gs.data_ptr() if gs is not None else None, _stream()),
                       "vrd_gemm_wgrad_x3")
                 want_db = False
             else:            # exact f32 products

@@ -169,22 +169,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ G,
 // LDS as above.  Used in the bf16x3 mode only (vrd_gemm_wgrad_x3); gradients then carry ~2^-17 relative product error like
 // the forward pass, the f32 mode keeps exact products.
 // ------------------------------------------------------------------------------------------------------------------
+// F16 (the f16x3 mode's backward): both operands as f16 planes of power-of-two multiples -- the gradient rows times gscale[0]
+// (vrd_absmax_scale: max |g| lands in [2^13, 2^14)), the activation rows times 2^VRD_F16_ACT_EXP as in the forward pass (they went
+// through a forward GEMM's range check) -- and the accumulators times gscale[1] * 2^-VRD_F16_ACT_EXP on the way out: ~22-bit
+// products at the cost of the bf16 split's ~17.
 using bf16x8 = vrd::bf16x8_t;
-struct WFrag { bf16x8 h, l; };
-__device__ __forceinline__ WFrag wsplit8(const float (&v)[8]) {
-    WFrag f;
+template <bool F16>
+struct WFragT { typename vrd::SplitFmt<F16>::x8 h, l; };
+template <bool F16>
+__device__ __forceinline__ WFragT<F16> wsplit8(const float (&v)[8], float mul) {
+    typedef typename vrd::SplitFmt<F16>::elem E;
+    WFragT<F16> f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)v[i];
+        const float y = F16 ? v[i] * mul : v[i];
+        const E h = (E)y;
         f.h[i] = h;
-        f.l[i] = (__bf16)(v[i] - (float)h);
+        f.l[i] = (E)(y - (float)h);
     }
     return f;
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
                                                        int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M, int N,
-                                                       int Cin, int taps, int T, int tiles_k, int chunk, float* __restrict__ dW) {
+                                                       int Cin, int taps, int T, int tiles_k, int chunk, float* __restrict__ dW,
+                                                       const float* __restrict__ gscale) {
+    const float gmul = F16 ? vrd::uniform_load(gscale) : 1.f;
+    const float unscale = F16 ? vrd::uniform_load(gscale + 1) * vrd::F16_ACT_INV : 1.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int K = Cin * taps;
     const int tile = blockIdx.x;
@@ -242,16 +254,17 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
         }
     };
     auto mac = [&](const float (&a)[2][8], const float (&b)[2][8]) {
-        const WFrag fa0 = wsplit8(a[0]), fa1 = wsplit8(a[1]), fb0 = wsplit8(b[0]), fb1 = wsplit8(b[1]);
+        const WFragT<F16> fa0 = wsplit8<F16>(a[0], gmul), fa1 = wsplit8<F16>(a[1], gmul);
+        const WFragT<F16> fb0 = wsplit8<F16>(b[0], vrd::F16_ACT_SCALE), fb1 = wsplit8<F16>(b[1], vrd::F16_ACT_SCALE);
 #pragma unroll
         for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
             for (int hj = 0; hj < 2; ++hj) {
-                const WFrag& fa = hn ? fa1 : fa0;
-                const WFrag& fb = hj ? fb1 : fb0;
-                acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.l, fb.h, acc[hn][hj], 0, 0, 0);
-                acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.l, acc[hn][hj], 0, 0, 0);
-                acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.h, fb.h, acc[hn][hj], 0, 0, 0);
+                const WFragT<F16>& fa = hn ? fa1 : fa0;
+                const WFragT<F16>& fb = hj ? fb1 : fb0;
+                acc[hn][hj] = vrd::mfma32(fa.l, fb.h, acc[hn][hj]);
+                acc[hn][hj] = vrd::mfma32(fa.h, fb.l, acc[hn][hj]);
+                acc[hn][hj] = vrd::mfma32(fa.h, fb.h, acc[hn][hj]);
             }
     };
     float a0[2][8], b0[2][8], a1[2][8], b1[2][8];
@@ -285,8 +298,8 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const float* __restrict__
         for (int e = 0; e < 16; ++e) {
             const int nn = n0 + 32 * (q >> 1) + (e & 3) + 8 * (e >> 2) + 4 * lh;
             if (nn < N) {
-                if (single) dW[(int64_t)nn * K + j] += v[e];
-                else atomicAdd(dW + (int64_t)nn * K + j, v[e]);
+                if (single) dW[(int64_t)nn * K + j] += v[e] * unscale;
+                else atomicAdd(dW + (int64_t)nn * K + j, v[e] * unscale);
             }
         }
     }
@@ -323,11 +336,16 @@ typedef __attribute__((ext_vector_type(4))) short wl_s16x4;
 typedef __attribute__((address_space(3))) wl_s16x4* wl_lds_s16x4_ptr;
 typedef __attribute__((ext_vector_type(8))) short wl_s16x8;
 
-template <int BIG, bool VEC, int TAPS>
+template <int BIG, bool VEC, int TAPS, bool F16>
 __global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_kernel(
     const float* __restrict__ G, int64_t ldg, const float* __restrict__ X, int64_t ldx, const uint8_t* __restrict__ row_mask, int64_t M,
-    int N, int Cin, int T, int tiles_k, int chunk, float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ partial) {
+    int N, int Cin, int T, int tiles_k, int chunk, float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ partial,
+    const float* __restrict__ gscale) {
     using Geo = WlGeo<BIG>;
+    typedef typename vrd::SplitFmt<F16>::x4 e16x4;
+    typedef typename vrd::SplitFmt<F16>::elem e16;
+    const float gmul = F16 ? vrd::uniform_load(gscale) : 1.f;                                        // (see wgrad_x3_kernel)
+    const float unscale = F16 ? vrd::uniform_load(gscale + 1) * vrd::F16_ACT_INV : 1.f;
     constexpr int TILE = Geo::TILE, ROWB = Geo::ROWB, PLANE = Geo::PLANE, STAGE = Geo::STAGE, SJ = Geo::SJ, NJ = SJ / 32;
     extern __shared__ __attribute__((aligned(16))) char lds[];          // 2 * STAGE
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -416,12 +434,13 @@ __global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_ke
         }
         frow += WL_ROWS;
     };
-    auto put = [&](char* plane_hi, int row, const float4& v) {
-        const vrd::bf16x4_t h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        const vrd::bf16x4_t l = {(__bf16)(v.x - (float)h[0]), (__bf16)(v.y - (float)h[1]), (__bf16)(v.z - (float)h[2]), (__bf16)(v.w - (float)h[3])};
+    auto put = [&](char* plane_hi, int row, float4 v, float mul) {
+        if (F16) v.x *= mul, v.y *= mul, v.z *= mul, v.w *= mul;
+        const e16x4 h = {(e16)v.x, (e16)v.y, (e16)v.z, (e16)v.w};
+        const e16x4 l = {(e16)(v.x - (float)h[0]), (e16)(v.y - (float)h[1]), (e16)(v.z - (float)h[2]), (e16)(v.w - (float)h[3])};
         const int off = row * ROWB + (((cg >> 1) ^ ((row & 3) << 2)) * 16) + (cg & 1) * 8;
-        *reinterpret_cast<vrd::bf16x4_t*>(plane_hi + off) = h;
-        *reinterpret_cast<vrd::bf16x4_t*>(plane_hi + PLANE + off) = l;
+        *reinterpret_cast<e16x4*>(plane_hi + off) = h;
+        *reinterpret_cast<e16x4*>(plane_hi + PLANE + off) = l;
     };
     // (a row contributes G[r, n] X[r', j]: zeroing G's row takes care of masked rows and of rows past the chunk -- their X values
     // are real rows of the input --, and columns of X at or beyond K only reach entries of dW that are never stored; what X
@@ -444,8 +463,8 @@ __global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_ke
                 x.z = x_ok[VEC ? 0 : 2] & (sq >> (VEC ? 0 : 2)) ? x.z : 0.f;
                 x.w = x_ok[VEC ? 0 : 3] & (sq >> (VEC ? 0 : 3)) ? x.w : 0.f;
             }
-            put(st, lr + 8 * i, g);
-            put(st + 2 * PLANE, lr + 8 * i, x);
+            put(st, lr + 8 * i, g, gmul);
+            put(st + 2 * PLANE, lr + 8 * i, x, vrd::F16_ACT_SCALE);
             if (do_bias) bsum.x += g.x, bsum.y += g.y, bsum.z += g.z, bsum.w += g.w;
         }
     };
@@ -462,7 +481,7 @@ __global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_ke
             for (int e = 0; e < 16; ++e) acc[hn][hj][e] = 0.f;
     // fragment (k16 step s, 32 columns from colbase) of the plane pair at `pl`: lane (column lane & 31, half) <- rows 16 s + 8 half .. + 7
     auto frag = [&](const char* pl, int s, int colbase) {
-        WFrag f;
+        WFragT<F16> f;
         wl_s16x8 rh, rl;
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
@@ -477,14 +496,14 @@ __global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_ke
                 rl[4 * part + q] = tl[q];
             }
         }
-        f.h = __builtin_bit_cast(bf16x8, rh);
-        f.l = __builtin_bit_cast(bf16x8, rl);
+        f.h = __builtin_bit_cast(typename vrd::SplitFmt<F16>::x8, rh);
+        f.l = __builtin_bit_cast(typename vrd::SplitFmt<F16>::x8, rl);
         return f;
     };
     auto compute = [&](const char* st) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            WFrag fa[2], fb[NJ];
+            WFragT<F16> fa[2], fb[NJ];
 #pragma unroll
             for (int hn = 0; hn < 2; ++hn) fa[hn] = frag(st, s, 64 * wn + 32 * hn);
 #pragma unroll
@@ -493,9 +512,9 @@ __global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_ke
             for (int hn = 0; hn < 2; ++hn)
 #pragma unroll
                 for (int hj = 0; hj < NJ; ++hj) {
-                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hn].l, fb[hj].h, acc[hn][hj], 0, 0, 0);
-                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hn].h, fb[hj].l, acc[hn][hj], 0, 0, 0);
-                    acc[hn][hj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[hn].h, fb[hj].h, acc[hn][hj], 0, 0, 0);
+                    acc[hn][hj] = vrd::mfma32(fa[hn].l, fb[hj].h, acc[hn][hj]);
+                    acc[hn][hj] = vrd::mfma32(fa[hn].h, fb[hj].l, acc[hn][hj]);
+                    acc[hn][hj] = vrd::mfma32(fa[hn].h, fb[hj].h, acc[hn][hj]);
                 }
         }
     };
@@ -581,9 +600,9 @@ __global__ __launch_bounds__(WlGeo<BIG>::NTHR, BIG ? 1 : 2) void wgrad_x3_lds_ke
         for (int e = 0; e < 16; ++e) {
             const int nn = n0 + 64 * wn + 32 * hn + (e & 3) + 8 * (e >> 2) + 4 * lh;
             if (nn < N) {
-                if (single) dst[(int64_t)nn * K + j] += acc[hn][hj][e];
-                else if (partial) dst[(int64_t)nn * K + j] = acc[hn][hj][e];
-                else atomicAdd(dst + (int64_t)nn * K + j, acc[hn][hj][e]);
+                if (single) dst[(int64_t)nn * K + j] += acc[hn][hj][e] * unscale;
+                else if (partial) dst[(int64_t)nn * K + j] = acc[hn][hj][e] * unscale;
+                else atomicAdd(dst + (int64_t)nn * K + j, acc[hn][hj][e] * unscale);
             }
         }
     }
@@ -628,7 +647,8 @@ constexpr int WL_BIG_ROWS = 256;     // rows per block from which the 256 x 256 
 // 2 (BIG: 1) blocks per CU
 template <int BIG>
 int launch_wgrad_lds(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
-                     int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, bool vec, int n_cu, hipStream_t s) {
+                     int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, bool vec, int n_cu, hipStream_t s,
+                     const float* gscale) {
     using Geo = WlGeo<BIG>;
     const int K = Cin * taps;
     const int tiles_n = (N + Geo::TILE - 1) / Geo::TILE, tiles_k = (K + Geo::TILE - 1) / Geo::TILE;
@@ -645,17 +665,22 @@ int launch_wgrad_lds(const float* G, int64_t ldg, const float* X, int64_t ldx, c
     const int64_t NK = (int64_t)N * K;
     float* partial = chunks > 1 && scratch && aligned16(scratch) && aligned16(dW) && scratch_floats >= chunks * NK ? scratch : nullptr;
     constexpr size_t lds = 2 * Geo::STAGE;
-#define VRD_WGRAD_LAUNCH(VEC_, TAPS_)                                                                                              \
+#define VRD_WGRAD_LAUNCH(VEC_, TAPS_, F16_)                                                                                        \
     do {                                                                                                                           \
-        auto kern = wgrad_x3_lds_kernel<BIG, VEC_, TAPS_>;                                                                         \
+        auto kern = wgrad_x3_lds_kernel<BIG, VEC_, TAPS_, F16_>;                                                                   \
         if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds, "vrd_gemm_wgrad_x3")) return rc;                   \
         hipLaunchKernelGGL(kern, grid, dim3(Geo::NTHR), lds, s, G, ldg, X, ldx, row_mask, M, N, Cin, T, tiles_k, (int)chunk, dW,   \
-                           dbias, partial);                                                                                        \
+                           dbias, partial, gscale);                                                                                \
     } while (0)
-    if (vec && taps == 1) VRD_WGRAD_LAUNCH(true, 1);
-    else if (vec) VRD_WGRAD_LAUNCH(true, 3);
-    else if (taps == 1) VRD_WGRAD_LAUNCH(false, 1);
-    else VRD_WGRAD_LAUNCH(false, 3);
+    if (gscale) {
+        if (vec && taps == 1) VRD_WGRAD_LAUNCH(true, 1, true);
+        else if (vec) VRD_WGRAD_LAUNCH(true, 3, true);
+        else if (taps == 1) VRD_WGRAD_LAUNCH(false, 1, true);
+        else VRD_WGRAD_LAUNCH(false, 3, true);
+    } else if (vec && taps == 1) VRD_WGRAD_LAUNCH(true, 1, false);
+    else if (vec) VRD_WGRAD_LAUNCH(true, 3, false);
+    else if (taps == 1) VRD_WGRAD_LAUNCH(false, 1, false);
+    else VRD_WGRAD_LAUNCH(false, 3, false);
 #undef VRD_WGRAD_LAUNCH
     VRD_LAUNCH_CHECK();
     if (partial) {
@@ -1648,7 +1673,8 @@ int vrd_gemm_wgrad(const float* G, int64_t ldg, const float* X, int64_t ldx, con
 }
 
 int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* row_mask, int64_t M, int N, int Cin,
-                      int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, void* stream) {
+                      int taps, int T, float* dW, float* dbias, float* scratch, int64_t scratch_floats, const float* g_scale,
+                      void* stream) {
     VRD_CHECK_ARG(G && X && dW, "vrd_gemm_wgrad_x3: null pointer");
     VRD_CHECK_ARG(M > 0 && N > 0 && Cin > 0 && (taps == 1 || taps == 3), "vrd_gemm_wgrad_x3: bad sizes M=%lld N=%d Cin=%d taps=%d", (long long)M, N, Cin, taps);
     VRD_CHECK_ARG(ldg >= N && ldx >= Cin, "vrd_gemm_wgrad_x3: leading dimension too small");
@@ -1667,8 +1693,8 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
         const int64_t big_tiles = (int64_t)((N + 255) / 256) * ((K + 255) / 256);
         const bool big = big_mode != 0 && vec && N >= 256 && K >= 256 &&
                          (big_mode == 2 || M * big_tiles >= (int64_t)WL_BIG_ROWS * n_cu);
-        return big ? launch_wgrad_lds<1>(G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, dW, dbias, scratch, scratch_floats, vec, n_cu, s)
-                   : launch_wgrad_lds<0>(G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, dW, dbias, scratch, scratch_floats, vec, n_cu, s);
+        return big ? launch_wgrad_lds<1>(G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, dW, dbias, scratch, scratch_floats, vec, n_cu, s, g_scale)
+                   : launch_wgrad_lds<0>(G, ldg, X, ldx, row_mask, M, N, Cin, taps, T, dW, dbias, scratch, scratch_floats, vec, n_cu, s, g_scale);
     }
     if (dbias) {                                 // the wave kernel has no bias path: a column-sum launch of its own
         const int col_blocks = (N + 63) / 64;
@@ -1688,8 +1714,12 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
     if (chunk > 1024) chunk = 1024;
     const int64_t chunks = (M + 4 * chunk - 1) / (4 * chunk);
     VRD_CHECK_ARG(chunks <= 65535, "vrd_gemm_wgrad_x3: too many rows (%lld)", (long long)M);
-    hipLaunchKernelGGL(wgrad_x3_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin, taps, T,
-                       tiles_k, (int)chunk, dW);
+    if (g_scale)
+        hipLaunchKernelGGL(wgrad_x3_kernel<true>, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin,
+                           taps, T, tiles_k, (int)chunk, dW, g_scale);
+    else
+        hipLaunchKernelGGL(wgrad_x3_kernel<false>, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, s, G, ldg, X, ldx, row_mask, M, N, Cin,
+                           taps, T, tiles_k, (int)chunk, dW, (const float*)nullptr);
     VRD_LAUNCH_CHECK();
     return 0;
 }

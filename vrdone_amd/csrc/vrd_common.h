@@ -192,6 +192,23 @@ __device__ __forceinline__ void split_n(const float (&x)[N], V& h, V& l, RangeTr
     }
 }
 
+// the same with a run-time factor in place of 2^VRD_F16_ACT_EXP (F16 only; bf16 planes take the values as they are)
+template <bool F16, int N, typename V>
+__device__ __forceinline__ void split_n_scaled(const float (&x)[N], float mul, V& h, V& l, RangeTrack* rt = nullptr) {
+    typedef typename SplitFmt<F16>::elem E;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float y = F16 ? x[j] * mul : x[j];
+        h[j] = (E)y;
+        l[j] = (E)(y - (float)h[j]);
+    }
+    if (F16 && rt) {
+        if (N == 1) rt->see(x[0] * mul);
+#pragma unroll
+        for (int j = 0; j + 1 < N; j += 2) rt->see(x[j] * mul, x[j + 1] * mul);
+    }
+}
+
 // 16-bit index of the hi half of channel c inside a pair row (the lo half is 32 further)
 __device__ __forceinline__ int pair_index(int c) { return ((c >> 5) << 6) + (c & 31); }
 

@@ -253,6 +253,8 @@ int validate_gemm_args(const vrd_gemm_args* a) {
     VRD_CHECK_ARG(a->split_fmt == 0 || a->split_fmt == VRD_PAIR_BF16 || a->split_fmt == VRD_PAIR_F16, "vrd_gemm: bad split_fmt %d", a->split_fmt);
     VRD_CHECK_ARG(a->split_fmt != VRD_PAIR_F16 || !a->W_split || a->w_scale, "vrd_gemm: a VRD_PAIR_F16 W_split needs w_scale");
     VRD_CHECK_ARG(a->c_pair == VRD_PAIR_NONE || a->c_pair == VRD_PAIR_BF16 || a->c_pair == VRD_PAIR_F16, "vrd_gemm: bad c_pair %d", a->c_pair);
+    VRD_CHECK_ARG(!a->a_scale || (a->split_fmt == VRD_PAIR_F16 && a->a_pair_width == 0),
+                  "vrd_gemm: a_scale goes with f32-row A in the VRD_PAIR_F16 format");
     VRD_CHECK_ARG(!a->c_pair || !a->W_split || a->c_pair == (a->split_fmt ? a->split_fmt : (int)VRD_PAIR_BF16),
                   "vrd_gemm: pair output (format %d) of a split-precision GEMM must be in its operand format (%d)", a->c_pair, a->split_fmt);
     VRD_CHECK_ARG(!a->row_blocks || (a->row_blocks_active && a->M % 32 == 0 && a->row_block_seg_len >= 8 &&
@@ -297,6 +299,7 @@ extern "C" int vrd_gemm(const vrd_gemm_args* a, void* stream) {
     vrd_gemm_args f = *a;
     f.split_fmt = 0;
     f.w_scale = nullptr;
+    f.a_scale = nullptr;
     VRD_CHECK_ARG(!f.c_pair || f.c_pair == VRD_PAIR_BF16 || f.c_pair == VRD_PAIR_F16, "vrd_gemm: bad c_pair");
     int rc;
     if (bk == 32) rc = staged ? launch_bk<32, true>(f, vec, tiles_m, tiles_n, s) : launch_bk<32, false>(f, vec, tiles_m, tiles_n, s);

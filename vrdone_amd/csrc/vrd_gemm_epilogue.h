@@ -25,7 +25,10 @@ struct EpiCols {
 };
 // the factor on the accumulators of a split-precision GEMM (wave-uniform; a scalar load)
 __device__ __forceinline__ float acc_alpha(const vrd_gemm_args& p) {
-    return (p.split_fmt == VRD_PAIR_F16 && p.w_scale) ? uniform_load(p.w_scale) : 1.0f;
+    if (!(p.split_fmt == VRD_PAIR_F16 && p.w_scale)) return 1.0f;
+    const float alpha = uniform_load(p.w_scale);          // 2^-(e_w + VRD_F16_ACT_EXP)
+    // (rows split with the caller's factor 2^e instead of 2^VRD_F16_ACT_EXP: a_scale[1] = 2^-e)
+    return (p.a_scale && p.a_pair_width == 0) ? alpha * F16_ACT_SCALE * uniform_load(p.a_scale + 1) : alpha;
 }
 __device__ __forceinline__ EpiCols load_epi_cols(const vrd_gemm_args& p, int nw, int lane) {
     EpiCols c;

@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles
     extern __shared__ __attribute__((aligned(16))) float smem[];
     e16* const lds = reinterpret_cast<e16*>(smem);      // buffer b: lds + b*4*TILE; tiles a_hi, a_lo, w_hi, w_lo
     vrd::RangeTrack rt_in;                              // f32 activation rows split while staged (vrd_common.h)
+    // the factor the f32 rows are multiplied by before the f16 split: 2^VRD_F16_ACT_EXP, or the caller's (vrd_gemm_args.a_scale:
+    // operands without a fixed range, i.e. gradients)
+    const float amul = (F16 && !APAIR && p.a_scale) ? vrd::uniform_load(p.a_scale) : vrd::F16_ACT_SCALE;
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles
             const int off = (f >> 3) * XP + (f & 7) * 4;
             const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
             e16x4 h, l;
-            vrd::split_n<F16>(x, h, l, &rt_in);
+            vrd::split_n_scaled<F16>(x, amul, h, l, &rt_in);
             *reinterpret_cast<e16x4*>(a_hi + off) = h;
             *reinterpret_cast<e16x4*>(a_lo + off) = l;
         }

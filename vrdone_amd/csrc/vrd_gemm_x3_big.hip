@@ -373,7 +373,9 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
         if (stored_all) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER + 32) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
     }
+    LAB_STAMP(6);
     __builtin_amdgcn_s_barrier();
+    LAB_STAMP(7);
     // The two waves of a SIMD share its matrix pipe, and between equals the older one (waves 0-3) wins every arbitration: it
     // runs its 48 MFMAs of a K step nearly alone, waits ~1,100 cycles at the step's barrier, and the younger one then issues its
     // requests with nobody to cover their stalls (profiles/r05_lab_gemm_tile_stamps.txt).  prio 1: the younger half runs at
@@ -415,6 +417,16 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
             const int mi = g & 3;
             if (prio == 2 && g == 0) __builtin_amdgcn_s_setprio(1);
             if (prio == 2 && g == 4) __builtin_amdgcn_s_setprio(0);
+            if (prio == 3) {                 // four levels, a quarter of the step each
+                if (g == 0) __builtin_amdgcn_s_setprio(3);
+                if (g == 2) __builtin_amdgcn_s_setprio(2);
+                if (g == 4) __builtin_amdgcn_s_setprio(1);
+                if (g == 6) __builtin_amdgcn_s_setprio(0);
+            }
+            if (prio == 4) {                 // two levels, the younger half holds the high one longer
+                if (g == 0) __builtin_amdgcn_s_setprio(1);
+                if (g == (wave >= 4 ? 5 : 3)) __builtin_amdgcn_s_setprio(0);
+            }
             // ---- reads for what comes next
             if (g < 7) a_nxt = M16 ? load_a(sa, 0, g + 1) : load_a(sa, (g + 1) >> 2, (g + 1) & 3);
             if (!M16 && g == 2) w_nxt = load_w(sw, 1);
@@ -604,7 +616,7 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch&
     ka.p = a, ka.tiles_m = tiles_m, ka.tiles_n = tiles_n, ka.bb = bb, ka.stagger = (PERSIST || nwg < 512) ? 0 : stagger;
     ka.rflag = a.c_pair == VRD_PAIR_F16 ? range_flag() : nullptr;
     ka.count = count;
-    static const int prio_env = [] { const char* e = getenv("VRD_BIG_PRIO"); return e ? atoi(e) : 0; }();
+    static const int prio_env = [] { const char* e = getenv("VRD_BIG_PRIO"); return e ? atoi(e) : 3; }();
     ka.prio = prio_env;
     if (PERSIST) hipLaunchKernelGGL(kern, dim3(nwg * count < n_cu ? nwg * count : n_cu), dim3(512), BIG_LDS, s, ka);
     else hipLaunchKernelGGL(kern, dim3(nwg, count), dim3(512), BIG_LDS, s, ka);

@@ -270,6 +270,62 @@ extern "C" int vrd_split_weights(const vrd_split_job* jobs, int n_jobs, const in
     return 0;
 }
 
+namespace {
+// max |x| over a matrix -> {2^e, 2^-e}, e = 140 - (biased exponent of the maximum): one launch, the last workgroup to finish
+// (a ticket in scale[3]) turns the running maximum (bits in scale[2]) into the two factors and zeroes both words again
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols4,
+                                                           float* __restrict__ scale) {
+    unsigned m = 0u;
+    const int64_t n = rows * cols4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx / cols4;
+        const int c = (int)(idx - r * cols4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+        const unsigned cc = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+        const unsigned ab = a > b ? a : b, cd = cc > d ? cc : d, q = ab > cd ? ab : cd;
+        m = q > m ? q : m;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    unsigned* const words = reinterpret_cast<unsigned*>(scale);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(words + 2, m);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = atomicAdd(words + 3, 1u);
+        if (ticket == gridDim.x - 1) {
+            __threadfence();
+            const unsigned mx = atomicMax(words + 2, 0u);                  // (an atomic read of the final maximum)
+            const int E = (int)((mx >> 23) & 0xffu);
+            int e = (E == 0 || E == 255) ? 0 : 140 - E;
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+            scale[0] = pow2i(e);
+            scale[1] = pow2i(-e);
+            __threadfence();
+            atomicExch(words + 2, 0u);
+            atomicExch(words + 3, 0u);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vrd_absmax_scale(const float* x, int64_t ldx, int64_t rows, int cols, float* scale, void* stream) {
+    VRD_CHECK_ARG(x && scale && rows > 0 && cols > 0 && ldx >= cols, "vrd_absmax_scale: bad arguments");
+    VRD_CHECK_ARG(cols % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0,
+                  "vrd_absmax_scale: rows must be float4-aligned (cols %d, ldx %lld)", cols, (long long)ldx);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t n = rows * (cols / 4);
+    const int64_t want = (n + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 2048 ? want : 2048);
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, rows, cols / 4, scale);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int vrd_split_weight(const float* src, int R, int Q, int taps, int64_t sr, int64_t st, int64_t sq, uint16_t* out, int fmt,
                                 float* scale, void* stream) {
     VRD_CHECK_ARG(src && out, "vrd_split_weight: null pointer");

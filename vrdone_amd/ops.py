@@ -104,9 +104,40 @@ def pair_fmt():
 
 
 def split_backward():
-    """True when the backward GEMMs (input and weight gradients) run as split-precision products.  Always the bf16 split --
-    gradients have no fixed scale, bf16 has f32's range -- so the f16x3 mode's backward is the bf16x3 mode's."""
+    """True when the backward GEMMs (input and weight gradients) run as split-precision products: bf16 planes in the bf16x3 mode;
+    in the f16x3 mode f16 planes of the gradient times a per-tensor power of two (backward_fmt, grad_scale) -- reference-grade
+    products like the forward pass's (the reference differentiates in float32, train.py:182-186)."""
     return _precision in ("bf16x3", "f16x3")
+
+
+_F16_BACKWARD = os.environ.get("VRDONE_F16_BACKWARD", "1") != "0"       # A/B switch: 0 = the f16x3 mode's backward on bf16 planes
+
+
+def backward_fmt():
+    """element format of the backward GEMMs' split operands"""
+    return _hip.PAIR_F16 if (_precision == "f16x3" and _F16_BACKWARD) else _hip.PAIR_BF16
+
+
+_grad_scales = {}
+
+
+def grad_scale(g):
+    """{2^e, 2^-e} (device floats [0], [1] of a 4-float buffer) with max |g| 2^e in [2^13, 2^14) for the (rows, C) gradient `g`
+    (vrd_absmax_scale, one launch), or None when g's rows are not float4-aligned (the caller then keeps the bf16 planes).  The
+    buffer is one per (device, stream): it is only read by the launches that directly follow on the same stream; launches
+    recorded into a graph get one of their own per call (from the graph's pool)."""
+    pg, rows, cols, ldg = _rows(g)
+    if cols % 4 or ldg % 4 or pg % 16:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        buf = torch.zeros(4, device=g.device, dtype=torch.float32)
+    else:
+        key = (g.device, torch.cuda.current_stream(g.device).cuda_stream)
+        buf = _grad_scales.get(key)
+        if buf is None:
+            buf = _grad_scales[key] = torch.zeros(4, device=g.device, dtype=torch.float32)
+    _hip.check(lib.vrd_absmax_scale(pg, ldg, rows, cols, buf.data_ptr(), _stream()), "vrd_absmax_scale")
+    return buf
 
 
 def _fmt(pair):
@@ -320,9 +351,10 @@ def split_conv_weight(w, fmt=None):
 
 def split_conv_weight_dgrad(w):
     """The same operand for the input-gradient GEMM of the conv: the (Cin, k*N) matrix [c][tap*N + n] = w[n][c][k-1-tap]
-    (transposed, taps flipped), straight from the parameter.  bf16x3 mode only (gradients have no fixed scale)."""
+    (transposed, taps flipped), straight from the parameter, in the backward GEMMs' element format (backward_fmt)."""
     N, Cin, k = w.shape
-    return _cached(w, "_vrd_split_t", lambda: _split_weight(w.detach(), k - 1, Cin, N, k, k, -1, Cin * k, _hip.PAIR_BF16))
+    fmt = backward_fmt()
+    return _cached(w, _split_slot("_vrd_split_t", fmt), lambda: _split_weight(w.detach(), k - 1, Cin, N, k, k, -1, Cin * k, fmt))
 
 
 # ---- all split operands of a training step in one launch
@@ -366,7 +398,7 @@ def presplit_weights(weights, plans):
     fmt = pair_fmt()
     # (the plan is keyed on the weights' addresses, shapes and the element format: another model whose parameters land on
     # the same addresses with other shapes, or a change of mode, builds its own)
-    key = (fmt,) + tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+    key = (fmt, backward_fmt()) + tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
     for old in [k for k in plans if k != key]:        # operands of another mode / of parameters that were replaced
         del plans[old]
     plan = plans.get(key)
@@ -381,10 +413,10 @@ def presplit_weights(weights, plans):
             forms = []
             if (Cin * k) % 32 == 0:
                 forms.append((_split_slot("_vrd_split"), 0, N, Cin, k, Cin * k, 1, k))           # = split_conv_weight
-            if (N * k) % 32 == 0:       # = split_conv_weight_dgrad: bf16 in either mode (split_backward)
-                forms.append(("_vrd_split_t", k - 1, Cin, N, k, k, -1, Cin * k))
+            if (N * k) % 32 == 0:       # = split_conv_weight_dgrad: the backward GEMMs' format
+                forms.append((_split_slot("_vrd_split_t", backward_fmt()), k - 1, Cin, N, k, k, -1, Cin * k))
             for slot, offset, R, Q, taps, sr, st, sq in forms:
-                jf = _hip.PAIR_BF16 if slot == "_vrd_split_t" else fmt
+                jf = backward_fmt() if slot.startswith("_vrd_split_t") else fmt
                 jf16 = jf == _hip.PAIR_F16
                 out = torch.empty(R, taps * Q // 32, 2, 32, device=w.device, dtype=torch.float16 if jf16 else torch.bfloat16)
                 scale = torch.empty(4, device=w.device, dtype=torch.float32) if jf16 else None
@@ -577,7 +609,8 @@ def row_blocks(mask):
 
 
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
-              res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None, _dgrad=False, _split_fmt=None):
+              res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None, _dgrad=False, _split_fmt=None,
+              _a_scale=None):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
     vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
     out_pair: write the result as pair rows of width N (returns a Pair).
@@ -585,7 +618,9 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     row_mask, which is then the default; without row_mask those rows hold bias-only filler, so pass it only where
     no valid row ever reads a padded one: projections feeding masked attention, an MLP's hidden layer).
     row_scale (rows,): per-row factor on the branch term (stochastic depth, blocks.py:1107-1120); autograd path only.
-    _split_fmt: element format of the split products instead of the mode's (the backward GEMMs pass PAIR_BF16: split_backward).
+    _split_fmt: element format of the split products instead of the mode's (the unfused backward GEMMs pass PAIR_BF16).
+    _dgrad / _a_scale: the conv's input-gradient GEMM on the parameter's transposed operand; x is then a gradient, and in the
+    f16 format its rows are split at the power-of-two factor of grad_scale(x) (vrd_gemm_args.a_scale).
     Under autograd (`recording`) the op runs as autograd.conv_gemm and returns a fresh tensor (`out` is ignored)."""
     # row_scale (stochastic depth, sampled whenever the model trains) lives in the autograd form's epilogue: it goes there even
     # when nothing of this call needs a gradient (a frozen sub-module under requires_grad_(False), reference blocks.py:1107-1120
@@ -616,6 +651,9 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
         wt = split_conv_weight_dgrad(weight)
         a.W = wt.data_ptr()
         wt.set_args(a)
+        if wt.fmt == _hip.PAIR_F16:      # x is a gradient: its f16 planes need its own power-of-two factor
+            assert _a_scale is not None
+            a.a_scale = _a_scale.data_ptr()
     else:
         a.W = _param_ptr(packed_conv_weight(weight), x, "conv weight")
     a.A, a.lda, a.bias = pa, lda, _param_ptr(bias, x, "conv bias")
@@ -627,6 +665,8 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     if a_width:
         assert pair_fmt() and x_fmt == pair_fmt() and Cin % 32 == 0, "pair input needs the split-precision mode it was made in and Cin % 32 == 0"
     w_fmt = pair_fmt() if _split_fmt is None else _split_fmt
+    if _dgrad:
+        w_fmt = a.split_fmt
     assert not (a_width and w_fmt != x_fmt) and not (out_pair and w_fmt != pair_fmt())
     if not _dgrad and w_fmt and (Cin * k) % 32 == 0:
         split_conv_weight(weight, w_fmt).set_args(a)
