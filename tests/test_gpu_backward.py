@@ -517,5 +517,8 @@ def test_split_weight_operands_are_the_tensor_expression_bit_for_bit(k):
             assert 2 ** 14 <= float(got.t[:, :, 0].float().abs().max()) <= 2 ** 15
         z = ops.split_conv_weight(torch.zeros(32, 32, 1, device=DEV))          # an all-zero weight: exponent 0
         assert z.scale.cpu().tolist()[:2] == [2.0 ** -_hip.F16_ACT_EXP, 1.0] and not bool(z.t.any())
-        # the input-gradient operand stays bf16 in this mode too (ops.split_backward)
-        assert ops.split_conv_weight_dgrad(w).fmt == _hip.PAIR_BF16
+        # the input-gradient operand is in the mode's format too (ops.backward_fmt): f16 planes of the transposed, tap-flipped
+        # weight at its own power of two
+        gd = ops.split_conv_weight_dgrad(w)
+        want_t, ew_t = expression(w.flip(2).permute(1, 0, 2).contiguous(), f16=True)
+        assert gd.fmt == _hip.PAIR_F16 and torch.equal(gd.t, want_t) and gd.scale.cpu().tolist()[1] == 2.0 ** ew_t

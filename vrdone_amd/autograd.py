@@ -165,6 +165,9 @@ class Linear(Function):
         y = ops.conv_gemm(x, weight, bias, row_mask=row_mask)
         ctx.save_for_backward(x, weight)
         ctx.row_mask, ctx.has_bias = row_mask, bias is not None
+        # the backward runs in the arithmetic of ITS forward, whatever the mode is by then (MaskVRD.forward_training repeats a
+        # step whose activations leave the f16 range in the f32 mode: the graph it returns is differentiated outside that block)
+        ctx.split_bwd, ctx.bfmt = ops.split_backward(), ops.backward_fmt()
         return y
 
     @staticmethod
@@ -183,35 +186,35 @@ class Linear(Function):
             # (the parameter object itself while autograd is not recording -- the usual case in a backward pass: its operand
             # caches, which ops.presplit_weights fills for the whole step, hang on the object; a detached view has none)
             wd = weight if not torch.is_grad_enabled() else weight.detach()
-            fused = (ops.split_backward() and (N * k) % 32 == 0 and N % 4 == 0 and dy.stride(-2) % 4 == 0 and
+            fused = (ctx.split_bwd and (N * k) % 32 == 0 and N % 4 == 0 and dy.stride(-2) % 4 == 0 and
                      dy.data_ptr() % 16 == 0 and weight.is_contiguous())
-            gfmt = PAIR_BF16 if ops.split_backward() else None       # (the unfused fallback splits gradients in bf16 in either mode)
+            gfmt = PAIR_BF16 if ctx.split_bwd else None       # (the unfused fallback splits gradients in bf16 in either mode)
             # f16x3 mode: the gradient's power-of-two factor for its f16 planes (one absmax launch, shared with the weight gradient)
-            gs = ops.grad_scale(dy) if (fused and ops.backward_fmt() == PAIR_F16) else None
-            if fused and ops.backward_fmt() == PAIR_F16 and gs is None:
+            gs = ops.grad_scale(dy) if (fused and ctx.bfmt == PAIR_F16) else None
+            if fused and ctx.bfmt == PAIR_F16 and gs is None:
                 fused = False
             if k == 1:       # masking the rows of dy = masking the rows of dx
                 if fused:
-                    dx = ops.conv_gemm(dy, wd, None, row_mask=mask, _dgrad=True, _a_scale=gs)
+                    dx = ops.conv_gemm(dy, wd, None, row_mask=mask, _dgrad=True, _a_scale=gs, _bfmt=ctx.bfmt)
                 else:
                     dx = ops.conv_gemm(dy, weight.detach().permute(1, 0, 2).contiguous(), None, row_mask=mask, _split_fmt=gfmt)
             else:            # dx[r] = sum_tap (dy * mask)[r - (tap - 1)] W[:, :, tap]: a k=3 conv with flipped, transposed taps
                 g = rowcol_scale(dy, row_mask=mask) if mask is not None else dy
                 if fused:
-                    dx = ops.conv_gemm(g, wd, None, _dgrad=True, _a_scale=gs)
+                    dx = ops.conv_gemm(g, wd, None, _dgrad=True, _a_scale=gs, _bfmt=ctx.bfmt)
                 else:
                     dx = ops.conv_gemm(g, weight.detach().flip(2).permute(1, 0, 2).contiguous(), None, _split_fmt=gfmt)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             packed = _zeros(N, k * Cin, device=dy.device)
             px, _, _, ldx = _rows(x)
-            if ops.split_backward():
+            if ctx.split_bwd:
                 # split-precision products like the forward GEMMs of the mode (bf16 planes; f16x3 mode: f16 planes, the gradient at
                 # its own power-of-two factor); the bias gradient (exact f32 column sums) in the same pass
                 if want_db:
                     db = _zeros(N, device=dy.device)
                 part = _partials(dy.device)
-                if ops.backward_fmt() == PAIR_F16:
+                if ctx.bfmt == PAIR_F16:
                     if not (ctx.needs_input_grad[0] and gs is not None):
                         gs = ops.grad_scale(dy)
                 else:
@@ -408,6 +411,7 @@ class Attention(Function):
             out = ops.attention(q, k, v, kv_mask, n_head)
         ctx.save_for_backward(q, k, v, out)
         ctx.kv_mask, ctx.n_head, ctx.lse = kv_mask, n_head, lse
+        ctx.split_bwd = ops.split_backward()          # (as in Linear: the backward follows its forward's mode)
         return out
 
     @staticmethod
@@ -418,7 +422,7 @@ class Attention(Function):
         Tk, H = k.shape[1], ctx.n_head
         hd = Cc // H
         dev = q.device
-        if FUSED_ATTN_BWD and ops.split_backward() and hd == 64 and Tq >= 32 and Tk >= 32:
+        if FUSED_ATTN_BWD and ctx.split_bwd and hd == 64 and Tq >= 32 and Tk >= 32:
             # flash style (vrd_attention_bwd): the scores are recomputed tile by tile in the bf16 split of the other backward
             # GEMMs; no (B, H, Tq, Tk) matrix exists
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)

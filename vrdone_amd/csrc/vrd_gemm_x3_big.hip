@@ -29,9 +29,9 @@ constexpr int TM = 256, TN = 256;
 constexpr int ROWB = 128;                      // bytes of a tile row per K step (32 hi + 32 lo bf16)
 constexpr int A_STAGE = TM * ROWB, W_STAGE = TN * ROWB;
 constexpr int NA_STG = 3, NW_STG = 2;
-constexpr int W_RING = NA_STG * A_STAGE;       // byte offset of the W ring
+__attribute__((unused)) constexpr int W_RING = NA_STG * A_STAGE;       // byte offset of the W ring
 constexpr size_t BIG_LDS = (size_t)NA_STG * A_STAGE + (size_t)NW_STG * W_STAGE;      // 163,840
-constexpr int PER = 4;                         // DMA instructions per wave, operand and K step (8 rows x 128 B each)
+__attribute__((unused)) constexpr int PER = 4;                         // DMA instructions per wave, operand and K step (8 rows x 128 B each)
 // LDS-DMA requests are buffer loads (buffer_load_dwordx4 ... lds): a wave-uniform descriptor per operand and tile, ONE per-lane
 // byte offset per operand that never changes (row inside the piece, swizzled chunk), and a scalar offset for piece, K step and
 // tap -- no vector arithmetic per request (the global_load_lds form needed a 64-bit per-lane pointer each: -4.5 % cycles per
@@ -147,7 +147,11 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     };
     reload();
     const int stagger = PERSIST ? 0 : load_karg<int>(kp, offsetof(BigKArgs, stagger));
-    const int prio = load_karg<int>(kp, offsetof(BigKArgs, prio));
+#ifdef VRD_LAB_STAMP
+    const int prio = load_karg<int>(kp, offsetof(BigKArgs, prio));      // (lab builds: VRD_BIG_PRIO picks the scheme at run time)
+#else
+    constexpr int prio = 3;      // measured best of 0 .. 4 (profiles/r05_lab_gemm_prio.txt); a constant: no tests in the K loop
+#endif
     unsigned* rflag = nullptr;
     // Phase stagger.  Every tile of a launch takes the same time, so without it all CUs reach their epilogues together and
     // 256 x 256 KiB of stores meet an HBM that was idle a moment before.  The first workgroup of every CU (the first 256 of
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     int vq = blockIdx.x, vb = blockIdx.x;
     do {
     if (PERSIST) {
-        zsel = vq / nwg;                 // (nwg does not depend on the problem)
+        zsel = (vq >= nwg) + (vq >= 2 * nwg) + (vq >= 3 * nwg);      // vq / nwg for at most four problems (nwg is the same for all)
         vb = vq - zsel * nwg;
         if (vq != (int)blockIdx.x || zsel) reload();      // (the per-lane request offsets do not depend on the tile: not recomputed)
     }
@@ -341,6 +345,11 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
         f.lo = *reinterpret_cast<const e16x8*>(sa + (off ^ 64));
         return f;
     };
+    auto load_w1 = [&](const char* sw, int t, WF& f) {       // M16: column block t only
+        const int off = w_base + t * 16 * ROWB;
+        f.hi[t] = *reinterpret_cast<const e16x8*>(sw + off);
+        f.lo[t] = *reinterpret_cast<const e16x8*>(sw + (off ^ 64));
+    };
     auto load_w = [&](const char* sw, int s2) {
         WF f;
 #pragma unroll
@@ -377,10 +386,12 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     __builtin_amdgcn_s_barrier();
     LAB_STAMP(7);
     // The two waves of a SIMD share its matrix pipe, and between equals the older one (waves 0-3) wins every arbitration: it
-    // runs its 48 MFMAs of a K step nearly alone, waits ~1,100 cycles at the step's barrier, and the younger one then issues its
-    // requests with nobody to cover their stalls (profiles/r05_lab_gemm_tile_stamps.txt).  prio 1: the younger half runs at
-    // priority 1 throughout; prio 2: a wave holds priority 1 through the first half of its K step and 0 through the second, so
-    // whichever wave is behind wins.
+    // runs its 48 MFMAs of a K step nearly alone, waits ~1,100-1,300 cycles at the step's barrier, and the younger one then
+    // issues its requests with nobody to cover their stalls (profiles/r05_lab_gemm_tile_stamps.txt).  Issue priority BY
+    // PROGRESS evens them out: a wave runs the quarters of its K step at priorities 3, 2, 1, 0, so whichever of the two is
+    // behind wins (prio 3: the barrier wait of the older half drops to ~650 cycles, the K step from ~3,700 to ~3,550 cycles,
+    // the whole step by 1.5 ms; schemes 1 = the younger half at a static priority 1: no gain; 2 = two levels per step: half
+    // the gain; 4 = two levels, the younger half holding the high one longer: between 2 and 3).
     if (prio == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     WF w_cur = load_w(lds + (g0 % NW_STG) * W_STAGE, 0), w_nxt = w_cur;
     AF a_cur = load_a(lds + (g0 % NA_STG) * A_STAGE, 0, 0), a_nxt = a_cur;
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
             if (g == 7 && !last) {
                 // (the barrier was passed at the end of group 6)
                 a_nxt = load_a(sa1, 0, 0);
-                w_nxt = load_w(sw1, 0);
+                if (!M16) w_nxt = load_w(sw1, 0);
             }
             // ---- the group's MFMAs (six 32x32x16 or twelve 16x16x32), this wave's DMA of the group in the middle or
             // at the end
@@ -445,6 +456,9 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
                         acc16[g][t] = vrd::mfma16(a_cur.lo, w_cur.hi[t], acc16[g][t]);
                         acc16[g][t] = vrd::mfma16(a_cur.hi, w_cur.lo[t], acc16[g][t]);
                         acc16[g][t] = vrd::mfma16(a_cur.hi, w_cur.hi[t], acc16[g][t]);
+                        // the step's last use of column block t's weight fragments: the next step's go straight into the same
+                        // registers (a second set of all four blocks' fragments, 32 registers, is what made hipcc spill)
+                        if (g == 7 && !last) load_w1(sw1, t, w_cur);
                     }
                 } else {
                     acc[mi][nj] = vrd::mfma32(a_cur.lo, w_cur.hi[nj], acc[mi][nj]);
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
             }
 #endif
             a_cur = a_nxt;
-            if ((!M16 && g == 3) || g == 7) w_cur = w_nxt;
+            if (!M16 && (g == 3 || g == 7)) w_cur = w_nxt;
             if (g == 6 && !last) {
                 // every fragment of stage kt is in registers or landed; stage kt+1 must be visible before group 7
                 // starts reading it
@@ -641,6 +655,8 @@ int launch_gemm_x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
         bb.w_scale[i - 1] = a[i].w_scale;
     }
     const bool f16 = a[0].split_fmt == VRD_PAIR_F16;
+    static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
+    if (m16 && f16 && big_persist(a[0])) return launch_big_one<1, true, true, true>(a[0], s, bb, count);
     if (big_persist(a[0])) return f16 ? launch_big_one<1, false, true, true>(a[0], s, bb, count) : launch_big_one<1, false, true, false>(a[0], s, bb, count);
     if (f16) return a[0].taps == 1 ? launch_big_one<1, false, false, true>(a[0], s, bb, count) : launch_big_one<3, false, false, true>(a[0], s, bb, count);
     return a[0].taps == 1 ? launch_big_one<1, false, false>(a[0], s, bb, count) : launch_big_one<3, false, false>(a[0], s, bb, count);
@@ -663,6 +679,7 @@ int launch_gemm_x3_big(const vrd_gemm_args& a, hipStream_t s) {
     static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
     const bool f16 = a.split_fmt == VRD_PAIR_F16;
     if (m16) {
+        if (f16 && big_persist(a)) return launch_big_one<1, true, true, true>(a, s);
         if (f16) return a.taps == 1 ? launch_big_one<1, true, false, true>(a, s) : launch_big_one<3, true, false, true>(a, s);
         return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
     }

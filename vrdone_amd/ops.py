@@ -349,11 +349,12 @@ def split_conv_weight(w, fmt=None):
     return _cached(w, _split_slot("_vrd_split", fmt), lambda: _split_weight(w.detach(), 0, N, Cin, k, Cin * k, 1, k, fmt))
 
 
-def split_conv_weight_dgrad(w):
+def split_conv_weight_dgrad(w, fmt=None):
     """The same operand for the input-gradient GEMM of the conv: the (Cin, k*N) matrix [c][tap*N + n] = w[n][c][k-1-tap]
-    (transposed, taps flipped), straight from the parameter, in the backward GEMMs' element format (backward_fmt)."""
+    (transposed, taps flipped), straight from the parameter, in the backward GEMMs' element format (backward_fmt; `fmt`: the
+    format the op's forward ran under, autograd.Linear)."""
     N, Cin, k = w.shape
-    fmt = backward_fmt()
+    fmt = backward_fmt() if fmt is None else fmt
     return _cached(w, _split_slot("_vrd_split_t", fmt), lambda: _split_weight(w.detach(), k - 1, Cin, N, k, k, -1, Cin * k, fmt))
 
 
@@ -610,7 +611,7 @@ def row_blocks(mask):
 
 def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, res=None, res_masked=False,
               res2=None, out=None, out_pair=False, skip_rows=None, row_scale=None, _launch=None, _dgrad=False, _split_fmt=None,
-              _a_scale=None):
+              _a_scale=None, _bfmt=None):
     """Dense Conv1d (k = 1 or 3, stride 1, zero padding k//2) with the fused epilogue of
     vrd_gemm.  x: (B, T, Cin) tensor or Pair; weight: the Conv1d parameter (N, Cin, k).
     out_pair: write the result as pair rows of width N (returns a Pair).
@@ -647,8 +648,8 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     if _dgrad:
         # split-precision only (autograd.Linear checks): the operand is built from the parameter in one launch; the f32
         # weight pointer is not read by the split-precision kernels and points at the same buffer
-        assert split_backward() and (Cin * k) % 32 == 0 and not a_width
-        wt = split_conv_weight_dgrad(weight)
+        assert (Cin * k) % 32 == 0 and not a_width
+        wt = split_conv_weight_dgrad(weight, _bfmt)
         a.W = wt.data_ptr()
         wt.set_args(a)
         if wt.fmt == _hip.PAIR_F16:      # x is a gradient: its f16 planes need its own power-of-two factor
