@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 30
+#define VRD_ABI_VERSION 31
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -448,11 +448,14 @@ int vrd_attn_bwd_softmax(float* P, float* dS, const uint8_t* kv_mask, int B, int
  * `out` and dO, the scores recomputed tile by tile in the bf16 split of the other backward GEMMs (two kernels: dq -- which also
  * leaves every query's log-sum-exp and sum_d dO O in `scratch` -- then dk / dv).  head_dim 64; q / out / dO / dq rows of
  * leading dimension ldq / ldo / ldo / ldq, k / v / dk / dv of ldkv; scratch: 2 * B * n_head * Tq floats.  The five-product form
- * above stays for other head sizes and for the exact-f32 mode. */
+ * above stays for other head sizes and for the exact-f32 mode.
+ * o_scale / v_scale (both or neither): vrd_absmax_scale's outputs for dO and v: the products are then formed on f16 planes (the
+ * f16x3 mode) -- q, k, v, P at 2^VRD_F16_ACT_EXP, dO at o_scale[0], dS at o_scale[0] * v_scale[0] * 2^-17, which bounds it below
+ * 2^15 whatever the scores are -- at ~2^-22 relative error; NULL: bf16 planes, ~2^-17. */
 int vrd_attention_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* out, const float* dO,
                       int64_t ldo, const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim, float* dq, float* dk,
                       float* dv, const float* lse /* (B, n_head, Tq) from vrd_attention_rows, or NULL: recomputed */, float* scratch,
-                      void* stream);
+                      const float* o_scale, const float* v_scale, void* stream);
 /* The forward of that pair for a training step: vrd_attention on f32 rows in split precision (fmt: VRD_PAIR_BF16 / VRD_PAIR_F16 --
  * the operands are split while they are staged, no pair rows), f32 rows out, plus every query's log-sum-exp of the scaled
  * scores, lse (B, n_head, Tq), which the backward then does not recompute.  head_dim 64. */

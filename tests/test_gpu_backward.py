@@ -428,7 +428,9 @@ def test_global_attention_backward_fused(n_head, C, Tq, Tk, masked, precision):
         return qd.grad, kd.grad, vd.grad, out.detach()
     got = run()
     fused = precision != "f32"
-    tol = 1e-4 if fused else 2e-5          # bf16-split products (2^-17 each, five in a chain) against exact f32 ones
+    # bf16-split products (2^-17 each, five in a chain) against exact f32 ones; the f16x3 mode's f16 planes (dO and dS at
+    # power-of-two factors from the absolute maxima of dO and v) are held to the exact-f32 form's bound
+    tol = 1e-4 if precision == "bf16x3" else 2e-5
     for name, a, r in zip(("dq", "dk", "dv"), got, (qr.grad, kr.grad, vr.grad)):
         rel_close(a, cl(r), tol, name)
     # the forward of the pair (vrd_attention_rows in the split modes): f16 planes are held to the f32 kernels' bound

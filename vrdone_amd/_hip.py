@@ -160,7 +160,7 @@ _SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p]),
     "vrd_bmm": (C.c_int, [C.POINTER(BmmArgs), C.c_void_p]),
     "vrd_attention_bwd": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+                                    C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "vrd_attention_rows": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "vrd_assign": (C.c_int, [c_f32p, C.c_int64, c_i32p, c_i32p, C.c_int, C.c_int, c_i32p, C.c_void_p]),
@@ -173,7 +173,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 
 class HipLibraryError(RuntimeError):

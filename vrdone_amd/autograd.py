@@ -411,7 +411,7 @@ class Attention(Function):
             out = ops.attention(q, k, v, kv_mask, n_head)
         ctx.save_for_backward(q, k, v, out)
         ctx.kv_mask, ctx.n_head, ctx.lse = kv_mask, n_head, lse
-        ctx.split_bwd = ops.split_backward()          # (as in Linear: the backward follows its forward's mode)
+        ctx.split_bwd, ctx.bfmt = ops.split_backward(), ops.backward_fmt()          # (as in Linear: the backward follows its forward's mode)
         return out
 
     @staticmethod
@@ -423,13 +423,20 @@ class Attention(Function):
         hd = Cc // H
         dev = q.device
         if FUSED_ATTN_BWD and ctx.split_bwd and hd == 64 and Tq >= 32 and Tk >= 32:
-            # flash style (vrd_attention_bwd): the scores are recomputed tile by tile in the bf16 split of the other backward
-            # GEMMs; no (B, H, Tq, Tk) matrix exists
+            # flash style (vrd_attention_bwd): the scores are recomputed tile by tile in the split of the other backward GEMMs
+            # (bf16 planes; f16x3 mode: f16 planes, dO and dS at power-of-two factors from the absolute maxima of dO and v);
+            # no (B, H, Tq, Tk) matrix exists
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
             scratch = torch.empty(2, B, H, Tq, device=dev, dtype=torch.float32)
+            so = sv = None
+            if ctx.bfmt == PAIR_F16:
+                so = ops.grad_scale(dO, slot=0)
+                sv = ops.grad_scale(v, slot=1) if so is not None else None
+                if sv is None:
+                    so = None
             check(lib.vrd_attention_bwd(q.data_ptr(), Cc, k.data_ptr(), v.data_ptr(), Cc, out.data_ptr(), dO.data_ptr(), Cc,
                                         _mask_ptr(ctx.kv_mask, B * Tk), B, Tq, Tk, H, hd, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                        _ptr(ctx.lse), scratch.data_ptr(), _stream()), "vrd_attention_bwd")
+                                        _ptr(ctx.lse), scratch.data_ptr(), _ptr(so), _ptr(sv), _stream()), "vrd_attention_bwd")
             return dq, dk, dv, None, None
         P = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)
         dS = torch.empty(B, H, Tq, Tk, device=dev, dtype=torch.float32)

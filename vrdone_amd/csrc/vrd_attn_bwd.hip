@@ -64,8 +64,10 @@ __device__ __forceinline__ TileRegs fetch_tile(const float* __restrict__ src, in
     return t;
 }
 // ... and the hi / lo split into the swizzled planes
+// (mul: the factor of the f16 format's planes when it is not the activations' fixed 2^VRD_F16_ACT_EXP: gradient operands)
 template <bool ROW, bool TR, bool F16 = false>
-__device__ __forceinline__ void commit_tile(const TileRegs& t, char* row_hi, char* tr_hi, vrd::RangeTrack* rt = nullptr) {
+__device__ __forceinline__ void commit_tile(const TileRegs& t, char* row_hi, char* tr_hi, vrd::RangeTrack* rt = nullptr,
+                                            float mul = vrd::F16_ACT_SCALE) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int p = threadIdx.x + 256 * i;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void commit_tile(const TileRegs& t, char* row_hi, cha
         const float4 v = t.v[i];
         const float x[4] = {v.x, v.y, v.z, v.w};
         e16x4<F16> h, l;
-        vrd::split_n<F16>(x, h, l, rt);
+        vrd::split_n_scaled<F16>(x, mul, h, l, rt);
         const int within = (c & 7) * 2;
         if (ROW) {
             const int off = r * ROWB + (((c >> 3) ^ rswz(r)) * 16) + within;
@@ -116,7 +118,7 @@ __device__ __forceinline__ e16x8<F16> tr_frag(const char* plane, int lane, int s
 // whose columns are this wave's 32 rows)
 template <bool F16 = false>
 __device__ __forceinline__ void load_col_frags(const float* __restrict__ rowp, int lh, bool ok, e16x8<F16> (&hi)[KS], e16x8<F16> (&lo)[KS],
-                                               vrd::RangeTrack* rt = nullptr) {
+                                               vrd::RangeTrack* rt = nullptr, float mul = vrd::F16_ACT_SCALE) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -125,7 +127,7 @@ __device__ __forceinline__ void load_col_frags(const float* __restrict__ rowp, i
             const float4 b = *reinterpret_cast<const float4*>(rowp + 16 * s + 8 * lh + 4);
             x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
         }
-        vrd::split_n<F16>(x, hi[s], lo[s], rt);
+        vrd::split_n_scaled<F16>(x, mul, hi[s], lo[s], rt);
     }
 }
 
@@ -139,11 +141,11 @@ __device__ __forceinline__ f32x16 mfma3(V ah, V al, V bh, V bl, f32x16 acc) {
 
 // registers 8 s .. 8 s + 7 of a 32 x 32 accumulator as the hi / lo B fragment of k16 step s
 template <bool F16 = false>
-__device__ __forceinline__ void split_acc(const f32x16& a, int s, e16x8<F16>& hi, e16x8<F16>& lo) {
+__device__ __forceinline__ void split_acc(const f32x16& a, int s, e16x8<F16>& hi, e16x8<F16>& lo, float mul = vrd::F16_ACT_SCALE) {
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = a[8 * s + j];
-    vrd::split_n<F16>(x, hi, lo);
+    vrd::split_n_scaled<F16>(x, mul, hi, lo);
 }
 
 __device__ __forceinline__ int acc_row(int e, int lh) { return (e & 3) + 8 * (e >> 2) + 4 * lh; }
@@ -259,12 +261,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_rows_kernel(const float* 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // lse_in: the forward's log-sum-exp (attn_fwd_rows_kernel), or NULL: pass 1 recomputes it
+// F16 (the f16x3 mode): every operand as f16 planes of a power-of-two multiple -- q, k, v, P at the activations' 2^VRD_F16_ACT_EXP
+// (they went through the forward's range check), dO at s_o = o_scale[0] (vrd_absmax_scale of dO), dS at s_s = s_o s_v 2^-17 with
+// s_v = v_scale[0] (vrd_absmax_scale of V): |dS| <= (|dP| + |delta|) / 8 <= 16 max|dO| max|V| < 2^32 / (s_o s_v), so dS s_s stays
+// below 2^15; what the bound gives away against the values that actually occur costs nothing but range, the planes keep 2^-25
+// absolute precision down to their subnormals.  The accumulators are rescaled where they leave the kernel.
+template <bool F16>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
                                                                 const float* __restrict__ v, int64_t ldkv, const float* __restrict__ o,
                                                                 const float* __restrict__ dO, int64_t ldo,
                                                                 const uint8_t* __restrict__ kv_mask, int Tq, int Tk, int n_head,
                                                                 float scale, float* __restrict__ dq, const float* __restrict__ lse_in,
-                                                                float* __restrict__ lse_out, float* __restrict__ delta_out) {
+                                                                float* __restrict__ lse_out, float* __restrict__ delta_out,
+                                                                const float* __restrict__ o_scale, const float* __restrict__ v_scale) {
+    typedef e16x8<F16> bf16x8;                                         // (this instantiation's eight 16-bit elements)
+    constexpr float a_inv = F16 ? vrd::F16_ACT_INV : 1.0f;
+    const float s_o = F16 ? vrd::uniform_load(o_scale) : 1.f, s_o_inv = F16 ? vrd::uniform_load(o_scale + 1) : 1.f;
+    const float s_s = F16 ? s_o * vrd::uniform_load(v_scale) * 0x1p-17f : 1.f;
+    const float s_s_inv = F16 ? s_o_inv * vrd::uniform_load(v_scale + 1) * 0x1p17f : 1.f;
     extern __shared__ __attribute__((aligned(16))) char lds[];        // 2 stages x (k row h/l, k tr h/l, v row h/l) + key bias: DQ_LDS
     float* const kbias = reinterpret_cast<float*>(lds + 2 * 6 * PLANE);               // [2][32]
     const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -280,8 +294,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const float* __
     const uint8_t* const mk = kv_mask ? kv_mask + (int64_t)b * Tk : nullptr;
 
     bf16x8 qh[KS], ql[KS], gh[KS], gl[KS];
-    load_col_frags(qrow, lh, q_ok, qh, ql);
-    load_col_frags(drow, lh, q_ok, gh, gl);
+    load_col_frags<F16>(qrow, lh, q_ok, qh, ql);
+    load_col_frags<F16>(drow, lh, q_ok, gh, gl, nullptr, s_o);
     // delta = sum_d dO O over the query's row: this lane holds half of the d's
     float delta = 0.f;
     if (q_ok) {
@@ -306,10 +320,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const float* __
     auto commit = [&](int buf, bool second) {
         char* st = lds + buf * 6 * PLANE;
         if (second) {
-            commit_tile<true, true>(rk, st, st + 2 * PLANE);
-            commit_tile<true, false>(rv, st + 4 * PLANE, nullptr);
+            commit_tile<true, true, F16>(rk, st, st + 2 * PLANE);
+            commit_tile<true, false, F16>(rv, st + 4 * PLANE, nullptr);
         } else {
-            commit_tile<true, false>(rk, st, nullptr);
+            commit_tile<true, false, F16>(rk, st, nullptr);
         }
         if (threadIdx.x < 32) kbias[buf * 32 + threadIdx.x] = rbias;
     };
@@ -318,9 +332,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) s = mfma3(row_frag(st, li, lh, t), row_frag(st + PLANE, li, lh, t), qh[t], ql[t], s);
+        for (int t = 0; t < KS; ++t) s = mfma3(row_frag<F16>(st, li, lh, t), row_frag<F16>(st + PLANE, li, lh, t), qh[t], ql[t], s);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = s[e] * scale + kbs[acc_row(e, lh)];
+        for (int e = 0; e < 16; ++e) s[e] = s[e] * (scale * a_inv * a_inv) + kbs[acc_row(e, lh)];
         return s;
     };
 
@@ -369,28 +383,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const float* __
 #pragma unroll
         for (int e = 0; e < 16; ++e) dp[e] = 0.f;
 #pragma unroll
-        for (int t = 0; t < KS; ++t) dp = mfma3(row_frag(st + 4 * PLANE, li, lh, t), row_frag(st + 5 * PLANE, li, lh, t), gh[t], gl[t], dp);
+        for (int t = 0; t < KS; ++t)
+            dp = mfma3(row_frag<F16>(st + 4 * PLANE, li, lh, t), row_frag<F16>(st + 5 * PLANE, li, lh, t), gh[t], gl[t], dp);
+        const float dp_unscale = a_inv * s_o_inv;              // (dP came out of V 2^a times dO s_o)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = __expf(s[e] - lse) * (dp[e] - delta) * scale;            // dS^T (scaled)
+        for (int e = 0; e < 16; ++e) s[e] = __expf(s[e] - lse) * (dp[e] * dp_unscale - delta) * scale;            // dS^T (scaled)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 dh, dl;
-            split_acc(s, s2, dh, dl);
+            split_acc<F16>(s, s2, dh, dl, s_s);
 #pragma unroll
             for (int d = 0; d < DT; ++d)
-                dqa[d] = mfma3(tr_frag(st + 2 * PLANE, lane, s2, d), tr_frag(st + 3 * PLANE, lane, s2, d), dh, dl, dqa[d]);
+                dqa[d] = mfma3(tr_frag<F16>(st + 2 * PLANE, lane, s2, d), tr_frag<F16>(st + 3 * PLANE, lane, s2, d), dh, dl, dqa[d]);
         }
         if (kt + 1 < nkt) commit((kt + 1) & 1, true);
         __syncthreads();
     }
     if (q_ok) {
         float* const out = dq + ((int64_t)b * Tq + tq) * ldq + h * HD;
+        const float u = a_inv * s_s_inv;         // (K 2^a times dS s_s)
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g)          // registers 4g .. 4g+3 are d = 32 d + 8 g + 4 lh + 0..3
                 *reinterpret_cast<float4*>(out + 32 * d + 8 * g + 4 * lh) =
-                    make_float4(dqa[d][4 * g], dqa[d][4 * g + 1], dqa[d][4 * g + 2], dqa[d][4 * g + 3]);
+                    make_float4(dqa[d][4 * g] * u, dqa[d][4 * g + 1] * u, dqa[d][4 * g + 2] * u, dqa[d][4 * g + 3] * u);
         if (lh == 0) {
             lse_out[((int64_t)b * n_head + h) * Tq + tq] = lse;
             delta_out[((int64_t)b * n_head + h) * Tq + tq] = delta;
@@ -399,12 +416,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
                                                                  const float* __restrict__ v, int64_t ldkv, const float* __restrict__ dO,
                                                                  int64_t ldo, const uint8_t* __restrict__ kv_mask, int Tq, int Tk,
                                                                  int n_head, float scale, const float* __restrict__ lse_in,
                                                                  const float* __restrict__ delta_in, float* __restrict__ dk,
-                                                                 float* __restrict__ dv) {
+                                                                 float* __restrict__ dv, const float* __restrict__ o_scale,
+                                                                 const float* __restrict__ v_scale) {
+    typedef e16x8<F16> bf16x8;
+    constexpr float a_inv = F16 ? vrd::F16_ACT_INV : 1.0f;                       // (scales: see attn_bwd_dq_kernel)
+    const float s_o = F16 ? vrd::uniform_load(o_scale) : 1.f, s_o_inv = F16 ? vrd::uniform_load(o_scale + 1) : 1.f;
+    const float s_s = F16 ? s_o * vrd::uniform_load(v_scale) * 0x1p-17f : 1.f;
+    const float s_s_inv = F16 ? s_o_inv * vrd::uniform_load(v_scale + 1) * 0x1p17f : 1.f;
     // 2 stages x (q row h/l, q tr h/l, dO row h/l, dO tr h/l) + lse / delta of the tile's 32 queries: DKV_LDS
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* const stat = reinterpret_cast<float*>(lds + 2 * 8 * PLANE);                // [2][lse 32 | delta 32]
@@ -422,8 +446,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(const float* _
     const float* const del_b = delta_in + ((int64_t)b * n_head + h) * Tq;
 
     bf16x8 kh[KS], kl[KS], vh[KS], vl[KS];
-    load_col_frags(krow, lh, k_in, kh, kl);
-    load_col_frags(vrow, lh, k_in, vh, vl);
+    load_col_frags<F16>(krow, lh, k_in, kh, kl);
+    load_col_frags<F16>(vrow, lh, k_in, vh, vl);
     f32x16 dka[DT], dva[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d)
@@ -444,8 +468,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(const float* _
     };
     auto commit = [&](int buf) {
         char* st = lds + buf * 8 * PLANE;
-        commit_tile<true, true>(rq, st, st + 2 * PLANE);
-        commit_tile<true, true>(rg, st + 4 * PLANE, st + 6 * PLANE);
+        commit_tile<true, true, F16>(rq, st, st + 2 * PLANE);
+        commit_tile<true, true, F16>(rg, st + 4 * PLANE, st + 6 * PLANE, nullptr, s_o);
         if (threadIdx.x < 32) {
             stat[buf * 64 + threadIdx.x] = rl;
             stat[buf * 64 + 32 + threadIdx.x] = rd;
@@ -463,25 +487,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(const float* _
         for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
 #pragma unroll
         for (int t = 0; t < KS; ++t) {
-            s = mfma3(row_frag(st, li, lh, t), row_frag(st + PLANE, li, lh, t), kh[t], kl[t], s);                          // S = Q K^T
-            dp = mfma3(row_frag(st + 4 * PLANE, li, lh, t), row_frag(st + 5 * PLANE, li, lh, t), vh[t], vl[t], dp);        // dP = dO V^T
+            s = mfma3(row_frag<F16>(st, li, lh, t), row_frag<F16>(st + PLANE, li, lh, t), kh[t], kl[t], s);                          // S = Q K^T
+            dp = mfma3(row_frag<F16>(st + 4 * PLANE, li, lh, t), row_frag<F16>(st + 5 * PLANE, li, lh, t), vh[t], vl[t], dp);        // dP = dO V^T
         }
         f32x16 p;
+        const float s_unscale = scale * a_inv * a_inv, dp_unscale = a_inv * s_o_inv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = acc_row(e, lh);
-            p[e] = k_ok ? __expf(s[e] * scale - sl[r]) : 0.f;
-            s[e] = p[e] * (dp[e] - sl[32 + r]) * scale;                                                             // dS (scaled)
+            p[e] = k_ok ? __expf(s[e] * s_unscale - sl[r]) : 0.f;
+            s[e] = p[e] * (dp[e] * dp_unscale - sl[32 + r]) * scale;                                                  // dS (scaled)
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             bf16x8 ph, pl, dh, dl;
-            split_acc(p, s2, ph, pl);
-            split_acc(s, s2, dh, dl);
+            split_acc<F16>(p, s2, ph, pl);
+            split_acc<F16>(s, s2, dh, dl, s_s);
 #pragma unroll
             for (int d = 0; d < DT; ++d) {
-                dva[d] = mfma3(tr_frag(st + 6 * PLANE, lane, s2, d), tr_frag(st + 7 * PLANE, lane, s2, d), ph, pl, dva[d]);      // dV^T += dO^T P
-                dka[d] = mfma3(tr_frag(st + 2 * PLANE, lane, s2, d), tr_frag(st + 3 * PLANE, lane, s2, d), dh, dl, dka[d]);      // dK^T += Q^T dS
+                dva[d] = mfma3(tr_frag<F16>(st + 6 * PLANE, lane, s2, d), tr_frag<F16>(st + 7 * PLANE, lane, s2, d), ph, pl, dva[d]);      // dV^T += dO^T P
+                dka[d] = mfma3(tr_frag<F16>(st + 2 * PLANE, lane, s2, d), tr_frag<F16>(st + 3 * PLANE, lane, s2, d), dh, dl, dka[d]);      // dK^T += Q^T dS
             }
         }
         if (qt + 1 < nqt) commit((qt + 1) & 1);
@@ -495,8 +520,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_kernel(const float* _
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c = 32 * d + 8 * g + 4 * lh;
-                *reinterpret_cast<float4*>(ok_ + c) = make_float4(dka[d][4 * g], dka[d][4 * g + 1], dka[d][4 * g + 2], dka[d][4 * g + 3]);
-                *reinterpret_cast<float4*>(ov + c) = make_float4(dva[d][4 * g], dva[d][4 * g + 1], dva[d][4 * g + 2], dva[d][4 * g + 3]);
+                const float uk = a_inv * s_s_inv, uv = a_inv * s_o_inv;       // (Q 2^a times dS s_s; P 2^a times dO s_o)
+                *reinterpret_cast<float4*>(ok_ + c) = make_float4(dka[d][4 * g] * uk, dka[d][4 * g + 1] * uk, dka[d][4 * g + 2] * uk, dka[d][4 * g + 3] * uk);
+                *reinterpret_cast<float4*>(ov + c) = make_float4(dva[d][4 * g] * uv, dva[d][4 * g + 1] * uv, dva[d][4 * g + 2] * uv, dva[d][4 * g + 3] * uv);
             }
     }
 }
@@ -507,9 +533,11 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 extern "C" int vrd_attention_bwd(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const float* out,
                                  const float* dO, int64_t ldo, const uint8_t* kv_mask, int B, int Tq, int Tk, int n_head, int head_dim,
-                                 float* dq, float* dk, float* dv, const float* lse, float* scratch, void* stream) {
+                                 float* dq, float* dk, float* dv, const float* lse, float* scratch, const float* o_scale,
+                                 const float* v_scale, void* stream) {
     VRD_CHECK_ARG(q && k && v && out && dO && dq && dk && dv && scratch, "vrd_attention_bwd: null pointer");
     VRD_CHECK_ARG(head_dim == HD, "vrd_attention_bwd: built for head_dim %d (got %d)", HD, head_dim);
+    VRD_CHECK_ARG((o_scale == nullptr) == (v_scale == nullptr), "vrd_attention_bwd: o_scale and v_scale go together");
     VRD_CHECK_ARG(B > 0 && B <= 65535 && n_head > 0 && n_head <= 65535 && Tq > 0 && Tk > 0, "vrd_attention_bwd: bad sizes");
     const int width = n_head * head_dim;
     VRD_CHECK_ARG(ldq >= width && ldkv >= width && ldo >= width && ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && aligned16(q) &&
@@ -521,13 +549,24 @@ extern "C" int vrd_attention_bwd(const float* q, int64_t ldq, const float* k, co
     vrd::ProfScope prof(VRD_K_BACKWARD, s, 2.0 * 9.0 * B * (double)n_head * Tq * Tk * head_dim, 0.0);
     float* lse_own = scratch;
     float* delta = scratch + (int64_t)B * n_head * Tq;
-    if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel), DQ_LDS, "vrd_attention_bwd(dq)")) return rc;
-    if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), DKV_LDS, "vrd_attention_bwd(dk, dv)")) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + NW * 32 - 1) / (NW * 32), n_head, B), dim3(NW * 64), DQ_LDS, s, q, ldq, k, v, ldkv, out, dO,
-                       ldo, kv_mask, Tq, Tk, n_head, scale, dq, lse, lse_own, delta);
-    VRD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + NW * 32 - 1) / (NW * 32), n_head, B), dim3(NW * 64), DKV_LDS, s, q, ldq, k, v, ldkv, dO, ldo,
-                       kv_mask, Tq, Tk, n_head, scale, lse ? lse : lse_own, delta, dk, dv);
+    const dim3 gq((Tq + NW * 32 - 1) / (NW * 32), n_head, B), gk((Tk + NW * 32 - 1) / (NW * 32), n_head, B);
+    if (o_scale) {
+        if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<true>), DQ_LDS, "vrd_attention_bwd(dq)")) return rc;
+        if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<true>), DKV_LDS, "vrd_attention_bwd(dk, dv)")) return rc;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, gq, dim3(NW * 64), DQ_LDS, s, q, ldq, k, v, ldkv, out, dO, ldo, kv_mask, Tq, Tk, n_head, scale, dq,
+                           lse, lse_own, delta, o_scale, v_scale);
+        VRD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, gk, dim3(NW * 64), DKV_LDS, s, q, ldq, k, v, ldkv, dO, ldo, kv_mask, Tq, Tk, n_head, scale,
+                           lse ? lse : lse_own, delta, dk, dv, o_scale, v_scale);
+    } else {
+        if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_bwd_dq_kernel<false>), DQ_LDS, "vrd_attention_bwd(dq)")) return rc;
+        if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<false>), DKV_LDS, "vrd_attention_bwd(dk, dv)")) return rc;
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, gq, dim3(NW * 64), DQ_LDS, s, q, ldq, k, v, ldkv, out, dO, ldo, kv_mask, Tq, Tk, n_head, scale, dq,
+                           lse, lse_own, delta, (const float*)nullptr, (const float*)nullptr);
+        VRD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, gk, dim3(NW * 64), DKV_LDS, s, q, ldq, k, v, ldkv, dO, ldo, kv_mask, Tq, Tk, n_head, scale,
+                           lse ? lse : lse_own, delta, dk, dv, (const float*)nullptr, (const float*)nullptr);
+    }
     VRD_LAUNCH_CHECK();
     return 0;
 }
