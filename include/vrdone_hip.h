@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 31
+#define VRD_ABI_VERSION 32
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -366,8 +366,10 @@ int vrd_gemm_wgrad_x3(const float* G, int64_t ldg, const float* X, int64_t ldx, 
 
 /* scale[0] = 2^e, scale[1] = 2^-e with e such that max |x| * 2^e lies in [2^13, 2^14) over the (rows x cols) matrix x (e = 0 for
  * an all-zero or non-finite matrix; |e| <= 100): the power-of-two factor that puts a tensor of unknown range -- a gradient -- into
- * the f16 planes of VRD_PAIR_F16 with headroom.  One launch; `scale` is FOUR floats of device memory that the caller zeroed
- * once: elements 2 and 3 are the running maximum's bits and the workgroup ticket, which the last workgroup leaves zeroed again. */
+ * the f16 planes of VRD_PAIR_F16 with headroom.  One launch; `scale` is VRD_ABSMAX_SCALE_FLOATS floats of device memory that the
+ * caller zeroed once: element 3 is the workgroup ticket, which the last workgroup leaves zeroed again, elements 4.. take the
+ * workgroups' partial maxima (at most one workgroup per CU); readers use elements 0 and 1 only. */
+#define VRD_ABSMAX_SCALE_FLOATS 516
 int vrd_absmax_scale(const float* x, int64_t ldx, int64_t rows, int cols, float* scale, void* stream);
 
 /* out[c] += sum_r a[r, c] * (b ? b[brow(r), c * b_cstride + b_coffset] : 1) * (row_mask ? row_mask[r] : 1) * (row_scale ?

@@ -149,10 +149,10 @@ def test_weight_gradient_through_partial_tiles(M, N, Cin, k, T):
     if N % 4 == 0:
         tiny = 1e-9
         Gs = (Gd * tiny).contiguous()
-        scale = torch.zeros(4, device=DEV)
+        scale = torch.zeros(_hip.ABSMAX_SCALE_FLOATS, device=DEV)
         _hip.check(_hip.lib.vrd_absmax_scale(Gs.data_ptr(), N, M, N, scale.data_ptr(), stream), "vrd_absmax_scale")
         mx = float(Gs.abs().max())
-        assert 2.0 ** 13 <= mx * float(scale[0]) < 2.0 ** 14 and float(scale[0] * scale[1]) == 1.0 and float(scale[2]) == 0.0 and float(scale[3]) == 0.0
+        assert 2.0 ** 13 <= mx * float(scale[0]) < 2.0 ** 14 and float(scale[0] * scale[1]) == 1.0 and float(scale[3]) == 0.0
         keep = Gd
         Gd = Gs
         try:
@@ -166,6 +166,34 @@ def test_weight_gradient_through_partial_tiles(M, N, Cin, k, T):
         print(f"dW error relative to the largest entry: f16 planes {err16:.2e}, bf16 planes {errbf:.2e}")
         assert err16 <= 2e-6 and err16 <= 0.5 * errbf + 1e-7
         rel_close(bf, Gm.sum(0) * tiny, 2e-5, "db (scaled gradient)")
+
+
+@pytest.mark.parametrize("rows,cols,ldx", [(1, 4, 4), (7, 12, 12), (768, 512, 512), (24576, 2048, 2048), (100003, 512, 512),
+                                           (3000, 132, 160), (4097, 8, 1024), (24576, 512, 1536)])
+def test_absmax_scale_over_flat_and_padded_rows(rows, cols, ldx):
+    """vrd_absmax_scale: the power-of-two factor of max |x| over the (rows, cols) window of a row-major buffer of pitch ldx --
+    values outside the window (far larger) must not count; the buffer is reusable without clearing (ticket back at zero); an
+    all-zero window gives e = 0."""
+    from vrdone_amd import _hip
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(rows * 31 + cols)
+    buf = torch.full((rows, ldx), 1e30)
+    win = torch.randn(rows, cols, generator=g) * torch.exp(4 * torch.randn(rows, 1, generator=g))
+    scale = torch.zeros(_hip.ABSMAX_SCALE_FLOATS, device=DEV)
+    for trial, factor in enumerate([1.0, 1e-12, 3e7, 0.0]):
+        w = win * factor
+        if trial == 1:                                            # the maximum as the window's very last element
+            w[-1, -1] = 5e-3
+        buf[:, :cols] = w
+        x = buf.to(DEV)
+        _hip.check(_hip.lib.vrd_absmax_scale(x.data_ptr(), ldx, rows, cols, scale.data_ptr(), stream), "vrd_absmax_scale")
+        s0, s1, ticket = float(scale[0]), float(scale[1]), float(scale[3])
+        mx = float(w.abs().max())
+        assert ticket == 0.0 and s0 * s1 == 1.0
+        if mx == 0.0:
+            assert s0 == 1.0
+        else:
+            assert 2.0 ** 13 <= mx * s0 < 2.0 ** 14, (rows, cols, ldx, trial, mx, s0)
 
 
 @pytest.mark.parametrize("ks,gin,stride,C,B,T", [(3, 1, 1, 512, 64, 64), (3, 1, 1, 260, 37, 50), (3, 2, 1, 256, 40, 50), (1, 1, 1, 256, 33, 64),

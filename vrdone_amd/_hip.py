@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("VRDONE_HIP_LIB") or os.path.join(_HERE, "csrc", "libv
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 PAIR_NONE, PAIR_BF16, PAIR_F16 = 0, 1, 2          # enum vrd_pair_format
 F16_ACT_EXP = 4                                   # VRD_F16_ACT_EXP
+ABSMAX_SCALE_FLOATS = 516                         # VRD_ABSMAX_SCALE_FLOATS: vrd_absmax_scale's buffer (factors, ticket, partial maxima)
 (K_GEMM, K_LAYERNORM, K_DWCONV_LN, K_LOCAL_ATTN, K_ATTN_SMALL, K_ATTN_FLASH, K_POOL, K_MASK_HEAD,
  K_TRANSPOSE, K_POSTPROC, K_GEMM_X3, K_GEMM_X3_DMA, K_GEMM_X3_BIG, K_BACKWARD, K_COUNT) = range(15)   # enum vrd_kernel_id
 KERNEL_NAMES = ["gemm_f32_mfma", "layernorm", "dwconv_ln", "local_attn", "attn_small", "attn_flash",
@@ -173,7 +174,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 
 class HipLibraryError(RuntimeError):

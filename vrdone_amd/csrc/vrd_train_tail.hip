@@ -271,20 +271,52 @@ extern "C" int vrd_split_weights(const vrd_split_job* jobs, int n_jobs, const in
 }
 
 namespace {
-// max |x| over a matrix -> {2^e, 2^-e}, e = 140 - (biased exponent of the maximum): one launch, the last workgroup to finish
-// (a ticket in scale[3]) turns the running maximum (bits in scale[2]) into the two factors and zeroes both words again
-__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols4,
-                                                           float* __restrict__ scale) {
+// max |x| over a matrix -> {2^e, 2^-e}, e = 140 - (biased exponent of the maximum), in one launch.  The tensors are read once
+// (a gradient that its two consumers read right after), so the launch is only as good as its loads in flight and its
+// serial tail: at most one 1,024-thread workgroup per CU, four independent float4 loads per lane and trip (16 MB in flight on
+// the chip), every workgroup's maximum as a plain store into scale[4 + block] and ONE atomic per workgroup (a ticket in
+// scale[3]); the last one in reduces the partial maxima and writes the factors.  (History: one atomicMax per wave of a 2,048
+// workgroup grid took 109 us on a 50 MB tensor that streams in 12 -- same-address atomics are worked off at 12-50 ns each;
+// one atomicMax + one ticket per workgroup of a 512-workgroup grid, one load in flight per lane: 13-35 us per call, ~3 ms of a
+// vidor-size training step.)
+constexpr int ABSMAX_THREADS = 1024, ABSMAX_UNROLL = 4;
+
+__device__ __forceinline__ unsigned absmax4(float4 v, unsigned m) {
+    const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
+    const unsigned c = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+    return q > m ? q : m;
+}
+
+template <bool FLAT>
+__global__ __launch_bounds__(ABSMAX_THREADS) void absmax_scale_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows, int cols4,
+                                                                      float* __restrict__ scale) {
     unsigned m = 0u;
-    const int64_t n = rows * cols4;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * 256) {
-        const int64_t r = idx / cols4;
-        const int c = (int)(idx - r * cols4) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
-        const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7fffffffu, b = __builtin_bit_cast(unsigned, v.y) & 0x7fffffffu;
-        const unsigned cc = __builtin_bit_cast(unsigned, v.z) & 0x7fffffffu, d = __builtin_bit_cast(unsigned, v.w) & 0x7fffffffu;
-        const unsigned ab = a > b ? a : b, cd = cc > d ? cc : d, q = ab > cd ? ab : cd;
-        m = q > m ? q : m;
+    const int64_t n = rows * cols4;                                       // float4 pieces
+    const int64_t stride = (int64_t)gridDim.x * ABSMAX_THREADS;
+    const int64_t first = (int64_t)blockIdx.x * ABSMAX_THREADS + threadIdx.x;
+    if (FLAT) {                                                           // ldx == cols: one run of float4
+        const float4* const x4 = reinterpret_cast<const float4*>(x);
+        int64_t idx = first;
+        for (; idx + (ABSMAX_UNROLL - 1) * stride < n; idx += ABSMAX_UNROLL * stride) {
+            float4 v[ABSMAX_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ABSMAX_UNROLL; ++u) v[u] = x4[idx + u * stride];
+#pragma unroll
+            for (int u = 0; u < ABSMAX_UNROLL; ++u) m = absmax4(v[u], m);
+        }
+        for (; idx < n; idx += stride) m = absmax4(x4[idx], m);
+    } else {                                                              // padded rows: (row, piece) stepped without a division per trip
+        int64_t r = first / cols4;
+        int c = (int)(first - r * cols4);
+        const int64_t dr = stride / cols4;
+        const int dc = (int)(stride - dr * cols4);
+        for (int64_t idx = first; idx < n; idx += stride) {
+            m = absmax4(*reinterpret_cast<const float4*>(x + r * ldx + 4 * c), m);
+            r += dr;
+            c += dc;
+            if (c >= cols4) { c -= cols4; ++r; }
+        }
     }
 #pragma unroll
     for (int o = 32; o; o >>= 1) {
@@ -292,30 +324,40 @@ __global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restri
         m = t > m ? t : m;
     }
     unsigned* const words = reinterpret_cast<unsigned*>(scale);
-    // one atomic per WORKGROUP: atomics on one address are worked off one after the other (~12-50 ns each); with one per wave
-    // of a 2,048-workgroup grid the launch took 109 us on a 50 MB tensor that is read in 12
-    __shared__ unsigned wave_max[4];
+    __shared__ unsigned wave_max[ABSMAX_THREADS / 64];
+    __shared__ bool last;
     if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned bm = wave_max[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) bm = wave_max[w] > bm ? wave_max[w] : bm;
-        if (bm) atomicMax(words + 2, bm);
+        for (int w = 1; w < ABSMAX_THREADS / 64; ++w) bm = wave_max[w] > bm ? wave_max[w] : bm;
+        __hip_atomic_store(words + 4 + blockIdx.x, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
-        const unsigned ticket = atomicAdd(words + 3, 1u);
-        if (ticket == gridDim.x - 1) {
-            __threadfence();
-            const unsigned mx = atomicMax(words + 2, 0u);                  // (an atomic read of the final maximum)
-            const int E = (int)((mx >> 23) & 0xffu);
-            int e = (E == 0 || E == 255) ? 0 : 140 - E;
-            e = e > 100 ? 100 : (e < -100 ? -100 : e);
-            scale[0] = pow2i(e);
-            scale[1] = pow2i(-e);
-            __threadfence();
-            atomicExch(words + 2, 0u);
-            atomicExch(words + 3, 0u);
-        }
+        last = atomicAdd(words + 3, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    unsigned t = threadIdx.x < gridDim.x ? __hip_atomic_load(words + 4 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned u = (unsigned)__shfl_xor((int)t, o, 64);
+        t = u > t ? u : t;
+    }
+    __syncthreads();                                  // (wave_max is read above by thread 0 only, before the first barrier's twin)
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned mx = wave_max[0];
+#pragma unroll
+        for (int w = 1; w < ABSMAX_THREADS / 64; ++w) mx = wave_max[w] > mx ? wave_max[w] : mx;
+        const int E = (int)((mx >> 23) & 0xffu);
+        int e = (E == 0 || E == 255) ? 0 : 140 - E;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        scale[0] = pow2i(e);
+        scale[1] = pow2i(-e);
+        __hip_atomic_store(words + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the ticket counter, for the next launch
     }
 }
 }  // namespace
@@ -326,10 +368,13 @@ extern "C" int vrd_absmax_scale(const float* x, int64_t ldx, int64_t rows, int c
                   "vrd_absmax_scale: rows must be float4-aligned (cols %d, ldx %lld)", cols, (long long)ldx);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int64_t n = rows * (cols / 4);
-    const int64_t want = (n + 255) / 256;
-    const int64_t cap = 2 * (int64_t)vrd::device_cu_count();       // two workgroups per CU stream the tensor; more only add atomics
+    const int64_t per_block = (int64_t)ABSMAX_THREADS * ABSMAX_UNROLL;
+    const int64_t want = (n + per_block - 1) / per_block;
+    int64_t cap = vrd::device_cu_count();                                  // one workgroup per CU, and never more than the partial slots
+    if (cap > VRD_ABSMAX_SCALE_FLOATS - 4) cap = VRD_ABSMAX_SCALE_FLOATS - 4;
     const unsigned blocks = (unsigned)(want < cap ? want : cap);
-    hipLaunchKernelGGL(absmax_scale_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, rows, cols / 4, scale);
+    if (ldx == cols) hipLaunchKernelGGL(absmax_scale_kernel<true>, dim3(blocks), dim3(ABSMAX_THREADS), 0, s, x, ldx, rows, cols / 4, scale);
+    else hipLaunchKernelGGL(absmax_scale_kernel<false>, dim3(blocks), dim3(ABSMAX_THREADS), 0, s, x, ldx, rows, cols / 4, scale);
     VRD_LAUNCH_CHECK();
     return 0;
 }

@@ -176,30 +176,59 @@ class MaskVRD(nn.Module):
         batched_masks._vrd_tight_plan = (key, plan)
         return plan
 
+    # buckets side by side: a bucket's launches are a fraction of the batch's, and from the third pyramid level on they no longer
+    # fill the chip (a 256 x 256 GEMM tile per CU needs 65 k rows); buckets are independent, so they run on TIGHT_STREAMS HIP
+    # streams and fill each other's tails.  (The first call runs them one after the other: it builds the per-weight operand
+    # caches every later call only reads.)
+    TIGHT_STREAMS = int(os.environ.get("VRDONE_TIGHT_STREAMS", "1"))
+
+    def _tight_side_streams(self, dev):
+        pool = self.__dict__.setdefault("_tight_stream_pool", {})
+        key = (str(dev), _ops().get_precision())
+        if key not in pool:
+            pool[key] = None if self.TIGHT_STREAMS <= 1 else []          # first call in this mode: sequential, caches get built
+            return None
+        if pool[key] is not None and not pool[key]:
+            pool[key] = [torch.cuda.Stream(device=dev) for _ in range(self.TIGHT_STREAMS - 1)]
+        return pool[key]
+
     def _mask_vrd_tight(self, x, masks2d, plan, with_aux):
         """_mask_vrd bucket by bucket (see `tight padding` above); outputs in the batch's own padded length."""
         B, T = masks2d.shape
         dev = x.device
         out = None
         fill = -10.0                                    # the predictor's value on padded frames (predictor.py:39)
-        for t2, idx, n in plan:
-            idx64 = idx.long()
-            m_all = masks2d[idx64, :t2].contiguous()
-            step = self._chunk_size(n)
-            for c0 in range(0, n, step):
-                sel, sel64 = idx[c0:c0 + step].contiguous(), idx64[c0:c0 + step]
-                m = m_all[c0:c0 + step]
-                o = self._heads(*self.backbone.cl_parts(*self.backbone._unpack(x, frames=t2, index=sel), m), with_aux)
-                if out is None:
-                    Q, K1 = o["pred_logits"].shape[1:]
-                    new = lambda: {"pred_logits": torch.empty(B, Q, K1, device=dev),                       # noqa: E731
-                                   "pred_masks": torch.full((B, Q, T), fill, device=dev)}
-                    out = new()
-                    if "aux_outputs" in o:
-                        out["aux_outputs"] = [new() for _ in o["aux_outputs"]]
-                for dst, src in [(out, o)] + list(zip(out.get("aux_outputs", []), o.get("aux_outputs", []))):
-                    dst["pred_logits"][sel64] = src["pred_logits"]
-                    dst["pred_masks"][sel64, :, :t2] = src["pred_masks"]
+        main = torch.cuda.current_stream(dev)
+        side = self._tight_side_streams(dev) if len(plan) > 1 and not torch.cuda.is_current_stream_capturing() else None
+        lanes = [main] + list(side or [])
+        fork = None
+        for k, (t2, idx, n) in enumerate(plan):
+            lane = lanes[k % len(lanes)] if out is not None else main           # (the first bucket also shapes the outputs)
+            if lane is not main:
+                lane.wait_event(fork)
+            with torch.cuda.stream(lane):
+                idx64 = idx.long()
+                m_all = masks2d[idx64, :t2].contiguous()
+                step = self._chunk_size(n)
+                for c0 in range(0, n, step):
+                    sel, sel64 = idx[c0:c0 + step].contiguous(), idx64[c0:c0 + step]
+                    m = m_all[c0:c0 + step]
+                    o = self._heads(*self.backbone.cl_parts(*self.backbone._unpack(x, frames=t2, index=sel), m), with_aux)
+                    if out is None:
+                        Q, K1 = o["pred_logits"].shape[1:]
+                        new = lambda: {"pred_logits": torch.empty(B, Q, K1, device=dev),                       # noqa: E731
+                                       "pred_masks": torch.full((B, Q, T), fill, device=dev)}
+                        out = new()
+                        if "aux_outputs" in o:
+                            out["aux_outputs"] = [new() for _ in o["aux_outputs"]]
+                        if len(lanes) > 1:
+                            fork = torch.cuda.Event()
+                            fork.record(main)            # the output buffers (and everything before this call) exist from here on
+                    for dst, src in [(out, o)] + list(zip(out.get("aux_outputs", []), o.get("aux_outputs", []))):
+                        dst["pred_logits"][sel64] = src["pred_logits"]
+                        dst["pred_masks"][sel64, :, :t2] = src["pred_masks"]
+        for lane in lanes[1:]:
+            main.wait_stream(lane)
         out["output_mask"] = masks2d[:, None, :]
         return out
 
@@ -279,7 +308,7 @@ class MaskVRD(nn.Module):
         # on the device (ops.f16_range_flag; a NaN would not reach the loss reliably).  The word is read once, behind the
         # step's own launches, and such a step is taken again in the f32 mode -- the arithmetic of the reference (train.py:182-186).
         pdev = next(self.parameters()).device
-        guard = ops.get_precision() == "f16x3" and pdev.type == "cuda"
+        guard = ops.get_precision() == "f16x3" and pdev.type == "cuda" and os.environ.get("VRDONE_RANGE_GUARD", "1") != "0"
         if guard:
             flag = ops.f16_range_flag(pdev)
             flag.zero_()

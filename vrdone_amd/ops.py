@@ -122,7 +122,7 @@ _grad_scales = {}
 
 
 def grad_scale(g, slot=0):
-    """{2^e, 2^-e} (device floats [0], [1] of a 4-float buffer) with max |g| 2^e in [2^13, 2^14) for the (rows, C) gradient `g`
+    """{2^e, 2^-e} (device floats [0], [1] of a buffer of _hip.ABSMAX_SCALE_FLOATS) with max |g| 2^e in [2^13, 2^14) for the (rows, C) gradient `g`
     (vrd_absmax_scale, one launch), or None when g's rows are not float4-aligned (the caller then keeps the bf16 planes).  The
     buffer is one per (device, stream): it is only read by the launches that directly follow on the same stream; launches
     recorded into a graph get one of their own per call (from the graph's pool)."""
@@ -130,12 +130,12 @@ def grad_scale(g, slot=0):
     if cols % 4 or ldg % 4 or pg % 16:
         return None
     if torch.cuda.is_current_stream_capturing():
-        buf = torch.zeros(4, device=g.device, dtype=torch.float32)
+        buf = torch.zeros(_hip.ABSMAX_SCALE_FLOATS, device=g.device, dtype=torch.float32)
     else:
         key = (g.device, torch.cuda.current_stream(g.device).cuda_stream, slot)      # (slot: a consumer that needs two at once)
         buf = _grad_scales.get(key)
         if buf is None:
-            buf = _grad_scales[key] = torch.zeros(4, device=g.device, dtype=torch.float32)
+            buf = _grad_scales[key] = torch.zeros(_hip.ABSMAX_SCALE_FLOATS, device=g.device, dtype=torch.float32)
     _hip.check(lib.vrd_absmax_scale(pg, ldg, rows, cols, buf.data_ptr(), _stream()), "vrd_absmax_scale")
     return buf
 
