@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 32
+#define VRD_ABI_VERSION 33
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -252,6 +252,18 @@ int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t ro
                   const float* gamma, const float* beta, int relu,
                   const float* post_add, int64_t ld_add, int add_period, int out_pair /* enum vrd_pair_format */, void* stream);
 
+/* A ragged row space (host memory): the rows of an activation are `count` groups of sequences back to back, group i =
+ * n[i] sequences of T[i] frames from row row[i] on -- the buckets of equal padded length of MaskVRD's tight padding
+ * (vrdone_amd/models/ragged.py; the reference pads every pair of a batch to one length, models/maskvrd.py:363-414).
+ * Kernels that walk sequences take it in place of (B, T): one launch for all groups. */
+#define VRD_MAX_SEGS 32
+typedef struct {
+    int32_t count;                 /* 1 .. VRD_MAX_SEGS */
+    int32_t n[VRD_MAX_SEGS];
+    int32_t T[VRD_MAX_SEGS];
+    int64_t row[VRD_MAX_SEGS];
+} vrd_row_segs;
+
 /* ---- depthwise conv (+ nearest-upsample add) * mask -> LayerNorm, fused -----------------
  * for o in [0, n_out): y_o[b,t',:] = LN_o( mask_out[b,t'] * (bias_o + sum_k w_o[c,g,k] *
  *        xin[b, stride*t' + k - ksize/2, group_in*c + g]) ), xin = x (+ x_up[b, t/2, :]), or, with pre_gamma set,
@@ -281,6 +293,9 @@ typedef struct {
                                    (group_in*ksize + 3) * C floats = taps [group_in][ksize][C] | bias [C] (zeros if
                                    none) | gamma [C] (ones) | beta [C] (zeros); replaces w / bias and the values of
                                    gamma / beta (whose pointers still say whether the set has a LayerNorm) */
+    const vrd_row_segs* segs;   /* nullable (host memory): the INPUT rows as groups of sequences (T[i] % stride == 0; row[i] even when
+                                   x_up or stride 2 is used) -- B and Tin are then ignored; group i's output rows start at
+                                   row[i] / stride, its x_up rows at row[i] / 2 */
 } vrd_dwconv_ln_args;
 int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
 
@@ -292,6 +307,10 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream);
 int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld,
                    const uint8_t* mask, const float* rel_pe, int B, int T, int C, int n_head, int half_win,
                    float* out, int64_t ldo, int out_pair, void* stream);
+/* The same over a ragged row space (segs: groups of sequences, see vrd_row_segs) in one launch. */
+int vrd_local_attn_segs(const float* q, const float* k, const float* v, int64_t ld,
+                        const uint8_t* mask, const float* rel_pe, const vrd_row_segs* segs, int C, int n_head, int half_win,
+                        float* out, int64_t ldo, int out_pair, void* stream);
 
 /* ---- global masked attention, models/local_transformer.py:163-183 and :44-63 -------------
  * out[b,tq,h,:] = softmax_j(q.k_j / sqrt(hd) | kv_mask[b,j]) . v_j ; keys with mask 0 get

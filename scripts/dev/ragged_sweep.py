@@ -16,10 +16,14 @@ lens = torch.randint(2, frames + 1, (pairs,), generator=gen)
 lens[0] = frames
 x, m = synth.synth_pairs(pairs, configs.input_channels(cfg), t_pad, lens.tolist(), seed=1234, device=dev)
 ref = None
-combos = [(int(a), int(b)) for a, b in (c.split(":") for c in sys.argv[1:])] or [(262144, 1)]
+# arguments: "min_rows:streams" = bucket by bucket, "rows:min_rows" = all buckets in one row space
+combos = [c.split(":") for c in sys.argv[1:]] or [["262144", "1"]]
 with torch.no_grad():
-    for min_rows, streams in combos:
-        model.TIGHT_MIN_ROWS, model.TIGHT_STREAMS = min_rows, streams
+    for a, b in combos:
+        if a == "rows":
+            model.row_space, model.ROWS_MIN_ROWS, min_rows, streams = True, int(b), int(b), 0
+        else:
+            model.row_space, model.TIGHT_MIN_ROWS, model.TIGHT_STREAMS, min_rows, streams = False, int(a), int(b), int(a), int(b)
         model.__dict__.pop("_tight_stream_pool", None)
         for _ in range(3):
             out = model._mask_vrd(x, m.clone(), with_aux=False)
@@ -30,11 +34,11 @@ with torch.no_grad():
             out = model._mask_vrd(x, m.clone(), with_aux=False)
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / K
-        plan = model._tight_plan(m, m.reshape(pairs, -1))
+        plan = model._tight_plan(m.clone(), m.reshape(pairs, -1))["buckets"]
         res = (out["pred_logits"].clone(), out["pred_masks"].clone())
         if ref is None:
             ref = res
         same = all(torch.equal(a, b) for a, b in zip(ref, res))
         dl = max(float((a - b).abs().max()) for a, b in zip(ref, res))
-        print(f"min_rows {min_rows:7d} streams {streams}: {ms:6.1f} ms/step, buckets {[(t, n) for t, _, n in plan]}, "
+        print(f"{'row space' if streams == 0 else 'buckets  '} min_rows {min_rows:7d} streams {streams}: {ms:6.1f} ms/step, buckets {[(t, n) for t, _, n, _ in plan]}, "
               f"{'bit-equal to the first setting' if same else 'max |diff| vs first %.3g' % dl}", flush=True)

@@ -165,16 +165,19 @@ def test_tight_padding_gives_the_same_outputs(precision):
     assert model.tight_padding
     try:
         model.TIGHT_MIN_ROWS = 16384           # (buckets this small only here: the default merges a 300-pair batch into one)
+        model.row_space = False                # (bucket by bucket here; the row-space form has its own test below)
         plan = model._tight_plan(md, md.reshape(B, T))
-        assert plan is not None and len(plan) >= 3 and sum(n for _, _, n in plan) == B and max(t for t, _, _ in plan) == T
-        for t2, idx, n in plan:
+        assert plan is not None and not plan["rows"]
+        plan = plan["buckets"]
+        assert len(plan) >= 3 and sum(n for _, _, n, _ in plan) == B and max(t for t, _, _, _ in plan) == T
+        for t2, idx, n, _ in plan:
             assert all(model.tight_len(int(lens[i]), T) <= t2 for i in idx.tolist())
         tight = model._mask_vrd(xd, md)
         model.tight_padding = False
         full = model._mask_vrd(xd, md.clone())
     finally:
         model.tight_padding = True
-        del model.TIGHT_MIN_ROWS
+        del model.TIGHT_MIN_ROWS, model.row_space
     tol = 2e-4 if precision == "bf16x3" else 2e-5
     close(tight["pred_logits"], full["pred_logits"], tol)
     close(tight["pred_masks"], full["pred_masks"], 10 * tol)
@@ -184,6 +187,48 @@ def test_tight_padding_gives_the_same_outputs(precision):
         close(a["pred_masks"], b["pred_masks"], 10 * tol)
     pad = ~m[:, 0][:, None, :].expand(-1, tight["pred_masks"].shape[1], -1)
     assert bool((tight["pred_masks"].cpu()[pad] == -10.0).all())
+
+
+@pytest.mark.parametrize("name,B,T,chunk", [("vidvrd", 300, 288, None), ("vidvrd", 130, 96, 48), ("vidor", 96, 512, None),
+                                            ("vidor_x", 64, 512, None), ("vidor_local", 64, 512, 40)])
+def test_row_space_form_gives_the_same_outputs(name, B, T, chunk, precision):
+    """A ragged batch with all its tight-padding buckets in ONE row space (models/ragged.py: LayerNorm and every dense conv GEMM
+    once over all rows -- the k = 3 embedding convs with every sequence's last, padded frame zeroed in their input --, the
+    kernels that need (sequences, frames) structure bucket by bucket) against the same batch computed at the batch's own padded
+    length: the same numbers up to the rounding of differently shaped launches, in the reference's layout; all four shipped
+    configs (banded and global SOS attention, CLIP slabs, 4 x 128 and 8 x 64 heads), also in waves (pair_chunk)."""
+    model, mc, _, _ = get_model(name)
+    gen = torch.Generator().manual_seed(177)
+    lens = torch.randint(2, T - 30, (B,), generator=gen)
+    lens[:7] = torch.tensor([T - 2, T - 8, T - 9, 2, 33, T, T - 1])    # (T, T - 1: no two padded frames behind them -- a bucket apart)
+    x, m = O.synth_pairs(B, c_in(mc), T, lens.tolist(), seed=178)
+    xd, md = x.to(DEV), m.to(DEV)
+    old_chunk = model.pair_chunk
+    try:
+        model.ROWS_MIN_ROWS = 2048             # (buckets this small only here)
+        if chunk:
+            model.pair_chunk = chunk
+        plan = model._tight_plan(md, md.reshape(B, T))
+        assert plan is not None and plan["rows"] and len(plan["buckets"]) >= 3
+        for t2, idx, n, flat in plan["buckets"]:
+            assert all((int(lens[i]) <= t2 - 2) == flat for i in idx.tolist())
+        assert [f for _, _, _, f in plan["buckets"]].count(False) == 1
+        rows = model._mask_vrd(xd, md)
+        model.tight_padding = False
+        full = model._mask_vrd(xd, md.clone())
+    finally:
+        model.tight_padding = True
+        model.pair_chunk = old_chunk
+        del model.ROWS_MIN_ROWS
+    tol = 2e-4 if precision == "bf16x3" else 2e-5
+    close(rows["pred_logits"], full["pred_logits"], tol)
+    close(rows["pred_masks"], full["pred_masks"], 10 * tol)
+    assert torch.equal(rows["output_mask"], full["output_mask"]) and len(rows["aux_outputs"]) == len(full["aux_outputs"]) == 3
+    for a, b in zip(rows["aux_outputs"], full["aux_outputs"]):
+        close(a["pred_logits"], b["pred_logits"], tol)
+        close(a["pred_masks"], b["pred_masks"], 10 * tol)
+    pad = ~m[:, 0][:, None, :].expand(-1, rows["pred_masks"].shape[1], -1)
+    assert bool((rows["pred_masks"].cpu()[pad] == -10.0).all())
 
 
 @pytest.mark.parametrize("scale", [1.0 / 1024, 1.0 / 32, 1.0, 48.0])

@@ -287,6 +287,63 @@ def test_local_attention_kernel(H, w):
     assert float((want_rel - want).abs().max()) > 0.1
 
 
+@pytest.mark.parametrize("C,ks,stride,gin,up,pre", [(512, 3, 1, 1, False, True), (512, 3, 2, 1, False, True), (256, 3, 1, 1, True, False),
+                                                     (256, 3, 1, 2, False, False), (512, 1, 1, 1, False, False)])
+def test_dwconv_ln_over_row_groups_equals_the_calls_per_group(C, ks, stride, gin, up, pre):
+    """vrd_dwconv_ln over a ragged row space (vrd_row_segs: groups of sequences of different lengths back to back, one
+    launch) gives, bit for bit, what one call per group gives -- strides, the FPN's upsample-add, the 2-in-per-group conv,
+    the input LayerNorm, pair-row outputs; 40 groups take two launches' worth of tables (the host side splits them)."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(C * 7 + ks + stride + gin)
+    groups = [(5, 32), (1, 64), (7, 96), (3, 160), (2, 34 if stride == 1 and not up else 36)]
+    R = sum(n * T for n, T in groups)
+    x = torch.randn(1, R, C * gin, generator=gen).to(DEV)
+    xu = torch.randn(1, R // 2, C * gin, generator=gen).to(DEV) if up else None
+    mask = (torch.rand(1, R // stride, generator=gen) > 0.4).to(DEV)
+    mask[0, :40] = False                                        # whole strips of padding
+    dv = lambda *shape: torch.randn(*shape, generator=gen).to(DEV)     # noqa: E731
+    sets = [dict(weight=dv(C, gin, ks), bias=dv(C) if o == 1 else None, gamma=None if o == 2 else dv(1, C, 1),
+                 beta=None if o == 2 else dv(1, C, 1), relu=(o == 0), pair=(o == 1 and ops.pair_mode()))
+            for o in range(3 if gin == 1 else 1)]
+    pre_ln = (dv(1, C, 1), dv(1, C, 1)) if pre else None
+    segs, off = [], 0
+    for n, T in groups:
+        segs.append((off, n, T))
+        off += n * T
+    got = ops.dwconv_ln(x, sets, mask_out=mask, stride=stride, x_up=xu, pre_ln=pre_ln, segs=segs)
+    for off, n, T in segs:
+        part = lambda t, d: None if t is None else t[0, off // d:(off + n * T) // d].unflatten(0, (n, T // d))   # noqa: E731
+        want = ops.dwconv_ln(part(x, 1), sets, mask_out=part(mask, stride), stride=stride, x_up=part(xu, 2), pre_ln=pre_ln)
+        for g, w in zip(got, want):
+            raw = lambda t: t.t if isinstance(t, ops.Pair) else t     # noqa: E731
+            assert torch.equal(part(raw(g), stride), raw(w))
+
+
+@pytest.mark.parametrize("H,w,rel", [(4, 3, False), (8, 4, True)])
+def test_local_attention_over_row_groups_equals_the_calls_per_group(H, w, rel):
+    """vrd_local_attn_segs (one launch over groups of sequences of different lengths) against vrd_local_attn per group: the
+    same bits; windows never reach across a sequence's end into the next group."""
+    from vrdone_amd import ops
+    gen = torch.Generator().manual_seed(H + w)
+    groups = [(4, 32), (1, 50), (6, 96), (2, 17), (3, 288)]
+    R = sum(n * T for n, T in groups)
+    q, k, v = (torch.randn(1, R, 512, generator=gen).to(DEV) for _ in range(3))
+    mask = (torch.rand(1, R, generator=gen) > 0.3).to(DEV)
+    mask[0, 32:64] = False
+    rel_pe = torch.randn(1, 1, H, 2 * w + 1, generator=gen).to(DEV) if rel else None
+    segs, off = [], 0
+    for n, T in groups:
+        segs.append((off, n, T))
+        off += n * T
+    for pair in (False, ops.pair_mode()):
+        got = ops.local_attention(q, k, v, mask, H, w, pair=pair, rel_pe=rel_pe, segs=segs)
+        for off, n, T in segs:
+            part = lambda t: t[0, off:off + n * T].unflatten(0, (n, T))     # noqa: E731
+            want = ops.local_attention(part(q), part(k), part(v), part(mask), H, w, pair=pair, rel_pe=rel_pe)
+            raw = lambda t: t.t if isinstance(t, ops.Pair) else t     # noqa: E731
+            assert torch.equal(part(raw(got)), raw(want))
+
+
 @pytest.mark.parametrize("algo", [1, 2])
 @pytest.mark.parametrize("H,hd,Tq,Tk", [(4, 128, 96, 96), (8, 64, 144, 144), (4, 128, 288, 288), (8, 64, 512, 512),
                                         (4, 128, 40, 77), (4, 64, 9, 36)])

@@ -51,6 +51,24 @@ class GemmArgs(C.Structure):
                 ("split_fmt", C.c_int32), ("w_scale", c_f32p), ("a_scale", c_f32p)]
 
 
+MAX_SEGS = 32                                     # VRD_MAX_SEGS
+
+
+class RowSegs(C.Structure):
+    """vrd_row_segs: a ragged row space as groups of sequences (n[i] sequences of T[i] frames from row row[i] on)"""
+    _fields_ = [("count", C.c_int32), ("n", C.c_int32 * MAX_SEGS), ("T", C.c_int32 * MAX_SEGS), ("row", C.c_int64 * MAX_SEGS)]
+
+    @classmethod
+    def of(cls, segs):
+        """segs: [(first row, sequences, frames)]"""
+        assert 1 <= len(segs) <= MAX_SEGS
+        s = cls()
+        s.count = len(segs)
+        for i, (row, n, T) in enumerate(segs):
+            s.row[i], s.n[i], s.T[i] = row, n, T
+        return s
+
+
 class DwconvLnArgs(C.Structure):
     _fields_ = [("x", c_f32p), ("ldx", C.c_int64), ("x_up", c_f32p), ("ldx_up", C.c_int64),
                 ("B", C.c_int32), ("Tin", C.c_int32), ("C", C.c_int32), ("ksize", C.c_int32),
@@ -58,7 +76,7 @@ class DwconvLnArgs(C.Structure):
                 ("mask_out", c_u8p), ("n_out", C.c_int32),
                 ("w", c_f32p * 3), ("bias", c_f32p * 3), ("gamma", c_f32p * 3), ("beta", c_f32p * 3),
                 ("relu", C.c_int32 * 3), ("y", c_f32p * 3), ("ldy", C.c_int64 * 3), ("out_pair", C.c_int32 * 3),
-                ("pre_gamma", c_f32p), ("pre_beta", c_f32p), ("packed", c_f32p * 3)]
+                ("pre_gamma", c_f32p), ("pre_beta", c_f32p), ("packed", c_f32p * 3), ("segs", C.POINTER(RowSegs))]
 
 
 class PackArgs(C.Structure):
@@ -129,6 +147,8 @@ _SIGNATURES = {
     "vrd_dwconv_ln": (C.c_int, [C.POINTER(DwconvLnArgs), C.c_void_p]),
     "vrd_local_attn": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_u8p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+    "vrd_local_attn_segs": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_u8p, c_f32p, C.POINTER(RowSegs), C.c_int, C.c_int,
+                                      C.c_int, c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "vrd_attention": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_attention_pair": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, c_u8p, c_u8p, C.c_int, C.c_int, C.c_int,
@@ -174,7 +194,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 
 class HipLibraryError(RuntimeError):

@@ -100,9 +100,9 @@ template <int W, int GROUP, int RW, bool REL>
 __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                const float* __restrict__ v, int64_t ld,
                                                                const uint8_t* __restrict__ mask, const float* __restrict__ rel,
-                                                               int B, int T, int strips_per_seq,
+                                                               int B, int T_u, int strips_per_seq,
                                                                float scale, float* __restrict__ out, int64_t ldo, int pair,
-                                                               unsigned* rflag) {
+                                                               unsigned* rflag, vrd::SegTable sg) {
     constexpr int HW = W / 2, R = W + 1;
     vrd::RangeTrack rt;
     const int lane = threadIdx.x & 63;
@@ -110,11 +110,18 @@ __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __re
     const int xcd = bid & 7, qq = nwg >> 3, rem = nwg & 7;
     const int lid = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (bid >> 3);
     const int64_t ws = (int64_t)lid * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = (int)(ws / strips_per_seq);
-    if (b >= B) return;
-    const int t0 = (int)(ws - (int64_t)b * strips_per_seq) * RW;
+    int T, t0;
+    int64_t row_b;
+    if (sg.count) {                                  // ragged row space: groups of sequences of different lengths
+        int g, b, strip;
+        if (!vrd::seg_find(sg, ws, g, b, strip)) return;
+        T = sg.T[g], t0 = strip * RW, row_b = sg.row[g] + (int64_t)b * T;
+    } else {
+        const int b = (int)(ws / strips_per_seq);
+        if (b >= B) return;
+        T = T_u, t0 = (int)(ws - (int64_t)b * strips_per_seq) * RW, row_b = (int64_t)b * T;
+    }
     const int t1 = min(t0 + RW, T);
-    const int64_t row_b = (int64_t)b * T;
     // validity of rows t0 - HW .. t0 + RW + HW - 1 as one bit each (bit i = row t0 - HW + i; outside [0, T) = 0)
     const int tm = t0 - HW + lane;
     const unsigned long long live = __ballot(lane < RW + 2 * HW && tm >= 0 && tm < T && mask[row_b + (tm >= 0 && tm < T ? tm : 0)] != 0);
@@ -500,16 +507,42 @@ inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr
 
 extern "C" {
 
+static int local_attn_launch(const float* q, const float* k, const float* v, int64_t ld, const uint8_t* mask, const float* rel_pe,
+                             int B, int T, const vrd_row_segs* segs, int C, int n_head, int half_win, float* out, int64_t ldo,
+                             int out_pair, void* stream);
+
 int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, const uint8_t* mask, const float* rel_pe,
                    int B, int T, int C, int n_head, int half_win, float* out, int64_t ldo, int out_pair, void* stream) {
+    VRD_CHECK_ARG(B > 0 && T > 0, "vrd_local_attn: bad B / T");
+    return local_attn_launch(q, k, v, ld, mask, rel_pe, B, T, nullptr, C, n_head, half_win, out, ldo, out_pair, stream);
+}
+
+int vrd_local_attn_segs(const float* q, const float* k, const float* v, int64_t ld, const uint8_t* mask, const float* rel_pe,
+                        const vrd_row_segs* segs, int C, int n_head, int half_win, float* out, int64_t ldo, int out_pair,
+                        void* stream) {
+    VRD_CHECK_ARG(segs, "vrd_local_attn_segs: null row groups");
+    return local_attn_launch(q, k, v, ld, mask, rel_pe, 0, 0, segs, C, n_head, half_win, out, ldo, out_pair, stream);
+}
+
+static int local_attn_launch(const float* q, const float* k, const float* v, int64_t ld, const uint8_t* mask, const float* rel_pe,
+                             int B, int T, const vrd_row_segs* segs, int C, int n_head, int half_win, float* out, int64_t ldo,
+                             int out_pair, void* stream) {
     VRD_CHECK_ARG(q && k && v && mask && out, "vrd_local_attn: null pointer");
     VRD_CHECK_ARG(C == 512, "vrd_local_attn: built for C = 512 (got %d)", C);
     VRD_CHECK_ARG(n_head == 4 || n_head == 8, "vrd_local_attn: n_head must be 4 or 8 (got %d)", n_head);
     VRD_CHECK_ARG(half_win == 3 || half_win == 4, "vrd_local_attn: window must be 7 or 9 (half %d)", half_win);
-    VRD_CHECK_ARG(B > 0 && T > 0 && ld >= C && ldo >= C && ld % 4 == 0 && ldo % 4 == 0 && aligned16(q) && aligned16(k) &&
+    VRD_CHECK_ARG(ld >= C && ldo >= C && ld % 4 == 0 && ldo % 4 == 0 && aligned16(q) && aligned16(k) &&
                       aligned16(v) && aligned16(out), "vrd_local_attn: bad layout");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t rows = (int64_t)B * T;
+    vrd::SegTable sg;
+    sg.count = 0;
+    int64_t rows = (int64_t)B * T, seg_strips = 0;
+    if (segs) {
+        seg_strips = vrd::seg_table(sg, segs, 1, 16);
+        VRD_CHECK_ARG(seg_strips >= 0, "vrd_local_attn_segs: bad row groups (1..%d groups)", VRD_MAX_SEGS);
+        rows = 0;
+        for (int g = 0; g < sg.count; ++g) rows += (int64_t)sg.n[g] * sg.T[g];
+    }
     const int W = 2 * half_win + 1;
     vrd::ProfScope prof(VRD_K_LOCAL_ATTN, s, 4.0 * (double)rows * W * C, 16.0 * (double)rows * C);
     const float scale = 1.0f / sqrtf((float)(C / n_head));
@@ -517,18 +550,18 @@ int vrd_local_attn(const float* q, const float* k, const float* v, int64_t ld, c
     // strips of 16 query rows per wave (default; 32 measured the same) or, VRD_LOCAL_STRIP=0, one wave per query row
     // (6.1 vs 5.6 ms per step at the benchmark shape)
     static const int strip_env = [] { const char* e = getenv("VRD_LOCAL_STRIP"); return e ? atoi(e) : 1; }();
-    if (strip_env) {
+    if (strip_env || segs) {
         constexpr int RW = 16;
         const int strips = (T + RW - 1) / RW;
-        dim3 grid((unsigned)(((int64_t)B * strips + 3) / 4)), block(256);
+        dim3 grid((unsigned)(((segs ? seg_strips : (int64_t)B * strips) + 3) / 4)), block(256);
 #define VRD_LS(Wn, G)                                                                                                     \
     do {                                                                                                                  \
         if (rel_pe)                                                                                                       \
             hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW, true>), grid, block, 0, s, q, k, v, ld, mask, rel_pe,   \
-                               B, T, strips, scale, out, ldo, out_pair, rflag);                                                  \
+                               B, T, strips, scale, out, ldo, out_pair, rflag, sg);                                              \
         else                                                                                                              \
             hipLaunchKernelGGL((local_attn_strip_kernel<Wn, G, RW, false>), grid, block, 0, s, q, k, v, ld, mask, rel_pe,  \
-                               B, T, strips, scale, out, ldo, out_pair, rflag);                                                  \
+                               B, T, strips, scale, out, ldo, out_pair, rflag, sg);                                              \
     } while (0)
         if (half_win == 3 && n_head == 4) VRD_LS(7, 16);
         else if (half_win == 3) VRD_LS(7, 8);

@@ -17,6 +17,41 @@ int reserve_lds(const void* kernel, size_t bytes, const char* what);
 // CUs of the CURRENT device (cached per device ordinal: a process may drive devices of different sizes / partition modes)
 int device_cu_count();
 
+// The device's image of a vrd_row_segs ragged row space for a kernel whose waves walk strips of `rw` rows of one sequence: group g
+// = n[g] sequences of T[g] frames from row row[g] on, sps[g] strips per sequence, the group's first strip strip0[g].  Passed by
+// value as a kernel argument (scalar loads); count == 0: the caller's uniform (B, T).
+struct SegTable {
+    int count;
+    int n[VRD_MAX_SEGS], T[VRD_MAX_SEGS], sps[VRD_MAX_SEGS];
+    int64_t row[VRD_MAX_SEGS], strip0[VRD_MAX_SEGS + 1];
+};
+// host: fill `t` for strips of rw rows over T[g] / t_div frames per sequence; returns the number of strips (or -1: bad table)
+inline int64_t seg_table(SegTable& t, const vrd_row_segs* s, int t_div, int rw) {
+    t.count = 0;
+    if (!s || s->count < 1 || s->count > VRD_MAX_SEGS) return -1;
+    int64_t at = 0;
+    for (int g = 0; g < s->count; ++g) {
+        if (s->n[g] <= 0 || s->T[g] <= 0 || s->T[g] % t_div || s->row[g] < 0) return -1;
+        t.n[g] = s->n[g], t.T[g] = s->T[g], t.row[g] = s->row[g];
+        t.sps[g] = (s->T[g] / t_div + rw - 1) / rw;
+        t.strip0[g] = at;
+        at += (int64_t)t.n[g] * t.sps[g];
+    }
+    t.count = s->count;
+    t.strip0[s->count] = at;
+    return at;
+}
+// device: strip ws -> (group g, sequence b of the group, strip of the sequence); false behind the last strip
+__device__ __forceinline__ bool seg_find(const SegTable& t, int64_t ws, int& g, int& b, int& strip) {
+    if (ws >= t.strip0[t.count]) return false;
+    g = 0;
+    while (g + 1 < t.count && ws >= t.strip0[g + 1]) ++g;
+    const int64_t r = ws - t.strip0[g];
+    b = (int)(r / t.sps[g]);
+    strip = (int)(r - (int64_t)b * t.sps[g]);
+    return true;
+}
+
 // A wave-uniform read of kernel INPUT data (written before the launch, never by it) through the scalar cache: s_load instead
 // of a flat_load, which hipcc would follow with `s_waitcnt vmcnt(0)` -- a wait for every vector memory operation the wave has
 // in flight (its LDS-DMA requests, its stores), not just for this value.

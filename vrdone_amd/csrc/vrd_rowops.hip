@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 constexpr int DW_RW = 16;                      // output rows per wave (default; the launcher may pick 8..32, see vrd_dwconv_ln)
 
 template <int NV, int KS, int GIN>
-__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout, int strips_per_seq, int strips_per_wave, int rw, unsigned* rflag) {
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, int Tout_u, int strips_per_seq, int strips_per_wave, int rw, unsigned* rflag,
+                                                        vrd::SegTable sg) {
     vrd::RangeTrack rt;
     constexpr int C = 256 * NV, NT = GIN * KS, SETF = (NT + 3) * C;
     constexpr bool WIDE = NV == 2 && GIN == 1;
@@ -359,9 +360,22 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     // the parameter blocks are filled once per workgroup; each wave then walks strips_per_wave consecutive strips
     for (int si = 0; si < strips_per_wave; ++si) {
     const int64_t ws = ((int64_t)lid * 4 + wave) * strips_per_wave + si;
-    const int b = (int)(ws / strips_per_seq);
-    if (b >= p.B) break;
-    const int to0 = (int)(ws - (int64_t)b * strips_per_seq) * rw;
+    // the strip's sequence: its frame counts and the first row of its input / coarser-level / output rows
+    int Tin, Tout, to0;
+    int64_t xrow0, urow0, orow0;
+    if (sg.count) {                                  // ragged row space: groups of sequences of different lengths
+        int g, b, strip;
+        if (!vrd::seg_find(sg, ws, g, b, strip)) break;
+        Tin = sg.T[g], Tout = Tin / p.stride, to0 = strip * rw;
+        xrow0 = sg.row[g] + (int64_t)b * Tin;
+        urow0 = sg.row[g] / 2 + (int64_t)b * (Tin / 2);
+        orow0 = sg.row[g] / p.stride + (int64_t)b * Tout;
+    } else {
+        const int b = (int)(ws / strips_per_seq);
+        if (b >= p.B) break;
+        Tin = p.Tin, Tout = Tout_u, to0 = (int)(ws - (int64_t)b * strips_per_seq) * rw;
+        xrow0 = (int64_t)b * Tin, urow0 = (int64_t)b * (Tin / 2), orow0 = (int64_t)b * Tout;
+    }
     const int to1 = min(to0 + rw, Tout);
 
     struct Row {
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     };
     auto load_row = [&](int ti) {
         Row r;
-        const bool ok = ti >= 0 && ti < p.Tin;
+        const bool ok = ti >= 0 && ti < Tin;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
@@ -377,8 +391,8 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok) {
                     const int64_t coff = (int64_t)GIN * lane_chan<NV, WIDE>(i, lane) + 4 * g;
-                    v = ld4(p.x + ((int64_t)b * p.Tin + ti) * p.ldx + coff);
-                    if (p.x_up) v = f4add(v, ld4(p.x_up + ((int64_t)b * (p.Tin / 2) + (ti >> 1)) * p.ldx_up + coff));
+                    v = ld4(p.x + (xrow0 + ti) * p.ldx + coff);
+                    if (p.x_up) v = f4add(v, ld4(p.x_up + (urow0 + (ti >> 1)) * p.ldx_up + coff));
                 }
                 r.v[i][g] = v;
             }
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     // ---- a strip of padded frames only (every mask_out byte 0): conv * 0 = 0, so each row is LayerNorm(0) = beta
     // (0 without LayerNorm), ReLU applied -- written without reading the input.  Same bits as the path below.
     if (p.mask_out) {
-        const int64_t r0 = (int64_t)b * Tout + to0;
+        const int64_t r0 = orow0 + to0;
         const bool mine = lane < to1 - to0 && p.mask_out[r0 + lane] != 0;
         if (!__any(mine)) {
 #pragma unroll
@@ -412,7 +426,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                     }
                 }
                 for (int to = to0; to < to1; ++to) {
-                    const int64_t row = (int64_t)b * Tout + to;
+                    const int64_t row = orow0 + to;
                     if (WIDE && p.out_pair[o]) {
                         vrd::store_pair8(p.y[o] + row * p.ldy[o], lane * 8, val[0], val[NV - 1], p.out_pair[o], &rt);
                     } else {
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 nxt[1] = load_row(tn + 2);
             }
         }
-        const int64_t row = (int64_t)b * Tout + to;
+        const int64_t row = orow0 + to;
         const float mk = p.mask_out ? (float)p.mask_out[row] : 1.f;
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
@@ -747,7 +761,7 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     VRD_CHECK_ARG(a->stride == 1 || a->stride == 2, "vrd_dwconv_ln: stride must be 1 or 2");
     VRD_CHECK_ARG(a->group_in == 1 || (a->group_in == 2 && a->C == 256 && a->ksize == 3),
                   "vrd_dwconv_ln: group_in=2 is only built for C=256, ksize=3");
-    VRD_CHECK_ARG(a->B > 0 && a->Tin > 0 && a->Tin % a->stride == 0, "vrd_dwconv_ln: Tin %% stride != 0");
+    VRD_CHECK_ARG(a->segs || (a->B > 0 && a->Tin > 0 && a->Tin % a->stride == 0), "vrd_dwconv_ln: Tin %% stride != 0");
     VRD_CHECK_ARG(a->n_out >= 1 && a->n_out <= 3, "vrd_dwconv_ln: n_out must be 1..3");
     VRD_CHECK_ARG((a->pre_gamma == nullptr) == (a->pre_beta == nullptr) && (!a->pre_gamma || (a->group_in == 1 && !a->x_up)),
                   "vrd_dwconv_ln: input LayerNorm needs gamma and beta, group_in == 1 and no x_up");
@@ -759,11 +773,25 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
                       "vrd_dwconv_ln: bad output set %d", o);
         VRD_CHECK_ARG((a->gamma[o] == nullptr) == (a->beta[o] == nullptr), "vrd_dwconv_ln: gamma/beta mismatch");
     }
-    const int Tout = a->Tin / a->stride;
-    const int64_t rows = (int64_t)a->B * Tout;
+    vrd::SegTable sg;
+    sg.count = 0;
+    int64_t rows_in = (int64_t)a->B * a->Tin;
+    int Tmax = a->Tin;
+    if (a->segs) {
+        const int even = (a->x_up || a->stride == 2) ? 2 : 1;
+        VRD_CHECK_ARG(vrd::seg_table(sg, a->segs, even, 16) >= 0, "vrd_dwconv_ln: bad row groups (1..%d groups, T %% %d == 0)", VRD_MAX_SEGS, even);
+        rows_in = 0, Tmax = 0;
+        for (int g = 0; g < sg.count; ++g) {
+            VRD_CHECK_ARG(sg.row[g] % even == 0, "vrd_dwconv_ln: a group's first row must be even with stride 2 / x_up");
+            rows_in += (int64_t)sg.n[g] * sg.T[g];
+            Tmax = sg.T[g] > Tmax ? sg.T[g] : Tmax;
+        }
+    }
+    const int Tout = Tmax / a->stride;
+    const int64_t rows = rows_in / a->stride;
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_DWCONV_LN, s, 0.0,
-                        4.0 * ((double)a->B * a->Tin * a->C * a->group_in * (a->x_up ? 1.5 : 1.0) + (double)rows * a->C * a->n_out));
+                        4.0 * ((double)rows_in * a->C * a->group_in * (a->x_up ? 1.5 : 1.0) + (double)rows * a->C * a->n_out));
     const size_t lds = ((size_t)a->n_out * (a->group_in * a->ksize + 3) + (a->pre_gamma ? 2 : 0)) * a->C * sizeof(float);
     // rows per strip: 16 when the launch is many rounds of resident waves; for a small launch (e.g. one GPU's
     // 256-pair shard: 4608 strips of 16 against 4096 resident waves = two rounds for 1.1 rounds of work) the strip
@@ -774,10 +802,13 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
         const int64_t wgs_per_cu = lds ? (int64_t)(160 * 1024 / lds) : 8;
         // (the 512-channel variants use ~110 VGPRs: four waves per SIMD, i.e. four workgroups per CU at most)
         const int64_t resident = 256 * (wgs_per_cu < 1 ? 1 : wgs_per_cu > 4 ? 4 : wgs_per_cu) * 4;      // waves
-        if ((int64_t)a->B * ((Tout + DW_RW - 1) / DW_RW) < 6 * resident) {
+        auto strips_at = [&](int r) -> int64_t {
+            return a->segs ? vrd::seg_table(sg, a->segs, a->stride, r) : (int64_t)a->B * ((Tout + r - 1) / r);
+        };
+        if (strips_at(DW_RW) < 6 * resident) {
             double best = 1e30;
             for (int r = 8; r <= 32; ++r) {
-                const int64_t n = (int64_t)a->B * ((Tout + r - 1) / r);
+                const int64_t n = strips_at(r);
                 const double cost = (double)((n + resident - 1) / resident) * (r + 3);
                 if (cost < best - 1e-9) best = cost, rw = r;
             }
@@ -790,13 +821,13 @@ int vrd_dwconv_ln(const vrd_dwconv_ln_args* a, void* stream) {
     // 16.1 ms per step): the kernel runs at ~4.8 TB/s, three quarters of it writes, and more, shorter workgroups
     // keep more of them in flight
     static const int spw_env = [] { const char* e = getenv("VRD_DW_SPW"); return e ? atoi(e) : 0; }();
-    const int64_t total_strips = (int64_t)a->B * strips;
+    const int64_t total_strips = a->segs ? vrd::seg_table(sg, a->segs, a->stride, rw) : (int64_t)a->B * strips;
     const int spw = spw_env > 0 ? spw_env : 1;
     dim3 grid((unsigned)((total_strips + 4 * spw - 1) / (4 * spw))), block(256);
     bool any_f16 = false;
     for (int o = 0; o < a->n_out; ++o) any_f16 |= a->out_pair[o] == VRD_PAIR_F16;
     unsigned* const rflag = any_f16 ? vrd::range_flag() : nullptr;
-#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips, spw, rw, rflag)
+#define VRD_DW(NV, KS, GIN) hipLaunchKernelGGL((dwconv_ln_kernel<NV, KS, GIN>), grid, block, lds, s, *a, Tout, strips, spw, rw, rflag, sg)
     if (a->group_in == 2) VRD_DW(1, 3, 2);
     else if (a->C == 256 && a->ksize == 3) VRD_DW(1, 3, 1);
     else if (a->C == 256) VRD_DW(1, 1, 1);

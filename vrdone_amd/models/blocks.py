@@ -200,13 +200,11 @@ class _ConvAttention(nn.Module):
         # the branch output feeds only its 1x1 projection GEMM
         return dict(weight=conv.conv.weight, gamma=norm.weight, beta=norm.bias, pair=_ops().pair_mode())
 
-    def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1, pre_ln=None, pre_ln_on="qkv"):
-        """dwconv * mask -> LN for the three branches; branches that read the same rows (same input tensor, mask,
-        kernel size and input-LayerNorm choice) share one kernel launch.
-        pre_ln (gamma, beta): inputs named in pre_ln_on ('q', 'k', 'v') are LayerNorm'ed as they are read."""
-        ops = _ops()
+    def _groups(self, q_in, k_in, v_in, q_mask, kv_mask, pre_ln=None, pre_ln_on="qkv"):
+        """[(x, mask, use_ln, kernel size, [branch names])]: branches that read the same rows (same input tensor, mask, kernel
+        size and input-LayerNorm choice) share one dwconv_ln launch."""
         specs = [("query", q_in, q_mask, "q"), ("key", k_in, kv_mask, "k"), ("value", v_in, kv_mask, "v")]
-        groups = []          # [(x, mask, use_ln, ks, [names])]
+        groups = []
         for name, x, m, tag in specs:
             ks = getattr(self, f"{name}_conv").conv.kernel_size
             use_ln = pre_ln is not None and tag in pre_ln_on
@@ -216,8 +214,14 @@ class _ConvAttention(nn.Module):
                     break
             else:
                 groups.append((x, m, use_ln, ks, [name]))
+        return groups
+
+    def _prep(self, q_in, k_in, v_in, q_mask, kv_mask, stride=1, pre_ln=None, pre_ln_on="qkv"):
+        """dwconv * mask -> LN for the three branches (one launch per group of _groups).
+        pre_ln (gamma, beta): inputs named in pre_ln_on ('q', 'k', 'v') are LayerNorm'ed as they are read."""
+        ops = _ops()
         outs = {}
-        for x, m, use_ln, _, names in groups:
+        for x, m, use_ln, _, names in self._groups(q_in, k_in, v_in, q_mask, kv_mask, pre_ln, pre_ln_on):
             res = ops.dwconv_ln(x, [self._branch_set(n) for n in names], mask_out=m, stride=stride,
                                 pre_ln=pre_ln if use_ln else None)
             outs.update(zip(names, res))

@@ -127,12 +127,14 @@ class MaskVRD(nn.Module):
         t = -(-need // unit) * unit
         return t if t < T else T
 
-    def tight_buckets(self, lens, t_refs):
-        """Padded length per pair: tight_len of its reference length t_refs[i], then buckets of fewer than TIGHT_MIN_ROWS rows
+    def tight_buckets(self, lens, t_refs, min_rows=None):
+        """Padded length per pair: tight_len of its reference length t_refs[i], then buckets of fewer than min_rows (TIGHT_MIN_ROWS) rows
         hand their pairs to the next longer bucket (a longer padding gives the same result; a handful of pairs per launch
         wave would run the small-shape kernels at a fraction of the large ones' rate) -- up to the pair's own reference length,
         never beyond.  Pairs that cannot shrink (no padded frame to spare: tight_len == their reference length) stay where the
         reference puts them."""
+        if min_rows is None:
+            min_rows = self.TIGHT_MIN_ROWS
         tight = [self.tight_len(L, T) for L, T in zip(lens, t_refs)]
         out = list(tight)
         flexible = {}
@@ -143,7 +145,7 @@ class MaskVRD(nn.Module):
                 flexible.setdefault(t, []).append(i)
         sizes = sorted(rows)
         for k, t in enumerate(sizes[:-1]):
-            if rows[t] < self.TIGHT_MIN_ROWS and t in flexible:
+            if rows[t] < min_rows and t in flexible:
                 nxt = sizes[k + 1]
                 moved = [i for i in flexible[t] if t_refs[i] >= nxt]        # (never beyond the reference's own padded length)
                 flexible[t] = [i for i in flexible[t] if t_refs[i] < nxt]
@@ -154,10 +156,19 @@ class MaskVRD(nn.Module):
                 flexible.setdefault(nxt, []).extend(moved)
         return out
 
+    # One row space for all buckets (models/ragged.py): the row-by-row kernels -- LayerNorm, every dense conv GEMM -- run once
+    # over all rows, so a bucket no longer has to fill the chip on its own and the buckets can be as fine as TIGHT_UNIT allows;
+    # only the kernels that need (sequences, frames) structure walk the buckets.  ROWS_MIN_ROWS: below this a bucket's own
+    # launches (depthwise convs, attention) are too small to be worth a launch each.
+    row_space = os.environ.get("VRDONE_ROW_SPACE", "1") != "0"
+    ROWS_MIN_ROWS = int(os.environ.get("VRDONE_ROWS_MIN_ROWS", "16384"))
+
     def _tight_plan(self, batched_masks, masks2d):
-        """[(T', pair indices (n,) int32 on the device, n)] for a batch whose masks are prefixes (t < len), or None when the
-        batch runs as it is (nothing to gain, masks with holes).  One small device-to-host copy per mask tensor (cached on it)."""
-        key = (batched_masks.data_ptr(), batched_masks._version, tuple(batched_masks.shape))
+        """{"buckets": [(T', pair indices (n,) int32 on the device, n)], "rows": the buckets can share one row space} for a
+        batch whose masks are prefixes (t < len), or None when the batch runs as it is (nothing to gain, masks with holes).
+        One small device-to-host copy per mask tensor (cached on it)."""
+        key = (batched_masks.data_ptr(), batched_masks._version, tuple(batched_masks.shape), self.row_space, self.TIGHT_MIN_ROWS,
+               self.ROWS_MIN_ROWS)
         hit = getattr(batched_masks, "_vrd_tight_plan", None)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -167,14 +178,42 @@ class MaskVRD(nn.Module):
         host = torch.stack([lens, last]).cpu()
         plan = None
         if bool((host[0] == host[1]).logical_or(host[0] == 0).all()):
+            lens_h = host[0].tolist()
+            rows = self.row_space and not self.use_abs_pe
             want = {}
-            for i, t2 in enumerate(self.tight_buckets(host[0].tolist(), [T] * B)):
-                want.setdefault(t2, []).append(i)
-            if not (len(want) == 1 and T in want):
+            for i, t2 in enumerate(self.tight_buckets(lens_h, [T] * B, self.ROWS_MIN_ROWS if rows else None)):
+                # the row-space form runs the dense k = 3 convs flat over the buckets whose sequences all end in two padded
+                # frames (models/ragged.py); a pair within one frame of its padded length goes into a bucket of its own kind
+                want.setdefault((not rows or lens_h[i] <= t2 - 2, t2), []).append(i)
+            if not all(t == T for _, t in want):           # (nothing shrinks: the batch runs as it is)
                 dev = masks2d.device
-                plan = [(t2, torch.tensor(idx, dtype=torch.int32, device=dev), len(idx)) for t2, idx in sorted(want.items())]
+                order = sorted(want, key=lambda k: (not k[0], k[1])) if rows else sorted(want, key=lambda k: k[1])
+                plan = {"buckets": [(t2, torch.tensor(want[(flat, t2)], dtype=torch.int32, device=dev), len(want[(flat, t2)]), flat)
+                                    for flat, t2 in order], "rows": rows}
         batched_masks._vrd_tight_plan = (key, plan)
         return plan
+
+    def _mask_vrd_rows(self, x, masks2d, plan, with_aux):
+        """_mask_vrd with all buckets in one row space (models/ragged.py), in waves of at most ~pair_chunk pairs."""
+        from . import ragged
+        buckets = plan["buckets"]
+        B = masks2d.shape[0]
+        step = self._chunk_size(B)
+        out, wave, room = None, [], step
+        for t2, idx, n, flat in buckets:
+            at = 0
+            while at < n:
+                take = min(n - at, room)
+                wave.append((t2, idx[at:at + take].contiguous(), take, flat))
+                at += take
+                room -= take
+                if room == 0:
+                    out = ragged.mask_vrd_rows(self, x, masks2d, wave, with_aux, out)
+                    wave, room = [], step
+        if wave:
+            out = ragged.mask_vrd_rows(self, x, masks2d, wave, with_aux, out)
+        out["output_mask"] = masks2d[:, None, :]
+        return out
 
     # buckets side by side: a bucket's launches are a fraction of the batch's, and from the third pyramid level on they no longer
     # fill the chip (a 256 x 256 GEMM tile per CU needs 65 k rows); buckets are independent, so they run on TIGHT_STREAMS HIP
@@ -199,10 +238,11 @@ class MaskVRD(nn.Module):
         out = None
         fill = -10.0                                    # the predictor's value on padded frames (predictor.py:39)
         main = torch.cuda.current_stream(dev)
+        plan = plan["buckets"]
         side = self._tight_side_streams(dev) if len(plan) > 1 and not torch.cuda.is_current_stream_capturing() else None
         lanes = [main] + list(side or [])
         fork = None
-        for k, (t2, idx, n) in enumerate(plan):
+        for k, (t2, idx, n, _) in enumerate(plan):
             lane = lanes[k % len(lanes)] if out is not None else main           # (the first bucket also shapes the outputs)
             if lane is not main:
                 lane.wait_event(fork)
@@ -242,6 +282,8 @@ class MaskVRD(nn.Module):
         if self.tight_padding and not torch.is_grad_enabled() and batched_masks.dtype == torch.bool and batched_inputs.is_contiguous():
             plan = self._tight_plan(batched_masks, masks2d)
             if plan is not None:
+                if plan["rows"]:
+                    return self._mask_vrd_rows(batched_inputs, masks2d, plan, with_aux)
                 return self._mask_vrd_tight(batched_inputs, masks2d, plan, with_aux)
         if self.training and torch.is_grad_enabled():
             # a training step: the split-precision operands of all dense conv weights (forward and input-gradient form) in one

@@ -764,10 +764,12 @@ def _dwconv_block(w, bias, gamma, beta):
     return val
 
 
-def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
+def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None, segs=None):
     """Fused depthwise conv * mask -> LayerNorm for up to three weight sets sharing x.
     sets: list of dicts(weight=(C, g, k) Conv1d weight, bias=None, gamma=None, beta=None, relu=False, out=None).
     pre_ln = (gamma, beta): the input rows are LayerNorm'ed as they are read (the block's ln1).
+    segs (inference path): x is a ragged row space (1, R, C) -- [(first row, sequences, frames)] groups of sequences back to
+    back (vrd_row_segs); outputs, mask_out and x_up follow the same grouping at their own frame counts.
     Returns the list of outputs, each (B, T/stride, C)."""
     if recording(x, x_up, *(t for st in sets for t in (st["weight"], st.get("bias"), st.get("gamma"), st.get("beta"))),
                  *(pre_ln or ())):
@@ -780,6 +782,11 @@ def dwconv_ln(x, sets, *, mask_out=None, stride=1, x_up=None, pre_ln=None):
     assert cols == Cout * g
     Tout = Tin // stride
     a = _hip.DwconvLnArgs()
+    seg_table = None
+    if segs is not None:
+        assert B == 1 and sum(n * T for _, n, T in segs) == Tin
+        seg_table = _hip.RowSegs.of(segs)
+        a.segs = C.pointer(seg_table)
     a.x, a.ldx = px, ldx
     if x_up is not None:
         pu, ru, cu, ldu = _rows(x_up)
@@ -819,8 +826,10 @@ def _rel_pe_ptr(rel_pe, like, n_head, half_win):
     return rel_pe.data_ptr()
 
 
-def local_attention(q, k, v, mask, n_head, half_win, pair=False, rel_pe=None):
-    """rel_pe: None or the module's (1, 1, n_head, window) relative position bias (reference blocks.py:739-743)."""
+def local_attention(q, k, v, mask, n_head, half_win, pair=False, rel_pe=None, out=None, segs=None):
+    """rel_pe: None or the module's (1, 1, n_head, window) relative position bias (reference blocks.py:739-743).
+    out: (B, T, C) contiguous rows to write instead of a fresh tensor (inference path).
+    segs (inference path): q / k / v / mask are a ragged row space (1, R, ...): [(first row, sequences, frames)] (vrd_row_segs)."""
     if recording(q, k, v, rel_pe):
         from . import autograd
         return autograd.LocalAttention.apply(q, k, v, mask, n_head, half_win, rel_pe)
@@ -830,14 +839,23 @@ def local_attention(q, k, v, mask, n_head, half_win, pair=False, rel_pe=None):
     pk, _, _, ldk = _rows(k)
     pv, _, _, ldv = _rows(v)
     assert ld == ldk == ldv
-    out = torch.empty(B, T, Cc, device=q.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, T, Cc, device=q.device, dtype=torch.float32)
+    assert out.shape == (B, T, Cc) and out.is_contiguous()
+    if segs is not None:
+        assert B == 1 and sum(n * t for _, n, t in segs) == T
+        table = _hip.RowSegs.of(segs)
+        _hip.check(lib.vrd_local_attn_segs(pq, pk, pv, ld, _mask_ptr(mask, rows), rel, C.byref(table), Cc, n_head, half_win,
+                                           out.data_ptr(), Cc, _fmt(pair), _stream()), "vrd_local_attn_segs")
+        return Pair(out, Cc) if _fmt(pair) else out
     _hip.check(lib.vrd_local_attn(pq, pk, pv, ld, _mask_ptr(mask, rows), rel, B, T, Cc, n_head, half_win,
                                   out.data_ptr(), Cc, _fmt(pair), _stream()), "vrd_local_attn")
     return Pair(out, Cc) if _fmt(pair) else out
 
 
-def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
+def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None, out=None):
     """Global masked attention; q: (B, Tq, C), k/v: (B, Tk, C); kv_mask (B, Tk) or None.
+    out: (B, Tq, C) contiguous rows to write instead of a fresh tensor (inference path).
     pair: pair-row output when the flash kernel runs (otherwise a plain tensor is returned).
     q_mask (B, Tq): rows the caller masks afterwards; the split-precision kernel leaves out query tiles without a valid
     row (they read 0)."""
@@ -855,7 +873,9 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
         pk, rows_k, _, ldk = _rows(k)
         pv, _, _, ldv = _rows(v)
         assert ldk == ldv
-        out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
+        assert out.shape == (B, Tq, Cc) and out.is_contiguous()
         _hip.check(lib.vrd_attention_pair(pq, ldq, pk, pv, ldk, _mask_ptr(kv_mask, rows_k), _mask_ptr(q_mask, B * Tq), B, Tq, Tk, n_head,
                                           Cc // n_head, out.data_ptr(), Cc, fmt if pair else 0, fmt, _stream()),
                    "vrd_attention_pair")
@@ -866,7 +886,9 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
     pk, rows_k, _, ldk = _rows(k)
     pv, _, _, ldv = _rows(v)
     assert ldk == ldv
-    out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, Tq, Cc, device=q.device, dtype=torch.float32)
+    assert out.shape == (B, Tq, Cc) and out.is_contiguous()
     hd = Cc // n_head
     flash = algo == 2 or (algo == 0 and hd in (64, 128))      # mirrors vrd_attention's auto choice
     pair = bool(pair and flash and pair_fmt())
@@ -875,15 +897,21 @@ def attention(q, k, v, kv_mask, n_head, algo=0, pair=False, q_mask=None):
     return Pair(out, Cc) if pair else out
 
 
-def maxpool_mask(x, mask_in):
-    """MaxPool1d(3, 2, 1)(x) * mask[::2]; returns (pooled (B, T/2, C), mask_out (B, T/2) bool)."""
+def maxpool_mask(x, mask_in, out=None):
+    """MaxPool1d(3, 2, 1)(x) * mask[::2]; returns (pooled (B, T/2, C), mask_out (B, T/2) bool).
+    out: (pooled, mask_out) contiguous buffers to write instead of fresh tensors (inference path)."""
     if recording(x):
         from . import autograd
         return autograd.MaxPoolMask.apply(x, mask_in)
     B, T, Cc = x.shape
     px, rows, cols, ldx = _rows(x)
-    y = torch.empty(B, T // 2, Cc, device=x.device, dtype=torch.float32)
-    m_out = torch.empty(B, T // 2, device=x.device, dtype=torch.bool)
+    if out is None:
+        y = torch.empty(B, T // 2, Cc, device=x.device, dtype=torch.float32)
+        m_out = torch.empty(B, T // 2, device=x.device, dtype=torch.bool)
+    else:
+        y, m_out = out
+        assert y.shape == (B, T // 2, Cc) and y.is_contiguous() and m_out.shape == (B, T // 2) and m_out.is_contiguous()
+        assert m_out.dtype == torch.bool
     _hip.check(lib.vrd_maxpool_mask(px, ldx, B, T, Cc, _mask_ptr(mask_in, rows), y.data_ptr(), Cc, m_out.data_ptr(),
                                     _stream()), "vrd_maxpool_mask")
     return y, m_out
