@@ -132,7 +132,8 @@ def test_ctypes_struct_layout_matches_header():
     header = open(os.path.join(REPO, "include", "vrdone_hip.h")).read()
     for cname, cls in (("vrd_gemm_args", _hip.GemmArgs), ("vrd_dwconv_ln_args", _hip.DwconvLnArgs),
                        ("vrd_criterion_args", _hip.CriterionArgs), ("vrd_criterion_grads", _hip.CriterionGrads),
-                       ("vrd_split_job", _hip.SplitJob), ("vrd_pack_args", _hip.PackArgs), ("vrd_gather_args", _hip.GatherArgs)):
+                       ("vrd_split_job", _hip.SplitJob), ("vrd_pack_args", _hip.PackArgs), ("vrd_gather_args", _hip.GatherArgs),
+                       ("vrd_row_segs", _hip.RowSegs)):
         body = re.search(r"typedef struct \{([^}]*)\} " + cname, header).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
@@ -141,7 +142,7 @@ def test_ctypes_struct_layout_matches_header():
             if not decl:
                 continue
             for part in decl.split(","):
-                names.append(re.sub(r"\[\d+\]", "", part.strip().split()[-1].lstrip("*")))
+                names.append(re.sub(r"\[\w+\]", "", part.strip().split()[-1].lstrip("*")))
         assert names == [f[0] for f in cls._fields_], cname
 
 
@@ -250,3 +251,25 @@ def test_synthetic_raw_video_has_the_dataloader_layout():
     assert len(raw["sids"]) == len(raw["oids"]) > 0
     for s, o in zip(raw["sids"].tolist(), raw["oids"].tolist()):
         assert s != o and min(spans[s, 1], spans[o, 1]) > max(spans[s, 0], spans[o, 0])
+
+
+def test_row_space_layout_and_filler_buckets():
+    """Host side of the ragged row space (vrdone_amd/models/ragged.py): bucket offsets, the stacked [subject | object] groups,
+    the last rows of the sequences whose k = 3 convs run flat, and the filler that rounds the row count to a multiple of 256."""
+    import torch
+    from vrdone_amd.models import ragged
+    from vrdone_amd import _hip
+    lay = ragged.Layout([(3, 32, True), (2, 96, True), (1, 48, False)])
+    assert lay.segs == [(0, 3, 32), (96, 2, 96), (288, 1, 48)] and lay.rows == 336 and lay.rows_flat == 288
+    assert lay.twice()[3:] == [(336, 3, 32), (432, 2, 96), (624, 1, 48)]
+    assert lay.tail_rows(1, "cpu").tolist() == [31, 63, 95, 191, 287]
+    assert lay.tail_rows(2, "cpu").tolist() == [31, 63, 95, 191, 287, 367, 399, 431, 527, 623]
+    with __import__("pytest").raises(AssertionError):
+        ragged.Layout([(1, 48, False), (3, 32, True)])            # the buckets with flat k = 3 convs come first
+    for rows in (65536, 65536 + 32, 65536 + 48, 317344, 311104, 23792 * 4, 100000):
+        fill = ragged.filler_buckets(rows, 288)
+        assert (rows + sum(n * t for n, t in fill)) % 256 == 0 and all(t % 8 == 0 and 32 <= t <= 56 for _, t in fill), (rows, fill)
+        assert sum(n * t for n, t in fill) < 512
+    assert ragged.filler_buckets(4096 + 32, 288) == [] and ragged.filler_buckets(65536 + 48, 40) == []
+    segs = _hip.RowSegs.of(lay.twice())
+    assert segs.count == 6 and list(segs.row)[:6] == [0, 96, 288, 336, 432, 624] and list(segs.T)[:3] == [32, 96, 48]

@@ -161,7 +161,7 @@ class MaskVRD(nn.Module):
     # only the kernels that need (sequences, frames) structure walk the buckets.  ROWS_MIN_ROWS: below this a bucket's own
     # launches (depthwise convs, attention) are too small to be worth a launch each.
     row_space = os.environ.get("VRDONE_ROW_SPACE", "1") != "0"
-    ROWS_MIN_ROWS = int(os.environ.get("VRDONE_ROWS_MIN_ROWS", "16384"))
+    ROWS_MIN_ROWS = int(os.environ.get("VRDONE_ROWS_MIN_ROWS", "4096"))
 
     def _tight_plan(self, batched_masks, masks2d):
         """{"buckets": [(T', pair indices (n,) int32 on the device, n)], "rows": the buckets can share one row space} for a
@@ -188,8 +188,14 @@ class MaskVRD(nn.Module):
             if not all(t == T for _, t in want):           # (nothing shrinks: the batch runs as it is)
                 dev = masks2d.device
                 order = sorted(want, key=lambda k: (not k[0], k[1])) if rows else sorted(want, key=lambda k: k[1])
-                plan = {"buckets": [(t2, torch.tensor(want[(flat, t2)], dtype=torch.int32, device=dev), len(want[(flat, t2)]), flat)
-                                    for flat, t2 in order], "rows": rows}
+                # (one upload for all buckets' pair indices; a bucket's are a slice of it)
+                every = torch.tensor([i for key in order for i in want[key]], dtype=torch.int32).to(dev)
+                buckets, at = [], 0
+                for flat, t2 in order:
+                    n = len(want[(flat, t2)])
+                    buckets.append((t2, every[at:at + n], n, flat))
+                    at += n
+                plan = {"buckets": buckets, "rows": rows}
         batched_masks._vrd_tight_plan = (key, plan)
         return plan
 
@@ -640,7 +646,7 @@ class MaskVRD(nn.Module):
             for i in sl:
                 t_pad[i] = self.max_seq_len if lens[i] <= self.max_seq_len else t_long
         # (the reference's padded length of every pair; then the shortest ones that give the same results: `tight padding`)
-        t_pad = self.tight_buckets(lens, t_pad)
+        t_pad = self.tight_buckets(lens, t_pad, self.ROWS_MIN_ROWS if self.row_space and not self.use_abs_pe else None)
         return sorted(range(P), key=lambda i: (t_pad[i], lens[i], i)), t_pad
 
     def _entity_streams(self, source, ids):
@@ -675,14 +681,13 @@ class MaskVRD(nn.Module):
         piece = -(-2 * reach // chunk) * chunk
         return rows, stream_row, (piece, piece + chunk), reach
 
-    def _shared_entity_rows(self, source, sel, shared, at, T):
-        """(2B, T, D) entity-stage rows of the pairs `sel` (device indices; positions at.. of the id list the streams were
-        planned for), the pairs' box features (B, T, S) and mask: frames further than `reach` from both window edges come
-        from the per-tracklet rows, the rest from L-frame pieces at the edges run through the same stage."""
+    def _shared_pieces(self, source, sel, shared, T):
+        """The window-edge pieces of the pairs `sel` (device indices) through the entity stage: (4B, L, D) = [subject start |
+        subject end | object start | object end] pieces.  T: the pairs' padded length (an int, or one per pair as a device
+        tensor: the pairs of several buckets in one batch)."""
         ops = _ops()
         bb = self.backbone
-        rows, stream_row, (piece, L), reach = shared
-        B = sel.shape[0]
+        _, _, (piece, L), _ = shared
         s_row, o_row, lens = source.s_row[sel], source.o_row[sel], source.lens_dev[sel].contiguous()
         # start pieces: the first `piece` frames.  End pieces: the last `piece` frames followed by padding, as in the pair's
         # own rows -- or, for a pair that fills its T frames, the last L frames filling the buffer (vrd_assemble_args)
@@ -694,7 +699,20 @@ class MaskVRD(nn.Module):
         piece_len = torch.cat([lens.clamp(max=piece), end_len])
         vis, clip, _, ent, m = ops.gather_rows(source, piece_s, piece_o, piece_len, L, bb.n_bbox_so, bb.n_bbox_entity,
                                                ops.pair_mode())
-        pieces = bb.entity_stage(vis, clip, ent, torch.cat([m, m], dim=0))                  # (4B, L, D)
+        return bb.entity_stage(vis, clip, ent, torch.cat([m, m], dim=0))                   # (4B, L, D)
+
+    def _shared_entity_rows(self, source, sel, shared, at, T, pieces=None):
+        """(2B, T, D) entity-stage rows of the pairs `sel` (device indices; positions at.. of the id list the streams were
+        planned for), the pairs' box features (B, T, S) and mask: frames further than `reach` from both window edges come
+        from the per-tracklet rows, the rest from L-frame pieces at the edges run through the same stage (`pieces`: those,
+        when the caller has them already -- _shared_pieces over the pairs of several buckets at once)."""
+        ops = _ops()
+        bb = self.backbone
+        rows, stream_row, (piece, L), reach = shared
+        B = sel.shape[0]
+        s_row, o_row, lens = source.s_row[sel], source.o_row[sel], source.lens_dev[sel].contiguous()
+        if pieces is None:
+            pieces = self._shared_pieces(source, sel, shared, T)
         _, _, so_box, _, mask = ops.gather_rows(source, s_row.contiguous(), o_row.contiguous(), lens, T, bb.n_bbox_so,
                                                 bb.n_bbox_entity, False, boxes_only=True)
         so = ops.assemble_pairs(rows, pieces, stream_row[:, at:at + B].reshape(-1), lens, T, piece, reach)
@@ -725,6 +743,11 @@ class MaskVRD(nn.Module):
             local = [feats[i] for i in ids]
             tables = ops.pair_table(local)      # None unless the features are the dataloader's frame-major matrices
         bb = self.backbone
+        if self.row_space and not self.use_abs_pe and (source is not None or tables is not None):
+            # all padded lengths of the video in one row space (models/ragged.py), in waves of ~pair_chunk pairs
+            self._candidates_rows(cand, lens, ids, t_pad, k, source, tables, shared, lens_dev,
+                                  ids_dev if source is not None else None)
+            return cand
         at = 0
         while at < len(ids):
             T = t_pad[ids[at]]
@@ -761,6 +784,125 @@ class MaskVRD(nn.Module):
             ints[at:at + n, :, 2 * k + 1] = sl_
             at += n
         return cand
+
+    def _candidates_rows(self, cand, lens, ids, t_pad, k, source, tables, shared, lens_dev, ids_dev):
+        """pair_candidates with the buckets (runs of one padded length in `ids`) of a wave in ONE row space: the entity stage
+        of the buckets that do not take it from the per-tracklet rows, then the pair stage, neck and predictor once over all
+        rows (models/ragged.py).  A bucket's pairs within one frame of its padded length (no two padded frames behind them)
+        are a bucket of their own, behind the others (they are the longest of their run: `ids` is sorted by length)."""
+        from . import ragged
+        ops = _ops()
+        bb = self.backbone
+        ints = cand.view(torch.int32)
+        runs, at = [], 0                                      # (T, first position, end position, flat)
+        while at < len(ids):
+            T = t_pad[ids[at]]
+            n = 1
+            while at + n < len(ids) and t_pad[ids[at + n]] == T:
+                n += 1
+            cut = at
+            while cut < at + n and lens[ids[cut]] <= T - 2:
+                cut += 1
+            if cut > at:
+                runs.append((T, at, cut, True))
+            if cut < at + n:
+                runs.append((T, cut, at + n, False))
+            at += n
+        step = self._chunk_size(len(ids))
+        waves, wave, room = [], [], step
+        for T, c0, c1, flat in runs:
+            while c0 < c1:
+                take = min(c1 - c0, room)
+                wave.append((T, c0, c0 + take, flat))
+                c0 += take
+                room -= take
+                if room == 0:
+                    waves.append(wave)
+                    wave, room = [], step
+        if wave:
+            waves.append(wave)
+        rows2 = lambda t: (t.t if isinstance(t, ops.Pair) else t)                                 # noqa: E731
+        for wave in waves:
+            wave.sort(key=lambda b: not b[3])                 # (stable: the flat buckets first, each kind by padded length)
+            # (filler buckets of all-padding sequences round the row count: ragged.filler_buckets; positions c0 < 0)
+            at_fill = sum(1 for b in wave if b[3])
+            wave[at_fill:at_fill] = [(T, -n, 0, True) for n, T in ragged.filler_buckets(sum((c1 - c0) * T for T, c0, c1, _ in wave), 1 << 30)]
+            lay = ragged.Layout([(c1 - c0, T, flat) for T, c0, c1, flat in wave])
+            got = []                                          # per bucket ("so", so, box, mask) | ("parts", vis, clip, box, ent, mask)
+            # the window-edge pieces of all buckets that take their entity rows from the per-tracklet streams: ONE pass through
+            # the entity stage (they are L frames long whatever the bucket)
+            from_streams = [(T, c0, c1) for T, c0, c1, _ in wave if c0 >= 0 and shared is not None and T > 2 * shared[2][1]]
+            pieces_all, n_all, q0 = None, sum(c1 - c0 for _, c0, c1 in from_streams), 0
+            if len(from_streams) > 1:
+                sel_all = torch.cat([ids_dev[c0:c1] for _, c0, c1 in from_streams])
+                t_all = torch.cat([torch.full((c1 - c0,), T, dtype=torch.int32, device=sel_all.device) for T, c0, c1 in from_streams])
+                pieces_all = self._shared_pieces(source, sel_all, shared, t_all)
+            for T, c0, c1, flat in wave:
+                if c0 < 0:                                    # the filler: zero rows under an all-false mask
+                    n, dev = c1 - c0, cand.device
+                    zeros = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)               # noqa: E731
+                    no_mask = torch.zeros(n, T, dtype=torch.bool, device=dev)
+                    if len(from_streams) == sum(1 for b in wave if b[1] >= 0):    # ... entity rows, when every bucket brings those
+                        got.append(("so", zeros(2 * n, T, bb.s_fuse_norm.num_channels), zeros(n, T, bb.n_bbox_so), no_mask))
+                    else:                                     # ... raw features: the entity stage's row space is rounded too
+                        wide = (lambda t, w: ops.Pair(t, w)) if ops.pair_mode() else (lambda t, w: t)         # noqa: E731
+                        got.append(("parts", wide(zeros(2 * n, T, bb.n_visual), bb.n_visual),
+                                    wide(zeros(2 * n, T, bb.n_clip), bb.n_clip) if bb.n_clip else None,
+                                    zeros(n, T, bb.n_bbox_so), zeros(2 * n, T, bb.n_bbox_entity), no_mask))
+                elif shared is not None and T > 2 * shared[2][1]:
+                    pieces = None
+                    if pieces_all is not None:
+                        pieces = torch.cat([pieces_all[j * n_all + q0:j * n_all + q0 + c1 - c0] for j in range(4)])
+                        q0 += c1 - c0
+                    got.append(("so",) + tuple(self._shared_entity_rows(source, ids_dev[c0:c1], shared, c0, T, pieces)))
+                elif source is not None:
+                    assert (source.n_visual, source.n_clip) == (bb.n_visual, bb.n_clip)
+                    got.append(("parts",) + tuple(ops.gather_pairs(source, ids_dev[c0:c1], T, bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())))
+                else:
+                    got.append(("parts",) + tuple(ops.pack_pairs(tables[0][c0:c1], tables[1][c0:c1], T, bb.n_visual, bb.n_clip,
+                                                                 bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())))
+            mask = torch.cat([g[-1].reshape(-1) for g in got]).view(1, lay.rows)
+            so_box = torch.cat([g[2 if g[0] == "so" else 3].reshape(-1, bb.n_bbox_so) for g in got]).view(1, lay.rows, -1)
+            # entity stage of the buckets that bring raw features: a row space of their own, [subject | object] like the joint one
+            ent_b = [(b, g) for b, g in zip(wave, got) if g[0] == "parts"]
+            so_e, lay_e = None, None
+            if ent_b:
+                lay_e = ragged.Layout([(c1 - c0, T, flat) for (T, c0, c1, flat), _ in ent_b])
+
+                def stacked(j):
+                    ts = [g[j] for _, g in ent_b]
+                    if ts[0] is None:
+                        return None
+                    halves = [rows2(t)[:t.shape[0] // 2] for t in ts] + [rows2(t)[t.shape[0] // 2:] for t in ts]
+                    flat_rows = torch.cat([h.reshape(-1, h.shape[-1]) for h in halves]).view(1, 2 * lay_e.rows, -1)
+                    return ops.Pair(flat_rows, ts[0].width, ts[0].fmt) if isinstance(ts[0], ops.Pair) else flat_rows
+                m_e = torch.cat([g[-1].reshape(-1) for _, g in ent_b]).view(1, lay_e.rows)
+                so_e = ragged.entity_rows(bb, stacked(1), stacked(2), stacked(4), torch.cat([m_e, m_e], dim=1), lay_e)
+            # the joint entity-stage rows: every bucket's subject rows, then every bucket's object rows
+            halves, e_at = ([], []), 0
+            for (T, c0, c1, flat), g in zip(wave, got):
+                n = c1 - c0
+                if g[0] == "so":
+                    halves[0].append(g[1][:n].reshape(n * T, -1))
+                    halves[1].append(g[1][n:].reshape(n * T, -1))
+                else:
+                    halves[0].append(so_e[0, e_at:e_at + n * T])
+                    halves[1].append(so_e[0, lay_e.rows + e_at:lay_e.rows + e_at + n * T])
+                    e_at += n * T
+            so = torch.cat(halves[0] + halves[1]).view(1, 2 * lay.rows, -1)
+            del got, so_e, halves
+            heads = ragged.heads_rows(self, *ragged.pair_rows(bb, so, so_box, mask, lay), False)
+            logits, segs = heads[-1]
+            p = 0
+            for (T, c0, c1, flat), seg in zip(wave, segs):
+                n = c1 - c0
+                if c0 >= 0:
+                    ts, tc, sf, sl_ = ops.postprocess(logits[p:p + n].contiguous(), seg, lens_dev[c0:c1], k)
+                    cand[c0:c1, :, :k] = ts
+                    ints[c0:c1, :, k:2 * k] = tc
+                    ints[c0:c1, :, 2 * k] = sf
+                    ints[c0:c1, :, 2 * k + 1] = sl_
+                p += n
 
     @torch.no_grad()
     def forward_test(self, input_data):

@@ -417,17 +417,48 @@ def heads_rows(model, feats, masks, lays, with_aux):
     return predictor_rows(model.predictor, feats[-1], mask_features, masks[-1], masks[0], lays[-1], lays[0], with_aux)
 
 
+def filler_buckets(rows, t_max):
+    """[(sequences, frames)] of all-padding sequences that round a row space of `rows` rows up to a multiple of 256: the
+    256 x 256 GEMM kernel takes row counts that are multiples of 64 (its epilogue has no row predicates), and with 256 that
+    holds for the first three pyramid levels -- the launches large enough for that kernel.  Sequences of 32 frames, plus one of
+    32 + (8, 16 or 24) when the buckets' lengths are not all multiples of 32 (reference padded lengths are multiples of the
+    window stride, e.g. 48); none when such a sequence would be longer than t_max (the frames the caller's batch has)."""
+    need = (-rows) % 256
+    if need == 0 or rows % 8 or rows < 65536:          # (below ~65 k rows no launch reaches the 256 x 256 kernel)
+        return []
+    odd = need % 32
+    first = 32 + odd if odd else 0
+    if first > t_max or t_max < 32:
+        return []
+    if need < first:
+        need += 256
+    out = [(1, first)] if first else []
+    if need - first:
+        out.insert(0, ((need - first) // 32, 32))
+    return out
+
+
+def with_filler(buckets, make, t_max):
+    """`buckets` [(frames, ..., sequences, flat)] plus, behind the last flat one, the filler buckets make(n, T) the row count asks
+    for -> (buckets, indices of the fillers)"""
+    fill = filler_buckets(sum(b[2] * b[0] for b in buckets), t_max)
+    at = sum(1 for b in buckets if b[-1])
+    return list(buckets[:at]) + [make(n, T) for n, T in fill] + list(buckets[at:]), set(range(at, at + len(fill)))
+
+
 def mask_vrd_rows(model, x, masks2d, plan, with_aux, out=None):
     """MaskVRD._mask_vrd for the buckets of `plan` = [(T_i, pair indices, n_i, flat_i)] in one row space; results written into (or
     returned as) the batch-shaped output dict: pred_logits (B, Q, K+1), pred_masks (B, Q, T) at the batch's own padded length,
     -10 behind a bucket's."""
     B, T = masks2d.shape
     dev = x.device
+    # (a filler bucket recomputes the first frames of some pair under an all-false mask: finite numbers nobody reads)
+    plan, filler = with_filler(plan, lambda n, t: (t, plan[0][1][:1].repeat(n), n, True), T)
     lay = Layout([(n, t2, flat) for t2, _, n, flat in plan])
     idx64 = [b[1].long() for b in plan]
-    mask = torch.cat([masks2d[i64, :b[0]].reshape(-1) for b, i64 in zip(plan, idx64)]).view(1, lay.rows)
+    mask = torch.cat([masks2d[i64, :b[0]].reshape(-1) if j not in filler else torch.zeros(b[2] * b[0], dtype=torch.bool, device=dev)
+                      for j, (b, i64) in enumerate(zip(plan, idx64))]).view(1, lay.rows)
     heads = heads_rows(model, *backbone_rows(model.backbone, x, plan, lay, mask), with_aux)
-    order = torch.cat(idx64)
     fill = -10.0                                        # the predictor's value on padded frames (predictor.py:39)
     if out is None:
         Q, K1 = heads[-1][0].shape[1:]
@@ -436,7 +467,10 @@ def mask_vrd_rows(model, x, masks2d, plan, with_aux, out=None):
         if len(heads) > 1:
             out["aux_outputs"] = [new() for _ in heads[:-1]]
     for dst, (logits, segs) in zip(out.get("aux_outputs", []) + [out], heads):
-        dst["pred_logits"][order] = logits
-        for b, i64, seg in zip(plan, idx64, segs):
-            dst["pred_masks"][i64, :, :b[0]] = seg
+        p = 0
+        for j, (b, i64, seg) in enumerate(zip(plan, idx64, segs)):
+            if j not in filler:
+                dst["pred_logits"][i64] = logits[p:p + b[2]]
+                dst["pred_masks"][i64, :, :b[0]] = seg
+            p += b[2]
     return out
