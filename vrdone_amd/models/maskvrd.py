@@ -173,12 +173,15 @@ class MaskVRD(nn.Module):
         if hit is not None and hit[0] == key:
             return hit[1]
         B, T = masks2d.shape
-        lens = masks2d.sum(dim=1)
-        last = T - torch.argmax(masks2d.flip(1).to(torch.uint8), dim=1)            # index behind the last valid frame
-        host = torch.stack([lens, last]).cpu()
+        known = getattr(batched_masks, "_vrd_lens", None)       # the lengths the mask was built from (MaskVRD._batch): no read-back
+        lens_h = known[1] if known is not None and known[0] == batched_masks._version and len(known[1]) == B else None
+        if lens_h is None:
+            lens = masks2d.sum(dim=1)
+            last = T - torch.argmax(masks2d.flip(1).to(torch.uint8), dim=1)        # index behind the last valid frame
+            host = torch.stack([lens, last]).cpu()
+            lens_h = host[0].tolist() if bool((host[0] == host[1]).logical_or(host[0] == 0).all()) else None
         plan = None
-        if bool((host[0] == host[1]).logical_or(host[0] == 0).all()):
-            lens_h = host[0].tolist()
+        if lens_h is not None:
             rows = self.row_space and not self.use_abs_pe
             want = {}
             for i, t2 in enumerate(self.tight_buckets(lens_h, [T] * B, self.ROWS_MIN_ROWS if rows else None)):
@@ -620,8 +623,11 @@ class MaskVRD(nn.Module):
         x = torch.zeros(len(ids), feats_list[0].shape[0], T, device=dev, dtype=torch.float32)
         for r, i in enumerate(ids):
             x[r, :, :feats_list[i].shape[1]].copy_(feats_list[i], non_blocking=True)
-        n = torch.tensor([feats_list[i].shape[1] for i in ids], device=dev)
-        return x, (torch.arange(T, device=dev)[None, :] < n[:, None])[:, None, :]
+        lens = [int(feats_list[i].shape[1]) for i in ids]
+        n = torch.tensor(lens, device=dev)
+        m = (torch.arange(T, device=dev)[None, :] < n[:, None])[:, None, :]
+        m._vrd_lens = (m._version, lens)              # (what _tight_plan would otherwise read back from the device)
+        return x, m
 
     def shard_pairs(self, group=None, enable=True):
         """Pair-sharded evaluation: with torch.distributed initialised, every rank of `group` calls
