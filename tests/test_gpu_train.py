@@ -315,10 +315,12 @@ def test_presplit_weights_equal_the_per_weight_launches(mode):
     builds a new plan and drops the old one."""
     from vrdone_amd import ops
     fwd = "_vrd_split_f16" if mode == "f16x3" else "_vrd_split"
-    bwd = "_vrd_split_t_f16" if mode == "f16x3" else "_vrd_split_t"       # (the backward GEMMs' operands are in the mode's format too)
-    slots = (fwd, bwd)
     bits = lambda sw: sw.t.view(torch.int16)        # noqa: E731
     with ops.use_precision(mode):
+        # (the backward GEMMs' operands are in the mode's format too, unless VRDONE_F16_BACKWARD=0 keeps them on bf16 planes)
+        from vrdone_amd import _hip
+        bwd = "_vrd_split_t_f16" if ops.backward_fmt() == _hip.PAIR_F16 else "_vrd_split_t"
+        slots = (fwd, bwd)
         model, _, _ = build()
         ws = model._dense_conv_weights()
         assert len(ws) > 100
