@@ -96,13 +96,21 @@ def test_eval_plan_follows_the_reference_slice_rule():
                 assert all(t_pad[s0 + i] == x.shape[-1] for i in ids)
     t_ref = t_pad
     model.tight_padding = True          # ... then the tight ones: never longer than the reference's, a padded frame left at every
-    assert model.eval_plan(lens)[1] == t_ref    # (431 pairs are fewer rows than one bucket: the default policy leaves them alone)
+    model.row_space = False             # pyramid level unless the reference has none either, multiples of 32.  Bucket by bucket:
+    assert model.eval_plan(lens)[1] == t_ref    # (431 pairs are fewer rows than one bucket: that policy leaves them alone)
     model.TIGHT_MIN_ROWS = 8192
-    order, t_pad = model.eval_plan(lens)    # pyramid level unless the reference has none either, multiples of 32
     down = 8
-    for L, t, T in zip(lens, t_pad, t_ref):
-        assert t <= T and t % 32 == 0 and (t == T or t // down > -(-L // down))
-    assert sum(t_pad) < 0.8 * sum(t_ref)
+
+    def check(t_pad):
+        for L, t, T in zip(lens, t_pad, t_ref):
+            assert t <= T and t % 32 == 0 and (t == T or t // down > -(-L // down))
+        assert sum(t_pad) < 0.8 * sum(t_ref)
+    order, t_coarse = model.eval_plan(lens)
+    check(t_coarse)
+    del model.row_space                 # the default, all buckets in one row space: buckets as fine as 4 k rows
+    order, t_pad = model.eval_plan(lens)
+    check(t_pad)
+    assert sum(t_pad) <= sum(t_coarse) and len(set(t_pad)) >= len(set(t_coarse))
     assert sorted(order) == list(range(len(lens)))
     keys = [(t_pad[i], lens[i]) for i in order]
     assert keys == sorted(keys)
