@@ -261,6 +261,10 @@ def main():
                 torch.cuda.synchronize()
                 log(f"[{mode}] warmup step {i} done")
             fence()
+            # The timed region records HIP events around the launches of the GEMM families only -- what `roofline` needs.  Two
+            # events around each of a step's ~600 launches cost 0.8 % of it (142.8 against 141.7 ms, three A/Bs on one box);
+            # the other families' times come from one more, untimed step with events around every launch.
+            _hip.prof_select(GEMM_FAMILIES)
             _hip.prof_enable(not args.no_prof)
             _hip.prof_reset()
             t0 = time.perf_counter()
@@ -269,12 +273,25 @@ def main():
             fence()
             elapsed = time.perf_counter() - t0
             _hip.prof_enable(False)
+            prof = _hip.prof_read() if (rank == 0 and not args.no_prof) else {}
+            if prof and world == 1:
+                _hip.prof_select(None)
+                _hip.prof_enable(True)
+                _hip.prof_reset()
+                step()
+                torch.cuda.synchronize()
+                _hip.prof_enable(False)
+                for fam, v in _hip.prof_read().items():
+                    if fam not in GEMM_FAMILIES:           # (scaled to the timed region's step count: the tables divide by it)
+                        prof[fam] = {k: val * steps for k, val in v.items()}
         assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         log(f"[{mode}] timed region: {steps} steps in {float(t.item()):.3f} s")
-        return float(t.item()), (_hip.prof_read() if (rank == 0 and not args.no_prof) else {})
+        return float(t.item()), prof
+
+    GEMM_FAMILIES = ["gemm_f32_mfma", "gemm_x3_mfma", "gemm_x3_dma", "gemm_x3_big"]
 
     def roofline(mode, prof):
         """Dominant kernel family of the mode: algorithmic FLOPs (2*M*N*K per launch) / HIP-event time."""
@@ -308,10 +325,6 @@ def main():
                      "algorithmic_bytes_per_launch": g["bytes"] / n,
                      "share_of_kernel_time": g["ms"] / tot if tot else 0.0}, **extra)
 
-    if world > 1:
-        # a rank's shard is a short step of ~520 launches: recording two events around each costs ~8 % of it, so the
-        # multi-GPU runs record the GEMM families only (what `roofline` needs); N = 1 records every family
-        _hip.prof_select(["gemm_f32_mfma", "gemm_x3_mfma", "gemm_x3_dma", "gemm_x3_big"])
     main_mode = args.precision or ops.get_precision()
     elapsed, prof = run(main_mode, args.warmup, args.steps)
     alts = {}
@@ -552,6 +565,9 @@ def main():
             line["roofline"] = roofline(main_mode, prof)
             if world > 1:
                 line["roofline"]["profiled_families"] = "GEMM families only (shares below are among those)"
+            else:
+                line["roofline"]["profiled_families"] = ("HIP events inside the timed region around the GEMM families' launches; the other "
+                                                         "families' times below: one more, untimed step with events around every launch")
             tot = sum(v["ms"] for v in prof.values())
             line["kernel_time_share"] = {k: round(v["ms"] / tot, 4) for k, v in prof.items() if v["launches"]}
             line["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
