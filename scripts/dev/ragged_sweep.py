@@ -18,8 +18,10 @@ x, m = synth.synth_pairs(pairs, configs.input_channels(cfg), t_pad, lens.tolist(
 ref = None
 # arguments: "min_rows:streams" = bucket by bucket, "rows:min_rows" = all buckets in one row space
 combos = [c.split(":") for c in sys.argv[1:]] or [["262144", "1"]]
+from vrdone_amd.models import ragged
 with torch.no_grad():
-    for a, b in combos:
+    for a, b, *rest in combos:
+        ragged.ATTN_LANES = int(rest[0]) if rest else ragged.ATTN_LANES          # "rows:min_rows:lanes"
         if a == "rows":
             model.row_space, model.ROWS_MIN_ROWS, min_rows, streams = True, int(b), int(b), 0
         else:
@@ -40,5 +42,5 @@ with torch.no_grad():
             ref = res
         same = all(torch.equal(a, b) for a, b in zip(ref, res))
         dl = max(float((a - b).abs().max()) for a, b in zip(ref, res))
-        print(f"{'row space' if streams == 0 else 'buckets  '} min_rows {min_rows:7d} streams {streams}: {ms:6.1f} ms/step, buckets {[(t, n) for t, _, n, _ in plan]}, "
+        print(f"{'row space' if streams == 0 else 'buckets  '} min_rows {min_rows:7d} streams {streams} attention lanes {ragged.ATTN_LANES}: {ms:6.1f} ms/step, buckets {[(t, n) for t, _, n, _ in plan]}, "
               f"{'bit-equal to the first setting' if same else 'max |diff| vs first %.3g' % dl}", flush=True)

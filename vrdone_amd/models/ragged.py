@@ -126,9 +126,24 @@ def _attention_rows(q, k, v, kv_mask, q_mask, n_head, qsegs, ksegs, *, half_win=
         assert list(qsegs) == list(ksegs)
         r = ops.local_attention(q, k, v, kv_mask, n_head, half_win, pair=pair, rel_pe=rel_pe, out=out, segs=list(qsegs))
         return ops.Pair(out, Cc, r.fmt) if isinstance(r, ops.Pair) else out
-    for (qo, n, Tq), (ko, nk, Tk) in zip(qsegs, ksegs):
+    # global attention walks the buckets; a bucket's launch is n x heads x query blocks workgroups of one per CU -- 4.02 rounds
+    # of the chip for 257 pairs x 4 heads take five --, so the buckets' launches alternate between ATTN_LANES streams and fill
+    # each other's last rounds
+    dev = _raw(q).device
+    lanes = _lanes(dev) if half_win is None and len(qsegs) > 2 else None
+    if lanes:
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for lane in lanes:
+            lane.wait_event(ready)
+    for i, ((qo, n, Tq), (ko, nk, Tk)) in enumerate(zip(qsegs, ksegs)):
         assert n == nk
         o = _part(out, qo, n, Tq)
+        if lanes and i % (len(lanes) + 1):
+            with torch.cuda.stream(lanes[i % (len(lanes) + 1) - 1]):
+                r = _attention_one(q, k, v, kv_mask, q_mask, n_head, (qo, n, Tq), (ko, nk, Tk), o, pair, plain)
+            continue
         if half_win is not None:
             assert Tq == Tk
             r = ops.local_attention(_part(q, qo, n, Tq), _part(k, ko, n, Tk), _part(v, ko, n, Tk), _mpart(kv_mask, ko, n, Tk),
@@ -138,7 +153,33 @@ def _attention_rows(q, k, v, kv_mask, q_mask, n_head, qsegs, ksegs, *, half_win=
         else:
             r = ops.attention(_part(q, qo, n, Tq), _part(k, ko, n, Tk), _part(v, ko, n, Tk), _mpart(kv_mask, ko, n, Tk), n_head,
                               pair=pair, q_mask=_mpart(q_mask, qo, n, Tq), out=o)
+    if lanes:
+        for lane in lanes:
+            main.wait_stream(lane)
     return ops.Pair(out, Cc, r.fmt) if isinstance(r, ops.Pair) else out
+
+
+def _attention_one(q, k, v, kv_mask, q_mask, n_head, qseg, kseg, o, pair, plain):
+    ops = _ops()
+    (qo, n, Tq), (ko, _, Tk) = qseg, kseg
+    if plain:
+        return ops.attention(_part(q, qo, n, Tq), _part(k, ko, n, Tk), _part(v, ko, n, Tk), _mpart(kv_mask, ko, n, Tk), n_head, out=o)
+    return ops.attention(_part(q, qo, n, Tq), _part(k, ko, n, Tk), _part(v, ko, n, Tk), _mpart(kv_mask, ko, n, Tk), n_head,
+                         pair=pair, q_mask=_mpart(q_mask, qo, n, Tq), out=o)
+
+
+ATTN_LANES = int(__import__("os").environ.get("VRDONE_ROWS_ATTN_STREAMS", "2"))      # streams the buckets' global attention alternates between
+_side_streams = {}
+
+
+def _lanes(dev):
+    """the side streams of `dev` (ATTN_LANES - 1 of them), or None: one stream, or a capture in progress"""
+    if ATTN_LANES <= 1 or torch.cuda.is_current_stream_capturing():
+        return None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), ATTN_LANES)
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(ATTN_LANES - 1)]
+    return _side_streams[key]
 
 
 def _attn_rows(mod, q_in, k_in, v_in, q_mask, kv_mask, qsegs, ksegs, *, stride=1, pre_ln=None, pre_ln_on="", **epilogue):
