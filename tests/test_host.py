@@ -273,3 +273,34 @@ def test_row_space_layout_and_filler_buckets():
     assert ragged.filler_buckets(4096 + 32, 288) == [] and ragged.filler_buckets(65536 + 48, 40) == []
     segs = _hip.RowSegs.of(lay.twice())
     assert segs.count == 6 and list(segs.row)[:6] == [0, 96, 288, 336, 432, 624] and list(segs.T)[:3] == [32, 96, 48]
+
+
+def test_flat_k3_conv_with_zeroed_tails_equals_the_per_sequence_conv_on_valid_rows():
+    """The invariant behind the row-space form's dense k = 3 convs (vrdone_amd/models/ragged.py): sequences of different
+    padded lengths back to back, the last row of every sequence zeroed in the conv's INPUT, one Conv1d(padding=1) over all
+    rows -- equals the reference's per-sequence Conv1d(padding=1) * mask (models/blocks.py:99-113) on every row whose mask is
+    set, provided the last TWO frames of every sequence are padded ones; with only one padded frame the last valid frame
+    differs (which is why such pairs are bucketed apart).  float64, plain torch."""
+    import torch
+    g = torch.Generator().manual_seed(5)
+    C, N = 6, 5
+    w, b = torch.randn(N, C, 3, generator=g, dtype=torch.float64), torch.randn(N, generator=g, dtype=torch.float64)
+    conv = lambda x: torch.nn.functional.conv1d(x, w, b, padding=1)          # noqa: E731  x (B, C, T)
+    seqs = [(32, 30), (32, 7), (64, 62), (96, 40), (32, 2)]                   # (padded length, valid frames <= padded - 2)
+    xs = [torch.randn(1, C, T, generator=g, dtype=torch.float64) + 3.0 for T, _ in seqs]     # padded frames hold junk, like LN(0) = beta
+    want = [conv(x)[0, :, :L] for x, (T, L) in zip(xs, seqs)]
+    flat = torch.cat([x.clone() for x in xs], dim=2)
+    at = 0
+    for T, _ in seqs:
+        at += T
+        flat[0, :, at - 1] = 0.0                                              # the sequence's last row
+    got, at = conv(flat)[0], 0
+    for (T, L), wnt in zip(seqs, want):
+        assert torch.allclose(got[:, at:at + L], wnt, rtol=0, atol=1e-12)
+        at += T
+    # one padded frame only: the last valid frame reads the zeroed row instead of the padded frame's value
+    T, L = 32, 31
+    x = torch.randn(1, C, T, generator=g, dtype=torch.float64) + 3.0
+    z = x.clone()
+    z[0, :, T - 1] = 0.0
+    assert not torch.allclose(conv(z)[0, :, L - 1], conv(x)[0, :, L - 1], atol=1e-6)
