@@ -231,6 +231,70 @@ def test_row_space_form_gives_the_same_outputs(name, B, T, chunk, precision):
     assert bool((rows["pred_masks"].cpu()[pad] == -10.0).all())
 
 
+def test_row_space_filler_sequences_change_nothing():
+    """From ~65 k rows on, the row-space form appends a few all-padding sequences so that the row count is a multiple of 256
+    (models/ragged.py filler_buckets: the 256 x 256 GEMM kernel then serves the first three pyramid levels).  A 700-pair ragged
+    batch, large enough for the filler: same outputs as the batch at its own padded length, and as bucket by bucket."""
+    from vrdone_amd.models import ragged
+    model, mc, _, _ = get_model("vidvrd")
+    gen = torch.Generator().manual_seed(277)
+    B, T = 700, 288
+    lens = torch.randint(2, T - 30, (B,), generator=gen)
+    lens[:3] = torch.tensor([T, T - 1, T - 2])
+    for k in range(9):                       # (a row count that is a multiple of 256 by itself needs none: move one pair up a bucket)
+        rows = sum(model.tight_buckets(lens.tolist(), [T] * B, model.ROWS_MIN_ROWS))
+        if rows % 256:
+            break
+        lens[10 + k] = 100 + 32 * (k % 4)
+    x, m = O.synth_pairs(B, c_in(mc), T, lens.tolist(), seed=278)
+    xd, md = x.to(DEV), m.to(DEV)
+    plan = model._tight_plan(md, md.reshape(B, T))
+    rows = sum(n * t for t, _, n, _ in plan["buckets"])
+    assert plan["rows"] and rows >= 65536 and ragged.filler_buckets(rows, T), "the batch was meant to need filler sequences"
+    try:
+        got = model._mask_vrd(xd, md, with_aux=False)
+        model.row_space = False
+        buckets = model._mask_vrd(xd, md.clone(), with_aux=False)
+        model.tight_padding = False
+        full = model._mask_vrd(xd, md.clone(), with_aux=False)
+    finally:
+        model.tight_padding = True
+        del model.row_space
+    close(got["pred_logits"], full["pred_logits"], 2e-5)
+    close(got["pred_masks"], full["pred_masks"], 2e-4)
+    close(got["pred_logits"], buckets["pred_logits"], 2e-5)
+    close(got["pred_masks"], buckets["pred_masks"], 2e-4)
+
+
+def test_forward_test_in_one_row_space_equals_bucket_by_bucket():
+    """forward_test on a video large enough for waves and filler sequences (1,260 pairs of 60-250 frames, pair_chunk 512): all
+    padded lengths of a wave in one row space against the bucket-by-bucket path -- the same triplets, tracks and durations, scores
+    to 1e-5; from per-pair matrices and from per-tracklet features (window-edge pieces of all buckets in one entity-stage pass)."""
+    from vrdone_amd import synth
+    from vrdone_amd.proposals import prepare_test_proposal
+    model, mc, ic, _ = get_model("vidvrd")
+    old_chunk = model.pair_chunk
+    video = synth.synth_video(36, c_in(mc), 60, 250, seed=11, device=DEV)
+    raw = synth.synth_raw_video(36, mc["visual_dim"], 60, 250, seed=11)
+    prop = prepare_test_proposal(raw, ic["feat_stride"], 0, 2, torch.device(DEV))
+    try:
+        model.pair_chunk = 512
+        for data in (video, prop):
+            got = model(data)
+            model.row_space = False
+            want = model(data)
+            del model.row_space
+            assert len(got["triplets"]) == len(want["triplets"]) > 50
+            for key in ("triplets", "pred_durations", "so_tids", "so_trajs"):
+                assert got[key] == want[key], key
+            for key in ("triple_scores", "triple_scores_avg"):
+                np.testing.assert_allclose(np.array(got[key]), np.array(want[key]), atol=1e-5, rtol=0)
+    finally:
+        model.pair_chunk = old_chunk
+        if "row_space" in model.__dict__:
+            del model.row_space
+
+
 @pytest.mark.parametrize("scale", [1.0 / 1024, 1.0 / 32, 1.0, 48.0])
 def test_f16x3_stays_reference_grade_across_input_magnitudes(scale):
     """The f16x3 mode's activation scale is fixed (2^4): inputs far below 1 push the lo halves of the FIRST layer's operands into
