@@ -133,3 +133,32 @@ def test_gather_predictions_world2(n_pairs):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_tight_plan_from_attached_lengths_equals_the_one_read_back_from_the_mask():
+    """Masks built by MaskVRD._batch carry the lengths they were built from, so the tight-padding plan needs no read-back;
+    a mask tensor from elsewhere (a clone: no attribute) gets the same plan from its own bits; editing the mask in place
+    invalidates the attached lengths (version counter).  Host logic only: runs on CPU tensors."""
+    from conftest import load_case
+    from vrdone_amd.models.maskvrd import MaskVRD
+    mc, _, _ = load_case("vidvrd")
+    model = MaskVRD(mc, device="cpu").eval()
+    g = torch.Generator().manual_seed(9)
+    lens = [96, 95, 94] + torch.randint(2, 90, (200,), generator=g).tolist()
+    feats = [torch.zeros(4, n) for n in lens]
+    model.ROWS_MIN_ROWS = 256
+    x, m = model._batch(feats, range(len(feats)), 96)
+    assert m._vrd_lens[1] == lens
+    plan = model._tight_plan(m, m.reshape(len(lens), 96))
+    other = m.clone()
+    assert not hasattr(other, "_vrd_lens")
+    plan2 = model._tight_plan(other, other.reshape(len(lens), 96))
+    assert plan["rows"] and plan2["rows"] and len(plan["buckets"]) == len(plan2["buckets"]) >= 3
+    for (t, idx, n, flat), (t2, idx2, n2, flat2) in zip(plan["buckets"], plan2["buckets"]):
+        assert (t, n, flat) == (t2, n2, flat2) and torch.equal(idx, idx2)
+        assert all((lens[i] <= t - 2) == flat and t % 32 == 0 for i in idx.tolist())
+    assert [f for _, _, _, f in plan["buckets"]] == sorted((f for _, _, _, f in plan["buckets"]), reverse=True)   # flat buckets first
+    m[0, 0, 50:] = False                                   # in place: pair 0 is 50 frames long now
+    plan3 = model._tight_plan(m, m.reshape(len(lens), 96))
+    t_of_0 = [t for t, idx, _, _ in plan3["buckets"] if 0 in idx.tolist()]
+    assert t_of_0 == [64]
