@@ -304,3 +304,15 @@ def test_flat_k3_conv_with_zeroed_tails_equals_the_per_sequence_conv_on_valid_ro
     z = x.clone()
     z[0, :, T - 1] = 0.0
     assert not torch.allclose(conv(z)[0, :, L - 1], conv(x)[0, :, L - 1], atol=1e-6)
+
+
+def test_every_host_side_switch_is_documented():
+    """Every VRDONE_* environment switch the host code reads is listed in INTEGRATION.md's table of switches."""
+    import glob
+    text = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    seen = set()
+    for f in glob.glob(os.path.join(REPO, "vrdone_amd", "**", "*.py"), recursive=True):
+        seen |= set(re.findall(r"VRDONE_[A-Z0-9_]+", open(f).read()))
+    assert len(seen) >= 12
+    missing = sorted(s for s in seen if s not in text)
+    assert not missing, f"switches read by the host code but not in INTEGRATION.md: {missing}"
