@@ -1,0 +1,3 @@
+#!/bin/bash
+cd /root/repo
+timeout -k 10 600 python scripts/dev/ft_hostprof.py 2>&1 | grep -v amdgpu.ids

@@ -58,14 +58,22 @@ class RowSegs(C.Structure):
     """vrd_row_segs: a ragged row space as groups of sequences (n[i] sequences of T[i] frames from row row[i] on)"""
     _fields_ = [("count", C.c_int32), ("n", C.c_int32 * MAX_SEGS), ("T", C.c_int32 * MAX_SEGS), ("row", C.c_int64 * MAX_SEGS)]
 
+    _made = {}
+
     @classmethod
     def of(cls, segs):
-        """segs: [(first row, sequences, frames)]"""
-        assert 1 <= len(segs) <= MAX_SEGS
-        s = cls()
-        s.count = len(segs)
-        for i, (row, n, T) in enumerate(segs):
-            s.row[i], s.n[i], s.T[i] = row, n, T
+        """segs: [(first row, sequences, frames)]; the structs are read-only and kept (a network pass asks for the same few
+        tables ~25 times)"""
+        key = tuple(segs)
+        s = cls._made.get(key)
+        if s is None:
+            assert 1 <= len(segs) <= MAX_SEGS
+            if len(cls._made) > 4096:
+                cls._made.clear()
+            s = cls._made[key] = cls()
+            s.count = len(segs)
+            for i, (row, n, T) in enumerate(segs):
+                s.row[i], s.n[i], s.T[i] = row, n, T
         return s
 
 

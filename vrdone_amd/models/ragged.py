@@ -43,6 +43,7 @@ class Layout:
     def __init__(self, buckets):
         """buckets: [(sequences, frames, flat)]"""
         self.segs, self.flat, off = [], [], 0
+        self._tails = {}
         for n, T, flat in buckets:
             self.segs.append((off, n, T))
             self.flat.append(bool(flat))
@@ -56,10 +57,14 @@ class Layout:
         return self.segs + [(self.rows + off, n, T) for off, n, T in self.segs]
 
     def tail_rows(self, halves, device):
-        """last row of every sequence of the flat buckets (of both halves of a stacked row space)"""
-        idx = [h * self.rows + off + T * torch.arange(1, n + 1, dtype=torch.int64) - 1
-               for h in range(halves) for (off, n, T), f in zip(self.segs, self.flat) if f]
-        return torch.cat(idx).to(device) if idx else None
+        """last row of every sequence of the flat buckets (of both halves of a stacked row space), built ON the device: a table
+        uploaded from the host in the middle of a call would wait for every launch queued before it"""
+        key = (halves, str(device))
+        if key not in self._tails:
+            idx = [torch.arange(h * self.rows + off + T - 1, h * self.rows + off + n * T, T, dtype=torch.int64, device=device)
+                   for h in range(halves) for (off, n, T), f in zip(self.segs, self.flat) if f]
+            self._tails[key] = (torch.cat(idx) if len(idx) > 1 else idx[0]) if idx else None
+        return self._tails[key]
 
 
 def _part(x, off, n, T):
