@@ -112,8 +112,11 @@ __device__ __forceinline__ T load_karg(kargs_ptr_t base, int byte_off) {
 // starts on landed data: the one-tile form spends ~9 k of a K = 512 tile's ~66 k cycles on its set-up and on waiting for its
 // first stage (profiles/r05_lab_gemm_tile_stamps.txt).  The epilogue then stages through 32-row slabs in the two ring
 // buffers the prefetch leaves free (activation stage 2, weight stage 1).
-template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
-__global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
+// WH = wave >> 2 as a compile-time constant: the two halves of the workgroup run their own copy of the whole body (the place
+// of a wave's LDS-DMA request inside an MFMA group is then no branch: 16 per K step before), and the copies never join, so the
+// register assignment of one does not constrain the other (joined behind the K loop, one copy spilled accumulators)
+template <int TAPS, bool M16, bool PERSIST, bool F16, int WH>
+__device__ __forceinline__ void gemm_x3_big_body() {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the buffer descriptor type exists in the device pass only)
     typedef typename vrd::SplitFmt<F16>::x8 e16x8;      // fragment of eight 16-bit elements (bf16 or f16)
     kargs_ptr_t kp = (kargs_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     };
     reload();
     const int stagger = PERSIST ? 0 : load_karg<int>(kp, offsetof(BigKArgs, stagger));
-#ifdef VRD_LAB_STAMP
+#ifdef VRD_LAB_PRIO_RT
     const int prio = load_karg<int>(kp, offsetof(BigKArgs, prio));      // (lab builds: VRD_BIG_PRIO picks the scheme at run time)
 #else
     constexpr int prio = 3;      // measured best of 0 .. 4 (profiles/r05_lab_gemm_prio.txt); a constant: no tests in the K loop
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     char* const lds = reinterpret_cast<char*>(smem);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wave = WH * 4 + (__builtin_amdgcn_readfirstlane(tid >> 6) & 3);
+    const int wm = WH, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
     // ---- tiles.  Virtual block id -> tile through the XCD-aware renumbering; the tile's rows are eight 32-row blocks,
     // slots tm*8 .. tm*8+7 of the block list (identity without one).  With a padding map (vrd_row_blocks) the list is
@@ -338,25 +341,33 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     struct AF { e16x8 hi, lo; };
     struct WF { e16x8 hi[NWF], lo[NWF]; };
     // 32x32x16: (s2, mi) = k16 half, 32-row block.  M16: s2 unused, mi = 16-row block 0..7 (g of the group)
+    // per-lane fragment bases, one register per (k16 half, hi / lo plane): XOR 32 = the other half, XOR 64 = the lo plane; row and
+    // column blocks are immediate offsets of the reads (laundered: left to itself hipcc keeps a register per block, and the
+    // 16x16x32 loop has none to spare)
+    int a_off[4], w_off[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        a_off[v] = a_base ^ (v * 32), w_off[v] = w_base ^ (v * 32);
+        if (M16 ? (v & 1) == 0 : true) asm volatile("" : "+v"(a_off[v]), "+v"(w_off[v]));
+    }
     auto load_a = [&](const char* sa, int s2, int mi) {
         AF f;
-        const int off = M16 ? a_base + mi * 16 * ROWB : (a_base ^ (s2 * 32)) + mi * 32 * ROWB;
-        f.hi = *reinterpret_cast<const e16x8*>(sa + off);
-        f.lo = *reinterpret_cast<const e16x8*>(sa + (off ^ 64));
+        const int blk = M16 ? mi * 16 * ROWB : mi * 32 * ROWB;
+        f.hi = *reinterpret_cast<const e16x8*>(sa + a_off[M16 ? 0 : s2] + blk);
+        f.lo = *reinterpret_cast<const e16x8*>(sa + a_off[M16 ? 2 : s2 + 2] + blk);
         return f;
     };
     auto load_w1 = [&](const char* sw, int t, WF& f) {       // M16: column block t only
-        const int off = w_base + t * 16 * ROWB;
-        f.hi[t] = *reinterpret_cast<const e16x8*>(sw + off);
-        f.lo[t] = *reinterpret_cast<const e16x8*>(sw + (off ^ 64));
+        f.hi[t] = *reinterpret_cast<const e16x8*>(sw + w_off[0] + t * 16 * ROWB);
+        f.lo[t] = *reinterpret_cast<const e16x8*>(sw + w_off[2] + t * 16 * ROWB);
     };
     auto load_w = [&](const char* sw, int s2) {
         WF f;
 #pragma unroll
         for (int t = 0; t < NWF; ++t) {
-            const int off = M16 ? w_base + t * 16 * ROWB : (w_base ^ (s2 * 32)) + t * 32 * ROWB;
-            f.hi[t] = *reinterpret_cast<const e16x8*>(sw + off);
-            f.lo[t] = *reinterpret_cast<const e16x8*>(sw + (off ^ 64));
+            const int blk = M16 ? t * 16 * ROWB : t * 32 * ROWB;
+            f.hi[t] = *reinterpret_cast<const e16x8*>(sw + w_off[M16 ? 0 : s2] + blk);
+            f.lo[t] = *reinterpret_cast<const e16x8*>(sw + w_off[M16 ? 2 : s2 + 2] + blk);
         }
         return f;
     };
@@ -392,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     // behind wins (prio 3: the barrier wait of the older half drops to ~650 cycles, the K step from ~3,700 to ~3,550 cycles,
     // the whole step by 1.5 ms; schemes 1 = the younger half at a static priority 1: no gain; 2 = two levels per step: half
     // the gain; 4 = two levels, the younger half holding the high one longer: between 2 and 3).
-    if (prio == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (prio == 1 && WH) __builtin_amdgcn_s_setprio(1);
     WF w_cur = load_w(lds + (g0 % NW_STG) * W_STAGE, 0), w_nxt = w_cur;
     AF a_cur = load_a(lds + (g0 % NA_STG) * A_STAGE, 0, 0), a_nxt = a_cur;
     LAB_PHASE_DECL;
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
             }
             if (prio == 4) {                 // two levels, the younger half holds the high one longer
                 if (g == 0) __builtin_amdgcn_s_setprio(1);
-                if (g == (wave >= 4 ? 5 : 3)) __builtin_amdgcn_s_setprio(0);
+                if (g == (WH ? 5 : 3)) __builtin_amdgcn_s_setprio(0);
             }
             // ---- reads for what comes next
             if (g < 7) a_nxt = M16 ? load_a(sa, 0, g + 1) : load_a(sa, (g + 1) >> 2, (g + 1) & 3);
@@ -446,51 +457,57 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
                 a_nxt = load_a(sa1, 0, 0);
                 if (!M16) w_nxt = load_w(sw1, 0);
             }
-            // ---- the group's MFMAs (six 32x32x16 or twelve 16x16x32), this wave's DMA of the group in the middle or
-            // at the end
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj) {
-                if (M16) {
-#pragma unroll
-                    for (int t = 2 * nj; t < 2 * nj + 2; ++t) {
-                        acc16[g][t] = vrd::mfma16(a_cur.lo, w_cur.hi[t], acc16[g][t]);
-                        acc16[g][t] = vrd::mfma16(a_cur.hi, w_cur.lo[t], acc16[g][t]);
-                        acc16[g][t] = vrd::mfma16(a_cur.hi, w_cur.hi[t], acc16[g][t]);
-                        // the step's last use of column block t's weight fragments: the next step's go straight into the same
-                        // registers (a second set of all four blocks' fragments, 32 registers, is what made hipcc spill)
-                        if (g == 7 && !last) load_w1(sw1, t, w_cur);
+            // ---- the group's MFMAs (six 32x32x16 or twelve 16x16x32), this wave's DMA of the group in the middle (waves 0-3)
+            // or at the end (waves 4-7): WH = wave >> 2 is a compile-time constant, the loop exists once per half
+            auto dma_of_group = [&]() __attribute__((always_inline)) {
+                __builtin_amdgcn_sched_barrier(0);
+#ifdef VRD_LAB_NODMA
+                if (POS == POS_STEADY) return;
+#endif
+                // groups 0..6 carry slots 1..7 of the batch opened in step kt-1, group 7 slot 0 of this step's
+                if (g < 7) {
+                    // the batch opened in step kt-1: W(kt+1) pieces 1..3, A(kt+2) pieces 0..3
+                    if (POS == POS_GENERIC) {
+                        if (kt > 0) dma_slot(kt - 1, g + 1, kt + 1 < nkt, kt + 2 < nkt);
+                        else if (g < PER && nkt > 2) issue_a1(cur, g0 + 2, 2, g);      // step 0 has no batch of its own yet
+                    } else if (POS == POS_FIRST) {
+                        if (g < PER) issue_a1(cur, g0 + 2, 2, g);
+                    } else if (POS == POS_STEADY) {
+                        dma_slot(kt - 1, g + 1, true, true);
+                    } else if (POS == POS_PEN) {
+                        // W(nkt-1) pieces 1..3; then (PERSIST) the next tile's A(0)
+                        if (g + 1 < PER) dma_slot(kt - 1, g + 1, true, false);
+                        else if (PERSIST) dma_slot_next(0, 0, g + 1);
+                    } else if (POS == POS_LAST && PERSIST) {
+                        dma_slot_next(0, 1, g + 1);        // the next tile's W(0) pieces 1..3, A(1) pieces 0..3
                     }
-                } else {
+                } else if (!last) {
+                    // slot 0 of this step's own batch: W(kt+2) piece 0 -- in the step before the last (PERSIST) the next
+                    // tile's W(0) piece 0
+                    if (POS == POS_PEN && PERSIST) dma_slot_next(0, 0, 0);
+                    else dma_slot(kt, 0, POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN, false);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (M16) {
+                // product-major order: consecutive MFMAs write different accumulators (a block's three products are four
+                // instructions apart); the step's last use of column block t's weight fragments is its hi x hi product: the
+                // next step's go straight into the same registers (a second set of all four blocks' fragments, 32
+                // registers, is what made hipcc spill)
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    const int pr = q >> 2, t = q & 3;
+                    acc16[g][t] = vrd::mfma16(pr == 0 ? a_cur.lo : a_cur.hi, pr == 1 ? w_cur.lo[t] : w_cur.hi[t], acc16[g][t]);
+                    if (pr == 2 && g == 7 && !last) load_w1(sw1, t, w_cur);
+                    if ((q == 5 && WH == 0) || (q == 11 && WH == 1)) dma_of_group();
+                }
+            } else {
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) {
                     acc[mi][nj] = vrd::mfma32(a_cur.lo, w_cur.hi[nj], acc[mi][nj]);
                     acc[mi][nj] = vrd::mfma32(a_cur.hi, w_cur.lo[nj], acc[mi][nj]);
                     acc[mi][nj] = vrd::mfma32(a_cur.hi, w_cur.hi[nj], acc[mi][nj]);
-                }
-                if ((wave >> 2) == nj) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    // groups 0..6 carry slots 1..7 of the batch opened in step kt-1, group 7 slot 0 of this step's
-                    if (g < 7) {
-                        // the batch opened in step kt-1: W(kt+1) pieces 1..3, A(kt+2) pieces 0..3
-                        if (POS == POS_GENERIC) {
-                            if (kt > 0) dma_slot(kt - 1, g + 1, kt + 1 < nkt, kt + 2 < nkt);
-                            else if (g < PER && nkt > 2) issue_a1(cur, g0 + 2, 2, g);      // step 0 has no batch of its own yet
-                        } else if (POS == POS_FIRST) {
-                            if (g < PER) issue_a1(cur, g0 + 2, 2, g);
-                        } else if (POS == POS_STEADY) {
-                            dma_slot(kt - 1, g + 1, true, true);
-                        } else if (POS == POS_PEN) {
-                            // W(nkt-1) pieces 1..3; then (PERSIST) the next tile's A(0)
-                            if (g + 1 < PER) dma_slot(kt - 1, g + 1, true, false);
-                            else if (PERSIST) dma_slot_next(0, 0, g + 1);
-                        } else if (POS == POS_LAST && PERSIST) {
-                            dma_slot_next(0, 1, g + 1);        // the next tile's W(0) pieces 1..3, A(1) pieces 0..3
-                        }
-                    } else if (!last) {
-                        // slot 0 of this step's own batch: W(kt+2) piece 0 -- in the step before the last (PERSIST) the next
-                        // tile's W(0) piece 0
-                        if (POS == POS_PEN && PERSIST) dma_slot_next(0, 0, 0);
-                        else dma_slot(kt, 0, POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN, false);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (WH == nj) dma_of_group();
                 }
             }
 #if defined(VRD_LAB_STAMP) && defined(VRD_LAB_VALU)
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
                                  : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
 #pragma unroll
                 for (int i = 0; i < VRD_LAB_LDSR / 8; ++i) {
-                    vrd::f32x4_t t = *reinterpret_cast<const vrd::f32x4_t*>(sa + ((a_base + i * 2048) & (A_STAGE - 16)));
+                    vrd::f32x4_t t = *reinterpret_cast<const vrd::f32x4_t*>(sa + ((a_off[0] + i * 2048) & (A_STAGE - 16)));
                     asm volatile("" ::"v"(t));
                 }
                 asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
             }
         }
     };
-    if (nkt >= 3) {
+    if (PERSIST || nkt >= 3) {          // (the host sends the persistent form only K loops of three steps or more)
         kstep(0, std::integral_constant<int, POS_FIRST>{});
         for (int kt = 1; kt + 2 < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_STEADY>{});
         kstep(nkt - 2, std::integral_constant<int, POS_PEN>{});
@@ -538,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     } else {
         for (int kt = 0; kt < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_GENERIC>{});
     }
-    LAB_PHASE_FLUSH(wave >> 2);
+    LAB_PHASE_FLUSH(WH);
     if (prio) __builtin_amdgcn_s_setprio(0);
     }       // contract
 #ifdef VRD_LAB_STAMP
@@ -561,6 +578,10 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
                                : smem + wave * (64 * vrd::STG_PITCH);
     bool all_stored = true;
     constexpr int SLAB = PERSIST ? 32 : 64;
+    // (a fresh copy of the lane index per tile: what the epilogue derives from it is computed here, behind the main loop --
+    // hoisted in front of the tile loop, those values held ~40 registers across a K loop that has none to spare)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
 #pragma unroll
     for (int hm = 0; hm < 2; ++hm) {          // the epilogue works on 64 x 64 halves of the wave's 128 x 64
         // (M % 64 == 0 and N % 64 == 0, checked on the host: the sub-tile is inside C or entirely outside)
@@ -582,18 +603,18 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) part[i][j] = acc16[M16 ? 4 * hm + i : 0][M16 ? j : 0];
-            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
-            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
+            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
+            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
         } else {
             f32x16 part[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) part[i][j] = acc[M16 ? 0 : 2 * hm + i][M16 ? 0 : j];
-            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
-            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane, cols, rflag);
+            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
+            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
+            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
         }
     }
     LAB_STAMP(3);
@@ -610,6 +631,12 @@ __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
     // (the last tile's look-ahead requests wrote into this workgroup's LDS: nothing may be in flight when it is handed on)
     if (PERSIST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+}
+
+template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
+__global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) gemm_x3_big_body<TAPS, M16, PERSIST, F16, 1>();
+    else gemm_x3_big_body<TAPS, M16, PERSIST, F16, 0>();
 }
 
 }  // namespace
