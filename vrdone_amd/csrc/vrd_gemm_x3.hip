@@ -1,5 +1,7 @@
 // Split-precision variant of the conv GEMM: the same C = epilogue(A' . W^T) as vrd_gemm.hip, with
-// every f32 product replaced by three 16-bit MFMA products (v_mfma_f32_32x32x16_bf16 / _f16, f32 accumulate):
+// every f32 product replaced by three 16-bit MFMA products (v_mfma_f32_16x16x32_bf16 / _f16, f32 accumulate; every
+// split-precision GEMM kernel sums a K step of 32 per instruction and the three products of a step in the order lo x hi,
+// hi x lo, hi x hi, so which kernel serves a shape does not change a bit of the result):
 //
 //     x = x_hi + x_lo,  x_hi = bf16(x),  x_lo = bf16(x - x_hi)            (|x - x_hi - x_lo| <= 2^-17 |x|)
 //     a * w  ~=  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi                          (drops a_lo*w_lo ~ 2^-18 |a w|)
@@ -12,7 +14,7 @@
 // F16 (VRD_PAIR_F16, the f16x3 mode): the same with f16 planes of power-of-two scaled operands (vrd_common.h): 2^-22 per
 // plane pair, ~2^-22 |a w| dropped; the epilogue multiplies the accumulator by the power of two that undoes the scaling.
 //
-// Tiling: 128 x 128 x 32 per 256-thread workgroup, four waves x (2 x 2) accumulators of 32 x 32, operand
+// Tiling: 128 x 128 x 32 per 256-thread workgroup, four waves x (2 x 2) blocks of 32 x 32 (each 2 x 2 accumulators of 16 x 16), operand
 // tiles [row][k] in bf16 with an 80-byte row pitch (16 consecutive rows hit 16 distinct 16-byte LDS slots,
 // so the ds_read_b128 fragment reads are conflict free).  Two LDS buffers (80 KiB, two workgroups per CU)
 // and a register prefetch two K steps ahead: while the MFMAs of step t run, the registers holding step
@@ -24,7 +26,7 @@
 
 namespace {
 
-using vrd::f32x16;
+using vrd::acc32q;
 constexpr int BK = 32;
 constexpr int XP = 40;                                   // row pitch in bf16 elements (80 B)
 // SMALL: 64 x 64 tiles, one 32 x 32 accumulator per wave -- for problems whose 128 x 128 tiles would leave most of the
@@ -35,7 +37,7 @@ template <bool SMALL>
 struct X3Geo {
     static constexpr int BM = SMALL ? 64 : 128, BN = BM;
     static constexpr int WT = BM / 2;                                    // rows / columns of a wave's sub-tile
-    static constexpr int NT = WT / 32;                                   // 32 x 32 accumulators per wave and dimension
+    static constexpr int NT = WT / 32;                                   // 32 x 32 blocks per wave and dimension
     static constexpr int TILE = BM * XP;                                 // elements per operand tile
     static constexpr size_t LDS = 2 * 4 * TILE * 2;         // 2 buffers x (a_hi, a_lo, w_hi, w_lo): 80 / 40 KiB
     static constexpr int NPA = BM / 32, NPAP = BM / 64, NPW = BN / 64;   // staging pieces per thread: f32 A, pair A, W
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
+    const int l15 = lane & 15, l4 = lane >> 4;      // v_mfma_f32_16x16x32 operand: row / column l15, k = 8 * l4 .. + 7
     const int K = p.Cin * TAPS;          // multiple of 32 (checked on the host)
     const int nkt = K / BK;
     const e16* Wsp = reinterpret_cast<const e16*>(p.W_split);      // [N][K/32][32 hi | 32 lo]
@@ -179,44 +181,45 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(vrd_gemm_args p, int tiles
         }
     };
 
-    f32x16 acc[NT][NT];
+    acc32q acc[NT][NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int j = 0; j < NT; ++j) vrd::acc_clear(acc[i][j]);
 
     fetch(0);
     stage(0);
     if (nkt > 1) fetch(1);
     __syncthreads();
-    const int arow = (wm * WT + li) * XP + 8 * lh, wrow = (wn * WT + li) * XP + 8 * lh;
+    const int arow = (wm * WT + l15) * XP + 8 * l4, wrow = (wn * WT + l15) * XP + 8 * l4;
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const e16* a_hi = lds + cur * 4 * TILE;
         const e16* a_lo = a_hi + TILE;
         const e16* w_hi = a_lo + TILE;
         const e16* w_lo = w_hi + TILE;
+        // fragments of the whole K step: 16-row / 16-column blocks t of the wave's sub-tile
+        e16x8 ah[2 * NT], al[2 * NT], wh[2 * NT], wl[2 * NT];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            e16x8 ah[NT], al[NT], wh[NT], wl[NT];
+        for (int t = 0; t < 2 * NT; ++t) {
+            ah[t] = *reinterpret_cast<const e16x8*>(a_hi + arow + t * 16 * XP);
+            al[t] = *reinterpret_cast<const e16x8*>(a_lo + arow + t * 16 * XP);
+            wh[t] = *reinterpret_cast<const e16x8*>(w_hi + wrow + t * 16 * XP);
+            wl[t] = *reinterpret_cast<const e16x8*>(w_lo + wrow + t * 16 * XP);
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                ah[t] = *reinterpret_cast<const e16x8*>(a_hi + arow + t * 32 * XP + 16 * s);
-                al[t] = *reinterpret_cast<const e16x8*>(a_lo + arow + t * 32 * XP + 16 * s);
-                wh[t] = *reinterpret_cast<const e16x8*>(w_hi + wrow + t * 32 * XP + 16 * s);
-                wl[t] = *reinterpret_cast<const e16x8*>(w_lo + wrow + t * 32 * XP + 16 * s);
-            }
+        for (int half = 0; half < 2; ++half) {
+            // product-major inside a row block: consecutive MFMAs write different accumulators
 #pragma unroll
-            for (int mi = 0; mi < NT; ++mi)
+            for (int bi = half * NT; bi < (half + 1) * NT; ++bi)
 #pragma unroll
-                for (int nj = 0; nj < NT; ++nj) {
-                    acc[mi][nj] = vrd::mfma32(al[mi], wh[nj], acc[mi][nj]);
-                    acc[mi][nj] = vrd::mfma32(ah[mi], wl[nj], acc[mi][nj]);
-                    acc[mi][nj] = vrd::mfma32(ah[mi], wh[nj], acc[mi][nj]);
-                }
-            if (s == 0 && kt + 1 < nkt) {
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int bj = 0; bj < 2 * NT; ++bj) {
+                        vrd::f32x4_t& c = acc[bi >> 1][bj >> 1].b[bi & 1][bj & 1];
+                        c = vrd::mfma16(pr == 0 ? al[bi] : ah[bi], pr == 1 ? wl[bj] : wh[bj], c);
+                    }
+            if (half == 0 && kt + 1 < nkt) {
                 // the registers hold step kt+1 (loaded one iteration ago): split + write them into the
                 // other buffer under this step's MFMAs, then reuse them for the loads of step kt+2
                 stage(cur ^ 1);

@@ -12,7 +12,9 @@
 // issue W(t+1) then A(t+2) (4 + 4 DMAs; W first so that the counted wait can leave A(t+2) in flight) ->
 // fragment reads and MFMAs of step t.  The barrier also tells everyone that stage t-1 is no longer being read,
 // which frees A buffer (t+2) % 3 and W buffer (t+1) % 2.
-// 8 waves as 2 (M) x 4 (N), each 128 x 64 = 4 x 2 accumulators of 32 x 32.
+// 8 waves as 2 (M) x 4 (N), each 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32 (round 6: on random operands the chip
+// holds a 10-17 % higher clock on this shape than on 32x32x16 at the same cycles per FLOP -- MI355X_MICROARCH.md, DVFS item 7;
+// profiles/r06_lab_gemm_m16.txt).
 // Operands are pair rows in 32-channel blocks [32 hi | 32 lo] (vrd_common.h): a tile row of one K step is one
 // 128-byte line; its 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the DMA source and on the reads.
 #include "vrd_common.h"
@@ -22,7 +24,6 @@
 
 namespace {
 
-using vrd::f32x16;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int TM = 256, TN = 256;
@@ -90,7 +91,6 @@ struct BigKArgs {
     BigBatch bb;
     int stagger;
     int count;                // problems of the launch (1 + the BigBatch entries in use)
-    int prio;                 // issue priority between the two waves of a SIMD (VRD_BIG_PRIO): 0 none, 1 static, 2 by progress
     unsigned* rflag;          // the device's f16 operand-range flag (vrd_common.h, RangeTrack) when C is written as f16 pair rows
 };
 typedef const __attribute__((address_space(4))) unsigned* kargs_ptr_t;
@@ -105,7 +105,7 @@ __device__ __forceinline__ T load_karg(kargs_ptr_t base, int byte_off) {
     return out;
 }
 
-// F16: operands in the scaled-f16 format (VRD_PAIR_F16) on v_mfma_f32_32x32x16_f16 -- the same bytes, instruction count and
+// F16: operands in the scaled-f16 format (VRD_PAIR_F16) on v_mfma_f32_16x16x32_f16 -- the same bytes, instruction count and
 // cycles; the epilogue multiplies the accumulators by *w_scale
 // PERSIST: one workgroup per CU walks tiles vb, vb + gridDim.x, ...; behind a tile's main loop, before its epilogue, the first
 // stages of the NEXT tile are requested (A(0), A(1): the operand that comes from HBM, microseconds away; W(0)), so that tile
@@ -115,7 +115,7 @@ __device__ __forceinline__ T load_karg(kargs_ptr_t base, int byte_off) {
 // WH = wave >> 2 as a compile-time constant: the two halves of the workgroup run their own copy of the whole body (the place
 // of a wave's LDS-DMA request inside an MFMA group is then no branch: 16 per K step before), and the copies never join, so the
 // register assignment of one does not constrain the other (joined behind the K loop, one copy spilled accumulators)
-template <int TAPS, bool M16, bool PERSIST, bool F16, int WH>
+template <int TAPS, bool PERSIST, bool F16, int WH>
 __device__ __forceinline__ void gemm_x3_big_body() {
 #if defined(__HIP_DEVICE_COMPILE__)       // (the buffer descriptor type exists in the device pass only)
     typedef typename vrd::SplitFmt<F16>::x8 e16x8;      // fragment of eight 16-bit elements (bf16 or f16)
@@ -150,11 +150,6 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     };
     reload();
     const int stagger = PERSIST ? 0 : load_karg<int>(kp, offsetof(BigKArgs, stagger));
-#ifdef VRD_LAB_PRIO_RT
-    const int prio = load_karg<int>(kp, offsetof(BigKArgs, prio));      // (lab builds: VRD_BIG_PRIO picks the scheme at run time)
-#else
-    constexpr int prio = 3;      // measured best of 0 .. 4 (profiles/r05_lab_gemm_prio.txt); a constant: no tests in the K loop
-#endif
     unsigned* rflag = nullptr;
     // Phase stagger.  Every tile of a launch takes the same time, so without it all CUs reach their epilogues together and
     // 256 x 256 KiB of stores meet an HBM that was idle a moment before.  The first workgroup of every CU (the first 256 of
@@ -170,7 +165,6 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     const int lane = tid & 63;
     const int wave = WH * 4 + (__builtin_amdgcn_readfirstlane(tid >> 6) & 3);
     const int wm = WH, wn = wave & 3;
-    const int li = lane & 31, lh = lane >> 5;
     // ---- tiles.  Virtual block id -> tile through the XCD-aware renumbering; the tile's rows are eight 32-row blocks,
     // slots tm*8 .. tm*8+7 of the block list (identity without one).  With a padding map (vrd_row_blocks) the list is
     // cut into segments -- one per XCD's contiguous share of the tiles when there are eight -- and inside a segment
@@ -300,76 +294,49 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     if (!contract && tid == 0 && tm * 8 < nblk)
         atomicAdd(&g_big_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
 
-    // ---- fragment read offsets (bytes inside a stage).  A tile row is 128 bytes: hi chunks 0..3, lo chunks 4..7,
-    // chunk index XOR-swizzled with (row >> 1) & 7 = (li >> 1) & 7 for every 32-row block.  Hence all fragment
-    // addresses of an operand derive from ONE per-lane base: k16 half s flips bit 5 (chunk ^ 2), lo flips bit 6
-    // (chunk ^ 4), and the 32-row blocks are constant offsets (kept out of registers: two VGPRs instead of 24).
-    // (M16: v_mfma_f32_16x16x32 -- lane l holds row l & 15, k = 8 * (l >> 4) .. +7 of the whole K step, i.e. hi chunk
-    //  l >> 4; the swizzle of rows (16-row block) + (l & 15) is again that of l & 15)
+    // ---- fragment read offsets (bytes inside a stage).  A tile row is 128 bytes: hi chunks 0..3, lo chunks 4..7, chunk index
+    // XOR-swizzled with (row >> 1) & 7.  v_mfma_f32_16x16x32: lane l holds row (or column) l & 15, k = 8 * (l >> 4) .. + 7 of the
+    // K step, i.e. hi chunk l >> 4 and the lo chunk 64 bytes (XOR) away; the swizzle of row (16-row block) + (l & 15) is that of
+    // l & 15, so an operand needs ONE per-lane base per plane and its blocks are immediate offsets of the reads (the bases are
+    // laundered: left to itself hipcc keeps a register per block).
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int a_base = M16 ? (wm * 128 + l15) * ROWB + ((l4 ^ swz(l15)) * 16) : (wm * 128 + li) * ROWB + ((lh ^ swz(li)) * 16);
-    const int w_base = W_RING + (M16 ? (wn * 64 + l15) * ROWB + ((l4 ^ swz(l15)) * 16) : (wn * 64 + li) * ROWB + ((lh ^ swz(li)) * 16));
+    int a_hi_off = (wm * 128 + l15) * ROWB + ((l4 ^ swz(l15)) * 16), a_lo_off = a_hi_off ^ 64;
+    int w_hi_off = W_RING + (wn * 64 + l15) * ROWB + ((l4 ^ swz(l15)) * 16), w_lo_off = w_hi_off ^ 64;
+    asm volatile("" : "+v"(a_hi_off), "+v"(a_lo_off), "+v"(w_hi_off), "+v"(w_lo_off));
 
-    // bias / scale of this lane's columns: requested now, used by the epilogue
+    // bias of this lane's columns: requested now, used by the epilogue
     // (through loads the compiler does not track: see load_epi_cols_async; they are older than every K-loop request, so the
     // first counted wait of the loop covers them)
     const vrd::EpiCols cols = vrd::load_epi_cols_async(p, n0 + wn * 64, lane);
-    f32x16 acc[M16 ? 1 : 4][M16 ? 1 : 2];
-    vrd::f32x4_t acc16[M16 ? 8 : 1][M16 ? 4 : 1];        // M16: 8 x 4 tiles of 16 x 16
+    vrd::f32x4_t acc[8][4];        // 8 x 4 accumulators of 16 x 16
 #pragma unroll
-    for (int i = 0; i < (M16 ? 1 : 4); ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < (M16 ? 1 : 2); ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-#pragma unroll
-    for (int i = 0; i < (M16 ? 8 : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < (M16 ? 4 : 1); ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    // ---- main loop.  A K step is eight groups g = (s, mi) of six MFMAs (k16 half s, 32-row block mi, both
-    // column blocks).  Fragment reads run one group ahead of the MFMAs (A fragments of group g+1, and the W
-    // fragments of the next half two groups ahead), so no LDS latency is exposed; for that to hold across K
-    // steps the step's barrier sits BEFORE its last group: by then every fragment of the step is in registers
+    // ---- main loop.  A K step is eight groups g of twelve MFMAs: 16-row block g against the four column blocks, the three
+    // products (lo x hi, hi x lo, hi x hi) product-major, so that consecutive MFMAs write different accumulators.  The A
+    // fragments of group g+1 are read during group g; the W fragments of the NEXT step go into the registers of the current
+    // ones as those are used for the last time (the step's last group runs block-major for that: block t's three products,
+    // then its reload -- a second set of weight fragments would be 32 registers the loop does not have); for the reads to
+    // cross K steps the step's barrier sits BEFORE its last group: by then every fragment of the step is in registers
     // (lgkmcnt(0)), so the barrier both publishes stage kt+1 (every wave waited for its own pieces first) and
     // frees the buffers of stage kt, which the DMAs issued after it refill: W(kt+2), then A(kt+3), one per
     // group over the next eight groups (a DMA issue stalls its wave for 100-200 cycles while MFMAs run; the
     // two waves of a SIMD place theirs half a group apart).
-    constexpr int NWF = M16 ? 4 : 2;                 // W fragments (column blocks) held at a time
     struct AF { e16x8 hi, lo; };
-    struct WF { e16x8 hi[NWF], lo[NWF]; };
-    // 32x32x16: (s2, mi) = k16 half, 32-row block.  M16: s2 unused, mi = 16-row block 0..7 (g of the group)
-    // per-lane fragment bases, one register per (k16 half, hi / lo plane): XOR 32 = the other half, XOR 64 = the lo plane; row and
-    // column blocks are immediate offsets of the reads (laundered: left to itself hipcc keeps a register per block, and the
-    // 16x16x32 loop has none to spare)
-    int a_off[4], w_off[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        a_off[v] = a_base ^ (v * 32), w_off[v] = w_base ^ (v * 32);
-        if (M16 ? (v & 1) == 0 : true) asm volatile("" : "+v"(a_off[v]), "+v"(w_off[v]));
-    }
-    auto load_a = [&](const char* sa, int s2, int mi) {
+    struct WF { e16x8 hi[4], lo[4]; };
+    auto load_a = [&](const char* sa, int mi) {
         AF f;
-        const int blk = M16 ? mi * 16 * ROWB : mi * 32 * ROWB;
-        f.hi = *reinterpret_cast<const e16x8*>(sa + a_off[M16 ? 0 : s2] + blk);
-        f.lo = *reinterpret_cast<const e16x8*>(sa + a_off[M16 ? 2 : s2 + 2] + blk);
+        f.hi = *reinterpret_cast<const e16x8*>(sa + a_hi_off + mi * 16 * ROWB);
+        f.lo = *reinterpret_cast<const e16x8*>(sa + a_lo_off + mi * 16 * ROWB);
         return f;
     };
-    auto load_w1 = [&](const char* sw, int t, WF& f) {       // M16: column block t only
-        f.hi[t] = *reinterpret_cast<const e16x8*>(sw + w_off[0] + t * 16 * ROWB);
-        f.lo[t] = *reinterpret_cast<const e16x8*>(sw + w_off[2] + t * 16 * ROWB);
-    };
-    auto load_w = [&](const char* sw, int s2) {
-        WF f;
-#pragma unroll
-        for (int t = 0; t < NWF; ++t) {
-            const int blk = M16 ? t * 16 * ROWB : t * 32 * ROWB;
-            f.hi[t] = *reinterpret_cast<const e16x8*>(sw + w_off[M16 ? 0 : s2] + blk);
-            f.lo[t] = *reinterpret_cast<const e16x8*>(sw + w_off[M16 ? 2 : s2 + 2] + blk);
-        }
-        return f;
+    auto load_w1 = [&](const char* sw, int t, WF& f) {       // column block t
+        f.hi[t] = *reinterpret_cast<const e16x8*>(sw + w_hi_off + t * 16 * ROWB);
+        f.lo[t] = *reinterpret_cast<const e16x8*>(sw + w_lo_off + t * 16 * ROWB);
     };
     if (contract) {
     if (!(PERSIST && staged)) {
@@ -401,11 +368,12 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     // issues its requests with nobody to cover their stalls (profiles/r05_lab_gemm_tile_stamps.txt).  Issue priority BY
     // PROGRESS evens them out: a wave runs the quarters of its K step at priorities 3, 2, 1, 0, so whichever of the two is
     // behind wins (prio 3: the barrier wait of the older half drops to ~650 cycles, the K step from ~3,700 to ~3,550 cycles,
-    // the whole step by 1.5 ms; schemes 1 = the younger half at a static priority 1: no gain; 2 = two levels per step: half
+    // the whole step by 1.5 ms; a static priority for the younger half: no gain; two levels per step: half
     // the gain; 4 = two levels, the younger half holding the high one longer: between 2 and 3).
-    if (prio == 1 && WH) __builtin_amdgcn_s_setprio(1);
-    WF w_cur = load_w(lds + (g0 % NW_STG) * W_STAGE, 0), w_nxt = w_cur;
-    AF a_cur = load_a(lds + (g0 % NA_STG) * A_STAGE, 0, 0), a_nxt = a_cur;
+    WF w_cur;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) load_w1(lds + (g0 % NW_STG) * W_STAGE, t, w_cur);
+    AF a_cur = load_a(lds + (g0 % NA_STG) * A_STAGE, 0), a_nxt = a_cur;
     LAB_PHASE_DECL;
     // DMA slot d (0..7) of the batch opened by the barrier inside step kt: W(kt+2) pieces 0..3, A(kt+3) pieces 0..3
     // Which of these requests exist depends only on where the step stands in the K loop, so the loop body exists in five
@@ -436,28 +404,15 @@ __device__ __forceinline__ void gemm_x3_big_body() {
         const bool last = POS == POS_GENERIC ? kt + 1 == nkt : POS == POS_LAST;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const int mi = g & 3;
-            if (prio == 2 && g == 0) __builtin_amdgcn_s_setprio(1);
-            if (prio == 2 && g == 4) __builtin_amdgcn_s_setprio(0);
-            if (prio == 3) {                 // four levels, a quarter of the step each
-                if (g == 0) __builtin_amdgcn_s_setprio(3);
-                if (g == 2) __builtin_amdgcn_s_setprio(2);
-                if (g == 4) __builtin_amdgcn_s_setprio(1);
-                if (g == 6) __builtin_amdgcn_s_setprio(0);
-            }
-            if (prio == 4) {                 // two levels, the younger half holds the high one longer
-                if (g == 0) __builtin_amdgcn_s_setprio(1);
-                if (g == (WH ? 5 : 3)) __builtin_amdgcn_s_setprio(0);
-            }
+            // four priority levels, a quarter of the step each
+            if (g == 0) __builtin_amdgcn_s_setprio(3);
+            if (g == 2) __builtin_amdgcn_s_setprio(2);
+            if (g == 4) __builtin_amdgcn_s_setprio(1);
+            if (g == 6) __builtin_amdgcn_s_setprio(0);
             // ---- reads for what comes next
-            if (g < 7) a_nxt = M16 ? load_a(sa, 0, g + 1) : load_a(sa, (g + 1) >> 2, (g + 1) & 3);
-            if (!M16 && g == 2) w_nxt = load_w(sw, 1);
-            if (g == 7 && !last) {
-                // (the barrier was passed at the end of group 6)
-                a_nxt = load_a(sa1, 0, 0);
-                if (!M16) w_nxt = load_w(sw1, 0);
-            }
-            // ---- the group's MFMAs (six 32x32x16 or twelve 16x16x32), this wave's DMA of the group in the middle (waves 0-3)
+            if (g < 7) a_nxt = load_a(sa, g + 1);
+            if (g == 7 && !last) a_nxt = load_a(sa1, 0);      // (the barrier was passed at the end of group 6)
+            // ---- the group's twelve MFMAs, this wave's DMA of the group in the middle (waves 0-3)
             // or at the end (waves 4-7): WH = wave >> 2 is a compile-time constant, the loop exists once per half
             auto dma_of_group = [&]() __attribute__((always_inline)) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -489,26 +444,19 @@ __device__ __forceinline__ void gemm_x3_big_body() {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            if (M16) {
-                // product-major order: consecutive MFMAs write different accumulators (a block's three products are four
-                // instructions apart); the step's last use of column block t's weight fragments is its hi x hi product: the
-                // next step's go straight into the same registers (a second set of all four blocks' fragments, 32
-                // registers, is what made hipcc spill)
+            // (block-major in a step's last group: a column block's weight fragments are reloaded right behind its third product;
+            // the generic body, whose `last` is a run-time value, reloads behind the group instead)
+            constexpr bool blockmajor = POS != POS_GENERIC && POS != POS_LAST;
 #pragma unroll
-                for (int q = 0; q < 12; ++q) {
-                    const int pr = q >> 2, t = q & 3;
-                    acc16[g][t] = vrd::mfma16(pr == 0 ? a_cur.lo : a_cur.hi, pr == 1 ? w_cur.lo[t] : w_cur.hi[t], acc16[g][t]);
-                    if (pr == 2 && g == 7 && !last) load_w1(sw1, t, w_cur);
-                    if ((q == 5 && WH == 0) || (q == 11 && WH == 1)) dma_of_group();
-                }
-            } else {
+            for (int q = 0; q < 12; ++q) {
+                const int pr = (blockmajor && g == 7) ? q % 3 : q >> 2, t = (blockmajor && g == 7) ? q / 3 : q & 3;
+                acc[g][t] = vrd::mfma16(pr == 0 ? a_cur.lo : a_cur.hi, pr == 1 ? w_cur.lo[t] : w_cur.hi[t], acc[g][t]);
+                if (blockmajor && g == 7 && pr == 2) load_w1(sw1, t, w_cur);
+                if ((q == 5 && WH == 0) || (q == 11 && WH == 1)) dma_of_group();
+            }
+            if (POS == POS_GENERIC && g == 7 && !last) {
 #pragma unroll
-                for (int nj = 0; nj < 2; ++nj) {
-                    acc[mi][nj] = vrd::mfma32(a_cur.lo, w_cur.hi[nj], acc[mi][nj]);
-                    acc[mi][nj] = vrd::mfma32(a_cur.hi, w_cur.lo[nj], acc[mi][nj]);
-                    acc[mi][nj] = vrd::mfma32(a_cur.hi, w_cur.hi[nj], acc[mi][nj]);
-                    if (WH == nj) dma_of_group();
-                }
+                for (int t = 0; t < 4; ++t) load_w1(sw1, t, w_cur);
             }
 #if defined(VRD_LAB_STAMP) && defined(VRD_LAB_VALU)
             // lab only (round 3, LABNOTES.md "producing the q / k / v operands inside the projection GEMM"): what the K loop
@@ -524,14 +472,13 @@ __device__ __forceinline__ void gemm_x3_big_body() {
                                  : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
 #pragma unroll
                 for (int i = 0; i < VRD_LAB_LDSR / 8; ++i) {
-                    vrd::f32x4_t t = *reinterpret_cast<const vrd::f32x4_t*>(sa + ((a_off[0] + i * 2048) & (A_STAGE - 16)));
+                    vrd::f32x4_t t = *reinterpret_cast<const vrd::f32x4_t*>(sa + ((a_hi_off + i * 2048) & (A_STAGE - 16)));
                     asm volatile("" ::"v"(t));
                 }
                 asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
             }
 #endif
             a_cur = a_nxt;
-            if (!M16 && (g == 3 || g == 7)) w_cur = w_nxt;
             if (g == 6 && !last) {
                 // every fragment of stage kt is in registers or landed; stage kt+1 must be visible before group 7
                 // starts reading it
@@ -556,10 +503,10 @@ __device__ __forceinline__ void gemm_x3_big_body() {
         for (int kt = 0; kt < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_GENERIC>{});
     }
     LAB_PHASE_FLUSH(WH);
-    if (prio) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     }       // contract
 #ifdef VRD_LAB_STAMP
-    asm volatile("" ::"v"(acc[0][0][0]), "v"(acc16[0][0][0]));
+    asm volatile("" ::"v"(acc[0][0][0]));
 #endif
     // every wave must be done with the rings before they are reused as epilogue staging
     if (!contract || nkt < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the bias / scale loads; otherwise waited for in step 0)
@@ -597,25 +544,14 @@ __device__ __forceinline__ void gemm_x3_big_body() {
         // loop the compiler tracks, and with them in the loop it opens every tile with `s_waitcnt vmcnt(0)` -- a wait for the
         // previous tile's stores to be acknowledged; their waits also queue behind the look-ahead requests.)
         const bool rowin = !PERSIST && (p.row_mask || p.scale || p.res || p.res2);
-        if (M16) {
-            vrd::f32x4_t part[4][4];
+        vrd::f32x4_t part[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) part[i][j] = acc16[M16 ? 4 * hm + i : 0][M16 ? j : 0];
-            if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
-            else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
-        } else {
-            f32x16 part[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) part[i][j] = acc[M16 ? 0 : 2 * hm + i][M16 ? 0 : j];
-            if (rowin) vrd::gemm_epilogue_lean<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
-            else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
-            else vrd::gemm_epilogue_lean<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
-        }
+            for (int j = 0; j < 4; ++j) part[i][j] = acc[4 * hm + i][j];
+        if (rowin) vrd::gemm_epilogue_lean16<true, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
+        else if (p.act == VRD_ACT_GELU) vrd::gemm_epilogue_lean16<false, VRD_ACT_GELU, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
+        else vrd::gemm_epilogue_lean16<false, VRD_ACT_NONE, SLAB>(p, part, stg, mw, mw1, nw, lane_e, cols, rflag);
     }
     LAB_STAMP(3);
     LAB_REAL(5);
@@ -633,19 +569,19 @@ __device__ __forceinline__ void gemm_x3_big_body() {
 #endif
 }
 
-template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
+template <int TAPS, bool PERSIST, bool F16 = false>
 __global__ __launch_bounds__(512) void gemm_x3_big_kernel(BigKArgs ka_unused_) {
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) gemm_x3_big_body<TAPS, M16, PERSIST, F16, 1>();
-    else gemm_x3_big_body<TAPS, M16, PERSIST, F16, 0>();
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8)) gemm_x3_big_body<TAPS, PERSIST, F16, 1>();
+    else gemm_x3_big_body<TAPS, PERSIST, F16, 0>();
 }
 
 }  // namespace
 
 namespace vrd {
 
-template <int TAPS, bool M16, bool PERSIST, bool F16 = false>
+template <int TAPS, bool PERSIST, bool F16 = false>
 static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch& bb = BigBatch{}, int count = 1) {
-    auto kern = gemm_x3_big_kernel<TAPS, M16, PERSIST, F16>;
+    auto kern = gemm_x3_big_kernel<TAPS, PERSIST, F16>;
     if (int rc = reserve_lds(reinterpret_cast<const void*>(kern), BIG_LDS, "vrd_gemm(bf16x3 256x256)")) return rc;
     const int tiles_m = (int)((a.M + TM - 1) / TM), tiles_n = (a.N + TN - 1) / TN;
     const int nwg = tiles_m * tiles_n;
@@ -657,8 +593,6 @@ static int launch_big_one(const vrd_gemm_args& a, hipStream_t s, const BigBatch&
     ka.p = a, ka.tiles_m = tiles_m, ka.tiles_n = tiles_n, ka.bb = bb, ka.stagger = (PERSIST || nwg < 512) ? 0 : stagger;
     ka.rflag = a.c_pair == VRD_PAIR_F16 ? range_flag() : nullptr;
     ka.count = count;
-    static const int prio_env = [] { const char* e = getenv("VRD_BIG_PRIO"); return e ? atoi(e) : 3; }();
-    ka.prio = prio_env;
     if (PERSIST) hipLaunchKernelGGL(kern, dim3(nwg * count < n_cu ? nwg * count : n_cu), dim3(512), BIG_LDS, s, ka);
     else hipLaunchKernelGGL(kern, dim3(nwg, count), dim3(512), BIG_LDS, s, ka);
     return 0;
@@ -671,7 +605,14 @@ static bool big_persist(const vrd_gemm_args& a) {
     return persist && a.taps == 1 && a.Cin >= 96 && !(a.row_mask || a.scale || a.res || a.res2);
 }
 
-// `count` (2 .. 4) problems that differ only in A, W_split, bias and C, as one launch of the default kernel
+static int launch_big_any(const vrd_gemm_args& a, hipStream_t s, const BigBatch& bb, int count) {
+    const bool f16 = a.split_fmt == VRD_PAIR_F16;
+    if (big_persist(a)) return f16 ? launch_big_one<1, true, true>(a, s, bb, count) : launch_big_one<1, true, false>(a, s, bb, count);
+    if (f16) return a.taps == 1 ? launch_big_one<1, false, true>(a, s, bb, count) : launch_big_one<3, false, true>(a, s, bb, count);
+    return a.taps == 1 ? launch_big_one<1, false, false>(a, s, bb, count) : launch_big_one<3, false, false>(a, s, bb, count);
+}
+
+// `count` (2 .. 4) problems that differ only in A, W_split, bias and C, as one launch
 int launch_gemm_x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
     BigBatch bb{};
     for (int i = 1; i < count; ++i) {
@@ -681,12 +622,7 @@ int launch_gemm_x3_big_batch(const vrd_gemm_args* a, int count, hipStream_t s) {
         bb.C[i - 1] = a[i].C;
         bb.w_scale[i - 1] = a[i].w_scale;
     }
-    const bool f16 = a[0].split_fmt == VRD_PAIR_F16;
-    static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
-    if (m16 && f16 && big_persist(a[0])) return launch_big_one<1, true, true, true>(a[0], s, bb, count);
-    if (big_persist(a[0])) return f16 ? launch_big_one<1, false, true, true>(a[0], s, bb, count) : launch_big_one<1, false, true, false>(a[0], s, bb, count);
-    if (f16) return a[0].taps == 1 ? launch_big_one<1, false, false, true>(a[0], s, bb, count) : launch_big_one<3, false, false, true>(a[0], s, bb, count);
-    return a[0].taps == 1 ? launch_big_one<1, false, false>(a[0], s, bb, count) : launch_big_one<3, false, false>(a[0], s, bb, count);
+    return launch_big_any(a[0], s, bb, count);
 }
 
 // FLOPs of contractions skipped through padding maps since the last call (reads and clears the device counter)
@@ -698,21 +634,6 @@ double take_big_skipped_flops() {
 }
 
 // same eligibility as the 128 x 256 DMA kernel (pair-row A, staged epilogue); the caller picks by tile count
-int launch_gemm_x3_big(const vrd_gemm_args& a, hipStream_t s) {
-    // MFMA shape: 32x32x16 (default) or 16x16x32 (VRD_BIG_M16=1).  Same fragments, LDS traffic and MFMA cycles per K
-    // step; interleaved A/B runs in one process put 16x16x32 0.5-1 % ahead on the whole step, but it sums the K
-    // dimension in a different order than the 32x32x16 kernels that serve small batches, and the path keeps its
-    // results independent of the batch composition to the last bit (tests/test_gpu_model.py), so it stays opt-in.
-    static const int m16 = [] { const char* e = getenv("VRD_BIG_M16"); return e ? atoi(e) : 0; }();
-    const bool f16 = a.split_fmt == VRD_PAIR_F16;
-    if (m16) {
-        if (f16 && big_persist(a)) return launch_big_one<1, true, true, true>(a, s);
-        if (f16) return a.taps == 1 ? launch_big_one<1, true, false, true>(a, s) : launch_big_one<3, true, false, true>(a, s);
-        return a.taps == 1 ? launch_big_one<1, true, false>(a, s) : launch_big_one<3, true, false>(a, s);
-    }
-    if (big_persist(a)) return f16 ? launch_big_one<1, false, true, true>(a, s) : launch_big_one<1, false, true, false>(a, s);
-    if (f16) return a.taps == 1 ? launch_big_one<1, false, false, true>(a, s) : launch_big_one<3, false, false, true>(a, s);
-    return a.taps == 1 ? launch_big_one<1, false, false>(a, s) : launch_big_one<3, false, false>(a, s);
-}
+int launch_gemm_x3_big(const vrd_gemm_args& a, hipStream_t s) { return launch_big_any(a, s, BigBatch{}, 1); }
 
 }  // namespace vrd
