@@ -496,6 +496,9 @@ def test_chunking_and_batch_independence():
     close(pad["pred_masks"][..., :50], whole["pred_masks"][1:2, :, :50], 5e-4)
 
 
+BF16X3_TIE = {"bf16x3": 5e-6}       # forward_test rankings: ties of the reference's own scores the 17-bit mode may permute
+
+
 def test_forward_test_matches_reference_golden(precision):
     model, mc, ic, _ = get_model("vidvrd")
     with open(os.path.join(GOLDEN, "forward_test_vidvrd.json")) as f:
@@ -504,9 +507,10 @@ def test_forward_test_matches_reference_golden(precision):
     dev_data = {k: ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV)) for k, v in data.items()}
     res = model(dev_data)
     assert len(res["triplets"]) == len(ref["triplets"]) == ic["n_max_pair"]
-    # identical ranking, records and box tracks in both precision modes; scores within 5e-6 (measured: 1e-7 / 7e-7)
+    # identical ranking, records and box tracks in the reference-grade modes; scores within 5e-6 (measured: 1e-7 / 7e-7).  The
+    # bf16x3 mode (17-bit products) may permute ranks whose reference scores lie closer together than its own score error
     from golden_cases import compare_forward_test
-    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0)
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0, tie_tol=BF16X3_TIE.get(precision, 0.0))
 
 
 def _on_device(data):
@@ -523,7 +527,7 @@ def test_forward_test_many_slices_matches_reference_golden(precision):
     data = synth_proposal(c_in=c_in(mc), **SLICES)
     assert len(data["sids"]) == ref["n_pairs"] > 2 * mc["max_so_pair"]
     res = model(_on_device(data))
-    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0)
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0, tie_tol=BF16X3_TIE.get(precision, 0.0))
 
 
 def test_forward_test_vidor_x_matches_reference_golden(precision):
@@ -536,7 +540,7 @@ def test_forward_test_vidor_x_matches_reference_golden(precision):
     data = synth_proposal(c_in=c_in(mc), **VIDOR_X)
     assert data["so_offset"].tolist() == ref["so_offset"]
     res = model(_on_device(data))
-    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0)
+    compare_forward_test(res, ref, ic["n_max_pair"], 5e-6, slack=0, tie_tol=BF16X3_TIE.get(precision, 0.0))
 
 
 @pytest.mark.parametrize("name", ["vidor", "vidor_local"])

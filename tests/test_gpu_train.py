@@ -183,7 +183,7 @@ def test_training_step_matches_reference_gradients(case, precision):
     assert all(len(call) <= 6 for call in differing), differing
     worst, median = compare_grads(((n, p.grad) for n, p in model.named_parameters()), g, meta, case,
                                   rtol=3e-2, atol_frac=1e-4, median_tol=2e-5 if precision == "f32" else 5e-4, outlier_tol=1e-3,
-                                  max_outliers=3, outlier_scope=None if case == "nodrop" else POOL_FREE)
+                                  max_outliers=3, outlier_scope=None if case == "nodrop" and precision != "bf16x3" else POOL_FREE)
     print(f"[{case}/{precision}] relative gradient error: worst {worst:.2e}, median {median:.2e}")
 
 
@@ -256,8 +256,11 @@ def test_training_step_gradients_against_float64_reference(case, precision):
     FIRST_LAYER = r"backbone\.visual_embd(_norm)?\.0\."
     bound = {"f32": 4.0, "f16x3": 4.0, "bf16x3": 500.0}[precision]
     median_bound = {"f32": 3.0, "f16x3": 3.0, "bf16x3": 80.0}[precision]
-    held = [n for n in ratio if re.match(POOL_FREE, n) or (case == "nodrop" and not re.match(FIRST_LAYER, n))]
-    assert len(held) >= (500 if case == "nodrop" else 250)
+    # (the 17-bit bf16x3 mode meets an arg-max tie of the branch pools in the no-drop case too -- which mode meets one on a given
+    # batch is chance: POOL_FREE's comment --, so it is held to the bound downstream of the pools only, in both cases)
+    wide = case == "nodrop" and precision != "bf16x3"
+    held = [n for n in ratio if re.match(POOL_FREE, n) or (wide and not re.match(FIRST_LAYER, n))]
+    assert len(held) >= (500 if wide else 250)
     beyond = sorted((n, round(ratio[n], 1)) for n in held if ratio[n] > bound)
     assert not beyond, f"{len(beyond)} parameters beyond {bound} x the reference's own f32 error: {beyond[:10]}"
     assert float(np.median([ratio[n] for n in held])) <= median_bound

@@ -60,8 +60,7 @@ __global__ __launch_bounds__(256) void local_attn_kernel(const float* __restrict
         if (tj < 0 || tj >= T) { s[j] = -INFINITY; continue; }
         const float* kr = k + (row + j - HW) * ld + lane * 8;
         float d = dot4(q0, ld4(kr)) + dot4(q1, ld4(kr + 4));
-#pragma unroll
-        for (int off = GROUP / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        d = vrd::group_sum<GROUP>(d);
         if (REL) d += rel[(lane / GROUP) * W + j];
         s[j] = d + (mask[row + j - HW] ? 0.f : -1e4f);
         m = fmaxf(m, s[j]);
@@ -180,8 +179,7 @@ __global__ __launch_bounds__(256) void local_attn_strip_kernel(const float* __re
                 if (tj < 0 || tj >= T) { sc[j] = -INFINITY; continue; }
                 const Row& kk = kr[(ph + j) % R];
                 float d = dot4(q0, kk.a) + dot4(q1, kk.b);
-#pragma unroll
-                for (int off = GROUP / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+                d = vrd::group_sum<GROUP>(d);
                 if (REL) d += rb[j];
                 sc[j] = d + (((live >> (bit0 + j)) & 1ull) ? 0.f : -1e4f);
                 m = fmaxf(m, sc[j]);

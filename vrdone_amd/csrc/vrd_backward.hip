@@ -1236,11 +1236,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(DwBwdArgs p) {
 // dv_j = sum_t P[t, j] dO_t over the (at most W) queries whose window holds j.
 // ------------------------------------------------------------------------------------------------------------------
 template <int GROUP>
-__device__ __forceinline__ float head_sum(float d) {
-#pragma unroll
-    for (int off = GROUP / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
-    return d;
-}
+__device__ __forceinline__ float head_sum(float d) { return vrd::group_sum<GROUP>(d); }
 __device__ __forceinline__ float dot8(const float4& a0, const float4& a1, const float4& b0, const float4& b1) {
     return (a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w) + (a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w);
 }

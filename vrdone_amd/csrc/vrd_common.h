@@ -131,6 +131,26 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Sum over aligned groups of G = 8 or 16 lanes, every lane of a group receiving the group's sum: the first steps of wave_sum
+// (three or four v_add_f32 with a DPP operand).  __shfl_xor compiles to ds_bpermute_b32 plus its address arithmetic, seven
+// instructions and an LDS round trip per step; the banded attention spends 28 of those per query row on its dot products.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(G == 8 || G == 16, "lanes per group");
+    float t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v += t;
+    t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += t;
+    if (G == 16) {
+        t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)); // row_mirror
+        v += t;
+    }
+    return v;
+}
+
 // "Pair" rows (GEMM-operand format of the split-precision modes): a row of W logical channels (W % 32 == 0) stored in the
 // 4*W bytes an f32 row would occupy, as blocks of 32 channels: [32 x 16-bit hi | 32 x 16-bit lo] per block.  One 128-byte
 // line therefore holds everything a K step of 32 needs from a row, which is what the GEMM's LDS-DMA wants (whole lines per

@@ -224,7 +224,7 @@ X3Choice choose_x3(const vrd_gemm_args* a, bool vec, bool staged) {
                      ((a->M + 127) / 128) * ((a->N + 255) / 256) >= dma_min_tiles;
     // the 256 x 256 kernel (DMA-issue cost per MFMA a third lower) once there are about two rounds of its tiles
     static const int64_t big_min_tiles = [] { const char* e = getenv("VRD_X3_BIG_MIN_TILES"); return e ? atoll(e) : 512; }();
-    const bool big = dma && a->N >= 256 && vrd::gemm_epilogue_lean_ok(*a) &&
+    const bool big = dma && a->N >= 256 && K >= 96 && vrd::gemm_epilogue_lean_ok(*a) &&      // (its K loop is written for >= 3 steps)
                      (a->taps == 1 || a->T >= 32) &&      // k = 3: the kernel steps its sequence position by 8 rows per piece
                      (reinterpret_cast<uintptr_t>(a->A) & 127u) == 0 && (reinterpret_cast<uintptr_t>(a->W_split) & 127u) == 0 &&
                      ((a->M + 255) / 256) * ((a->N + 255) / 256) >= big_min_tiles;

@@ -267,6 +267,13 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     // PERSIST: vq walks the tiles of all `count` problems of the launch, problem after problem; vb = the tile inside its problem
     const int count = PERSIST ? load_karg<int>(kp, offsetof(BigKArgs, count)) : 1;
     int vq = blockIdx.x, vb = blockIdx.x;
+#ifdef VRD_BIG_NOCARRY
+    constexpr bool CARRY = false;
+#else
+    constexpr bool CARRY = true;
+#endif
+    Tile nt_keep = Tile{0, 0, false};
+    Src nx_keep = src_of(nt_keep);
     do {
     if (PERSIST) {
         zsel = (vq >= nwg) + (vq >= 2 * nwg) + (vq >= 3 * nwg);      // vq / nwg for at most four problems (nwg is the same for all)
@@ -275,22 +282,26 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     }
     LAB_STAMP(0);
     LAB_REAL(4);
-    const Tile tile = tile_of(vb);
+    // (PERSIST: a tile whose first stages were requested by the previous one was described then: tile and sources are carried over
+    // instead of being worked out again -- the set-up is bound by its scalar instructions, 8 waves on the CU's one scalar unit)
+    const Tile tile = (PERSIST && staged && CARRY) ? nt_keep : tile_of(vb);
     const int tm = tile.tm, n0 = tile.n0;
     const bool contract = tile.contract;
-    const Src cur = src_of(tile);
+    const Src cur = (PERSIST && staged && CARRY) ? nx_keep : src_of(tile);
     // PERSIST: the tile this workgroup computes next, if it is a contraction tile too (its first stages are requested inside
     // this tile's last two K steps); otherwise those requests re-read this tile's own first stages into the free ring slots
     // (harmless, keeps the loop free of tests) and the next tile starts like a first one
     bool next_staged = false;
     Src nx = cur;
-    if (PERSIST && contract && nkt >= 3 && vb + (int)gridDim.x < nwg) {      // (inside the same problem)
+    if (PERSIST && contract && vb + (int)gridDim.x < nwg) {      // (inside the same problem)
         const Tile nt = tile_of(vb + (int)gridDim.x);
         if (nt.contract) {
             nx = src_of(nt);
             next_staged = true;
+            nt_keep = nt;
         }
     }
+    nx_keep = nx;
     if (!contract && tid == 0 && tm * 8 < nblk)
         atomicAdd(&g_big_skipped_kn, (unsigned long long)K * (unsigned)(p.N - n0 < TN ? p.N - n0 : TN));
 
@@ -308,13 +319,19 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     // (through loads the compiler does not track: see load_epi_cols_async; they are older than every K-loop request, so the
     // first counted wait of the loop covers them)
     const vrd::EpiCols cols = vrd::load_epi_cols_async(p, n0 + wn * 64, lane);
-    vrd::f32x4_t acc[8][4];        // 8 x 4 accumulators of 16 x 16
+    // 8 x 4 accumulators of 16 x 16.  A contraction tile's first K step starts every accumulator from the constant 0 (the MFMA's
+    // C operand): zeroing 128 registers per tile was ~1 k cycles of vector issue in the set-up of every tile
+    vrd::f32x4_t acc[8][4];
+    if (!contract) {
+        float z;          // (a zero the compiler cannot hoist: it moves plain constant initialisation in front of the branch)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = z;
+    }
 
     // ---- main loop.  A K step is eight groups g of twelve MFMAs: 16-row block g against the four column blocks, the three
     // products (lo x hi, hi x lo, hi x hi) product-major, so that consecutive MFMAs write different accumulators.  The A
@@ -342,14 +359,11 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     if (!(PERSIST && staged)) {
         issue_a(cur, g0, 0);
         issue_w(cur, g0, 0);
-        if (nkt > 1) {
-            issue_a(cur, g0 + 1, 1);
-            issue_w(cur, g0 + 1, 1);
-        }
+        issue_a(cur, g0 + 1, 1);
+        issue_w(cur, g0 + 1, 1);
         LAB_STAMP(1);
         // stage 0: what was issued after A(0), W(0) may stay in flight (A(2) follows inside step 0, see below)
-        if (nkt > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
     } else {
         // In this wave's queue, oldest first: A(0), W(0), A(1) (requested inside the previous tile's last two K steps), that
         // tile's epilogue loads and stores, and now W(1).  The counter retires in order, so the wait for W(0) must not ask
@@ -364,23 +378,22 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     __builtin_amdgcn_s_barrier();
     LAB_STAMP(7);
     // The two waves of a SIMD share its matrix pipe, and between equals the older one (waves 0-3) wins every arbitration: it
-    // runs its 48 MFMAs of a K step nearly alone, waits ~1,100-1,300 cycles at the step's barrier, and the younger one then
+    // runs its MFMAs of a K step nearly alone, waits ~1,100-1,300 cycles at the step's barrier, and the younger one then
     // issues its requests with nobody to cover their stalls (profiles/r05_lab_gemm_tile_stamps.txt).  Issue priority BY
     // PROGRESS evens them out: a wave runs the quarters of its K step at priorities 3, 2, 1, 0, so whichever of the two is
-    // behind wins (prio 3: the barrier wait of the older half drops to ~650 cycles, the K step from ~3,700 to ~3,550 cycles,
-    // the whole step by 1.5 ms; a static priority for the younger half: no gain; two levels per step: half
-    // the gain; 4 = two levels, the younger half holding the high one longer: between 2 and 3).
+    // behind wins (round 5: the barrier wait of the older half dropped to ~650 cycles, the K step from ~3,700 to ~3,550,
+    // the whole step by 1.5 ms; a static priority for the younger half: no gain; two levels per step: half the gain).
     WF w_cur;
 #pragma unroll
     for (int t = 0; t < 4; ++t) load_w1(lds + (g0 % NW_STG) * W_STAGE, t, w_cur);
     AF a_cur = load_a(lds + (g0 % NA_STG) * A_STAGE, 0), a_nxt = a_cur;
     LAB_PHASE_DECL;
     // DMA slot d (0..7) of the batch opened by the barrier inside step kt: W(kt+2) pieces 0..3, A(kt+3) pieces 0..3
-    // Which of these requests exist depends only on where the step stands in the K loop, so the loop body exists in five
-    // copies with the tests resolved at compile time: first step, steady steps (1 .. nkt-3), the step before the last, the
-    // last, and a generic one with run-time tests for K loops of fewer than three steps.  (The per-slot scalar branches of the
+    // Which of these requests exist depends only on where the step stands in the K loop, so the loop body exists in four
+    // copies with the tests resolved at compile time: first step, steady steps (1 .. nkt-3), the step before the last and the
+    // last (the host sends K loops of three steps or more: vrd_gemm.hip, choose_x3).  (Per-slot scalar branches in one
     // generic body cost the steady loop 7 %: 4,300 -> 3,730-4,060 cycles per K step.)
-    enum { POS_GENERIC, POS_FIRST, POS_STEADY, POS_PEN, POS_LAST };
+    enum { POS_FIRST, POS_STEADY, POS_PEN, POS_LAST };
     auto kstep = [&](int kt, auto pos_c) __attribute__((always_inline)) {
         constexpr int POS = decltype(pos_c)::value;
         // W(kt_open+2) pieces / A(kt_open+3) pieces exist?
@@ -401,7 +414,7 @@ __device__ __forceinline__ void gemm_x3_big_body() {
         const char* sw = lds + ((g0 + kt) % NW_STG) * W_STAGE;
         const char* sa1 = lds + ((g0 + kt + 1) % NA_STG) * A_STAGE;
         const char* sw1 = lds + ((g0 + kt + 1) % NW_STG) * W_STAGE;
-        const bool last = POS == POS_GENERIC ? kt + 1 == nkt : POS == POS_LAST;
+        constexpr bool last = POS == POS_LAST;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             // four priority levels, a quarter of the step each
@@ -422,11 +435,8 @@ __device__ __forceinline__ void gemm_x3_big_body() {
                 // groups 0..6 carry slots 1..7 of the batch opened in step kt-1, group 7 slot 0 of this step's
                 if (g < 7) {
                     // the batch opened in step kt-1: W(kt+1) pieces 1..3, A(kt+2) pieces 0..3
-                    if (POS == POS_GENERIC) {
-                        if (kt > 0) dma_slot(kt - 1, g + 1, kt + 1 < nkt, kt + 2 < nkt);
-                        else if (g < PER && nkt > 2) issue_a1(cur, g0 + 2, 2, g);      // step 0 has no batch of its own yet
-                    } else if (POS == POS_FIRST) {
-                        if (g < PER) issue_a1(cur, g0 + 2, 2, g);
+                    if (POS == POS_FIRST) {
+                        if (g < PER) issue_a1(cur, g0 + 2, 2, g);                       // step 0 has no batch of its own yet
                     } else if (POS == POS_STEADY) {
                         dma_slot(kt - 1, g + 1, true, true);
                     } else if (POS == POS_PEN) {
@@ -440,51 +450,27 @@ __device__ __forceinline__ void gemm_x3_big_body() {
                     // slot 0 of this step's own batch: W(kt+2) piece 0 -- in the step before the last (PERSIST) the next
                     // tile's W(0) piece 0
                     if (POS == POS_PEN && PERSIST) dma_slot_next(0, 0, 0);
-                    else dma_slot(kt, 0, POS == POS_GENERIC ? kt + 2 < nkt : POS != POS_PEN, false);
+                    else dma_slot(kt, 0, POS != POS_PEN, false);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            // (block-major in a step's last group: a column block's weight fragments are reloaded right behind its third product;
-            // the generic body, whose `last` is a run-time value, reloads behind the group instead)
-            constexpr bool blockmajor = POS != POS_GENERIC && POS != POS_LAST;
+            // (block-major in a step's last group: a column block's weight fragments are reloaded right behind its third product)
+            constexpr bool blockmajor = !last;
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 const int pr = (blockmajor && g == 7) ? q % 3 : q >> 2, t = (blockmajor && g == 7) ? q / 3 : q & 3;
-                acc[g][t] = vrd::mfma16(pr == 0 ? a_cur.lo : a_cur.hi, pr == 1 ? w_cur.lo[t] : w_cur.hi[t], acc[g][t]);
+                const vrd::f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+                acc[g][t] = vrd::mfma16(pr == 0 ? a_cur.lo : a_cur.hi, pr == 1 ? w_cur.lo[t] : w_cur.hi[t], (POS == POS_FIRST && pr == 0) ? zero4 : acc[g][t]);
                 if (blockmajor && g == 7 && pr == 2) load_w1(sw1, t, w_cur);
                 if ((q == 5 && WH == 0) || (q == 11 && WH == 1)) dma_of_group();
             }
-            if (POS == POS_GENERIC && g == 7 && !last) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) load_w1(sw1, t, w_cur);
-            }
-#if defined(VRD_LAB_STAMP) && defined(VRD_LAB_VALU)
-            // lab only (round 3, LABNOTES.md "producing the q / k / v operands inside the projection GEMM"): what the K loop
-            // pays for VRD_LAB_VALU extra vector instructions (and VRD_LAB_LDSR extra 16-byte LDS reads) per wave and K step,
-            // an eighth of them behind each MFMA group -- the in-loop LayerNorm -> depthwise conv -> LayerNorm -> hi / lo split
-            // of a fused attention-input stage would need ~210 + ~36 per K step
-            {
-                static_assert(VRD_LAB_VALU % 8 == 0 && VRD_LAB_LDSR % 8 == 0, "per group");
-                float d0 = acc[0][0][0] * 0.f + 1.f, d1 = 2.f, d2 = 3.f, d3 = 4.f;
-#pragma unroll
-                for (int i = 0; i < VRD_LAB_VALU / 8 / 4; ++i)
-                    asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %2, %2, %3, %0\n\tv_fma_f32 %3, %3, %0, %1"
-                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
-#pragma unroll
-                for (int i = 0; i < VRD_LAB_LDSR / 8; ++i) {
-                    vrd::f32x4_t t = *reinterpret_cast<const vrd::f32x4_t*>(sa + ((a_hi_off + i * 2048) & (A_STAGE - 16)));
-                    asm volatile("" ::"v"(t));
-                }
-                asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3));
-            }
-#endif
             a_cur = a_nxt;
             if (g == 6 && !last) {
                 // every fragment of stage kt is in registers or landed; stage kt+1 must be visible before group 7
                 // starts reading it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 LAB_PHASE(3);
-                if (POS == POS_GENERIC ? kt + 2 < nkt : (POS != POS_PEN || PERSIST)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+                if (POS != POS_PEN || PERSIST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 LAB_PHASE(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -494,14 +480,10 @@ __device__ __forceinline__ void gemm_x3_big_body() {
             }
         }
     };
-    if (PERSIST || nkt >= 3) {          // (the host sends the persistent form only K loops of three steps or more)
-        kstep(0, std::integral_constant<int, POS_FIRST>{});
-        for (int kt = 1; kt + 2 < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_STEADY>{});
-        kstep(nkt - 2, std::integral_constant<int, POS_PEN>{});
-        kstep(nkt - 1, std::integral_constant<int, POS_LAST>{});
-    } else {
-        for (int kt = 0; kt < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_GENERIC>{});
-    }
+    kstep(0, std::integral_constant<int, POS_FIRST>{});
+    for (int kt = 1; kt + 2 < nkt; ++kt) kstep(kt, std::integral_constant<int, POS_STEADY>{});
+    kstep(nkt - 2, std::integral_constant<int, POS_PEN>{});
+    kstep(nkt - 1, std::integral_constant<int, POS_LAST>{});
     LAB_PHASE_FLUSH(WH);
     __builtin_amdgcn_s_setprio(0);
     }       // contract
@@ -509,7 +491,7 @@ __device__ __forceinline__ void gemm_x3_big_body() {
     asm volatile("" ::"v"(acc[0][0][0]));
 #endif
     // every wave must be done with the rings before they are reused as epilogue staging
-    if (!contract || nkt < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the bias / scale loads; otherwise waited for in step 0)
+    if (!contract) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the bias loads; otherwise waited for in step 0)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     LAB_STAMP(2);
