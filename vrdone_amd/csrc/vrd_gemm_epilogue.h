@@ -2,6 +2,7 @@
 // wave as 2 x 2 blocks of 32 x 32 (one 32x32 MFMA accumulator each, or 2 x 2 16x16 ones: forall32 below).
 #pragma once
 #include "vrd_common.h"
+#include <type_traits>
 
 namespace vrd {
 
@@ -160,6 +161,12 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
     // two requests go out before the transposition
     constexpr int NPASS = ROWS / 16;
     RowIn q0 = fetch(0), q1 = fetch(1);
+    unsigned rd_addr[4];          // LDS byte addresses of rows rb0 + 4 j, this lane's (swizzled) float4 column group
+    {
+        typedef __attribute__((address_space(3))) const float* lds_cf;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rd_addr[j] = (unsigned)reinterpret_cast<uintptr_t>((lds_cf)(stg + (rb0 + 4 * j) * STG_PITCH + (c4 ^ (16 * j))));
+    }
     transpose_into(stg, SLAB == 64 ? -1 : 0);            // the wave's 64 x 64 sub-tile (or its upper half), accumulator layout -> slab rows
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -168,19 +175,20 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
         q0 = q1;
         if (pass + 2 < NPASS) q1 = fetch(pass + 2);
         float v[4][4];
-        const int srow = (SLAB == 64 ? pass : (pass & 1)) * 16 + rb0;
         // The slab is read back by instructions the compiler does not see: next to LDS-DMA requests in flight (the persistent
         // kernel's look-ahead for its next tile, which lands in OTHER ring slots) hipcc puts `s_waitcnt vmcnt(0)` in front of
         // every LDS read it cannot tell apart from them.  DS operations of a wave execute in order, so the reads see the
         // transposition's writes.
+        // (slab columns are swizzled in blocks of 16 with (row >> 2) & 3 -- see gemm_epilogue_lean16 --, which for the rows
+        // srow + 4 j of this lane is j: one address per j, the pass is an immediate offset)
         float4 tr[4];
         {
-            typedef __attribute__((address_space(3))) const float* lds_cf;
-            const unsigned a0 = (unsigned)reinterpret_cast<uintptr_t>((lds_cf)(stg + srow * STG_PITCH + c4));
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:%5\n\tds_read_b128 %2, %4 offset:%6\n\tds_read_b128 %3, %4 offset:%7\n\t"
+            constexpr int PASS_OFF = (SLAB == 64 ? 1 : 0);      // (SLAB 64: pass p reads rows 16 p ..; SLAB 32: rows 16 (p & 1) ..)
+            const int poff = (PASS_OFF ? pass : (pass & 1)) * 16 * STG_PITCH * 4;
+            asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : "=&v"(tr[0]), "=&v"(tr[1]), "=&v"(tr[2]), "=&v"(tr[3])
-                         : "v"(a0), "n"(4 * STG_PITCH * 4), "n"(8 * STG_PITCH * 4), "n"(12 * STG_PITCH * 4)
+                         : "v"(rd_addr[0]), "v"(rd_addr[1]), "v"(rd_addr[2]), "v"(rd_addr[3]), "n"(poff)
                          : "memory");
         }
 #pragma unroll
@@ -258,7 +266,9 @@ __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Tr
     if (p.c_pair == VRD_PAIR_F16) rt.report(rflag, RANGE_GEMM_OUT);
 }
 
-// 16 x 16 accumulators (v_mfma_f32_16x16x32): element j of lane l is C[4 * (l >> 4) + j][l & 15]
+// 16 x 16 accumulators (v_mfma_f32_16x16x32): element j of lane l is C[4 * (l >> 4) + j][l & 15].  The four row groups of a
+// wave (l >> 4) write the same 16 columns of rows 4 apart: with a 64-float slab pitch that is one bank for all four, so the slab's
+// 16-column blocks are XOR-swizzled with (row >> 2) & 3 = l >> 4 (the 128 transposition writes per wave and tile ran 4-way conflicted).
 template <bool ROWIN, int ACT, int SLAB = 64>
 __device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, const f32x4_t (&acc)[4][4], float* stg, int64_t mw,
                                                      int64_t mw1, int nw, int lane, const EpiCols& cols, unsigned* rflag = nullptr) {
@@ -273,7 +283,7 @@ __device__ __forceinline__ void gemm_epilogue_lean16(const vrd_gemm_args& p, con
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) slab[(r0 + 4 * lq + j) * STG_PITCH + tj * 16 + lc] = acc[ti][tj][j];
+                    for (int j = 0; j < 4; ++j) slab[(r0 + 4 * lq + j) * STG_PITCH + (tj ^ lq) * 16 + lc] = acc[ti][tj][j];
             }
         },
         stg, mw, mw1, nw, lane, cols, rflag);
@@ -292,6 +302,11 @@ template <bool STAGED, int SLAB_ROWS = 32, typename Acc>
 __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const Acc (&acc)[2][2], float* smem, int64_t mw,
                                               int nw, int wave, int lane, unsigned* rflag = nullptr) {
     RangeTrack rt;
+    // 16 x 16 accumulators: the four row groups of a wave write the same 16 columns of rows 4 apart -- one bank for all four at a
+    // 64-float slab pitch --, so the slab's 16-column blocks are XOR-swizzled with (row >> 2) & 3 (as in gemm_epilogue_lean16);
+    // the 32 x 32 layout's two half-rows stay as they are (two addresses per element instead of an immediate offset cost the
+    // exact-f32 kernel more than the 2-way conflict)
+    constexpr bool SWZ = std::is_same<Acc, acc32q>::value;
     if (STAGED) {
         // Through LDS: each wave transposes its sub-tile, 32 rows at a time, through a private 32 x 64 slab
         // so that global traffic is whole 256-B row segments as float4 (the raw accumulator layout would
@@ -403,7 +418,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const Acc 
 #pragma unroll
                     for (int nj = 0; nj < 2; ++nj)
                         forall32(acc[mt][nj], lane, [&](int r, int c, float x) {
-                            stg[((SLAB_ROWS == 64 ? mt * 32 : 0) + r) * STG_PITCH + nj * 32 + c] = x;
+                            stg[((SLAB_ROWS == 64 ? mt * 32 : 0) + r) * STG_PITCH + ((nj * 32 + c) ^ (SWZ ? ((r >> 2) & 3) << 4 : 0))] = x;
                         });
                 }
             }
@@ -412,7 +427,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const Acc 
             float v[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 t = *reinterpret_cast<const float4*>(stg + (slab_row0 + rb0 + h * 16 + 4 * j) * STG_PITCH + c4);
+                const float4 t = *reinterpret_cast<const float4*>(stg + (slab_row0 + rb0 + h * 16 + 4 * j) * STG_PITCH + (c4 ^ (SWZ ? 16 * j : 0)));
                 v[j][0] = fmaf(t.x, alpha, bias[0]), v[j][1] = fmaf(t.y, alpha, bias[1]);
                 v[j][2] = fmaf(t.z, alpha, bias[2]), v[j][3] = fmaf(t.w, alpha, bias[3]);
             }
