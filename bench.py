@@ -252,6 +252,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    LAB_ABLATION = os.environ.get("BENCH_LAB_ABLATION") == "1"
+    range_ok = {}
+
     def run(mode, warmup, steps):
         """W untimed + K timed steps in one GEMM precision mode; returns (seconds, per-family profile)."""
         ops.set_precision(mode)
@@ -284,7 +287,14 @@ def main():
                 for fam, v in _hip.prof_read().items():
                     if fam not in GEMM_FAMILIES:           # (scaled to the timed region's step count: the tables divide by it)
                         prof[fam] = {k: val * steps for k, val in v.items()}
-        assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
+        # A timed region counts only if its results do: finite logits, and (f16x3) no operand beyond the f16 format's range anywhere
+        # in its steps -- a direct caller of _mask_vrd checks the device flag itself, so the bench does.
+        # (BENCH_LAB_ABLATION=1: timing-only lab builds of the library, whose results are wrong by design.)
+        if not LAB_ABLATION:
+            assert logits.shape[0] == args.pairs and bool(torch.isfinite(logits).all())
+            bits = ops.f16_range_exceeded(dev)
+            assert not bits, f"[{mode}] f16 operand range exceeded inside the timed region ({ops.describe_range(bits)}): the line is void"
+        range_ok[mode] = True
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -547,6 +557,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": DTYPE[main_mode],
+            "f16_range_exceeded": False,      # (read from the device after every timed region; a set flag fails the run above)
             "data": "synthetic",
             "config": {"workload": f"{args.config}.yaml MaskVRD._mask_vrd, {args.pairs} pairs x {args.frames} frames "
                                    f"(T_pad {t_pad}) x C_in {c_in}, embd 512, eval, last-layer heads",
@@ -559,6 +570,8 @@ def main():
                        "world_size": dist.get_world_size() if use_dist else 1,
                        "backend": dist.get_backend() if use_dist else None},
         }
+        if LAB_ABLATION:
+            line["lab_ablation"] = True
         if fpp:
             line["algorithmic_tflops"] = fpp * args.pairs * args.steps / elapsed / 1e12
         if prof:
