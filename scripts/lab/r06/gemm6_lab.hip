@@ -19,7 +19,6 @@ __device__ unsigned long long g_lab_phase[16 * 4096];   // [tile][group][5 phase
 #include "../../../vrdone_amd/csrc/vrd_gemm_x3_big.hip"
 #include <algorithm>
 #include <vector>
-namespace vrd { double take_row_skipped_flops() { return 0.0; } }
 // random pair rows in the scaled-f16 format: hi = f16(16 x), lo = f16(16 x - hi), x ~ roughly N(0, 1) (sum of four uniforms)
 __global__ void fill_pair_f16(uint32_t* dst, size_t n_pairs_of_channels, float scale, uint32_t seed) {
     // dst viewed as rows of 32-channel blocks [32 hi | 32 lo]; thread i fills 16-bit slots for channel pair (2i, 2i+1)

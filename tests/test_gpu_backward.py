@@ -85,6 +85,29 @@ def test_linear_backward(k, Cin, N, precision):
     rel_close(bd.grad, br.grad, tol(precision), "db")
 
 
+@pytest.mark.parametrize("k,Cin,N", [(1, 64, 130), (3, 8, 512)])          # shapes the fused input-gradient GEMM does not take
+def test_linear_backward_of_an_f32_forward_stays_exact_in_another_mode(k, Cin, N):
+    """A step the range guard repeats in f32 (MaskVRD.forward_training) is differentiated after the f32 block has been left:
+    the unfused input-gradient GEMM must still form exact f32 products -- with the mode's fixed-scale f16 planes a gradient of
+    ~1e-6 would land in f16 subnormals and nothing would flag it."""
+    from vrdone_amd import ops
+    g = torch.Generator().manual_seed(77 + k)
+    B, T = 3, 40
+    x = torch.randn(B, T, Cin, generator=g)
+    w = torch.randn(N, Cin, k, generator=g) / (Cin * k) ** 0.5
+    dy = torch.randn(B, T, N, generator=g) * 1e-6
+    xd, wd = leaf(x), leaf(w)
+    with ops.use_precision("f32"), torch.enable_grad():
+        y = ops.conv_gemm(xd, wd, None)
+    with ops.use_precision("f16x3"):
+        y.backward(dy.to(DEV))
+    xr, wr = ref64(x.transpose(1, 2).contiguous()), ref64(w)
+    yr = torch.nn.functional.conv1d(xr, wr, padding=k // 2)
+    yr.backward(dy.transpose(1, 2).double())
+    rel_close(xd.grad, cl(xr.grad), 2e-5, "dx")
+    rel_close(wd.grad, wr.grad, 2e-5, "dW")
+
+
 @pytest.mark.parametrize("k,Cin,N,B,T", [(3, 96, 160, 7, 100), (1, 64, 64, 40, 90), (3, 21, 132, 7, 100), (1, 130, 66, 9, 64),
                                          (3, 64, 128, 40, 9), (3, 32, 64, 100, 3)])      # (sequences shorter than a 32-row step)
 def test_linear_weight_gradient_over_many_row_chunks(k, Cin, N, B, T, precision):

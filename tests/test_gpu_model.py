@@ -800,9 +800,24 @@ def test_forward_test_from_tracklet_features_equals_pair_matrices(precision):
     a = model(_on_device(P.test_getitem(raw, **dl_kw)))
     prop = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], DEV)
     b = model({k: (v if k == "pair_source" else ([t.to(DEV) for t in v] if isinstance(v, list) else v.to(DEV))) for k, v in prop.items()})
-    assert a["triplets"] == b["triplets"] and a["pred_durations"] == b["pred_durations"] and a["so_tids"] == b["so_tids"]
-    np.testing.assert_allclose(a["triple_scores_avg"], b["triple_scores_avg"], rtol=0, atol=2e-6)
-    assert a["so_trajs"] == b["so_trajs"]
+    np.testing.assert_allclose(a["triple_scores_avg"], b["triple_scores_avg"], rtol=0, atol=2e-6 if precision != "bf16x3" else 2e-5)
+    if precision == "bf16x3":
+        # the 17-bit mode may rank two records differently where their scores lie closer together than its own score error (the
+        # two input forms round the features differently): the same records, each at a rank whose score is within that error
+        rec = lambda r, i: (tuple(r["triplets"][i]), tuple(r["so_tids"][i]), tuple(r["pred_durations"][i]),           # noqa: E731
+                            tuple(map(tuple, r["so_trajs"][i][0])) if r["so_trajs"] else ())
+        n = len(a["triplets"])
+        assert len(b["triplets"]) == n
+        where = {}
+        for j in range(n):
+            where.setdefault(rec(b, j), []).append(j)
+        sc = a["triple_scores_avg"]
+        lost = [i for i in range(n) if not any(abs(sc[j] - sc[i]) <= 2e-5 for j in where.get(rec(a, i), []))]
+        # (a record whose score ties with the n_max_pair-th may fall off the end of one list)
+        assert len(lost) <= 2 and all(abs(sc[i] - sc[-1]) <= 2e-5 for i in lost), lost
+    else:
+        assert a["triplets"] == b["triplets"] and a["pred_durations"] == b["pred_durations"] and a["so_tids"] == b["so_tids"]
+        assert a["so_trajs"] == b["so_trajs"]
     # the plain-tensor form of the same source (what a dataset returns under the reference's eval loop), moved to the device
     # the way utils.dict_to_device does
     flat = prepare_test_proposal(raw, dl_kw["feat_stride"], dl_kw["stride_offset"], dl_kw["proposal_min_frames"], None)

@@ -188,7 +188,10 @@ class Linear(Function):
             wd = weight if not torch.is_grad_enabled() else weight.detach()
             fused = (ctx.split_bwd and (N * k) % 32 == 0 and N % 4 == 0 and dy.stride(-2) % 4 == 0 and
                      dy.data_ptr() % 16 == 0 and weight.is_contiguous())
-            gfmt = PAIR_BF16 if ctx.split_bwd else None       # (the unfused fallback splits gradients in bf16 in either mode)
+            # the unfused fallback: bf16 planes in either split mode (gradients have no fixed scale), and EXACT f32 products
+            # (_split_fmt 0, not None = "the mode at hand") behind an f32 forward -- the backward of a step that was repeated in
+            # f32 runs after that block has been left, in whatever mode is current by then
+            gfmt = PAIR_BF16 if ctx.split_bwd else 0
             # f16x3 mode: the gradient's power-of-two factor for its f16 planes (one absmax launch, shared with the weight gradient)
             gs = ops.grad_scale(dy) if (fused and ctx.bfmt == PAIR_F16) else None
             if fused and ctx.bfmt == PAIR_F16 and gs is None:

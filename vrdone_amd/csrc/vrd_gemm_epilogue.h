@@ -114,7 +114,7 @@ __device__ __forceinline__ EpiCols load_epi_cols_async(const vrd_gemm_args& p, i
 // 16-row pass).   ROWIN: any of row_mask / scale / res / res2 may be set;  ACT: VRD_ACT_NONE or VRD_ACT_GELU.
 // SLAB: rows of the wave's private staging slab `stg`: 64 (both 32-row halves transposed up front) or 32 (the second
 // half is transposed after the first one's passes, into the same slab: DS operations of a wave execute in order).
-// ROWS: 64 (four passes), or 32: one 32-row block, two passes, mw1 unused (the one-block-per-wave kernel, vrd_gemm_x3_row.hip).
+// ROWS: 64 (four passes), or 32: one 32-row block, two passes, mw1 unused.
 template <bool ROWIN, int ACT, int SLAB, int ROWS, typename Transposer>
 __device__ __forceinline__ void gemm_epilogue_lean_tr(const vrd_gemm_args& p, Transposer&& transpose_into, float* stg, int64_t mw,
                                                       int64_t mw1, int nw, int lane, const EpiCols& cols, unsigned* rflag = nullptr) {

@@ -1,7 +1,7 @@
 // Split-precision conv GEMM, 256 x 256 tile (see vrd_gemm_x3.hip for the arithmetic and vrd_gemm_x3_dma.hip for
 // the LDS-DMA staging it shares).
 //
-// Why a second DMA kernel: measured on the 128 x 256 kernel (scripts/lab/gemm_lab.hip), a 1-KiB LDS-DMA
+// Why a second DMA kernel: measured on the 128 x 256 kernel (round 2's lab harness; LABNOTES.md), a 1-KiB LDS-DMA
 // instruction costs the CU ~45 cycles while MFMAs are running -- whoever issues it and at whatever priority --
 // so a 48-KiB K step costs ~2,100 cycles of DMA issue against 1,536 cycles of MFMA: the step is DMA-issue-bound.
 // A 256 x 256 tile moves 64 KiB per K step for twice the MFMAs (3,072 cycles), which puts the MFMAs back in
@@ -42,7 +42,7 @@ __attribute__((unused)) constexpr int PER = 4;                         // DMA in
 // were launched but not executed (vrd_prof_read_skipped; the profile keeps executed and launched work apart)
 __device__ unsigned long long g_big_skipped_kn;
 
-#ifndef VRD_LAB_STAMP      // the lab harness (scripts/lab/gemm_lab.hip) defines these before including this file
+#ifndef VRD_LAB_STAMP      // the lab harness (scripts/lab/r06/gemm6_lab.hip) defines these before including this file
 #define LAB_STAMP(slot)
 #define LAB_REAL(slot)
 #define LAB_PHASE_DECL

@@ -381,9 +381,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     struct Row {
         float4 v[NV][GIN];
     };
-    // a row's loads (zeros outside the sequence), and -- separately, so that a row can be requested well before it is needed --
-    // the block's ln1, applied to a real row once, as it enters the window
-    auto load_raw = [&](int ti) {
+    auto load_row = [&](int ti) {
         Row r;
         const bool ok = ti >= 0 && ti < Tin;
 #pragma unroll
@@ -398,10 +396,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
                 }
                 r.v[i][g] = v;
             }
-        return r;
-    };
-    auto pre_ln = [&](Row& r, int ti) {
-        if (GIN == 1 && p.pre_gamma && ti >= 0 && ti < Tin) {
+        if (GIN == 1 && p.pre_gamma && ok) {       // the block's ln1, applied to a real row once, as it enters the window
             float4 t[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) t[i] = r.v[i][0];
@@ -409,10 +404,6 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
 #pragma unroll
             for (int i = 0; i < NV; ++i) r.v[i][0] = t[i];
         }
-    };
-    auto load_row = [&](int ti) {
-        Row r = load_raw(ti);
-        pre_ln(r, ti);
         return r;
     };
     // ---- a strip of padded frames only (every mask_out byte 0): conv * 0 = 0, so each row is LayerNorm(0) = beta
@@ -453,31 +444,14 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
     }
     // window win[k] = input row stride*to + k - KS/2; between consecutive output rows it moves by `stride`
     Row win[KS];
-    // k = 3, stride 1 (the attention-input stage: what this kernel's time is): the row the window gains TWO output rows from
-    // now is requested before this output row is worked on, and the one it gains next -- requested an iteration ago -- gets
-    // its ln1 behind this row's stores: a wave keeps two input rows in flight instead of one (the reads are latency-bound:
-    // ~13 waves per CU x 2 KiB per row in flight is well short of what HBM's latency asks for)
-    const bool deep = KS == 3 && p.stride == 1;
-    Row ahead;                                                  // deep: input row to + 2, in flight
-    if (deep) {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) win[k] = load_raw(to0 + k - 1);
-        ahead = load_raw(to0 + 2);
-#pragma unroll
-        for (int k = 0; k < KS; ++k) pre_ln(win[k], to0 + k - 1);
-    } else {
-#pragma unroll
-        for (int k = 0; k < KS; ++k) win[k] = load_row(p.stride * to0 + k - KS / 2);
-    }
+    for (int k = 0; k < KS; ++k) win[k] = load_row(p.stride * to0 + k - KS / 2);
     for (int to = to0; to < to1; ++to) {
-        // request what the next output row(s) add to the window before working on this one
+        // request what the next output row adds to the window before working on this one
         Row nxt[2];
         const int tn = p.stride * (to + 1) - KS / 2;            // first input row of the next window
         const bool more = to + 1 < to1;
-        if (deep) {
-            nxt[0] = ahead;                                     // row to + 2 (requested one iteration ago)
-            if (to + 2 < to1) ahead = load_raw(to + 3);
-        } else if (KS == 1) {
+        if (KS == 1) {
             if (more) nxt[0] = load_row(tn);
         } else if (p.stride == 1) {
             if (more) nxt[0] = load_row(tn + 2);
@@ -538,7 +512,6 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(vrd_dwconv_ln_args p, in
             }
         }
         if (more) {
-            if (deep) pre_ln(nxt[0], to + 2);
             if (KS == 1) {
                 win[0] = nxt[0];
             } else if (p.stride == 1) {

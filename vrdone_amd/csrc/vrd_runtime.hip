@@ -1,5 +1,6 @@
 // Error string + event-based per-family profiling for libvrdone_hip.so.
 #include "vrd_common.h"
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <utility>
@@ -23,9 +24,6 @@ static double g_ms[VRD_K_COUNT], g_flops[VRD_K_COUNT], g_bytes[VRD_K_COUNT];
 static int64_t g_launches[VRD_K_COUNT];
 static double g_skipped[VRD_K_COUNT];        // launched-but-skipped FLOPs (padding maps), folded in by drain()
 double take_big_skipped_flops();             // vrd_gemm_x3_big.hip
-#ifdef VRD_LAB_STAMP
-double take_row_skipped_flops();             // scripts/lab/vrd_gemm_x3_row.hip (lab harness only)
-#endif
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -68,18 +66,32 @@ int device_cu_count() {
 // kept for the life of the process.  Every producer of VRD_PAIR_F16 rows ORs its tag into it when an element's scaled value
 // does not fit an f16 (vrd_common.h, RangeTrack).  nullptr when the allocation fails (producers then skip the report).
 unsigned* range_flag() {
+    // hot path (every producer launch): a lock-free read of the per-device table; the slow path below runs once per device
+    constexpr int MAX_DEV = 64;
+    static std::atomic<unsigned*> flags[MAX_DEV];
+    static std::atomic<bool> failed[MAX_DEV];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev < 0 || dev >= MAX_DEV) return nullptr;
+    if (unsigned* q = flags[dev].load(std::memory_order_acquire)) return q;
+    if (failed[dev].load(std::memory_order_relaxed)) return nullptr;          // (an allocation that failed is not retried per launch)
     std::lock_guard<std::mutex> lk(g_mu);
-    static std::vector<unsigned*> flags;
-    if (dev >= (int)flags.size()) flags.resize(dev + 1, nullptr);
-    if (!flags[dev]) {
-        unsigned* q = nullptr;
-        if (hipMalloc(&q, 64) != hipSuccess) return nullptr;
-        if (hipMemset(q, 0, 64) != hipSuccess) return nullptr;
-        flags[dev] = q;
+    if (unsigned* q = flags[dev].load(std::memory_order_acquire)) return q;
+    // (allocation and a default-stream memset are not legal inside a stream capture: the word must exist before the first one --
+    // every recording path of the host mirror calls ops.f16_range_flag(device) first: train_graph's warm-up,
+    // MaskVRD.forward_training, the eval recordings)
+    unsigned* q = nullptr;
+    if (hipMalloc(&q, 64) != hipSuccess) {
+        failed[dev].store(true);
+        return nullptr;
     }
-    return flags[dev];
+    if (hipMemset(q, 0, 64) != hipSuccess) {
+        (void)hipFree(q);
+        failed[dev].store(true);
+        return nullptr;
+    }
+    flags[dev].store(q, std::memory_order_release);
+    return q;
 }
 
 static hipEvent_t get_event() {
@@ -131,9 +143,6 @@ static void drain() {
     }
     g_recs.clear();
     g_skipped[VRD_K_GEMM_X3_BIG] += take_big_skipped_flops();     // synchronous copy: every launch above has finished
-#ifdef VRD_LAB_STAMP
-    g_skipped[VRD_K_GEMM_X3_BIG] += take_row_skipped_flops();
-#endif
 }
 
 }  // namespace vrd

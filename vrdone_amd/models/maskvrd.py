@@ -370,7 +370,16 @@ class MaskVRD(nn.Module):
             predictions = self._mask_vrd(x, m, with_aux=self.deep_supervision)
         losses = self.criterion(predictions, input_data)
         if guard:
-            bits = int(flag.item())
+            # (one 4-byte read behind the step's launches: a host synchronisation, like the loss.item() of the reference's loop,
+            # train.py:188-191.  Under torch.distributed every rank must take the same branch -- a rank that repeated its step
+            # alone would leave its peers waiting in the gradient all-reduce while it records a new f32 graph --, so the flag is
+            # reduced over the default group first: MAX keeps "some rank saw it")
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                seen = (flag != 0).to(torch.int32)
+                torch.distributed.all_reduce(seen, op=torch.distributed.ReduceOp.MAX)
+                bits = int(flag.item()) or (64 if int(seen.item()) else 0)        # (64: "other" -- a peer's producer)
+            else:
+                bits = int(flag.item())
             if bits:
                 import warnings
                 flag.zero_()

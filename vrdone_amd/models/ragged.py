@@ -127,6 +127,9 @@ def _attention_rows(q, k, v, kv_mask, q_mask, n_head, qsegs, ksegs, *, half_win=
     Cc = q.shape[-1]
     out = torch.empty(1, sum(n * T for _, n, T in qsegs), Cc, device=_raw(q).device, dtype=torch.float32)
     r = None
+    # buckets of one frame count on both sides (the predictor's query self-attention: every segment is n x Q rows) are one launch
+    if len(qsegs) > 1 and len(_merged(qsegs)) == 1 and len(_merged(ksegs)) == 1:
+        qsegs, ksegs = _merged(qsegs), _merged(ksegs)
     if half_win is not None and 1 < len(qsegs) <= _MAX_SEGS:      # banded attention: the buckets as the kernel's row groups
         assert list(qsegs) == list(ksegs)
         r = ops.local_attention(q, k, v, kv_mask, n_head, half_win, pair=pair, rel_pe=rel_pe, out=out, segs=list(qsegs))

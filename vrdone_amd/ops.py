@@ -619,7 +619,8 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     row_mask, which is then the default; without row_mask those rows hold bias-only filler, so pass it only where
     no valid row ever reads a padded one: projections feeding masked attention, an MLP's hidden layer).
     row_scale (rows,): per-row factor on the branch term (stochastic depth, blocks.py:1107-1120); autograd path only.
-    _split_fmt: element format of the split products instead of the mode's (the unfused backward GEMMs pass PAIR_BF16).
+    _split_fmt: element format of the split products instead of the mode's (the unfused backward GEMMs pass PAIR_BF16; 0 = exact
+    f32 products whatever the mode, None = the mode's format).
     _dgrad / _a_scale: the conv's input-gradient GEMM on the parameter's transposed operand; x is then a gradient, and in the
     f16 format its rows are split at the power-of-two factor of grad_scale(x) (vrd_gemm_args.a_scale).
     Under autograd (`recording`) the op runs as autograd.conv_gemm and returns a fresh tensor (`out` is ignored)."""
