@@ -321,7 +321,7 @@ def main():
             peak = PEAK_BF16_MFMA_TFLOPS / 3.0
             extra = {"mfma_tflops_executed": 3.0 * achieved, "mfma_peak": PEAK_BF16_MFMA_TFLOPS,
                      "note": "peak = 16-bit dense MFMA peak / 3 (a_hi*w_hi + a_hi*w_lo + a_lo*w_hi per product); the kernel family is "
-                             "named for its first format: the f16x3 mode runs its F16 = true instantiations (v_mfma_f32_32x32x16_f16)"}
+                             "named for its first format: the f16x3 mode runs its F16 = true instantiations (v_mfma_f32_16x16x32_f16)"}
             kern = fam + "_kernel"
         else:
             peak, extra, kern = PEAK_F32_MFMA_TFLOPS, {}, "gemm_f32_mfma_kernel"

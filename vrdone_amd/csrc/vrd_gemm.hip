@@ -81,6 +81,10 @@ __device__ __forceinline__ void load_w(const vrd_gemm_args& p, int n, int k, int
 #ifndef VRD_F32_WAVES
 #define VRD_F32_WAVES 3
 #endif
+// sum over the tiles that skipped their contraction (padding map) of K * tile columns: 2 * 128 * this = FLOPs that were launched
+// but not executed (the profile keeps executed and launched work apart, as for the 256 x 256 split kernel)
+__device__ unsigned long long g_f32_skipped_kn;
+
 template <bool VEC, int TAPS, int BK, bool STAGED>
 __global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_gemm_args p, int tiles_m, int tiles_n, unsigned* rflag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -102,17 +106,37 @@ __global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_g
     const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = tn * BN;
+    // Padding map (vrd_gemm_args.row_blocks, the 256 x 256 split kernel's: vrd_gemm_x3_big.hip): the tile's rows are four 32-row
+    // blocks, slots tm*4 .. tm*4+3 of the block list; inside a segment of the list the blocks holding valid frames come first, so
+    // a tile is a contraction tile or, behind those, a tile of fully padded blocks that only runs the epilogue on a zero
+    // accumulator (the reference's value wherever row_mask zeroes the row).
+    const int32_t* blist = p.row_blocks;
+    bool contract = true;
+    int64_t brow[4];                                    // first row of the tile's four blocks (p.M: a block outside the matrix)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) brow[j] = m0 + 32 * j;
+    if (blist) {
+        const int nblk = (int)(p.M >> 5), seg_len = p.row_block_seg_len;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) brow[j] = tm * 4 + j < nblk ? (int64_t)vrd::uniform_load(blist + tm * 4 + j) * 32 : p.M;
+        const int seg = (tm * 4) / seg_len;
+        contract = tm * 4 < nblk && tm * 4 - seg * seg_len < vrd::uniform_load(p.row_blocks_active + seg);
+        if (!contract && tid == 0 && tm * 4 < nblk)
+            atomicAdd(&g_f32_skipped_kn, (unsigned long long)(p.Cin * TAPS) * (unsigned)(p.N - n0 < BN ? p.N - n0 : BN));
+    }
 
     // staging assignment: NP (row, 4-wide k chunk) pieces of each operand per thread
     constexpr int NP = BK / 8, KQ = BK / 4;
     int srow[NP], skq[NP], st[NP];
+    int64_t arow[NP];                                   // the piece's row of A
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         int f = tid + 256 * i;
         srow[i] = f / KQ;
         skq[i] = (f % KQ) * 4;
-        int64_t r = m0 + srow[i];
-        st[i] = (TAPS == 3 && r < p.M) ? (int)(r % p.T) : 0;
+        const int b4 = srow[i] >> 5;
+        arow[i] = (b4 == 0 ? brow[0] : b4 == 1 ? brow[1] : b4 == 2 ? brow[2] : brow[3]) + (srow[i] & 31);
+        st[i] = (TAPS == 3 && arow[i] < p.M) ? (int)(arow[i] % p.T) : 0;
     }
 
     float ra[NP][4], rb[NP][4];
@@ -127,7 +151,7 @@ __global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_g
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            load_a<VEC, TAPS>(p, m0 + srow[i], st[i], kt * BK + skq[i], K, ra[i]);
+            load_a<VEC, TAPS>(p, arow[i], st[i], kt * BK + skq[i], K, ra[i]);
             load_w<VEC>(p, n0 + srow[i], kt * BK + skq[i], K, rb[i]);
         }
     };
@@ -141,6 +165,7 @@ __global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_g
             }
     };
 
+    if (contract) {
     fetch(0);
     stage(0);
     __syncthreads();
@@ -174,8 +199,9 @@ __global__ __launch_bounds__(256, VRD_F32_WAVES) void gemm_f32_mfma_kernel(vrd_g
         __syncthreads();
         cur ^= 1;
     }
+    }       // contract
 
-    vrd::gemm_epilogue<STAGED>(p, acc, smem, m0 + wm * 64, n0 + wn * 64, wave, lane, rflag);
+    vrd::gemm_epilogue<STAGED>(p, acc, smem, wm ? brow[2] : brow[0], n0 + wn * 64, wave, lane, rflag, wm ? brow[3] : brow[1]);
 }
 
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
@@ -201,6 +227,13 @@ int launch_bk(const vrd_gemm_args& a, bool vec, int tiles_m, int tiles_n, hipStr
 }  // namespace
 
 namespace vrd {
+// FLOPs of contractions the exact-f32 kernel skipped through padding maps since the last call (reads and clears the device counter)
+double take_f32_skipped_flops() {
+    unsigned long long v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_f32_skipped_kn), sizeof(v)) != hipSuccess) return 0.0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f32_skipped_kn), &zero, sizeof(zero));
+    return 2.0 * BM * (double)v;
+}
 int launch_gemm_x3(const vrd_gemm_args& a, bool staged, hipStream_t s);
 bool gemm_x3_dma_ok(const vrd_gemm_args& a, bool staged);
 int launch_gemm_x3_dma(const vrd_gemm_args& a, hipStream_t s);

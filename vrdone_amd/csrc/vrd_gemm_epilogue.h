@@ -298,9 +298,13 @@ inline bool gemm_epilogue_lean_ok(const vrd_gemm_args& a) {
 
 // SLAB_ROWS: rows of the wave's private staging slab.  64 (16 KiB per wave) lets both accumulator halves be
 // transposed up front so their registers are dead for the rest of the epilogue; 32 for kernels with less LDS.
+// mw / mw1: first row of the sub-tile's two 32-row blocks (mw1 < 0: the block behind the first; apart when the tile's blocks come
+// from a block list: vrd_gemm_args.row_blocks)
 template <bool STAGED, int SLAB_ROWS = 32, typename Acc>
 __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const Acc (&acc)[2][2], float* smem, int64_t mw,
-                                              int nw, int wave, int lane, unsigned* rflag = nullptr) {
+                                              int nw, int wave, int lane, unsigned* rflag = nullptr, int64_t mw1 = -1) {
+    if (mw1 < 0) mw1 = mw + 32;
+    auto rowbase = [&](int mi) { return mi ? mw1 : mw; };
     RangeTrack rt;
     // 16 x 16 accumulators: the four row groups of a wave write the same 16 columns of rows 4 apart -- one bank for all four at a
     // 64-float slab pitch --, so the slab's 16-column blocks are XOR-swizzled with (row >> 2) & 3 (as in gemm_epilogue_lean16);
@@ -355,7 +359,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const Acc 
                 in.r2[j] = in.r1[j];
             }
             if (!row_inputs) return in;
-            const int64_t mr = mw + (pass >> 1) * 32 + rb0 + (pass & 1) * 16;     // rows mr + 4*j
+            const int64_t mr = rowbase(pass >> 1) + rb0 + (pass & 1) * 16;     // rows mr + 4*j
             if (!ragged) {
                 // unpredicated: rows past M and column groups past N read a clamped, valid address and are
                 // dropped at the store
@@ -453,7 +457,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const Acc 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t m = mw + mi * 32 + rb0 + h * 16 + 4 * j;
+                const int64_t m = rowbase(mi) + rb0 + h * 16 + 4 * j;
                 if (m >= p.M || n >= p.N) continue;
                 float* crow = p.C + m * p.ldc + n;
                 if (p.c_pair) {          // pair rows of width N (host checks N % 8 == 0, so a float4 group is whole)
@@ -479,7 +483,7 @@ __device__ __forceinline__ void gemm_epilogue(const vrd_gemm_args& p, const Acc 
         for (int mi = 0; mi < 2; ++mi)
             forall32(acc[mi][nj], lane, [&](int r, int c, float x) {
                 const int n = nw + nj * 32 + c;
-                const int64_t m = mw + mi * 32 + r;
+                const int64_t m = rowbase(mi) + r;
                 if (n >= p.N || m >= p.M) return;
                 const float bias = p.bias ? p.bias[n] : 0.f;
                 const float scale = p.scale ? p.scale[n] : 1.f;

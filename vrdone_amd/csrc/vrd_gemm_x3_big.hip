@@ -411,7 +411,6 @@ __device__ __forceinline__ void gemm_x3_big_body() {
             else issue_a1(nx, g0 + nkt + j_a, j_a, d - PER);
         };
         const char* sa = lds + ((g0 + kt) % NA_STG) * A_STAGE;
-        const char* sw = lds + ((g0 + kt) % NW_STG) * W_STAGE;
         const char* sa1 = lds + ((g0 + kt + 1) % NA_STG) * A_STAGE;
         const char* sw1 = lds + ((g0 + kt + 1) % NW_STG) * W_STAGE;
         constexpr bool last = POS == POS_LAST;

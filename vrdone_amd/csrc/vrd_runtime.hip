@@ -24,6 +24,7 @@ static double g_ms[VRD_K_COUNT], g_flops[VRD_K_COUNT], g_bytes[VRD_K_COUNT];
 static int64_t g_launches[VRD_K_COUNT];
 static double g_skipped[VRD_K_COUNT];        // launched-but-skipped FLOPs (padding maps), folded in by drain()
 double take_big_skipped_flops();             // vrd_gemm_x3_big.hip
+double take_f32_skipped_flops();             // vrd_gemm.hip
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -143,6 +144,7 @@ static void drain() {
     }
     g_recs.clear();
     g_skipped[VRD_K_GEMM_X3_BIG] += take_big_skipped_flops();     // synchronous copy: every launch above has finished
+    g_skipped[VRD_K_GEMM] += take_f32_skipped_flops();
 }
 
 }  // namespace vrd

@@ -17,7 +17,15 @@ from . import _hip
 from ._hip import ACT_GELU, ACT_NONE, ACT_RELU, lib  # noqa: F401
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """torch's current stream of the current device as a hipStream_t.  (Through the raw-handle call: torch.cuda.current_stream()
+    builds a Stream object per call, ~5 us of the ~15 us an op of this module spends on the host -- a forward_test call on a
+    real-sized video is ~230 launches and bound by exactly that.)"""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -676,7 +684,9 @@ def conv_gemm(x, weight, bias=None, *, act=ACT_NONE, row_mask=None, scale=None, 
     a.c_pair = _fmt(out_pair)
     if skip_rows is None:
         skip_rows = row_mask
-    if _skip_padding and skip_rows is not None and a_width and rows >= SKIP_MIN_ROWS and skip_rows.numel() == rows:
+    # (the kernels that take the block list: the 256 x 256 split kernel -- pair-row input -- and the exact-f32 kernel)
+    f32_kernel = not a_width and not _dgrad and not (w_fmt and (Cin * k) % 32 == 0)
+    if _skip_padding and skip_rows is not None and (a_width or f32_kernel) and rows >= SKIP_MIN_ROWS and skip_rows.numel() == rows:
         blocks = row_blocks(skip_rows)
         if blocks is not None:
             a.row_blocks, a.row_blocks_active = blocks[0].data_ptr(), blocks[1].data_ptr()
