@@ -291,21 +291,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         int pair, unsigned* rflag) {
     vrd::RangeTrack rt;
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
+    // Waves walk the rows with the stride of the grid (row = wave, wave + waves of the grid, ...) and request their next row before
+    // working on the current one.  All resident waves then read and write one compact, moving window of memory, which is what HBM
+    // serves fastest when reads and writes mix (profiles/r06_lab_hbm_rw.txt: a wave per row 5.8 TB/s, a strip of >= 12 rows per
+    // wave 3.3 TB/s for one read : one write), and a wave's load latency hides behind its own previous row.
+    int64_t row = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: addresses on the scalar unit
+    const int64_t stride = (int64_t)gridDim.x * 4;
     if (row >= rows) return;
-    float4 v[NV];
+    float4 v[NV], vn[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = ld4(x + row * ldx + i * 256 + lane * 4);
-    ln_rows<NV>(v, gamma, beta, lane, relu != 0);
-    if (post_add) {
-        const float* a = post_add + (row % period) * ld_add;
+    for (;;) {
+        const int64_t nxt = row + stride;
+        if (nxt < rows) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = f4add(v[i], ld4(a + i * 256 + lane * 4));
-    }
+            for (int i = 0; i < NV; ++i) vn[i] = ld4(x + nxt * ldx + i * 256 + lane * 4);
+        }
+        ln_rows<NV>(v, gamma, beta, lane, relu != 0);
+        if (post_add) {
+            const float* a = post_add + (row % period) * ld_add;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        if (pair) vrd::store_pair4(y + row * ldy, i * 256 + lane * 4, 256 * NV, v[i], pair, &rt);
-        else st4(y + row * ldy + i * 256 + lane * 4, v[i]);
+            for (int i = 0; i < NV; ++i) v[i] = f4add(v[i], ld4(a + i * 256 + lane * 4));
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (pair) vrd::store_pair4(y + row * ldy, i * 256 + lane * 4, 256 * NV, v[i], pair, &rt);
+            else st4(y + row * ldy + i * 256 + lane * 4, v[i]);
+        }
+        if (nxt >= rows) break;
+        row = nxt;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = vn[i];
     }
     rt.report(rflag, vrd::RANGE_LAYERNORM);
 }
@@ -745,7 +761,10 @@ int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t ro
     hipStream_t s = static_cast<hipStream_t>(stream);
     vrd::ProfScope prof(VRD_K_LAYERNORM, s, 0.0, 8.0 * (double)rows * C);
     unsigned* const rflag = out_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr;
-    dim3 grid((unsigned)((rows + 3) / 4));
+    // workgroups: at most VRD_LN_BLOCKS (default 32 per CU: the waves then walk the rows with the grid's stride; 7.4 -> 7.1 ms per step), one row per wave below that
+    static const int64_t max_blocks = [] { const char* e = getenv("VRD_LN_BLOCKS"); return e ? atoll(e) : 8192; }();
+    const int64_t want = (rows + 3) / 4;
+    dim3 grid((unsigned)(max_blocks > 0 && want > max_blocks ? max_blocks : want));
     if (C == 256)
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair, rflag);
     else
