@@ -3,6 +3,7 @@
 // on the path's shapes; GEMM_LAB_F16=1 runs the product's default format on random data.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DVRD_LAB_STAMP [-DVRD_BIG_BUFDMA=1] scripts/lab/r06/gemm6_lab.hip -o ...
 #include "../../../vrdone_amd/csrc/vrd_runtime.hip"
+namespace vrd { double take_f32_skipped_flops() { return 0.0; } }      // (vrd_gemm.hip is not part of this harness)
 __device__ int g_lab_mode;
 __device__ unsigned long long g_lab[8 * 65536];
 __device__ unsigned long long g_lab_phase[16 * 4096];   // [tile][group][5 phase accumulators]
