@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define VRD_ABI_VERSION 33
+#define VRD_ABI_VERSION 34
 
 enum vrd_act { VRD_ACT_NONE = 0, VRD_ACT_RELU = 1, VRD_ACT_GELU = 2 };
 
@@ -243,6 +243,34 @@ int vrd_gemm_batch(const vrd_gemm_args* a, int count, void* stream);
  * tile order, so every XCD gets the same amount of padding to skip.  The reference computes every padded frame
  * (T_pad = 288 for 256 valid frames; max_seq_len for short pairs). */
 int vrd_row_blocks(const uint8_t* mask, int64_t rows, int seg_len, int32_t* order, int32_t* n_active, void* stream);
+
+/* ---- dense conv with FEW input channels * mask -> [LayerNorm -> ReLU] as one row kernel (round 6) ----------------------
+ * The box-feature embeddings: MaskedConv1D(n_bbox_entity = 8 -> 512, k = 3) -> LayerNorm -> ReLU (models/backbones.py:174-178 with
+ * blocks.py:45-48, 143-158) and MaskedConv1D(n_bbox_so = 5 -> 512, k = 3) (backbones.py:208-210).  With taps * Cin <= 32 the
+ * contraction is 24 (15) multiply-adds per output: as a GEMM it ran on the exact-f32 MFMA kernel, bound by writing its 2.4 GB
+ * output, which the LayerNorm then read back and wrote again; here a wave computes a row's N outputs on the vector units (f32 FMAs,
+ * the row's inputs through the scalar cache, the weights from LDS), normalises them in registers and stores them once.
+ *   y[r, n] = act(LN_n((bias[n] + sum_{tap, ci} W[n, ci, tap] * x[r + tap - taps/2, ci]) * row_mask[r]))
+ * x: rows of Cin f32 (leading dimension ldx); rows outside r's length-T sequence read 0 (Conv1d zero padding); W: the Conv1d
+ * parameter (N, Cin, taps) contiguous; N in {256, 512}; taps in {1, 3}; taps * Cin <= 32 and (3 + taps) * Cin <= 64 (the inputs of four
+ * output rows are one wave-wide load); gamma / beta NULL: no LayerNorm;
+ * y: f32 rows or (out_pair) pair rows of width N. */
+typedef struct {
+    const float* x;
+    int64_t ldx;
+    int64_t rows;
+    int Cin, taps, T, N;
+    const float* w;
+    const float* bias;              /* nullable */
+    const uint8_t* row_mask;        /* nullable: rows */
+    const float* gamma;             /* nullable (with beta): N */
+    const float* beta;
+    int relu;
+    float* y;
+    int64_t ldy;
+    int out_pair;                   /* enum vrd_pair_format */
+} vrd_conv_ln_args;
+int vrd_conv_ln(const vrd_conv_ln_args* a, void* stream);
 
 /* ---- channel LayerNorm (models/blocks.py:143-158), C in {256, 512} ----------------------
  * y[r,:] = LN(x[r,:]) * gamma + beta; optional ReLU (backbones.py:174); optional

@@ -801,3 +801,39 @@ def test_gemm_batch_equals_single_calls(precision):
     got = ops.conv_gemm_batch([((xs[0], ws[0], bs[0]), dict(out_pair=True)), ((xs[1], w_small, None), dict(row_mask=mask))])
     assert torch.equal(got[0].t, ops.conv_gemm(xs[0], ws[0], bs[0], out_pair=True).t)
     assert torch.equal(got[1], ops.conv_gemm(xs[1], w_small, None, row_mask=mask))
+
+@pytest.mark.parametrize("Cin,N,ln,pair", [(8, 512, True, True), (8, 512, True, False), (5, 512, False, True), (5, 512, False, False),
+                                           (7, 256, True, False), (10, 256, False, False)])
+def test_few_channel_conv_layernorm_row_kernel(Cin, N, ln, pair, precision):
+    """vrd_conv_ln (the box-feature embeddings: k = 3 conv with 5 / 8 input channels * mask -> [LayerNorm -> ReLU]) against the GEMM +
+    LayerNorm launches it replaces and against the oracle's Conv1d: sequence ends (zero padding), masked rows, pair-row output."""
+    from vrdone_amd import ops
+    if pair and precision not in SPLIT:
+        pytest.skip("pair rows exist in the split-precision modes")
+    g = torch.Generator().manual_seed(Cin * 10 + N)
+    B, T = 37, 53
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    mask = (torch.arange(T)[None, :] < lens[:, None])
+    x = torch.randn(B, T, Cin, generator=g) * 3
+    w = torch.randn(N, Cin, 3, generator=g) / (3 * Cin) ** 0.5
+    b = torch.randn(N, generator=g) * 0.3
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    xd, wd, bd, md = x.to(DEV), w.to(DEV), b.to(DEV), mask.to(DEV)
+    assert ops.conv_ln_ok(xd, wd, bd)
+    got = ops.conv_ln(xd, wd, bd, row_mask=md, gamma=gamma.to(DEV) if ln else None, beta=beta.to(DEV) if ln else None, relu=ln, pair=pair)
+    want = torch.nn.functional.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding=1).transpose(1, 2) * mask[..., None]
+    if ln:
+        mu = want.mean(-1, keepdim=True)
+        var = ((want - mu) ** 2).mean(-1, keepdim=True)
+        want = torch.relu((want - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double())
+    gotf = (got.float() if isinstance(got, ops.Pair) else got).cpu().double()
+    tol = 2e-5 if not pair else (2e-4 if precision == "bf16x3" else 2e-5)
+    assert float((gotf - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    # ... and the launches it replaces (exact-f32 GEMM, then the LayerNorm kernel)
+    h = ops.conv_gemm(xd, wd, bd, row_mask=md)
+    if ln:
+        h = ops.layernorm(h, gamma.to(DEV), beta.to(DEV), relu=True, pair=pair)
+    elif pair:
+        h = ops.conv_gemm(xd, wd, bd, row_mask=md, out_pair=True)
+    hf = (h.float() if isinstance(h, ops.Pair) else h).cpu().double()
+    assert float((gotf - hf).abs().max()) <= tol * max(1.0, float(want.abs().max()))

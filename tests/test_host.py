@@ -133,7 +133,7 @@ def test_ctypes_struct_layout_matches_header():
     for cname, cls in (("vrd_gemm_args", _hip.GemmArgs), ("vrd_dwconv_ln_args", _hip.DwconvLnArgs),
                        ("vrd_criterion_args", _hip.CriterionArgs), ("vrd_criterion_grads", _hip.CriterionGrads),
                        ("vrd_split_job", _hip.SplitJob), ("vrd_pack_args", _hip.PackArgs), ("vrd_gather_args", _hip.GatherArgs),
-                       ("vrd_row_segs", _hip.RowSegs)):
+                       ("vrd_row_segs", _hip.RowSegs), ("vrd_conv_ln_args", _hip.ConvLnArgs)):
         body = re.search(r"typedef struct \{([^}]*)\} " + cname, header).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []

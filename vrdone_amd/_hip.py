@@ -87,6 +87,13 @@ class DwconvLnArgs(C.Structure):
                 ("pre_gamma", c_f32p), ("pre_beta", c_f32p), ("packed", c_f32p * 3), ("segs", C.POINTER(RowSegs))]
 
 
+class ConvLnArgs(C.Structure):
+    _fields_ = [("x", c_f32p), ("ldx", C.c_int64), ("rows", C.c_int64),
+                ("Cin", C.c_int32), ("taps", C.c_int32), ("T", C.c_int32), ("N", C.c_int32),
+                ("w", c_f32p), ("bias", c_f32p), ("row_mask", c_u8p), ("gamma", c_f32p), ("beta", c_f32p),
+                ("relu", C.c_int32), ("y", c_f32p), ("ldy", C.c_int64), ("out_pair", C.c_int32)]
+
+
 class PackArgs(C.Structure):
     _fields_ = [("src", C.c_void_p), ("lens", C.c_void_p),
                 ("P", C.c_int32), ("C_in", C.c_int32), ("T", C.c_int32), ("V", C.c_int32), ("Cc", C.c_int32),
@@ -150,6 +157,7 @@ _SIGNATURES = {
     "vrd_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "vrd_gemm_batch": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_void_p]),
     "vrd_row_blocks": (C.c_int, [c_u8p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vrd_conv_ln": (C.c_int, [C.POINTER(ConvLnArgs), C.c_void_p]),
     "vrd_layernorm": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, c_f32p, C.c_int,
                                 c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "vrd_dwconv_ln": (C.c_int, [C.POINTER(DwconvLnArgs), C.c_void_p]),
@@ -202,7 +210,7 @@ _SIGNATURES = {
                                   C.c_void_p]),
 }
 
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 
 class HipLibraryError(RuntimeError):

@@ -327,6 +327,112 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// dense conv with few input channels (taps * Cin <= 32) * mask -> [LayerNorm -> ReLU]: the box-feature embeddings
+// (include/vrdone_hip.h, vrd_conv_ln).  A wave per row, rows walked with the grid's stride (layernorm_kernel's pattern: the
+// kernel writes N floats per row and reads next to nothing); a row's taps * Cin inputs are wave-uniform and come through the
+// scalar cache, the weights sit in LDS k-major ([taps * Cin][N]: a lane's channels of one k are one or two float4).
+// ------------------------------------------------------------------------------------------
+constexpr int CL_MAXK = 32;
+template <int NV>
+__global__ __launch_bounds__(256) void conv_ln_kernel(vrd_conv_ln_args p, unsigned* rflag) {
+    vrd::RangeTrack rt;
+    constexpr int N = 256 * NV;
+    constexpr bool WIDE = NV == 2;
+    extern __shared__ __attribute__((aligned(16))) float cl_lds[];      // [K][N] weights | bias [N]
+    const int K = p.Cin * p.taps;
+    // W (N, Cin, taps) -> k = tap * Cin + ci major
+    for (int idx = threadIdx.x; idx < N * K; idx += 256) {
+        const int n = idx / K, rem = idx - n * K, ci = rem / p.taps, tap = rem - ci * p.taps;
+        cl_lds[(tap * p.Cin + ci) * N + n] = p.w[idx];
+    }
+    for (int n = threadIdx.x; n < N; n += 256) cl_lds[K * N + n] = p.bias ? p.bias[n] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // a wave takes RG consecutive rows per trip (groups walked with the grid's stride): a weight fragment read from LDS serves RG
+    // rows -- with one row per trip the kernel was bound by its 48 LDS reads per row
+    constexpr int RG = 4;
+    int64_t grp = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    const int half = p.taps / 2;
+    // the inputs of a trip -- rows row0 - half .. row0 + RG - 1 + half, Cin floats each, at most 64 values -- are ONE load: lane l
+    // holds value l % Cin of row l / Cin (0 outside the matrix), the contraction reads them back with v_readlane.  (As scalar loads
+    // they were 96 dependent round trips per trip.)  The next trip's are requested before this trip's arithmetic.
+    const int lrow = lane / p.Cin, lci = lane - lrow * p.Cin;
+    auto load_in = [&](int64_t g) {
+        const int64_t r = g * RG - half + lrow;
+        float val = 0.f;
+        if (lrow < RG + 2 * half && r >= 0 && r < p.rows) val = p.x[r * p.ldx + lci];
+        return val;
+    };
+    float xin = grp * RG < p.rows ? load_in(grp) : 0.f;
+    for (; grp * RG < p.rows; grp += stride) {
+        const int64_t row0 = grp * RG;
+        const float xcur = xin;
+        if ((grp + stride) * RG < p.rows) xin = load_in(grp + stride);
+        float4 v[RG][NV];
+        int t[RG];
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            t[j] = (int)((row0 + j) % p.T);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[j][i] = *reinterpret_cast<const float4*>(cl_lds + K * N + lane_chan<NV, WIDE>(i, lane));
+        }
+        for (int tap = 0; tap < p.taps; ++tap) {
+            for (int ci = 0; ci < p.Cin; ++ci) {
+                const float* wk = cl_lds + (tap * p.Cin + ci) * N;
+                float4 w[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) w[i] = *reinterpret_cast<const float4*>(wk + lane_chan<NV, WIDE>(i, lane));
+#pragma unroll
+                for (int j = 0; j < RG; ++j) {
+                    const int tt = t[j] + tap - half;
+                    // (Conv1d zero padding at the sequence's ends, rows past the end of the matrix; wave-uniform: a scalar load)
+                    const bool ok = tt >= 0 && tt < p.T && row0 + j < p.rows;
+                    const float xl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xcur), (j + tap) * p.Cin + ci));
+                    const float xv = ok ? xl : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        v[j][i].x = fmaf(w[i].x, xv, v[j][i].x); v[j][i].y = fmaf(w[i].y, xv, v[j][i].y);
+                        v[j][i].z = fmaf(w[i].z, xv, v[j][i].z); v[j][i].w = fmaf(w[i].w, xv, v[j][i].w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RG; ++j) {
+            const int64_t row = row0 + j;
+            if (row >= p.rows) break;
+            if (p.row_mask) {
+                const float mk = (float)vrd::uniform_load(p.row_mask + row);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[j][i].x *= mk, v[j][i].y *= mk, v[j][i].z *= mk, v[j][i].w *= mk;
+            }
+            if (p.gamma) {
+                ln_rows<NV, WIDE>(v[j], p.gamma, p.beta, lane, p.relu != 0);
+            } else if (p.relu) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    v[j][i].x = fmaxf(v[j][i].x, 0.f); v[j][i].y = fmaxf(v[j][i].y, 0.f);
+                    v[j][i].z = fmaxf(v[j][i].z, 0.f); v[j][i].w = fmaxf(v[j][i].w, 0.f);
+                }
+            }
+            float* yr = p.y + row * p.ldy;
+            if (WIDE && p.out_pair) {
+                vrd::store_pair8(yr, lane * 8, v[j][0], v[j][NV - 1], p.out_pair, &rt);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c = lane_chan<NV, WIDE>(i, lane);
+                    if (p.out_pair) vrd::store_pair4(yr, c, N, v[j][i], p.out_pair, &rt);
+                    else st4(yr + c, v[j][i]);
+                }
+            }
+        }
+    }
+    rt.report(rflag, vrd::RANGE_LAYERNORM);
+}
+
+// ------------------------------------------------------------------------------------------
 // depthwise (or 2-in-per-group) conv along t, * mask, -> LayerNorm, up to three weight sets
 // sharing the input rows (the q/k/v branches of the conv-attention modules)
 // ------------------------------------------------------------------------------------------
@@ -769,6 +875,38 @@ int vrd_layernorm(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t ro
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair, rflag);
     else
         hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, x, ldx, y, ldy, rows, gamma, beta, relu, post_add, ld_add, add_period, out_pair, rflag);
+    VRD_LAUNCH_CHECK();
+    return 0;
+}
+
+int vrd_conv_ln(const vrd_conv_ln_args* a, void* stream) {
+    VRD_CHECK_ARG(a && a->x && a->w && a->y, "vrd_conv_ln: null pointer");
+    VRD_CHECK_ARG(a->N == 256 || a->N == 512, "vrd_conv_ln: N must be 256 or 512 (got %d)", a->N);
+    VRD_CHECK_ARG((a->taps == 1 || a->taps == 3) && a->Cin > 0 && a->Cin * a->taps <= CL_MAXK && (4 + a->taps - 1) * a->Cin <= 64,
+                  "vrd_conv_ln: taps in {1, 3}, taps * Cin <= %d and (3 + taps) * Cin <= 64 (got %d x %d)", CL_MAXK, a->taps, a->Cin);
+    VRD_CHECK_ARG(a->rows >= 0 && a->T > 0 && a->rows % a->T == 0 && a->ldx >= a->Cin, "vrd_conv_ln: bad rows / T / ldx");
+    VRD_CHECK_ARG((a->gamma == nullptr) == (a->beta == nullptr), "vrd_conv_ln: gamma and beta go together");
+    VRD_CHECK_ARG(a->ldy >= a->N && a->ldy % 4 == 0 && aligned16(a->y) && aligned16(a->gamma) && aligned16(a->beta),
+                  "vrd_conv_ln: output rows and LayerNorm parameters must be 16-byte aligned");
+    VRD_CHECK_ARG(!a->out_pair || (a->ldy % 32 == 0 && (a->out_pair == VRD_PAIR_BF16 || a->out_pair == VRD_PAIR_F16)),
+                  "vrd_conv_ln: pair output needs rows that start on a 128-byte block");
+    if (a->rows == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int K = a->Cin * a->taps;
+    vrd::ProfScope prof(VRD_K_LAYERNORM, s, 2.0 * (double)a->rows * a->N * K, 4.0 * (double)a->rows * (a->N + a->Cin));
+    unsigned* const rflag = a->out_pair == VRD_PAIR_F16 ? vrd::range_flag() : nullptr;
+    const size_t lds = (size_t)(K + 1) * a->N * sizeof(float);
+    const int64_t want = (a->rows + 15) / 16;                   // (workgroup = 4 waves x 4 rows per trip)
+    dim3 grid((unsigned)(want > 4096 ? 4096 : want));          // (the weights are staged per workgroup: a bounded grid, row groups by its stride)
+    if (a->N == 256) {
+        if (lds > 48 * 1024)
+            if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(conv_ln_kernel<1>), lds, "vrd_conv_ln")) return rc;
+        hipLaunchKernelGGL(conv_ln_kernel<1>, grid, dim3(256), lds, s, *a, rflag);
+    } else {
+        if (lds > 48 * 1024)
+            if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(conv_ln_kernel<2>), lds, "vrd_conv_ln")) return rc;
+        hipLaunchKernelGGL(conv_ln_kernel<2>, grid, dim3(256), lds, s, *a, rflag);
+    }
     VRD_LAUNCH_CHECK();
     return 0;
 }

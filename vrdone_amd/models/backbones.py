@@ -110,6 +110,11 @@ class MaskConvTransformerBackbone(nn.Module):
         slab of the consumer GEMM's input buffer (pair rows in bf16x3 mode)."""
         ops = _ops()
         last = len(convs) - 1
+        if last == 0 and post_add is None and ops.conv_ln_ok(h, convs[0].conv.weight, convs[0].conv.bias, norms[0].weight, norms[0].bias):
+            # few input channels (the box features): conv, mask, LayerNorm and ReLU as one row kernel
+            c, nm = convs[0].conv, norms[0]
+            return ops.conv_ln(h, c.weight, c.bias, row_mask=mask2, gamma=nm.weight.reshape(-1), beta=nm.bias.reshape(-1), relu=True,
+                               out=out, pair=ops.pair_mode())
         for i, (conv, norm) in enumerate(zip(convs, norms)):
             h = ops.conv_gemm(h, conv.conv.weight, conv.conv.bias, row_mask=mask2)
             h = norm.cl(h, relu=True, out=out if i == last else None, pair=ops.pair_mode(), post_add=post_add if i == last else None)
@@ -206,7 +211,10 @@ class MaskConvTransformerBackbone(nn.Module):
         pair_box = new(B, T, 2 * D)
         a = self.so_fuse.cl(cat(ops.join(so_in, (a, b))), row_mask=mask, out=pair_box[..., :D], out_pair=pair)
         conv = self.bbox_so_embd.conv
-        b = ops.conv_gemm(so_box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:], out_pair=pair)
+        if ops.conv_ln_ok(so_box, conv.weight, conv.bias):
+            b = ops.conv_ln(so_box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:], pair=pair)
+        else:
+            b = ops.conv_gemm(so_box, conv.weight, conv.bias, row_mask=mask, out=pair_box[..., D:], out_pair=pair)
         e = self.so_visual_bbox_fuse.cl(cat(ops.join(pair_box, (a, b))), row_mask=mask)
 
         feats, masks = [e], [mask]

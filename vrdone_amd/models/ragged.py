@@ -279,9 +279,11 @@ def _rows_of(x, sl):
     return ops.Pair(x.t[:, sl], x.width, x.fmt) if isinstance(x, ops.Pair) else x[:, sl]
 
 
-def _conv3_rows(h, conv, row_mask, lay, halves, tails, out=None, out_pair=False):
+def _conv3_rows(h, conv, row_mask, lay, halves, tails, out=None, out_pair=False, norm=None):
     """A dense k = 3 conv * mask over the row space: one flat launch per half over the rows of the buckets whose sequences end
-    in two padded frames (their last rows zeroed in the input first), bucket by bucket for the others."""
+    in two padded frames (their last rows zeroed in the input first), bucket by bucket for the others.
+    norm: the LayerNorm (+ ReLU) behind a few-channel conv, fused into the same launches (ops.conv_ln); with few input channels
+    and no norm the conv alone runs as that row kernel."""
     ops = _ops()
     assert conv.kernel_size[0] == 3
     N = conv.weight.shape[0]
@@ -289,15 +291,23 @@ def _conv3_rows(h, conv, row_mask, lay, halves, tails, out=None, out_pair=False)
         out = torch.empty(1, halves * lay.rows, N, device=_raw(h).device, dtype=torch.float32)
     if tails is not None:
         _zero_rows(h, tails)
+    small = ops.conv_ln_ok(h, conv.weight, conv.bias, *((norm.weight, norm.bias) if norm is not None else ()))
+    assert small or norm is None
+
+    def one(x, m, o):
+        if small:
+            ops.conv_ln(x, conv.weight, conv.bias, row_mask=m, out=o, pair=out_pair, relu=norm is not None,
+                        gamma=None if norm is None else norm.weight.reshape(-1), beta=None if norm is None else norm.bias.reshape(-1))
+        else:
+            ops.conv_gemm(x, conv.weight, conv.bias, row_mask=m, out=o, out_pair=out_pair)
     for hf in range(halves):
         base = hf * lay.rows
         if lay.rows_flat:
             sl = slice(base, base + lay.rows_flat)
-            ops.conv_gemm(_rows_of(h, sl), conv.weight, conv.bias, row_mask=row_mask[:, sl], out=out[:, sl], out_pair=out_pair)
+            one(_rows_of(h, sl), row_mask[:, sl], out[:, sl])
         for (off, n, T), flat in zip(lay.segs, lay.flat):
             if not flat:
-                ops.conv_gemm(_part(h, base + off, n, T), conv.weight, conv.bias, row_mask=_mpart(row_mask, base + off, n, T),
-                              out=_part(out, base + off, n, T), out_pair=out_pair)
+                one(_part(h, base + off, n, T), _mpart(row_mask, base + off, n, T), _part(out, base + off, n, T))
     return ops.Pair(out, N) if out_pair else out
 
 
@@ -305,6 +315,9 @@ def _embed(h, convs, norms, mask2, out, lay, tails2):
     """backbones.py _embed on the stacked rows: k = 3 conv * mask -> LN -> ReLU"""
     ops = _ops()
     last = len(convs) - 1
+    if last == 0 and ops.conv_ln_ok(h, convs[0].conv.weight, convs[0].conv.bias, norms[0].weight, norms[0].bias):
+        # few input channels (the box features): conv, mask, LayerNorm and ReLU as one row kernel, straight into the consumer's slab
+        return _conv3_rows(h, convs[0].conv, mask2, lay, 2, tails2, out=out, out_pair=bool(ops.pair_mode()), norm=norms[0])
     for i, (conv, norm) in enumerate(zip(convs, norms)):
         h = _conv3_rows(h, conv.conv, mask2, lay, 2, tails2)
         h = norm.cl(h, relu=True, out=out if i == last else None, pair=ops.pair_mode())

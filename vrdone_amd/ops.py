@@ -744,6 +744,40 @@ def layernorm(x, gamma, beta, *, relu=False, post_add=None, out=None, pair=False
     return Pair(out, cols) if _fmt(pair) else out
 
 
+CONV_LN_MAXK = 32
+_conv_ln_on = os.environ.get("VRDONE_CONV_LN", "1") != "0"
+
+
+def conv_ln_ok(x, weight, *tensors):
+    """The fused few-channel conv -> LayerNorm row kernel takes this call: inference, f32 rows, taps * Cin <= 32, 256 / 512 outputs."""
+    N, Cin, k = weight.shape
+    return (_conv_ln_on and not isinstance(x, Pair) and k in (1, 3) and Cin * k <= CONV_LN_MAXK and (3 + k) * Cin <= 64 and N in (256, 512) and
+            not recording(x, weight, *tensors))
+
+
+def conv_ln(x, weight, bias, *, row_mask=None, gamma=None, beta=None, relu=False, out=None, pair=False):
+    """Dense Conv1d with few input channels (k = 1 or 3, zero padding k // 2) * row_mask -> [LayerNorm(gamma, beta)] -> [ReLU] as one
+    row kernel (vrd_conv_ln): the box-feature embeddings.  x: (B, T, Cin) f32 rows; out: (B, T, N) buffer or column slab of one;
+    pair: write pair rows (returns a Pair)."""
+    N, Cin, k = weight.shape
+    px, rows, cols, ldx = _rows(x)
+    assert cols == Cin and weight.is_contiguous()
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    py, rows_y, cols_y, ldy = _rows(out)
+    assert rows_y == rows and cols_y == N
+    a = _hip.ConvLnArgs()
+    a.x, a.ldx, a.rows = px, ldx, rows
+    a.Cin, a.taps, a.T, a.N = Cin, k, x.shape[-2], N
+    a.w, a.bias = _param_ptr(weight, x, "conv weight"), _param_ptr(bias, x, "conv bias")
+    a.row_mask = _mask_ptr(row_mask, rows)
+    a.gamma, a.beta = _param_ptr(gamma, x, "LayerNorm weight"), _param_ptr(beta, x, "LayerNorm bias")
+    a.relu = 1 if relu else 0
+    a.y, a.ldy, a.out_pair = py, ldy, _fmt(pair)
+    _hip.check(lib.vrd_conv_ln(C.byref(a), _stream()), "vrd_conv_ln")
+    return Pair(out, N) if a.out_pair else out
+
+
 _CONST_ROWS = {}
 
 
