@@ -677,6 +677,15 @@ def test_flash_attention_one_wave_per_simd_kernel(H, hd, Tq, Tk, precision, monk
         assert bool((masked[~tile_live.to(DEV)] == 0).all())
         out[flag] = got
     close(out["1"], out["0"], 5e-5)
+    # persistent workgroups that walk several (sequence, head) items each -- the next item's masks are staged under the current
+    # item's tiles -- give the same bits as one item per workgroup, with and without the staging
+    for grid, pf, walk in (("2", "1", "1"), ("5", "1", "1"), ("2", "0", "1"), ("5", "1", "0")):
+        monkeypatch.setenv("VRD_FLASH_GRID", grid)
+        monkeypatch.setenv("VRD_FLASH_PREFETCH", pf)
+        monkeypatch.setenv("VRD_FLASH_WALK", walk)
+        assert torch.equal(ops.attention(qp, kp, vp, mask.to(DEV), H), out["1"])
+        masked2 = ops.attention(qp, kp, vp, mask.to(DEV), H, q_mask=qm.to(DEV))
+        assert torch.equal(masked2, masked)
 
 
 @pytest.mark.parametrize("Tk", [288, 2304])

@@ -387,13 +387,28 @@ struct SmBlock {
     u32x4 ph[2], pl[2];         // P^T fragments: k16 step s -> hi / lo (bf16x8 as four dwords)
 };
 
+// lab builds (-DVRD_ATTN_STAMP): s_memtime stamps of workgroup 0's items, summed per stamp index (scripts/dev/flash_stamps.py)
+#ifdef VRD_ATTN_STAMP
+__device__ unsigned long long g_attn_stamp[65];
+#define VRD_STAMP(i)                                                                      \
+    do {                                                                                  \
+        if (wave == 0) {                                                                  \
+            unsigned long long t_;                                                        \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");    \
+            if (lane == 0) stamp_lds[i] = t_;                                             \
+        }                                                                                 \
+    } while (0)
+#else
+#define VRD_STAMP(i) do { } while (0)
+#endif
+
 template <int HD, bool F16>
 __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* __restrict__ q, int64_t ldq,
                                                                   const float* __restrict__ k, const float* __restrict__ v,
                                                                   int64_t ldkv, const uint8_t* __restrict__ kv_mask,
                                                                   const uint8_t* __restrict__ q_mask, int Tq, int Tk, int width,
                                                                   float scale_log2e, float* __restrict__ out, int64_t ldo,
-                                                                  int pair_out, int q_blocks, int n_head_, int n_batch) {
+                                                                  int pair_out, int q_blocks, int n_head_, int n_batch, int prefetch, int item_step) {
     using G = AG<HD>;
     constexpr int KS = HD / 16;                   // k16 steps of the S^T contraction
     constexpr int DT = HD / 32;                   // 32-row d tiles of O^T
@@ -411,61 +426,168 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     static_assert(G::N_DMA % 4 == 0 && NG_S >= 24 && NG_O >= 24 && VRD_AQ(1, KS - 1) + 8 <= 128, "layout assumptions");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
+    // behind the ring: key bias of the item's row of tiles, per tile whether none / some / all of its keys are valid, per group
+    // of 32 queries whether any is live; then (prefetch mode) the NEXT item's mask bytes as LDS-DMA leaves them, a dword each
+    const int nkt = (Tk + 31) / 32, nqg = (Tq + 31) / 32;
     float* const kbias = reinterpret_cast<float*>(lds + NS * G::STAGE);      // [32 * nkt]: 0 or -inf per key
+    int* const tile_on = reinterpret_cast<int*>(kbias + nkt * 32);           // [nkt]
+    int* const qgrp = tile_on + nkt;                                         // [nqg]
+    const int nk64 = (nkt * 32 + 63) & ~63, nq64 = (nqg * 32 + 63) & ~63;
+    int* const raw_k = qgrp + nqg;                                           // [nk64]  (prefetch mode only)
+    int* const raw_q = raw_k + nk64;                                         // [nq64]
+#ifdef VRD_ATTN_STAMP
+    unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + 163840 - 64 * 8);
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)lds);
     // Persistent workgroups (one per CU: the grid is min(items, CUs)) walk the (b, h) items blockIdx.x, + gridDim.x, ...: a
     // workgroup of this size has its CU to itself, so every dispatch is a drained CU (measured: ~9 us per workgroup between
     // the end of one and the first instruction of the next).
+    //
+    // The masks of an item (Tk + Tq bytes) decide which tiles are requested, so they sit in front of everything else: read
+    // with ordinary loads at the start of the item they were two round trips to HBM in series with the first tile's (mask
+    // bytes -> barrier -> requests).  With `prefetch` (the host sets it when the staging area fits in LDS) the NEXT item's
+    // bytes are requested by LDS-DMA (global_load_lds_ubyte: a dword per byte, no registers held) before the item's first
+    // tile, land under its tile loop -- the vector-memory counter is in order: every counted wait for a tile covers them --
+    // and are turned into the three tables between two barriers at the start of their item.
     const int n_items = n_head_ * n_batch;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    if (item != (int)blockIdx.x) __syncthreads();       // ring, key-bias row and output slabs of the previous item are free
+    bool masks_pending = true;                    // mask bytes requested that no wait of this wave has covered yet
+    // (per-lane values of the mask staging are formed from a lane id read afresh: as loop invariants the compiler computed
+    // them once, spilled them -- every register is spoken for in the tile loop -- and reloaded them at the start of each
+    // item behind an s_waitcnt vmcnt(0), i.e. behind the previous item's output stores)
+    auto fresh_lane = [&]() {
+        int ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        return ln;
+    };
+    auto dma_masks = [&](int it2) {
+        const int b2 = it2 / n_head_;
+        const int ln = fresh_lane();
+        if (kv_mask) {
+            const uint8_t* base = kv_mask + (int64_t)b2 * Tk;
+            for (int j = wave; j < nk64 / 64; j += 4) {
+                const int key = j * 64 + ln;
+                const unsigned voff = (unsigned)(key < Tk ? key : Tk - 1);
+                const unsigned dst = lds_base + (unsigned)(reinterpret_cast<char*>(raw_k) - lds) + j * 256;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2" ::"s"(dst), "v"(voff), "s"(base) : "memory");
+            }
+        }
+        if (q_mask) {
+            const uint8_t* base = q_mask + (int64_t)b2 * Tq;
+            for (int j = wave; j < nq64 / 64; j += 4) {
+                const int r = j * 64 + ln;
+                const unsigned voff = (unsigned)(r < Tq ? r : Tq - 1);
+                const unsigned dst = lds_base + (unsigned)(reinterpret_cast<char*>(raw_q) - lds) + j * 256;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_ubyte %1, %2" ::"s"(dst), "v"(voff), "s"(base) : "memory");
+            }
+        }
+    };
+    // item walk: strided (item_step = grid) or, item_step = 1, a contiguous run of items per workgroup
+    const int item_first = item_step == 1 ? (int)(((long long)n_items * blockIdx.x) / gridDim.x) : (int)blockIdx.x;
+    const int item_end = item_step == 1 ? (int)(((long long)n_items * (blockIdx.x + 1)) / gridDim.x) : n_items;
+    for (int item = item_first; item < item_end; item += item_step) {
+    VRD_STAMP(0);
     const int h = item % n_head_, b = item / n_head_;
+    if (prefetch && item == item_first) dma_masks(item);
+    // The ring, the tables and the output slabs of the previous item are free; (prefetch) this item's mask bytes have landed:
+    // they are older than the rows of Q every live block waits for, so only an item without one has to wait here.  The
+    // barriers are for LDS only (not __syncthreads, which would also drain the previous item's output stores: 3-4 k cycles).
+    if (prefetch && masks_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        const int ln = fresh_lane(), tn = wave * 64 + ln;
+        for (int key = tn; key < nkt * 32; key += 256) {
+            const bool ok = key < Tk && (!kv_mask || (prefetch ? raw_k[key] != 0 : kv_mask[(int64_t)b * Tk + (key < Tk ? key : Tk - 1)] != 0));
+            kbias[key] = ok ? 0.f : -INFINITY;
+            const unsigned long long bal = __ballot(ok);
+            const unsigned bits = (unsigned)((bal >> (ln & 32)) & 0xffffffffull);
+            if ((ln & 31) == 0) tile_on[key >> 5] = bits == 0u ? 0 : (bits == 0xffffffffu ? 2 : 1);      // keys of the tile: none / some / all valid
+        }
+        for (int r = tn; r < nqg * 32; r += 256) {
+            const bool ok = r < Tq && (!q_mask || (prefetch ? raw_q[r] != 0 : q_mask[(int64_t)b * Tq + (r < Tq ? r : Tq - 1)] != 0));
+            const unsigned long long bal = __ballot(ok);
+            if ((ln & 31) == 0) qgrp[r >> 5] = ((bal >> (ln & 32)) & 0xffffffffull) != 0ull;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (prefetch && item + item_step < item_end) {
+        dma_masks(item + item_step);
+        masks_pending = true;
+    }
+    VRD_STAMP(1);
     // One workgroup per (b, h) walks the 256-query blocks of the sequence.  (A grid with one workgroup per block made the
     // blocks of pure padding -- rows 256 .. 287 at the benchmark shape -- cost 22 us each: a workgroup of this size has a CU
     // to itself, so even one that leaves at once waits for the CU to drain.  Measured: 1.92 ms per launch against 1.2.)
     for (int qblk = 0; qblk < q_blocks; ++qblk) {
-    if (qblk) __syncthreads();                    // the ring and the output slabs of the previous block are no longer in use
+    if (qblk) {                                   // the ring and the output slabs of the previous block are no longer in use
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     const int q0 = qblk * 256 + wave * 64;        // the wave's two blocks: q0 .. q0+31, q0+32 .. q0+63
     const char* kb = reinterpret_cast<const char*>(k + (int64_t)b * Tk * ldkv) + h * HD * 4;
     const char* vb = reinterpret_cast<const char*>(v + (int64_t)b * Tk * ldkv) + h * HD * 4;
 
-    auto row_live = [&](int tq) { return tq < Tq && (!q_mask || q_mask[(int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)] != 0); };
-    const bool live0 = __any(row_live(q0 + li)), live1 = __any(row_live(q0 + 32 + li));
+    // which of the block's eight groups of 32 queries have a live one: one LDS read, the same answer in every wave
+    const int gq = qblk * 8 + (lane & 7);
+    const unsigned blk_bits = (unsigned)(__ballot(gq < nqg && qgrp[gq < nqg ? gq : 0] != 0) & 0xffull);
+    const bool live0 = (blk_bits >> (2 * wave)) & 1u, live1 = (blk_bits >> (2 * wave + 1)) & 1u;
     const bool q_live = live0 || live1;
-    if (!__syncthreads_or(q_live)) {              // no live query in these 256 rows: zeros, K / V are not streamed
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int tq = q0 + 32 * qb + li;
-            if (tq < Tq) {
-                float* orow = out + ((int64_t)b * Tq + tq) * ldo + h * HD;
-                for (int c = lh * 4; c < HD; c += 8) *reinterpret_cast<float4*>(orow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+    if (blk_bits == 0u) {                         // no live query in these 256 rows: zeros, K / V are not streamed
+#ifndef VRD_ATTN_LAB_NOZERO
+        {   // whole rows of the head's channels, 16 bytes per lane; the block's rows go round the four waves
+            constexpr int LPRZ = HD / 4, RPIZ = 64 / LPRZ;
+            const int row_end = Tq < qblk * 256 + 256 ? Tq : qblk * 256 + 256;
+            const int ln = fresh_lane();
+            int row = qblk * 256 + wave * RPIZ + ln / LPRZ;
+            char* zp = reinterpret_cast<char*>(out + ((int64_t)b * Tq + row) * ldo) + h * HD * 4 + (ln % LPRZ) * 16;
+            const int64_t zstep = ldo * 4 * (4 * RPIZ);
+            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll 1
+            for (; row < row_end; row += 4 * RPIZ, zp += zstep) *reinterpret_cast<u32x4*>(zp) = zero4;
         }
+#endif
         continue;
     }
+    VRD_STAMP(55);
     // every accumulator-half register is named in a clobber list once: that is what makes the kernel descriptor allocate them
     asm volatile("" ::: VRD_ALL_AGPRS);
-    // Q^T fragments of both blocks: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo.  All loads
-    // first (volatile asm statements keep their order: a load next to its register write would make 32 serial round trips)
-    u32x4 qtmp[2][KS][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int tq = q0 + 32 * qb + li;
-        const char* qr = reinterpret_cast<const char*>(q + ((int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)) * ldq) + h * HD * 4;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int off = vrd::pair_index(16 * s + 8 * lh) * 2;
-            qtmp[qb][s][0] = *reinterpret_cast<const u32x4*>(qr + off);
-            qtmp[qb][s][1] = *reinterpret_cast<const u32x4*>(qr + off + 64);
-        }
+    // Q^T fragments of both blocks: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo -- the shape of
+    // a K fragment.  Read straight into registers that is 32 loads per lane that touch 32 rows each, 32 bytes of a row: the
+    // address unit took ~12 k cycles over them, a sixth of the item (stamps; nothing else of the workgroup can run meanwhile).
+    // So the wave's 64 rows come by LDS-DMA, whole rows per instruction, into the wave's own quarter of the ring laid out
+    // as two K tiles (planes q_hi, q_lo of block 0, then of block 1; the K swizzle), and are read back as K fragments are.
+    // Nobody else touches that quarter between the previous epilogue's barrier and the barrier below.
+    {
+        const char* qbase = reinterpret_cast<const char*>(q + (int64_t)b * Tq * ldq) + h * HD * 4;
+        const int rin_q = lane / G::CPR, pch_q = lane % G::CPR;
+        const unsigned qrowbytes = (unsigned)(ldq * 4);                 // (host-checked: a (b) slab of Q is below 2 GiB)
+        static_for<2 * PPP>([&](auto u_c) {
+            constexpr int qb = decltype(u_c)::value / PPP, rb = decltype(u_c)::value % PPP;
+            const int row = rb * G::RPI + rin_q;
+            const int tq = q0 + 32 * qb + row;
+            const int lc = pch_q ^ G::kswz(row);
+            const unsigned voff = (unsigned)(tq < Tq ? tq : Tq - 1) * qrowbytes + (unsigned)((lc >> 2) * 128 + (lc & 3) * 16);
+            const unsigned dst = lds_base + wave * G::STAGE + 2 * qb * G::PLANE + rb * 1024;
+            const char* const src_hi = qbase + 0;          // (named inside the lambda: an asm operand alone does not capture)
+            const char* const src_lo = src_hi + 64;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(src_hi) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + G::PLANE), "v"(voff), "s"(src_lo) : "memory");
+        });
     }
+    VRD_STAMP(56);
     // O^T accumulators = 0
     static_for<2 * DT * 16>([&](auto r_c) {
         asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "n"(128 + decltype(r_c)::value));
     });
+    VRD_STAMP(57);
 
     // ---- LDS-DMA.  Piece i (0 .. PER_WAVE-1) of a tile: plane (wave + 4i) / PPP (k_hi, k_lo, v_hi, v_lo), row block
     // rb = (wave + 4i) % PPP, key row rb * RPI + rin.  Row blocks differ by multiples of 4 rows (head_dim 128: by 16), which
@@ -478,7 +600,6 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         const int lc = pch ^ (is_v ? G::vswz(row) : G::kswz(row));     // logical 16-byte chunk of the plane row
         return (lc >> 2) * 128 + (lc & 3) * 16;
     };
-    const unsigned lds_base = (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)lds);
     constexpr int HALF_ROWS = HD == 128 ? 16 : 0;                      // rows between an even piece and the odd piece behind it
     // what the pieces of one tile share: scalar bases of the K and V slabs at the tile, per-lane offsets for even / odd pieces
     struct Req {
@@ -519,16 +640,6 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory");
     };
 
-    const int nkt = (Tk + 31) / 32;
-    int* const tile_on = reinterpret_cast<int*>(kbias + nkt * 32);
-    for (int key = tid; key < nkt * 32; key += 256) {
-        const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
-        kbias[key] = ok ? 0.f : -INFINITY;
-        const unsigned long long bal = __ballot(ok);
-        const unsigned bits = (unsigned)((bal >> (lane & 32)) & 0xffffffffull);
-        if ((lane & 31) == 0) tile_on[key >> 5] = bits == 0u ? 0 : (bits == 0xffffffffu ? 2 : 1);      // keys of the tile: none / some / all valid
-    }
-    __syncthreads();
     unsigned long long act = ~0ull;                      // rows of more than 64 tiles: every tile is visited
     if (nkt <= 64) act = __ballot(lane < nkt && tile_on[lane < nkt ? lane : 0] != 0);
     auto next_on = [&](int from) {                       // first tile >= from that has a valid key, or nkt
@@ -828,25 +939,33 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             ++issued;
         }
     };
-    request_next(0);
-    // the Q^T fragments move to their accumulator-half registers.  The vector-memory counter is in order and the compiler does
-    // not see the asm requests: its waits for the Q loads (issued before them) also cover tile 0 -- which is needed now
-    // anyway -- so the tiles behind it are requested after the moves
+    VRD_STAMP(51);
+    // the Q^T fragments move to their accumulator-half registers; then the wave's quarter of the ring belongs to the tiles
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the wave's own rows (and, older, the next item's mask bytes) have landed
+    masks_pending = false;
+    VRD_STAMP(52);
     static_for<2>([&](auto qb_c) {
         constexpr int qb = decltype(qb_c)::value;
         static_for<KS>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
-            static_for<2>([&](auto l_c) {
-                constexpr int r = VRD_AQ(qb, s) + 4 * decltype(l_c)::value;
-                const u32x4 t = qtmp[qb][s][decltype(l_c)::value];
-                asm volatile("v_accvgpr_write_b32 a%c4, %0\n\tv_accvgpr_write_b32 a%c5, %1\n\tv_accvgpr_write_b32 a%c6, %2\n\t"
-                             "v_accvgpr_write_b32 a%c7, %3"
-                             :: "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "n"(r), "n"(r + 1), "n"(r + 2), "n"(r + 3));
-            });
+            const char* stq = lds + wave * G::STAGE + qb * 2 * G::PLANE;
+            const int off = li * G::ROWB + (((2 * s + lh) ^ G::kswz(li)) * 16);
+            const u32x4 th = *reinterpret_cast<const u32x4*>(stq + off), tl = *reinterpret_cast<const u32x4*>(stq + G::PLANE + off);
+            constexpr int r = VRD_AQ(qb, s);
+            asm volatile("v_accvgpr_write_b32 a%c8, %0\n\tv_accvgpr_write_b32 a%c9, %1\n\tv_accvgpr_write_b32 a%c10, %2\n\t"
+                         "v_accvgpr_write_b32 a%c11, %3\n\tv_accvgpr_write_b32 a%c12, %4\n\tv_accvgpr_write_b32 a%c13, %5\n\t"
+                         "v_accvgpr_write_b32 a%c14, %6\n\tv_accvgpr_write_b32 a%c15, %7"
+                         :: "v"(th[0]), "v"(th[1]), "v"(th[2]), "v"(th[3]), "v"(tl[0]), "v"(tl[1]), "v"(tl[2]), "v"(tl[3]), "n"(r), "n"(r + 1),
+                            "n"(r + 2), "n"(r + 3), "n"(r + 4), "n"(r + 5), "n"(r + 6), "n"(r + 7));
         });
     });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    request_next(0);
+    VRD_STAMP(53);
 #pragma unroll
     for (int jq = 1; jq < NS - 1; ++jq) request_next(jq);
+    VRD_STAMP(2);
     int kt_cur = next_on(0);                             // tile whose raw scores the next step consumes
     f32x16 s0a, s0b, s1a, s1b;
 #pragma unroll
@@ -857,6 +976,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         else if (n_act == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        VRD_STAMP(54);
         if (q_live) {
             KF kf = load_k(lds, 0), kn = kf;
             static_for<KS>([&](auto s_c) {
@@ -868,6 +988,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             asm volatile("s_nop 15" : "+v"(s0a), "+v"(s0b));       // MFMA result -> vector read: wait states by hand
         }
     }
+    VRD_STAMP(3);
     // a step: wait for tile it+1, barrier, pipeline step (scores of tile `it` in (ca, cb), of tile it+1 into (na, nb))
     int it = 0;
     auto step = [&](f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) __attribute__((always_inline)) {
@@ -879,7 +1000,9 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             if (it + 2 < issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        VRD_STAMP(4 + 3 * it);
         __builtin_amdgcn_s_barrier();
+        VRD_STAMP(5 + 3 * it);
         const bool do_req = issued < n_act;
         if (do_req) {
             kt_iss = next_on(kt_iss + 1);
@@ -898,6 +1021,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             static_for<PER_WAVE>([&](auto i_c) { issue1(req, buf_req, i_c); });
         }
         kt_cur = kt_next;
+        VRD_STAMP(6 + 3 * it);
         ++it;
     };
     while (it < n_act) {
@@ -914,6 +1038,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     // c ^ (r % chunks) (conflict-free writes -- lanes are rows -- and reads -- lanes are chunks).
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    VRD_STAMP(40);
     constexpr int CH = HD / 4;                                       // 16-byte chunks per output row of this head
     char* const slab = lds + wave * (64 * HD * 4);
     static_for<2>([&](auto qb_c) {
@@ -938,6 +1063,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             });
         });
     });
+    VRD_STAMP(41);
     // (wave-private slab: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt wait)
     // Rows leave in batches of eight wave instructions: the reads of a batch together, then its stores; the row pointer
     // advances by a constant (no 64-bit multiply per row), and the rows-inside-the-sequence test is per wave unless the
@@ -970,8 +1096,12 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
                     split_pair<F16>(va[u].z, va[u].w, hi.y, lo.y);
                     split_pair<F16>(vb[u].x, vb[u].y, hi.z, lo.z);
                     split_pair<F16>(vb[u].z, vb[u].w, hi.w, lo.w);
+#ifndef VRD_ATTN_LAB_NOSTORE
                     *reinterpret_cast<uint4*>(gp) = hi;
                     *reinterpret_cast<uint4*>(gp + 64) = lo;
+#else
+                    asm volatile("" ::"v"(hi.x), "v"(hi.y), "v"(hi.z), "v"(hi.w), "v"(lo.x), "v"(lo.y), "v"(lo.z), "v"(lo.w));
+#endif
                 }
                 gp += gstep;
             }
@@ -998,7 +1128,16 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             }
         }
     }
+    VRD_STAMP(42 + qblk);
     }       // 256-query blocks
+#ifdef VRD_ATTN_STAMP
+    VRD_STAMP(50);
+    if (blockIdx.x == 0 && wave == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g_attn_stamp[lane] += stamp_lds[lane] - stamp_lds[0];
+        if (lane == 0) g_attn_stamp[64] += 1;
+    }
+#endif
     }       // items
 #undef VRD_AQ
 #undef VRD_AO
@@ -1009,23 +1148,42 @@ template <int HD, bool F16>
 int launch_w64(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv, const uint8_t* kv_mask, const uint8_t* q_mask, int B,
                int Tq, int Tk, int n_head, float scale, float* out, int64_t ldo, int pair_out, hipStream_t s) {
     auto kern = attn_flash_x3_w64_kernel<HD, F16>;
-    constexpr size_t lds_max = 4 * AG<HD>::STAGE + (4096 + 128) * sizeof(float);       // key bias + tile flags for Tk <= 4096
-    const size_t lds = 4 * AG<HD>::STAGE + (size_t)((Tk + 31) / 32) * 33 * sizeof(float);
-    if (lds > lds_max) {
+    // behind the ring: key bias + tile flags for Tk <= 4096, a flag per 32 queries (Tq <= 65536: the dispatch keeps longer ones
+    // away), and -- if it fits in what is left of the 160 KiB -- the staging area of the next item's mask bytes, a dword each
+    constexpr size_t lds_all = 160 * 1024;
+    constexpr size_t lds_max = 4 * AG<HD>::STAGE + (4096 + 128 + 2048) * sizeof(float);
+    const size_t nkt = (size_t)(Tk + 31) / 32, nqg = (size_t)(Tq + 31) / 32;
+    const size_t lds_tables = 4 * AG<HD>::STAGE + (nkt * 33 + nqg) * sizeof(float);
+    const size_t lds_staged = lds_tables + (((nkt * 32 + 63) & ~(size_t)63) + ((nqg * 32 + 63) & ~(size_t)63)) * sizeof(float);
+    if (lds_tables > lds_max) {
         vrd::set_error("vrd_attention_pair: Tk = %d exceeds the 4096 keys the key-bias row is sized for", Tk);
         return -1;
     }
-    if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds_max, "vrd_attention_pair(w64)")) return rc;
+    const char* const pf_e = getenv("VRD_FLASH_PREFETCH");                  // (read per call, as VRD_FLASH_W64)
+    const int prefetch = (!pf_e || atoi(pf_e) != 0) && lds_staged <= lds_all;
+    if (int rc = vrd::reserve_lds(reinterpret_cast<const void*>(kern), lds_all, "vrd_attention_pair(w64)")) return rc;
     const int q_blocks = (Tq + 255) / 256;
-    const size_t lds_launch = lds;
+#ifdef VRD_ATTN_STAMP
+    const size_t lds_launch = lds_all;
+#else
+    const size_t lds_launch = prefetch ? lds_staged : lds_tables;
+#endif
     static const int n_cu = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
     const int n_items = n_head * B;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(n_items < n_cu ? n_items : n_cu)), dim3(256), lds_launch, s, q, ldq, k, v, ldkv, kv_mask, q_mask,
-                       Tq, Tk, n_head * HD, scale * 1.44269504088896340736f, out, ldo, pair_out, q_blocks, n_head, B);      // (scale: see vrd_attention_pair)
+    // VRD_FLASH_GRID caps the number of workgroups (read per call: the tests walk several items per workgroup on small inputs)
+    const char* const grid_e = getenv("VRD_FLASH_GRID");
+    const int grid_cap = grid_e && atoi(grid_e) > 0 ? atoi(grid_e) : n_cu;
+    const int grid = n_items < grid_cap ? n_items : grid_cap;
+    // a workgroup walks a contiguous run of items (the heads of a sequence, then the next sequence: measured 2 % faster than
+    // items blockIdx.x, + grid, ... -- 37 MB apart in each tensor at the benchmark shape); VRD_FLASH_WALK=0: the strided walk
+    const char* const walk_e = getenv("VRD_FLASH_WALK");
+    const int item_step = walk_e && atoi(walk_e) == 0 ? grid : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_launch, s, q, ldq, k, v, ldkv, kv_mask, q_mask,
+                       Tq, Tk, n_head * HD, scale * 1.44269504088896340736f, out, ldo, pair_out, q_blocks, n_head, B, prefetch, item_step);      // (scale: see vrd_attention_pair)
     return 0;
 }
 
@@ -1050,6 +1208,17 @@ int launch(const float* q, int64_t ldq, const float* k, const float* v, int64_t 
 inline bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0; }
 
 }  // namespace
+
+#ifdef VRD_ATTN_STAMP
+extern "C" int vrd_lab_attn_stamps(unsigned long long* dst65, int reset) {
+    if (hipMemcpyFromSymbol(dst65, HIP_SYMBOL(g_attn_stamp), 65 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[65] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
                                   const uint8_t* kv_mask, const uint8_t* q_mask, int B, int Tq, int Tk, int n_head, int head_dim,
@@ -1084,8 +1253,9 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     // VRD_FLASH_W64=0 / 1 forces the choice (read per call: tests compare the two kernels in one process).
     const char* const w64_e = getenv("VRD_FLASH_W64");
     const int w64_env = w64_e ? atoi(w64_e) : -1;
-    // (its LDS-DMA offsets are 32-bit: a batch element's K / V slab has to stay below 2 GiB)
-    const bool w64 = (w64_env >= 0 ? w64_env != 0 : (head_dim == 128 && Tq >= 224)) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31);
+    // (its LDS-DMA offsets are 32-bit: a batch element's Q and K / V slabs have to stay below 2 GiB)
+    const bool w64 = (w64_env >= 0 ? w64_env != 0 : (head_dim == 128 && Tq >= 224)) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31) &&
+                     (int64_t)Tq * ldq * 4 < (int64_t(1) << 31) && Tq <= 65536;
     int rc;
 #define VRD_ATTN_ARGS q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s
     if (w64) rc = head_dim == 128 ? (f16 ? launch_w64<128, true>(VRD_ATTN_ARGS) : launch_w64<128, false>(VRD_ATTN_ARGS))
