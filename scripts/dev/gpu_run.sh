@@ -7,4 +7,3 @@ grep -q passed $O/tests.txt || { tail -40 $O/tests.txt; exit 1; }
 timeout -k 10 120 python scripts/flash_bench.py --pair > $O/flash.txt 2>&1; grep "w64" $O/flash.txt
 VRDONE_HIP_LIB=$PWD/scripts/lab/libs/libvrdone_stamp.so timeout -k 10 120 python scripts/dev/flash_stamps.py > $O/stamps.txt 2>&1
 grep -v "it[1-6] " $O/stamps.txt
-bash scripts/lab/ab_lib.sh libvrdone_r05.so base

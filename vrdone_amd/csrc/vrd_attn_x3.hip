@@ -562,9 +562,11 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
     // Q^T fragments of both blocks: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo -- the shape of
     // a K fragment.  Read straight into registers that is 32 loads per lane that touch 32 rows each, 32 bytes of a row: the
     // address unit took ~12 k cycles over them, a sixth of the item (stamps; nothing else of the workgroup can run meanwhile).
-    // So the wave's 64 rows come by LDS-DMA, whole rows per instruction, into the wave's own quarter of the ring laid out
-    // as two K tiles (planes q_hi, q_lo of block 0, then of block 1; the K swizzle), and are read back as K fragments are.
-    // Nobody else touches that quarter between the previous epilogue's barrier and the barrier below.
+    // So the wave's 64 rows come by LDS-DMA, whole rows per instruction, into the ring, laid out as K tiles are (planes q_hi, q_lo
+    // of 32 rows; the K swizzle) and read back as K fragments are: the first 32 rows of waves 0, 1 / 2, 3 into the two halves
+    // of stage 0 / 1, the other 32 rows into stages 2 / 3 -- once every wave has moved its first 32 rows, stages 0 and 1 take
+    // the first two tiles, which then travel while the other rows move (the ring is free from the barrier at the start of the
+    // item, or of the block, to the barriers below).
     {
         const char* qbase = reinterpret_cast<const char*>(q + (int64_t)b * Tq * ldq) + h * HD * 4;
         const int rin_q = lane / G::CPR, pch_q = lane % G::CPR;
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
             const int tq = q0 + 32 * qb + row;
             const int lc = pch_q ^ G::kswz(row);
             const unsigned voff = (unsigned)(tq < Tq ? tq : Tq - 1) * qrowbytes + (unsigned)((lc >> 2) * 128 + (lc & 3) * 16);
-            const unsigned dst = lds_base + wave * G::STAGE + 2 * qb * G::PLANE + rb * 1024;
+            const unsigned dst = lds_base + (2 * qb + (wave >> 1)) * G::STAGE + (wave & 1) * 2 * G::PLANE + rb * 1024;
             const char* const src_hi = qbase + 0;          // (named inside the lambda: an asm operand alone does not capture)
             const char* const src_lo = src_hi + 64;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(src_hi) : "memory");
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
         constexpr int qb = decltype(qb_c)::value;
         static_for<KS>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
-            const char* stq = lds + wave * G::STAGE + qb * 2 * G::PLANE;
+            const char* stq = lds + (2 * qb + (wave >> 1)) * G::STAGE + (wave & 1) * 2 * G::PLANE;
             const int off = li * G::ROWB + (((2 * s + lh) ^ G::kswz(li)) * 16);
             const u32x4 th = *reinterpret_cast<const u32x4*>(stq + off), tl = *reinterpret_cast<const u32x4*>(stq + G::PLANE + off);
             constexpr int r = VRD_AQ(qb, s);
@@ -958,13 +960,16 @@ __global__ __launch_bounds__(256, 1) void attn_flash_x3_w64_kernel(const float* 
                          :: "v"(th[0]), "v"(th[1]), "v"(th[2]), "v"(th[3]), "v"(tl[0]), "v"(tl[1]), "v"(tl[2]), "v"(tl[3]), "n"(r), "n"(r + 1),
                             "n"(r + 2), "n"(r + 3), "n"(r + 4), "n"(r + 5), "n"(r + 6), "n"(r + 7));
         });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if constexpr (qb == 0) {                 // stages 0 and 1 are free
+            request_next(0);
+            request_next(1);
+        } else {
+            request_next(2);
+        }
     });
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    request_next(0);
-    VRD_STAMP(53);
-#pragma unroll
-    for (int jq = 1; jq < NS - 1; ++jq) request_next(jq);
+    static_assert(NS == 4, "the prologue requests three tiles");
     VRD_STAMP(2);
     int kt_cur = next_on(0);                             // tile whose raw scores the next step consumes
     f32x16 s0a, s0b, s1a, s1b;
