@@ -295,7 +295,7 @@ def test_forward_test_in_one_row_space_equals_bucket_by_bucket():
             del model.row_space
 
 
-@pytest.mark.parametrize("scale", [1.0 / 1024, 1.0, 48.0])          # (each case is two CPU oracle runs, ~18 s: the ends and the middle)
+@pytest.mark.parametrize("scale", [1.0 / 1024, 48.0])          # (each case is two CPU oracle runs, ~18-30 s: the two ends; scale 1 is every other test)
 def test_f16x3_stays_reference_grade_across_input_magnitudes(scale):
     """The f16x3 mode's activation scale is fixed (2^4): inputs far below 1 push the lo halves of the FIRST layer's operands into
     f16 subnormals (2^-25 absolute instead of 2^-22 relative).  Against the oracle in float64 on inputs scaled by 1/1024 .. 48 the

@@ -82,31 +82,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     const char* vb = reinterpret_cast<const char*>(v + (int64_t)b * Tk * ldkv) + h * HD * 4;
     const char* zero_src = reinterpret_cast<const char*>(g_attn_zero);
 
-    // a wave whose 32 queries are all padding (q_mask) takes part in the staging and the barriers only; its rows are
-    // written as zeros (the caller masks them)
-    const bool q_live = __any(q0 + li < Tq && (!q_mask || q_mask[(int64_t)b * Tq + (q0 + li < Tq ? q0 + li : Tq - 1)] != 0));
-    // a workgroup without a single live query (the padded tail of the sequence, or tiles past Tq) does not stream K / V
-    if (!__syncthreads_or(q_live)) {
-        const int tq = q0 + li;
-        if (tq < Tq) {
-            float* orow = out + ((int64_t)b * Tq + tq) * ldo + h * HD;
-            for (int c = lh * 4; c < HD; c += 8) *reinterpret_cast<float4*>(orow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
-    // Q^T fragments: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo
-    bf16x8 qh[KS], ql[KS];
-    {
-        const int tq = q0 + li;
-        const char* qr = reinterpret_cast<const char*>(q + ((int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)) * ldq) + h * HD * 4;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int off = vrd::pair_index(16 * s + 8 * lh) * 2;
-            qh[s] = *reinterpret_cast<const bf16x8*>(qr + off);
-            ql[s] = *reinterpret_cast<const bf16x8*>(qr + off + 64);
-        }
-    }
-
     // DMA of tile kt: instruction j covers plane j / (32/RPI) rows (j % (32/RPI))*RPI ...; planes k_hi, k_lo, v_hi, v_lo
     const int rin = lane / G::CPR, pch = lane % G::CPR;
     auto issue = [&](int kt, int buf) {
@@ -124,10 +99,63 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
                 const uintptr_t pa = reinterpret_cast<uintptr_t>(base + (lc >> 2) * 128 + (lc & 3) * 16);
                 const uintptr_t pz = reinterpret_cast<uintptr_t>(zero_src + lc * 16);
                 const char* src = reinterpret_cast<const char*>(pz ^ ((pa ^ pz) & (uintptr_t)0 - (uintptr_t)(key < Tk)));
-                __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + buf * G::STAGE + plane * G::PLANE + rb * 1024), 16, 0, 0);
+                // as an asm statement: the compiler put an s_waitcnt vmcnt(0) in front of the tile's V^T reads for the builtin (it
+                // cannot tell the stage being filled from the one being read), i.e. the NEXT tile's bytes were waited for in the
+                // middle of the current tile.  The loop's own wait at its top is the only one needed.
+                const unsigned dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)reinterpret_cast<uintptr_t>((lds_ptr_t)(lds + buf * G::STAGE + plane * G::PLANE + rb * 1024)));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
             }
         }
     };
+    // Everything the workgroup reads before its first tile goes out together -- the first key tile (requested before its mask
+    // is known: a tile without a valid key adds exact zeros to every sum and leaves the running maxima alone, so visiting it
+    // changes no bit), the query-mask byte, the rows of Q, the key-mask bytes -- one round trip where the mask bytes, Q and the
+    // first tile used to be three in series (a third of a three-tile sequence's time).
+    issue(0, 0);
+    const int tq = q0 + li;
+    const bool q_row_live = tq < Tq && (!q_mask || q_mask[(int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)] != 0);
+    // Q^T fragments: lane (query li, half lh) holds d = 16s + 8*lh + 0..7 of its query, hi and lo
+    bf16x8 qh[KS], ql[KS];
+    {
+        const char* qr = reinterpret_cast<const char*>(q + ((int64_t)b * Tq + (tq < Tq ? tq : Tq - 1)) * ldq) + h * HD * 4;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int off = vrd::pair_index(16 * s + 8 * lh) * 2;
+            qh[s] = *reinterpret_cast<const bf16x8*>(qr + off);
+            ql[s] = *reinterpret_cast<const bf16x8*>(qr + off + 64);
+        }
+    }
+    const int nkt = (Tk + 31) / 32;
+    // key bias of the whole row of tiles, once: an ordinary global load inside the loop would make the compiler
+    // drain the LDS-DMA queue (vmcnt(0)) at its first use, every tile
+    // ... and, per tile of 32 keys, whether any key is valid: a tile of masked keys only adds exp(-inf) = 0 to every
+    // sum and leaves the running maxima alone, so it is not loaded or multiplied at all (padding behind the pair's
+    // frames: 32 of 288 keys at the benchmark shape, most of a max_seq_len batch of short pairs)
+    int* const tile_on = reinterpret_cast<int*>(kbias + nkt * 32);
+    for (int key = tid; key < nkt * 32; key += NW * 64) {
+        const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
+        kbias[key] = ok ? 0.f : -INFINITY;
+        const unsigned long long bal = __ballot(ok);
+        if ((lane & 31) == 0) tile_on[key >> 5] = ((bal >> (lane & 32)) & 0xffffffffull) != 0ull;
+    }
+    // a wave whose 32 queries are all padding (q_mask) takes part in the staging and the barriers only; its rows are
+    // written as zeros (the caller masks them)
+    const bool q_live = __any(q_row_live);
+    // a workgroup without a single live query (the padded tail of the sequence, or tiles past Tq) does not stream K / V
+    // (the barrier also publishes the key-bias row and the tile flags)
+    if (!__syncthreads_or(q_live)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the tile requested above: not into LDS that is no longer ours
+        if (tq < Tq) {
+            float* orow = out + ((int64_t)b * Tq + tq) * ldo + h * HD;
+            for (int c = lh * 4; c < HD; c += 8) *reinterpret_cast<float4*>(orow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    // the fragments are in their registers before the tile loop: the compiler does not see the asm requests, and its own
+    // counted waits for these loads, placed at their first use inside the loop, would wait for every tile's successor there
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qh[s]), "+v"(ql[s]));
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -142,20 +170,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     const int vq = (lane >> 2) & 3, vp = lane & 3;
     const int vcol0 = 16 * ((lane >> 4) & 1) + 4 * vp;          // column inside a 32-wide d tile
 
-    const int nkt = (Tk + 31) / 32;
-    // key bias of the whole row of tiles, once: an ordinary global load inside the loop would make the compiler
-    // drain the LDS-DMA queue (vmcnt(0)) at its first use, every tile
-    // ... and, per tile of 32 keys, whether any key is valid: a tile of masked keys only adds exp(-inf) = 0 to every
-    // sum and leaves the running maxima alone, so it is not loaded or multiplied at all (padding behind the pair's
-    // frames: 32 of 288 keys at the benchmark shape, most of a max_seq_len batch of short pairs)
-    int* const tile_on = reinterpret_cast<int*>(kbias + nkt * 32);
-    for (int key = tid; key < nkt * 32; key += NW * 64) {
-        const bool ok = key < Tk && (!kv_mask || kv_mask[(int64_t)b * Tk + key]);
-        kbias[key] = ok ? 0.f : -INFINITY;
-        const unsigned long long bal = __ballot(ok);
-        if ((lane & 31) == 0) tile_on[key >> 5] = ((bal >> (lane & 32)) & 0xffffffffull) != 0ull;
-    }
-    __syncthreads();
     unsigned long long act = ~0ull;                      // rows of more than 64 tiles: every tile is visited
     if (nkt <= 64) act = __ballot(lane < nkt && tile_on[lane < nkt ? lane : 0] != 0);
     auto next_on = [&](int from) {                       // first tile >= from that has a valid key, or nkt
@@ -164,8 +178,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
         const unsigned long long m = act & (~0ull << from);
         return m ? (int)__builtin_ctzll(m) : nkt;
     };
-    int kt = next_on(0);
-    if (kt < nkt) issue(kt, 0);
+    int kt = 0;                                          // tile 0 is on its way (requested above) and is visited whatever its mask
     for (int it = 0; kt < nkt; ++it) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
         __builtin_amdgcn_s_barrier();                           // ... and everybody else's; the previous tile is fully consumed
@@ -267,7 +280,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_flash_x3_kernel(const float* 
     const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
     // f16: the accumulators hold sum (P 2^e)(V 2^e); l is the sum of the unscaled P
     const float inv = q_live ? (F16 ? vrd::F16_ACT_INV * vrd::F16_ACT_INV : 1.0f) / l_tot : 0.f;
-    const int tq = q0 + li;
     if (tq < Tq) {
         float* orow = out + ((int64_t)b * Tq + tq) * ldo;
 #pragma unroll
@@ -1251,15 +1263,16 @@ extern "C" int vrd_attention_pair(const float* q, int64_t ldq, const float* k, c
     // barrier for a tile.
     static const int nw_env = [] { const char* e = getenv("VRD_FLASH_NW"); return e ? atoi(e) : 0; }();
     const int nw = nw_env == 3 || nw_env == 4 ? nw_env : 4;
-    // 64 queries per wave, one wave per SIMD (attn_flash_x3_w64_kernel): head_dim 128 with at least one nearly full block of
-    // 256 query rows.  Measured per launch (scripts/flash_bench.py, MI355X): 4 heads x 128, 2048 sequences x 288 rows (256
-    // valid) 1.18 ms against 1.25-1.33 ms; at head_dim 64 the kernel has half the MFMAs per softmax instruction and loses
-    // (8 heads x 64, 512 x 512 rows: 1.10 against 0.95 ms), as it does with short sequences (192 rows: 0.39 against 0.36).
+    // 64 queries per wave, one wave per SIMD (attn_flash_x3_w64_kernel): head_dim 128 from 160 query rows.  Measured per launch
+    // (scripts/flash_bench.py --pair, MI355X, round 6: its item loop rebuilt), 4 heads x 128, 2048 sequences of T rows, this kernel
+    // against the two-waves-per-SIMD one: T = 96: 0.51 / 0.36 ms, 128: 0.60 / 0.48, 160: 0.68 / 0.78, 192: 0.78 / 0.91, 224: 0.95 / 1.08,
+    // 288 (256 valid): 1.07 / 1.25-1.33.  At head_dim 64 it has half the MFMAs per softmax instruction and no more than ties (8 heads x
+    // 64, 1024 sequences: T = 128: 0.37 / 0.25, 256: 0.63 / 0.63, 288: 1.13 / 0.88 -- a second block of 32 rows --, 512: 2.00 / 2.01).
     // VRD_FLASH_W64=0 / 1 forces the choice (read per call: tests compare the two kernels in one process).
     const char* const w64_e = getenv("VRD_FLASH_W64");
     const int w64_env = w64_e ? atoi(w64_e) : -1;
     // (its LDS-DMA offsets are 32-bit: a batch element's Q and K / V slabs have to stay below 2 GiB)
-    const bool w64 = (w64_env >= 0 ? w64_env != 0 : (head_dim == 128 && Tq >= 224)) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31) &&
+    const bool w64 = (w64_env >= 0 ? w64_env != 0 : (head_dim == 128 && Tq >= 160)) && (int64_t)Tk * ldkv * 4 < (int64_t(1) << 31) &&
                      (int64_t)Tq * ldq * 4 < (int64_t(1) << 31) && Tq <= 65536;
     int rc;
 #define VRD_ATTN_ARGS q, ldq, k, v, ldkv, kv_mask, q_mask, B, Tq, Tk, n_head, scale, out, ldo, out_pair, s
