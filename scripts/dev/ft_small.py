@@ -19,8 +19,13 @@ with torch.no_grad():
         raw = synth.synth_raw_video(n_trk, cfg["visual_dim"], lo, hi, seed=3)
         prop = prepare_test_proposal(raw, ic["feat_stride"], 0, 2, dev)
         for name, data in (("matrices ", video), ("tracklets", prop)):
-            for rs in (True, False):
-                model.row_space = rs
+            for rs in (True, False, "auto"):      # True / False: the form forced; auto: the default policy (MaskVRD.ROWS_MIN_PAIRS), measured last
+                for attr in ("row_space", "ROWS_MIN_PAIRS"):
+                    if attr in model.__dict__:
+                        delattr(model, attr)
+                if rs != "auto":
+                    model.row_space = rs
+                    model.ROWS_MIN_PAIRS = 0
                 ts = []
                 for it in range(6):
                     torch.cuda.synchronize(); t0 = time.perf_counter()

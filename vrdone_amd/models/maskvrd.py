@@ -162,6 +162,13 @@ class MaskVRD(nn.Module):
     # launches (depthwise convs, attention) are too small to be worth a launch each.
     row_space = os.environ.get("VRDONE_ROW_SPACE", "1") != "0"
     ROWS_MIN_ROWS = int(os.environ.get("VRDONE_ROWS_MIN_ROWS", "4096"))
+    # forward_test takes the row-space form from this many pairs per video: below it the form's own host work (row-group tables,
+    # the per-bucket walks of a finer bucket plan) costs more than its flat launches save -- 48 pairs 7.7 against 6.4 ms per call,
+    # 226 pairs 12.2 / 11.9, 540 pairs 18.9 / 23.1 (profiles/r06_forward_test_small.json)
+    ROWS_MIN_PAIRS = int(os.environ.get("VRDONE_ROWS_MIN_PAIRS", "256"))
+
+    def _eval_rows_form(self, n_pairs):
+        return self.row_space and not self.use_abs_pe and n_pairs >= self.ROWS_MIN_PAIRS
 
     def _tight_plan(self, batched_masks, masks2d):
         """{"buckets": [(T', pair indices (n,) int32 on the device, n)], "rows": the buckets can share one row space} for a
@@ -661,7 +668,7 @@ class MaskVRD(nn.Module):
             for i in sl:
                 t_pad[i] = self.max_seq_len if lens[i] <= self.max_seq_len else t_long
         # (the reference's padded length of every pair; then the shortest ones that give the same results: `tight padding`)
-        t_pad = self.tight_buckets(lens, t_pad, self.ROWS_MIN_ROWS if self.row_space and not self.use_abs_pe else None)
+        t_pad = self.tight_buckets(lens, t_pad, self.ROWS_MIN_ROWS if self._eval_rows_form(P) else None)
         return sorted(range(P), key=lambda i: (t_pad[i], lens[i], i)), t_pad
 
     def _entity_streams(self, source, ids):
@@ -758,7 +765,7 @@ class MaskVRD(nn.Module):
             local = [feats[i] for i in ids]
             tables = ops.pair_table(local)      # None unless the features are the dataloader's frame-major matrices
         bb = self.backbone
-        if self.row_space and not self.use_abs_pe and (source is not None or tables is not None):
+        if self._eval_rows_form(len(lens)) and (source is not None or tables is not None):
             # all padded lengths of the video in one row space (models/ragged.py), in waves of ~pair_chunk pairs
             self._candidates_rows(cand, lens, ids, t_pad, k, source, tables, shared, lens_dev,
                                   ids_dev if source is not None else None)
