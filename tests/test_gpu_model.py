@@ -266,6 +266,49 @@ def test_row_space_filler_sequences_change_nothing():
     close(got["pred_masks"], buckets["pred_masks"], 2e-4)
 
 
+def test_forward_test_graph_replay_equals_eager():
+    """Small videos (the sizes real vidvrd data has) run bucket by bucket, each bucket's device side as a recorded HIP graph
+    (vrdone_amd/eval_graph.py): the replayed call returns exactly what the eager call returns -- on the recording call, on
+    replays, on another video that shares the recordings (other pair counts under the same padded sizes), and after the
+    weights were changed in place (derived operands are rebuilt inside the graph)."""
+    from vrdone_amd import eval_graph, synth
+    model, mc, ic, _ = get_model("vidvrd")
+    eval_graph.forget(model)
+    videos = [synth.synth_video(n_trk, c_in(mc), lo, hi, seed=seed, device=DEV)
+              for n_trk, lo, hi, seed in ((8, 10, 60, 3), (7, 12, 70, 5), (14, 20, 90, 7))]
+
+    def run(data, graphs):
+        old = eval_graph.ENABLED
+        eval_graph.ENABLED = graphs
+        try:
+            return model(data)
+        finally:
+            eval_graph.ENABLED = old
+
+    def same(a, b):
+        assert len(a["triplets"]) == len(b["triplets"]) > 10
+        for key in ("triplets", "pred_durations", "so_tids", "so_trajs", "triple_scores", "triple_scores_avg"):
+            assert a[key] == b[key], key
+
+    weight = model.backbone.stem[0].mlp[0].weight if hasattr(model.backbone.stem[0], "mlp") else next(model.parameters())
+    try:
+        for data in videos:
+            want = run(data, False)
+            same(run(data, True), want)            # records (first video) or replays
+            same(run(data, True), want)            # replays
+        n_rec = len(eval_graph.recordings(model))
+        assert 0 < n_rec <= eval_graph.MAX_RECORDINGS
+        with torch.no_grad():
+            weight.mul_(1.03125)
+        want = run(videos[0], False)
+        same(run(videos[0], True), want)
+        assert len(eval_graph.recordings(model)) == n_rec          # no new recording: the old ones saw the new weights
+    finally:
+        with torch.no_grad():
+            weight.div_(1.03125)
+        eval_graph.forget(model)
+
+
 def test_forward_test_in_one_row_space_equals_bucket_by_bucket():
     """forward_test on a video large enough for waves and filler sequences (1,260 pairs of 60-250 frames, pair_chunk 512): all
     padded lengths of a wave in one row space against the bucket-by-bucket path -- the same triplets, tracks and durations, scores

@@ -340,6 +340,16 @@ class MaskVRD(nn.Module):
         waves = -(-n // self.pair_chunk)
         return -(-n // waves)
 
+    def _bucket_candidates(self, table, lens_dev, T, k):
+        """The device side of one bucket of forward_test: the pairs `table` (device pointers to their (L, C_in) matrices) /
+        `lens_dev` at padded length T -> vrd_postprocess's (top scores, top classes, first, last frame).  No host read-back,
+        shapes fixed by (T, number of pairs): what eval_graph.py records."""
+        ops = _ops()
+        bb = self.backbone
+        *parts, m2 = ops.pack_pairs(table, lens_dev, T, bb.n_visual, bb.n_clip, bb.n_bbox_so, bb.n_bbox_entity, ops.pair_mode())
+        out = self._heads(*bb.cl_parts(*parts, m2), False)
+        return ops.postprocess(out["pred_logits"].contiguous(), out["pred_masks"].contiguous(), lens_dev, k)
+
     def _heads(self, feats, masks, with_aux):
         fpn_feat, _ = self.neck.cl(feats, masks)
         return self.predictor.cl(feats[-1], fpn_feat, masks[-1], masks[0], with_aux=with_aux)
@@ -770,12 +780,29 @@ class MaskVRD(nn.Module):
             self._candidates_rows(cand, lens, ids, t_pad, k, source, tables, shared, lens_dev,
                                   ids_dev if source is not None else None)
             return cand
+        from .. import eval_graph
+        storage = None
         at = 0
         while at < len(ids):
             T = t_pad[ids[at]]
             n = 1
             while at + n < len(ids) and t_pad[ids[at + n]] == T:
                 n += 1
+            replayed = None
+            if tables is not None and source is None and n <= eval_graph.MAX_PAIRS:
+                # a small bucket of the dataloader's per-pair matrices: its whole device side as one recorded graph (eval_graph.py)
+                if storage is None:
+                    storage = eval_graph.storage_key(self)
+                replayed = eval_graph.bucket_candidates(self, tables[0][at:at + n], tables[1][at:at + n], T, k,
+                                                        int(local[0].shape[0]), storage)
+            if replayed is not None:
+                ts, tc, sf, sl_ = replayed
+                cand[at:at + n, :, :k] = ts
+                ints[at:at + n, :, k:2 * k] = tc
+                ints[at:at + n, :, 2 * k] = sf
+                ints[at:at + n, :, 2 * k + 1] = sl_
+                at += n
+                continue
             if source is not None or tables is not None:
                 # per-tracklet rows (gathered, box features computed on the device) or the dataloader's (L, C_in)
                 # matrices go straight into the backbone's operand buffers
