@@ -33,3 +33,21 @@ with torch.no_grad():
         replay = timed(lambda: rec(table, lens))
         bare = timed(lambda: rec.graph.replay())
         print(f"T {T:4d}  {n:4d} pairs: eager {eager:6.2f} ms per call, recorded {replay:6.2f} ms (graph.replay() alone {bare:6.2f})", flush=True)
+
+# where a bucket's launches go (library families; the tensor ops between them are not counted)
+from vrdone_amd import _hip
+with torch.no_grad():
+    T, n = 64, 48
+    g = torch.Generator(device=dev).manual_seed(1)
+    mats = [torch.randn(T - 3 - i % 7, c_in, device=dev, generator=g) for i in range(n)]
+    table = torch.tensor([m.data_ptr() for m in mats], dtype=torch.int64, device=dev)
+    lens = torch.tensor([m.shape[0] for m in mats], dtype=torch.int32, device=dev)
+    model._bucket_candidates(table, lens, T, k)
+    torch.cuda.synchronize()
+    _hip.prof_enable(True); _hip.prof_reset()
+    model._bucket_candidates(table, lens, T, k)
+    torch.cuda.synchronize()
+    _hip.prof_enable(False)
+    pr = _hip.prof_read()
+    print("launches per family (48 pairs x 64 frames):", {f: (v["launches"], round(v["ms"], 3)) for f, v in sorted(pr.items(), key=lambda kv: -kv[1]["launches"]) if v["launches"]})
+    print("total", sum(v["launches"] for v in pr.values()), "launches,", round(sum(v["ms"] for v in pr.values()), 2), "ms")
