@@ -132,6 +132,33 @@ class ConvMLP(nn.Module):
         return _from_cl(self.cl(_to_cl(x)))
 
 
+class _FactorPool:
+    """Stochastic-depth factors floor(keep_prob + U[0, 1)) / keep_prob (reference drop_path, blocks.py:1107-1120), drawn POOL at
+    a time and handed out in slices: a training step has ~30 AffineDropPath modules, and drawing per module was four tiny
+    launches each (rand, add, floor, div) -- 120 of the step's ~560 tensor-op launches, each a node of a recorded step.
+    A pool drawn while a HIP graph is being recorded belongs to that recording (its `rand` is replayed, so every replay gets
+    fresh factors; the slices recorded into the graph point into it) and is dropped when the capture state changes, as
+    autograd._ZeroArena's blocks are."""
+    POOL = 4096
+
+    def __init__(self):
+        self.pools = {}                # (device, keep_prob) -> [factors, next index, drawn during a capture]
+
+    def take(self, n, keep_prob, device):
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (device, keep_prob)
+        ent = self.pools.get(key)
+        if ent is None or ent[2] != capturing or ent[1] + n > ent[0].numel():
+            size = max(self.POOL, n)
+            ent = self.pools[key] = [torch.floor(keep_prob + torch.rand(size, device=device)) / keep_prob, 0, capturing]
+        out = ent[0][ent[1]:ent[1] + n]
+        ent[1] += n
+        return out
+
+
+_factor_pool = _FactorPool()
+
+
 class AffineDropPath(nn.Module):
     """Per-channel scale (+ stochastic depth when training); reference models/blocks.py:1134-1149.
     In eval it is a channel scale, which the GEMM epilogue applies (``scale`` argument)."""
@@ -151,10 +178,10 @@ class AffineDropPath(nn.Module):
         keep_prob = 1.0 - self.drop_prob
         if self.keep is not None:
             assert self.keep.numel() >= n_samples
-            keep = self.keep[:n_samples].to(device=device, dtype=torch.float32)
+            factors = self.keep[:n_samples].to(device=device, dtype=torch.float32) / keep_prob
         else:
-            keep = torch.floor(keep_prob + torch.rand(n_samples, device=device))
-        return (keep / keep_prob)[:, None].expand(n_samples, rows_per_sample).contiguous().view(-1)
+            factors = _factor_pool.take(n_samples, keep_prob, torch.device(device))
+        return factors[:, None].expand(n_samples, rows_per_sample).contiguous().view(-1)
 
     def forward(self, x):
         """(B, C, T) * scale, with the training-time drop (plain tensor arithmetic: the hot path applies scale and

@@ -138,7 +138,9 @@ def grad_scale(g, slot=0):
     if cols % 4 or ldg % 4 or pg % 16:
         return None
     if torch.cuda.is_current_stream_capturing():
-        buf = torch.zeros(_hip.ABSMAX_SCALE_FLOATS, device=g.device, dtype=torch.float32)
+        # (a slice of a zeroed block of the recording: one fill node per block instead of one per call -- ~140 per recorded step)
+        from .autograd import _zeros
+        buf = _zeros(_hip.ABSMAX_SCALE_FLOATS, device=g.device)
     else:
         key = (g.device, torch.cuda.current_stream(g.device).cuda_stream, slot)      # (slot: a consumer that needs two at once)
         buf = _grad_scales.get(key)
