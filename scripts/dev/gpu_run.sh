@@ -1,12 +1,14 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-O=gpurun_out/r06_train; mkdir -p $O
-timeout -k 10 800 python -m pytest tests/test_gpu_train.py tests/test_gpu_backward.py -x -q > $O/tests.txt 2>&1; echo "pytest rc $?"; tail -3 $O/tests.txt
-grep -q passed $O/tests.txt || { tail -40 $O/tests.txt; exit 1; }
-timeout -k 10 400 python bench.py --steps 2 --warmup 1 --no-alt --no-ragged --no-cpu-baseline --no-forward-test --no-shard-projection > $O/bench.json 2> $O/bench.err
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/r06_train/bench.json').read().strip().splitlines()[-1])
-ts=d['train_step']; print('train', ts['ms_forward_backward'], ts['ms_forward_backward_hip_graphs'], ts['launches_forward_backward'], {k:v for k,v in ts.get('vidor_48x512',{}).items() if 'ms' in k or 'launch' in k})
-PY
+O=gpurun_out/r06_attn; mkdir -p $O; rm -f $O/ab.txt
+for rep in 1 2; do for lib in prev base; do
+  if [ $lib = base ]; then unset VRDONE_HIP_LIB; else export VRDONE_HIP_LIB=$PWD/scripts/lab/libs/libvrdone_prev.so; fi
+  for prec in bf16x3 f16x3; do
+  echo "== $lib $prec hd64 T=512 / hd64 T=288 / hd128 T=128" >> $O/ab.txt
+  FB_PREC=$prec timeout -k 10 120 python scripts/flash_bench.py --pair --heads 8 --hd 64 --T 512 --valid 506 --B 1024 2>&1 | grep "w32 again" >> $O/ab.txt
+  FB_PREC=$prec timeout -k 10 120 python scripts/flash_bench.py --pair --heads 8 --hd 64 --T 288 --valid 282 --B 1024 2>&1 | grep "w32 again" >> $O/ab.txt
+  FB_PREC=$prec timeout -k 10 120 python scripts/flash_bench.py --pair --heads 4 --hd 128 --T 128 --valid 122 --B 2048 2>&1 | grep "w32 again" >> $O/ab.txt
+  done
+done; done
+cat $O/ab.txt

@@ -15,8 +15,13 @@ from vrdone_amd import ops  # noqa: E402
 
 
 def to_pair(t):
-    hi = t.to(torch.bfloat16)
-    lo = (t - hi.float()).to(torch.bfloat16)
+    """pair rows of the current precision mode: bf16 planes of x, or f16 planes of x * 2^F16_ACT_EXP"""
+    from vrdone_amd import _hip
+    f16 = ops.get_precision() == "f16x3"
+    el = torch.float16 if f16 else torch.bfloat16
+    y = t * 2.0 ** _hip.F16_ACT_EXP if f16 else t
+    hi = y.to(el)
+    lo = (y - hi.float()).to(el)
     C = t.shape[-1]
     raw = torch.stack([hi.reshape(*t.shape[:-1], C // 32, 32), lo.reshape(*t.shape[:-1], C // 32, 32)], dim=-2)
     return ops.Pair(raw.reshape(*t.shape[:-1], 2 * C).contiguous().view(torch.float32), C)
@@ -33,7 +38,7 @@ def main():
     ap.add_argument("--pair", action="store_true", help="pair-row output (what the model asks for)")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    ops.set_precision("bf16x3")
+    ops.set_precision(os.environ.get("FB_PREC", "bf16x3"))          # FB_PREC=f16x3: the default mode's element format
     g = torch.Generator(device=dev).manual_seed(1)
     C = a.heads * a.hd
     q, k, v = (to_pair(torch.randn(a.B, a.T, C, device=dev, generator=g)) for _ in range(3))
